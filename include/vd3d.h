@@ -1,0 +1,209 @@
+/*
+ * vd3d.h -- C ABI of libvd3d_hip.so: the MI355X (gfx950) depth-image-based stereo renderer.
+ *
+ * This is the drop-in boundary for ONE hot path of VisionDepth3D (reference tree
+ * /root/reference, Python): the per-frame 2D->3D chain of core/render_3d.py.
+ * The reference has no FFI; the boundary is a pair of Python call sites
+ * (SURVEY.md 8(b)).  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain C, no torch types.  All image pointers are DEVICE (HBM) pointers unless a
+ *    name ends in _host.  Sizes are in pixels.  Planes are dense row-major.
+ *  - "rgb_chw"  = float32 [3][h][w], R,G,B planes, values in [0,1]  (reference frame_to_tensor layout,
+ *                 core/render_3d.py:135-138)
+ *  - "bgr_hwc"  = uint8  [h][w][3], B,G,R interleaved                (OpenCV frame layout,
+ *                 core/render_3d.py:289-291)
+ *  - every call is ASYNCHRONOUS on the ctx's HIP stream and performs no host
+ *    synchronisation; temporal-tracker scalars live in device memory inside the
+ *    ctx and are advanced by a device-side scalar stage.  Use vd3d_sync() or
+ *    vd3d_state_export() to observe results on the host.
+ *  - return value: 0 on success, negative vd3d_status on error; vd3d_last_error()
+ *    returns a thread-local message.
+ */
+#ifndef VD3D_H
+#define VD3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VD3D_ABI_VERSION 1
+
+typedef enum vd3d_status {
+  VD3D_OK = 0,
+  VD3D_E_INVALID = -1,    /* bad argument (the reference raises AssertionError/ValueError) */
+  VD3D_E_HIP = -2,        /* HIP runtime error */
+  VD3D_E_NOMEM = -3,
+  VD3D_E_UNSUPPORTED = -4 /* valid in the reference, not built yet here (fails loudly, never falls back) */
+} vd3d_status;
+
+/* output_format strings of format_3d_output, core/render_3d.py:837-860 */
+typedef enum vd3d_format {
+  VD3D_FMT_HALF_SBS = 0,
+  VD3D_FMT_FULL_SBS = 1,
+  VD3D_FMT_VR = 2,
+  VD3D_FMT_ANAGLYPH = 3,
+  VD3D_FMT_INTERLACED = 4
+} vd3d_format;
+
+/* depth input encodings accepted by vd3d_render_frame */
+typedef enum vd3d_depth_fmt {
+  VD3D_DEPTH_F32 = 0,     /* float32 [h][w] already in [0,1] (precomputed; BASELINE configs 1 and 3) */
+  VD3D_DEPTH_BGR_U8 = 1,  /* uint8 [h][w][3] depth-video frame; depth_to_tensor, core/render_3d.py:140-143 */
+  VD3D_DEPTH_GRAY_U8 = 2  /* uint8 [h][w]: same as BGR_U8 with B=G=R (BGR2GRAY is the identity on gray) */
+} vd3d_depth_fmt;
+
+/*
+ * Keyword parameters of pixel_shift_cuda(), core/render_3d.py:561-590, same names,
+ * same meaning, same defaults (vd3d_shift_params_default).  Python floats are doubles
+ * and are narrowed to float32 at the same point torch narrows them.
+ */
+typedef struct vd3d_shift_params {
+  double fg_shift, mg_shift, bg_shift;     /* positional args 5-7 */
+  int32_t blur_ksize;                      /* 9   */
+  int32_t use_subject_tracking;            /* 1   */
+  int32_t enable_floating_window;          /* 1   */
+  int32_t enable_feathering;               /* 1   */
+  int32_t enable_edge_masking;             /* 1   */
+  int32_t enable_dynamic_convergence;      /* 1   */
+  double feather_strength;                 /* 10.0 */
+  double max_pixel_shift_percent;          /* 0.02 */
+  double parallax_balance;                 /* 0.8  */
+  double zero_parallax_strength;           /* 0.0  */
+  double convergence_strength;             /* 0.0  */
+  double depth_pop_gamma;                  /* 0.85 */
+  double depth_pop_mid;                    /* 0.50 */
+  double depth_stretch_lo;                 /* 0.05 */
+  double depth_stretch_hi;                 /* 0.95 */
+  double fg_pop_multiplier;                /* 1.20 */
+  double bg_push_multiplier;               /* 1.10 */
+  double subject_lock_strength;            /* 1.00 */
+} vd3d_shift_params;
+
+/*
+ * Per-clip constants of the render_sbs_3d loop body, core/render_3d.py:1227-1419.
+ * The geometry block is what lines 1074-1138 and 1236-1259 derive once per clip
+ * (host helper: visiondepth3d_amd.geometry.plan_geometry mirrors them).
+ */
+typedef struct vd3d_render_params {
+  /* geometry */
+  int32_t src_w, src_h;          /* decoded frame size */
+  int32_t crop_x, crop_y;        /* centre crop to the target aspect (:1236-1248) */
+  int32_t crop_w, crop_h;
+  int32_t eye_w, eye_h;          /* target_eye_w/h : size both tensors are resized to (:1250-1263) */
+  int32_t warp_w, warp_h;        /* resized_width/height: size pixel_shift_cuda warps at (:1285) */
+  int32_t fit_w, fit_h;          /* per_eye_w/h: size each eye is fitted to before muxing (:1409-1417) */
+  int32_t out_w, out_h;          /* muxed frame size */
+  int32_t format;                /* vd3d_format */
+  /* sliders */
+  vd3d_shift_params shift;       /* fg/mg/bg are the UNSCALED slider values; dyn_scale/ipd are applied per frame */
+  double ipd_factor;             /* :1283,1308 */
+  double dof_strength;           /* max_sigma of apply_dof_cuda; 0 disables (:1340) */
+  double sharpness_factor;       /* apply_sharpening factor (:1406) */
+  double color_saturation, color_contrast, color_brightness; /* apply_color_grade (:1362-1365) */
+} vd3d_render_params;
+
+/*
+ * All temporal-tracker scalars of the reference, made explicit (the reference keeps four of
+ * them as never-reset module singletons, core/render_3d.py:284-285,500,511).
+ */
+typedef struct vd3d_state {
+  /* FloatingWindowTracker :479-500 (alpha 0.97) */
+  double fw_prev_offset;
+  int32_t fw_frame_counter;
+  /* DepthPercentileEMA :233-262 (float32 0-d tensors in the reference) */
+  int32_t ema_valid;
+  float ema_lo, ema_hi;
+  /* ConvergenceEMA :273-280 (alpha 0.97) */
+  int32_t conv_valid;
+  int32_t bar_prev_width;        /* FloatingBarEaser :502-511 */
+  double conv_val;
+  /* FocalDepthTracker :895-922 */
+  int32_t focal_valid;
+  int32_t smooth_valid;          /* ShiftSmoother :463-477 */
+  double focal;
+  double sm_fg, sm_mg, sm_bg;
+  /* plane state validity: TemporalDepthFilter.prev_depth (:220-229) and prev_depth_tensor (:1181,1463) */
+  int32_t tdf_valid;
+  int32_t prev_depth_valid;
+} vd3d_state;
+
+/* Per-frame scalars the device-side scalar stage produced (diagnostics, multi-GPU exchange, tests). */
+typedef struct vd3d_frame_scalars {
+  float q_lo, q_hi;              /* quantile(d,0.02/0.98) of the filtered depth (a5 inputs) */
+  float ema_lo, ema_hi;          /* after the EMA */
+  float mean_c, var_c;           /* centre-crop mean / unbiased variance (a6) */
+  double dyn_scale;
+  float s_norm;                  /* estimate_subject_depth(normalised eye-res depth): focal candidate, bar input */
+  float mad;                     /* mean |d_t - d_{t-1}| (a15) */
+  float s0, q05, q95, s1;        /* pixel_shift_cuda internals */
+  float zpo_raw;                 /* zero-parallax offset before the tracker */
+  double zpo;                    /* after FloatingWindowTracker */
+  double focal;
+  double stable_zero;
+  int32_t bar_width;
+  int32_t bar_side;              /* 0 none, 1 = mask right columns, 2 = mask left columns */
+  int32_t collapse;              /* DepthPercentileEMA "hi-lo<1e-5" guard taken */
+  int32_t reserved;
+} vd3d_frame_scalars;
+
+typedef struct vd3d_ctx vd3d_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int vd3d_abi_version(void);
+const char* vd3d_last_error(void);
+void vd3d_shift_params_default(vd3d_shift_params* p);   /* defaults of core/render_3d.py:569-589 */
+void vd3d_render_params_default(vd3d_render_params* p);
+
+/* One ctx per device per thread.  `stream` is a hipStream_t (NULL = create a private stream). */
+int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out);
+int vd3d_ctx_destroy(vd3d_ctx* ctx);
+int vd3d_sync(vd3d_ctx* ctx);                            /* hipStreamSynchronize */
+void* vd3d_ctx_stream(vd3d_ctx* ctx);
+
+/* ---- tracker state (replaces the module singletons; lets ranks exchange it) -- */
+int vd3d_state_reset(vd3d_ctx* ctx);                     /* fresh process + fresh render */
+int vd3d_state_new_clip(vd3d_ctx* ctx);                  /* what render_sbs_3d re-creates per call (:1174-1182) */
+int vd3d_state_export(vd3d_ctx* ctx, vd3d_state* host_out);      /* synchronises */
+int vd3d_state_import(vd3d_ctx* ctx, const vd3d_state* host_in);
+/* plane state: TemporalDepthFilter.prev_depth and prev_depth_tensor, float32 [eye_h][eye_w] device planes */
+int vd3d_state_planes(vd3d_ctx* ctx, float** tdf_prev, float** norm_prev, int* eye_h, int* eye_w);
+int vd3d_last_scalars(vd3d_ctx* ctx, vd3d_frame_scalars* host_out); /* synchronises */
+
+/* ---- B1: pixel_shift_cuda, core/render_3d.py:561-712 --------------------------------------
+ * rgb_chw [3][in_h][in_w] f32, depth [in_h][in_w] f32 (device) -> left/right bgr_hwc u8 [H][W][3]
+ * (device), optional final_shift f32 [H][W].  Mutates the FloatingWindowTracker in ctx state
+ * exactly as the reference mutates its module global (:651). */
+int vd3d_pixel_shift(vd3d_ctx* ctx, const float* rgb_chw, const float* depth, int in_h, int in_w,
+                     int W, int H, const vd3d_shift_params* p,
+                     uint8_t* left_bgr, uint8_t* right_bgr, float* shift_or_null);
+
+/* ---- B2: one iteration of the render_sbs_3d loop body, core/render_3d.py:1227-1419 ---------
+ * frame_bgr u8 [src_h][src_w][3], depth per depth_fmt (device) -> out u8 [out_h][out_w][3] (device). */
+int vd3d_render_frame(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
+                      const vd3d_render_params* p, uint8_t* out_bgr);
+
+/* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
+/* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux
+ * (core/render_3d.py:1340-1419) on two u8 eyes. depth_norm is the eye-res normalised depth. */
+int vd3d_finish_frame(vd3d_ctx* ctx, const uint8_t* left_bgr, const uint8_t* right_bgr,
+                      const float* depth_norm, int eye_h, int eye_w,
+                      const vd3d_render_params* p, double focal_depth, int bar_width, int bar_side,
+                      uint8_t* out_bgr);
+/* exact order statistics on a device plane: torch.quantile semantics (float32 rank, two-branch lerp) */
+int vd3d_quantiles(vd3d_ctx* ctx, const float* plane, int64_t n, const float* q_host, int nq, float* out_host);
+/* estimate_subject_depth, core/render_3d.py:145-172 (synchronises; test/diagnostic entry) */
+int vd3d_subject_depth(vd3d_ctx* ctx, const float* plane, int H, int W, float* out_host);
+/* device-to-device streaming copy used as the measured-peak yardstick for roofline.frac */
+int vd3d_stream_copy(vd3d_ctx* ctx, const void* src, void* dst, size_t bytes);
+/* time (ms) between two internal events bracketing the last call of the named stage; -1 if unknown */
+float vd3d_last_stage_ms(vd3d_ctx* ctx, const char* stage);
+int vd3d_set_profiling(vd3d_ctx* ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VD3D_H */

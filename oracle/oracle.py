@@ -1,0 +1,296 @@
+"""ctypes front-end of the CPU oracle (oracle/vd3d_oracle.c).
+
+TEST INFRASTRUCTURE: imported only by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of bench.py -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from visiondepth3d_amd._abi import FrameScalars, RenderParams, ShiftParams, State
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvd3d_oracle.so")
+_lib = None
+
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class ShiftDebug(C.Structure):
+    _fields_ = [("s0", C.c_float), ("q05", C.c_float), ("q95", C.c_float), ("s1", C.c_float),
+                ("zpo_raw", C.c_float), ("zpo", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "vd3d_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.vo_quantile.restype = C.c_float
+        _lib.vo_quantile.argtypes = [_f32p, C.c_int64, C.c_float]
+        _lib.vo_subject_depth.restype = C.c_float
+        _lib.vo_dynamic_parallax_scale.restype = C.c_double
+        _lib.vo_dynamic_parallax_scale.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_double, _f32p, _f32p]
+        _lib.vo_motion_metric.restype = C.c_double
+        _lib.vo_motion_metric.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
+        _lib.vo_fw_smooth_offset.restype = C.c_double
+        _lib.vo_fw_smooth_offset.argtypes = [C.POINTER(State), C.c_double, C.c_double]
+        _lib.vo_focal_update.restype = C.c_double
+        _lib.vo_focal_update.argtypes = [C.POINTER(State), C.c_double, C.c_double]
+        _lib.vo_conv_update.restype = C.c_double
+        _lib.vo_conv_update.argtypes = [C.POINTER(State), C.c_double]
+        _lib.vo_bar_ease.argtypes = [C.POINTER(State), C.c_int]
+        _lib.vo_apply_dof.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_double, C.c_double, _f32p]
+        _lib.vo_color_grade.argtypes = [_f32p, C.c_size_t, C.c_double, C.c_double, C.c_double, _f32p]
+        _lib.vo_sharpen.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, _u8p]
+        _lib.vo_shape_depth_for_pop.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                C.c_float, _f32p, _f32p, _f32p]
+        _lib.vo_curvature_clamp.argtypes = [_f32p, C.c_int, C.c_int, C.c_float]
+        _lib.vo_gaussian_kernel1d.argtypes = [C.c_int, C.c_float, _f32p]
+        _lib.vo_finish_frame.argtypes = [_u8p, _u8p, _f32p, C.c_int, C.c_int, C.POINTER(RenderParams), C.c_double,
+                                         C.c_int, C.c_int, _u8p]
+        _lib.vo_temporal_filter.argtypes = [C.POINTER(State), _f32p, _f32p, C.c_size_t]
+        _lib.vo_percentile_ema_normalize.argtypes = [C.POINTER(State), _f32p, C.c_size_t, _f32p, _f32p, _f32p]
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _u(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+# ----------------------------------------------------------------------------- leaf functions
+def frame_to_tensor(bgr):
+    bgr, pb = _u(bgr)
+    h, w = bgr.shape[:2]
+    out = np.empty((3, h, w), np.float32)
+    lib().vo_frame_to_tensor(pb, h, w, out.ctypes.data_as(_f32p))
+    return out
+
+
+def depth_to_tensor(bgr):
+    bgr, pb = _u(bgr)
+    h, w = bgr.shape[:2]
+    out = np.empty((1, h, w), np.float32)
+    lib().vo_depth_to_tensor(pb, h, w, out.ctypes.data_as(_f32p))
+    return out
+
+
+def tensor_to_frame(t):
+    t, pt = _f(t)
+    _, h, w = t.shape
+    out = np.empty((h, w, 3), np.uint8)
+    lib().vo_tensor_to_frame(pt, h, w, out.ctypes.data_as(_u8p))
+    return out
+
+
+def interp_bilinear(t, oh, ow):
+    t, pt = _f(t)
+    c, ih, iw = t.shape
+    out = np.empty((c, oh, ow), np.float32)
+    lib().vo_interp_bilinear(pt, c, ih, iw, out.ctypes.data_as(_f32p), oh, ow)
+    return out
+
+
+def quantile(v, q):
+    v, pv = _f(np.ravel(v))
+    return float(lib().vo_quantile(pv, v.size, C.c_float(np.float32(q))))
+
+
+def subject_depth(d):
+    d, pd = _f(d)
+    H, W = d.shape[-2:]
+    return float(lib().vo_subject_depth(pd, H, W))
+
+
+def dynamic_parallax_scale(d, min_scale=0.6, max_scale=1.0):
+    d, pd = _f(d)
+    H, W = d.shape[-2:]
+    m, v = C.c_float(), C.c_float()
+    return float(lib().vo_dynamic_parallax_scale(pd, H, W, min_scale, max_scale, C.byref(m), C.byref(v)))
+
+
+def motion_metric(prev, cur):
+    prev, pp = _f(prev)
+    cur, pc = _f(cur)
+    mad = C.c_float()
+    return float(lib().vo_motion_metric(pp, pc, cur.size, C.byref(mad)))
+
+
+def curvature_clamp(d, strength=0.08):
+    d = np.array(d, dtype=np.float32, copy=True)
+    H, W = d.shape[-2:]
+    lib().vo_curvature_clamp(d.ctypes.data_as(_f32p), H, W, C.c_float(np.float32(strength)))
+    return d
+
+
+def shape_depth_for_pop(d, subject, stretch_lo=0.05, stretch_hi=0.95, depth_mid=0.5, gamma=0.85):
+    d, pd = _f(d)
+    out = np.empty_like(d)
+    lo, hi = C.c_float(), C.c_float()
+    f = lambda x: C.c_float(np.float32(x))
+    lib().vo_shape_depth_for_pop(pd, d.size, f(subject), f(stretch_lo), f(stretch_hi), f(depth_mid), f(gamma),
+                                 out.ctypes.data_as(_f32p), C.byref(lo), C.byref(hi))
+    return out, lo.value, hi.value
+
+
+def gaussian_kernel1d(k, sigma):
+    out = np.empty(k, np.float32)
+    lib().vo_gaussian_kernel1d(k, C.c_float(np.float32(sigma)), out.ctypes.data_as(_f32p))
+    return out
+
+
+def apply_dof(rgb, depth, focal_depth, max_sigma=2.0):
+    rgb, pr = _f(rgb)
+    depth, pd = _f(depth)
+    _, H, W = rgb.shape
+    out = np.empty_like(rgb)
+    lib().vo_apply_dof(pr, pd, H, W, float(focal_depth), float(max_sigma), out.ctypes.data_as(_f32p))
+    return out
+
+
+def color_grade(rgb, saturation=1.0, contrast=1.0, brightness=0.0):
+    rgb, pr = _f(rgb)
+    out = np.empty_like(rgb)
+    lib().vo_color_grade(pr, rgb.shape[1] * rgb.shape[2], float(saturation), float(contrast), float(brightness),
+                         out.ctypes.data_as(_f32p))
+    return out
+
+
+def sharpen(img, factor=1.0):
+    img, pi = _u(img)
+    out = np.empty_like(img)
+    lib().vo_sharpen(pi, img.shape[0], img.shape[1], float(factor), out.ctypes.data_as(_u8p))
+    return out
+
+
+def side_mask(img, side, width):
+    img = np.array(img, dtype=np.uint8, copy=True)
+    lib().vo_side_mask(img.ctypes.data_as(_u8p), img.shape[0], img.shape[1],
+                       {"right": 1, "left": 2, None: 0}.get(side, side), int(width))
+    return img
+
+
+def resize_area_int(img, dw, dh):
+    img, pi = _u(img)
+    out = np.empty((dh, dw, 3), np.uint8)
+    rc = lib().vo_resize_area_int(pi, img.shape[0], img.shape[1], out.ctypes.data_as(_u8p), dh, dw)
+    if rc:
+        raise NotImplementedError("oracle: non-integer INTER_AREA ratio")
+    return out
+
+
+def pad_to_aspect(img, tw, th):
+    img, pi = _u(img)
+    out = np.empty((th, tw, 3), np.uint8)
+    rc = lib().vo_pad_to_aspect(pi, img.shape[0], img.shape[1], out.ctypes.data_as(_u8p), th, tw)
+    if rc:
+        raise NotImplementedError("oracle: non-integer INTER_AREA ratio")
+    return out
+
+
+def format_output(L, R, fmt):
+    L, pl = _u(L)
+    R, pr = _u(R)
+    h, w = L.shape[:2]
+    out = np.empty((h, 2 * w, 3) if fmt in (0, 1) else (h, w, 3), np.uint8)
+    rc = lib().vo_format_output(pl, pr, h, w, int(fmt), out.ctypes.data_as(_u8p))
+    if rc:
+        raise NotImplementedError(f"oracle: format {fmt}")
+    return out
+
+
+# ------------------------------------------------------------------------------ composite
+def pixel_shift(rgb_chw, depth, W, H, params: ShiftParams, state: State | None = None,
+                want_shift=False, want_dshaped=False):
+    """Restatement of pixel_shift_cuda.  Returns dict(left,right[,shift,dshaped],dbg)."""
+    rgb, pr = _f(rgb_chw)
+    d, pd = _f(depth)
+    in_h, in_w = rgb.shape[1:]
+    st = state if state is not None else State()
+    L = np.empty((H, W, 3), np.uint8)
+    R = np.empty((H, W, 3), np.uint8)
+    S = np.empty((1, H, W), np.float32) if want_shift else None
+    Dm = np.empty((1, H, W), np.float32) if want_dshaped else None
+    dbg = ShiftDebug()
+    lib().vo_pixel_shift(pr, pd, in_h, in_w, int(W), int(H), C.byref(params), C.byref(st),
+                         L.ctypes.data_as(_u8p), R.ctypes.data_as(_u8p),
+                         S.ctypes.data_as(_f32p) if want_shift else None,
+                         Dm.ctypes.data_as(_f32p) if want_dshaped else None, C.byref(dbg))
+    out = {"left": L, "right": R, "dbg": {k: getattr(dbg, k) for k, _ in ShiftDebug._fields_}}
+    if want_shift:
+        out["shift"] = S
+    if want_dshaped:
+        out["dshaped"] = Dm
+    return out
+
+
+def finish_frame(L, R, depth_norm, params: RenderParams, focal_depth, bar_width=0, bar_side=0):
+    L, pl = _u(L)
+    R, pr = _u(R)
+    dn, pd = _f(depth_norm)
+    eh, ew = dn.shape[-2:]
+    out = np.empty((params.out_h, params.out_w, 3), np.uint8)
+    rc = lib().vo_finish_frame(pl, pr, pd, eh, ew, C.byref(params), float(focal_depth), int(bar_width),
+                               int(bar_side), out.ctypes.data_as(_u8p))
+    if rc:
+        raise NotImplementedError("oracle: unsupported fit/format")
+    return out
+
+
+class RenderOracle:
+    """Stateful CPU restatement of the render_sbs_3d loop body (one call per frame)."""
+
+    def __init__(self, params: RenderParams, state: State | None = None):
+        self.p = params
+        self.state = state if state is not None else State()
+        ne = params.eye_h * params.eye_w
+        self.tdf_prev = np.zeros(ne, np.float32)
+        self.norm_prev = np.zeros(ne, np.float32)
+        self.last = FrameScalars()
+
+    def new_clip(self):
+        """What render_sbs_3d re-creates per call (:1174-1182); the module singletons persist."""
+        s = self.state
+        s.smooth_valid = 0
+        s.tdf_valid = 0
+        s.prev_depth_valid = 0
+        s.focal_valid = 0
+
+    def render(self, frame_bgr, depth, depth_fmt, want_eyes=False):
+        p = self.p
+        fb, pf = _u(frame_bgr)
+        if depth_fmt == 0:
+            dd = np.ascontiguousarray(depth, dtype=np.float32)
+        else:
+            dd = np.ascontiguousarray(depth, dtype=np.uint8)
+        out = np.empty((p.out_h, p.out_w, 3), np.uint8)
+        L = np.empty((p.warp_h, p.warp_w, 3), np.uint8) if want_eyes else None
+        R = np.empty((p.warp_h, p.warp_w, 3), np.uint8) if want_eyes else None
+        rc = lib().vo_render_frame(pf, dd.ctypes.data_as(C.c_void_p), int(depth_fmt), C.byref(p),
+                                   C.byref(self.state), self.tdf_prev.ctypes.data_as(_f32p),
+                                   self.norm_prev.ctypes.data_as(_f32p), out.ctypes.data_as(_u8p),
+                                   C.byref(self.last),
+                                   L.ctypes.data_as(_u8p) if want_eyes else None,
+                                   R.ctypes.data_as(_u8p) if want_eyes else None)
+        if rc:
+            raise NotImplementedError("oracle: unsupported fit/format")
+        return (out, L, R) if want_eyes else out

@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors by running the REFERENCE itself (development container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Inputs are procedural (visiondepth3d_amd.synth) or integer formulas, so the fixtures hold
+expected outputs + the parameters that produced them.  The reference is imported from
+/root/reference through tests/golden/ref_loader.py (third-party modules that are absent here are
+restated in ref_stubs.py -- those parts are "parity unpinned").
+"""
+from __future__ import annotations
+
+import hashlib
+import io
+import contextlib
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import ref_loader as rl  # noqa: E402
+import ref_stubs  # noqa: E402
+from visiondepth3d_amd import synth  # noqa: E402
+
+r = rl.load()
+torch.set_num_threads(8)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------------------------------
+# 1. SURVEY Appendix A known answers (integer-defined input)
+# ------------------------------------------------------------------------------------------
+def kat_inputs(H=144, W=256):
+    y, x = np.mgrid[0:H, 0:W]
+    bgr = np.stack([((3 * x + 5 * y + k) % 256) for k in (0, 7, 14)], axis=2).astype(np.uint8)
+    d = (((4 * x + 3 * y) % 256) / 255).astype(np.float32)[None]
+    return bgr, d
+
+
+def gen_kat():
+    bgr, d = kat_inputs()
+    ft = r.frame_to_tensor(bgr)
+    dt = torch.from_numpy(d)
+    out = {}
+    dc = r.enhance_curvature(dt, 0.08).clamp(0, 1)
+    s0 = r.estimate_subject_depth(dc)
+    out["s0"] = np.float32(s0.item())
+    out["q05"] = np.float32(torch.quantile(dc, 0.05).item())
+    out["q95"] = np.float32(torch.quantile(dc, 0.95).item())
+    D = r.shape_depth_for_pop(dc, s0)
+    out["D"] = D.numpy()
+    out["s1"] = np.float32(r.estimate_subject_depth(D).item())
+    out["dyn_scale"] = np.float64(r.compute_dynamic_parallax_scale(dt, 0.90, 1.15))
+    for tag, kw in (("trk", dict(use_subject_tracking=True, enable_floating_window=True)),
+                    ("notrk", dict(use_subject_tracking=False, enable_floating_window=False))):
+        rl.reset_state()
+        L, R, S = r.pixel_shift_cuda(ft, dt, 256, 144, 10, -2.5, -5, blur_ksize=9, feather_strength=10, **kw)
+        out[f"{tag}_L"], out[f"{tag}_R"], out[f"{tag}_S"] = L, R, S.numpy()
+        out[f"{tag}_prev_offset"] = np.float64(r.floating_window_tracker.prev_offset)
+    out["grade_sum"] = np.float64(r.apply_color_grade(ft, 1.35, 1.10, 0.04).double().sum().item())
+    save("kat_appendix_a.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# 2. pixel_shift_cuda parameter sweep on a synthetic frame
+# ------------------------------------------------------------------------------------------
+SHIFT_CASES = [
+    ("cli_defaults", (10.0, -2.5, -5.0), dict()),
+    ("gui_defaults", (4.5, -1.5, -6.0), dict(blur_ksize=1, feather_strength=0.0, zero_parallax_strength=0.01)),
+    ("no_tracking", (10.0, -2.5, -5.0), dict(use_subject_tracking=False, enable_floating_window=False)),
+    ("track_no_float", (10.0, -2.5, -5.0), dict(enable_floating_window=False, zero_parallax_strength=0.01)),
+    ("conv_dynamic", (10.0, -2.5, -5.0), dict(convergence_strength=0.02)),
+    ("conv_static", (10.0, -2.5, -5.0), dict(convergence_strength=-0.03, enable_dynamic_convergence=False)),
+    ("no_edge_mask", (10.0, -2.5, -5.0), dict(enable_edge_masking=False)),
+    ("no_feather", (10.0, -2.5, -5.0), dict(enable_feathering=False)),
+    ("pop_controls", (8.0, -2.0, -4.0), dict(blur_ksize=4, feather_strength=3.0, depth_pop_gamma=0.7, depth_pop_mid=0.45,
+                                             depth_stretch_lo=0.1, depth_stretch_hi=0.9, fg_pop_multiplier=1.4,
+                                             bg_push_multiplier=0.9, subject_lock_strength=0.8, parallax_balance=0.6,
+                                             max_pixel_shift_percent=0.05)),
+    ("big_shift_k15", (30.0, -8.0, -20.0), dict(blur_ksize=15, feather_strength=20.0, max_pixel_shift_percent=0.08)),
+]
+
+
+def gen_pixel_shift():
+    out = {}
+    meta = {}
+    # identity-size case (preview path: frame and depth already at warp size) and an upsampling case (render path)
+    for size_tag, (ih, iw, H, W) in (("id", (96, 160, 96, 160)), ("up", (54, 96, 108, 192))):
+        bgr, d = synth.synth_frame(3, ih, iw)
+        ft = r.frame_to_tensor(bgr)
+        dt = torch.from_numpy(d)[None]
+        for name, (fg, mg, bg), kw in SHIFT_CASES:
+            if size_tag == "up" and name not in ("cli_defaults", "gui_defaults", "pop_controls"):
+                continue
+            rl.reset_state()
+            L, R, S = r.pixel_shift_cuda(ft, dt, W, H, fg, mg, bg, **kw)
+            key = f"{size_tag}__{name}"
+            out[key + "__L"], out[key + "__R"] = L, R
+            out[key + "__S"] = S.numpy().astype(np.float32)
+            out[key + "__prev_offset"] = np.float64(r.floating_window_tracker.prev_offset)
+            meta[key] = dict(ih=ih, iw=iw, H=H, W=W, fg=fg, mg=mg, bg=bg, kw=kw, frame_idx=3)
+    # tracker persistence: three consecutive calls WITHOUT reset (module singleton semantics)
+    rl.reset_state()
+    offs = []
+    for idx in range(3):
+        bgr, d = synth.synth_frame(idx, 96, 160)
+        L, R = r.pixel_shift_cuda(r.frame_to_tensor(bgr), torch.from_numpy(d)[None], 160, 96, 10.0, -2.5, -5.0,
+                                  return_shift_map=False)
+        offs.append(r.floating_window_tracker.prev_offset)
+        out[f"seq{idx}__L"], out[f"seq{idx}__R"] = L, R
+    out["seq_prev_offsets"] = np.array(offs, np.float64)
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("pixel_shift_cases.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# 3. helper functions / trackers
+# ------------------------------------------------------------------------------------------
+def gen_helpers():
+    out = {}
+    rng = np.random.default_rng(20250905)
+    # estimate_subject_depth: normal, <20 valid, value==1.0, tie
+    planes = {
+        "ramp": synth.synth_frame(0, 60, 100)[1],
+        "few_valid": np.full((60, 100), 0.99, np.float32),
+        "ones_edge": np.clip(rng.random((60, 100)).astype(np.float32) * 1.2, 0, 1),
+        "two_peaks": np.where(np.mgrid[0:60, 0:100][1] % 2 == 0, np.float32(0.30), np.float32(0.70)).astype(np.float32),
+        "const_mid": np.full((60, 100), 0.5, np.float32),
+    }
+    for k, p in planes.items():
+        out[f"subj_in__{k}"] = p
+        out[f"subj_out__{k}"] = np.float32(r.estimate_subject_depth(torch.from_numpy(p)[None]).item())
+    # quantiles incl. the float32-rank case
+    for n in (1000, 36864, 518400):
+        v = rng.random(n).astype(np.float32)
+        out[f"quant_in__{n}"] = v if n <= 36864 else np.zeros(0, np.float32)
+        out[f"quant_seed__{n}"] = np.int64(n)
+        if n > 36864:
+            v = np.random.default_rng(n).random(n).astype(np.float32)
+        out[f"quant_out__{n}"] = np.array([torch.quantile(torch.from_numpy(v), q).item() for q in (0.02, 0.05, 0.5, 0.95, 0.98)],
+                                          np.float32)
+    # DepthPercentileEMA over a sequence incl. a collapsed (constant) frame; TemporalDepthFilter before it
+    rl.reset_state()
+    tdf = r.TemporalDepthFilter(alpha=0.5)
+    seq = [synth.synth_frame(i, 54, 96)[1] for i in range(4)]
+    seq.insert(2, np.full((54, 96), 0.4, np.float32))
+    ema_state = []
+    for i, d in enumerate(seq):
+        dt = torch.from_numpy(d.copy())[None]
+        f = tdf.smooth(dt)
+        n = r.depth_ema_norm.normalize(f)
+        out[f"ema_seq_filtered__{i}"] = f.numpy().copy()
+        out[f"ema_seq_norm__{i}"] = n.numpy().copy()
+        ema_state.append([float(r.depth_ema_norm._lo), float(r.depth_ema_norm._hi)])
+        out[f"ema_seq_dyn__{i}"] = np.float64(r.compute_dynamic_parallax_scale(n, 0.90, 1.15))
+    out["ema_seq_state"] = np.array(ema_state, np.float64)
+    # constant frame FIRST (collapse with no state), then a normal one
+    rl.reset_state()
+    n0 = r.depth_ema_norm.normalize(torch.full((1, 54, 96), 0.4))
+    out["ema_collapse_first"] = n0.numpy()
+    out["ema_collapse_first_state_none"] = np.int64(r.depth_ema_norm._lo is None)
+    # trackers
+    fw = r.FloatingWindowTracker(alpha=0.97)
+    xs = [0.01, 0.0105, 0.02, -0.01] + list(np.linspace(-0.3, 0.3, 120))
+    out["fw_in"] = np.array(xs, np.float64)
+    out["fw_out"] = np.array([fw.smooth_offset(float(v), threshold=0.0015) for v in xs], np.float64)
+    ft_ = r.FocalDepthTracker(alpha=0.15, deadband=0.03, max_step=0.02)
+    cands = [0.5, 0.52, 0.7, 0.7, 0.2, 0.21, 0.9, 0.05, 0.5, 0.5]
+    mots = [0.0, 0.1, 0.5, 1.2, -0.3, 0.2, 0.7, 0.0, 0.3, 0.9]
+    fo = []
+    for c, m in zip(cands, mots):
+        ft_.set_scene_motion(m)
+        fo.append(ft_.update(c))
+    out["focal_cand"], out["focal_motion"], out["focal_out"] = np.array(cands), np.array(mots), np.array(fo, np.float64)
+    ce = r.ConvergenceEMA(alpha=0.97)
+    cx = list(np.linspace(-0.01, 0.02, 12))
+    out["conv_in"] = np.array(cx, np.float64)
+    out["conv_out"] = np.array([ce.update(float(v)) for v in cx], np.float64)
+    be = r.FloatingBarEaser(alpha=0.85)
+    bx = [40, 40, 40, 0, 120, 7, 7, 7]
+    out["bar_in"] = np.array(bx, np.int64)
+    out["bar_out"] = np.array([be.ease(v) for v in bx], np.int64)
+    ss = r.ShiftSmoother(0.15)
+    so = [ss.smooth(4.5, -1.5, -6.0) for _ in range(4)]
+    out["smoother_out"] = np.array(so, np.float64)
+    # motion metric
+    a, b = seq[0], seq[1]
+    out["motion_out"] = np.float64(r.compute_motion_metric(torch.from_numpy(a)[None], torch.from_numpy(b)[None]))
+    # color grade / dof on a small eye
+    bgr, d = synth.synth_frame(2, 72, 128)
+    t = r.frame_to_tensor(bgr)
+    out["grade_identity"] = r.tensor_to_frame(r.apply_color_grade(t, 1.0, 1.0, 0.0))
+    out["grade_strong"] = r.tensor_to_frame(r.apply_color_grade(t, 1.35, 1.10, 0.04))
+    for ms in (2.0, 1.0, 3.3):
+        o = r.apply_dof_cuda(t, torch.from_numpy(d)[None], 0.37, max_sigma=ms, focus_width=0.35)
+        out[f"dof_ms{ms}"] = o.numpy()
+    for k, sg in ((3, 0.5), (5, 1.0), (7, 1.5), (9, 2.0)):
+        out[f"gauss_k{k}"] = ref_stubs._gaussian_kernel1d(k, sg).numpy()
+    # sharpen / INTER_AREA / formats (OpenCV semantics restated in ref_stubs: unpinned)
+    out["sharp_0.15"] = r.apply_sharpening(bgr, 0.15)
+    out["sharp_0.2"] = r.apply_sharpening(bgr, 0.2)
+    import cv2
+    out["area_half_w"] = cv2.resize(bgr, (64, 72), interpolation=cv2.INTER_AREA)
+    out["area_2x2"] = cv2.resize(bgr, (64, 36), interpolation=cv2.INTER_AREA)
+    bgr2 = synth.synth_frame(5, 72, 128)[0]
+    for fmt in ("Half-SBS", "Full-SBS", "Red-Cyan Anaglyph", "Passive Interlaced"):
+        out[f"fmt__{fmt}"] = r.format_3d_output(bgr, bgr2, fmt)
+    out["side_left_7"] = r.apply_side_mask(bgr, side="left", width=7)
+    out["side_right_0"] = r.apply_side_mask(bgr, side="right", width=0)
+    out["side_right_9"] = r.apply_side_mask(bgr, side="right", width=9)
+    out["pad_wide"] = r.pad_to_aspect_ratio(synth.synth_frame(1, 54, 128)[0], 128, 72)
+    save("helpers.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# 4. the real render_sbs_3d loop driven through a fake VideoCapture / VideoWriter
+# ------------------------------------------------------------------------------------------
+class _Aspect:
+    def __init__(self, label):
+        self.label = label
+
+    def get(self):
+        return self.label
+
+
+LOOP_CASES = {
+    # name: (src_h, src_w, n_frames, kwargs for render_sbs_3d)
+    "half_sbs_cli": (108, 192, 6, dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5,
+                                       bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0,
+                                       blur_ksize=9, use_subject_tracking=True, use_floating_window=True)),
+    "half_sbs_gui_nodof": (108, 192, 5, dict(output_format="Half-SBS", output_height=108, fg_shift=4.5, mg_shift=-1.5,
+                                            bg_shift=-6.0, sharpness_factor=0.2, dof_strength=0.0, feather_strength=0.0,
+                                            blur_ksize=1, use_subject_tracking=True, use_floating_window=True,
+                                            zero_parallax_strength=0.01, color_saturation=1.2, color_contrast=1.05,
+                                            color_brightness=0.02, ipd_factor=1.0)),
+    "full_sbs_preserve": (90, 160, 4, dict(output_format="Full-SBS", output_height=90, fg_shift=10.0, mg_shift=-2.5,
+                                           bg_shift=-5.0, sharpness_factor=0.15, dof_strength=1.5, feather_strength=10.0,
+                                           blur_ksize=9, use_subject_tracking=True, use_floating_window=False,
+                                           preserve_original_aspect=True, original_video_width=160,
+                                           original_video_height=90, ipd_factor=0.0)),
+    "interlaced": (90, 160, 3, dict(output_format="Passive Interlaced", output_height=90, fg_shift=10.0, mg_shift=-2.5,
+                                    bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0,
+                                    blur_ksize=9, use_subject_tracking=False, use_floating_window=False)),
+    "anaglyph_43crop": (120, 160, 3, dict(output_format="Red-Cyan Anaglyph", output_height=90, fg_shift=10.0,
+                                          mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
+                                          feather_strength=10.0, blur_ksize=9, use_subject_tracking=True,
+                                          use_floating_window=True, ipd_factor=1.1)),
+}
+
+
+def run_loop(name, reset=True):
+    sh, sw, n, kw = LOOP_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ref_stubs._Clip.clips["in.mp4"] = frames
+    ref_stubs._Clip.clips["depth.mp4"] = [synth.depth_to_u8_bgr(d) for d in depths]
+    if reset:
+        rl.reset_state()
+    kw = dict(kw)
+    args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0,
+                output_width=sw, selected_aspect_ratio=_Aspect("Default (16:9)"), aspect_ratios=r.aspect_ratios,
+                suspend_flag=threading.Event(), cancel_flag=threading.Event())
+    args.update(kw)
+    with contextlib.redirect_stdout(io.StringIO()) as so:
+        r.render_sbs_3d(**args)
+    if "crashed" in so.getvalue():
+        raise RuntimeError(so.getvalue())
+    return ref_stubs._Clip.written["out.avi"]
+
+
+def gen_loops():
+    out = {}
+    for name in LOOP_CASES:
+        written = run_loop(name)
+        out[f"{name}__frames"] = np.stack(written)
+        print(f"  loop {name}: {len(written)} frames of {written[0].shape}")
+    # singleton leak: a second render in the same process WITHOUT resetting the module singletons
+    run_loop("half_sbs_cli", reset=True)
+    w2 = run_loop("half_sbs_cli", reset=False)
+    out["half_sbs_cli__second_render_frames"] = np.stack(w2)
+    out["cases_json"] = np.frombuffer(json.dumps(LOOP_CASES).encode(), dtype=np.uint8)
+    save("render_loop.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops"]
+    if "kat" in which:
+        gen_kat()
+    if "shift" in which:
+        gen_pixel_shift()
+    if "helpers" in which:
+        gen_helpers()
+    if "loops" in which:
+        gen_loops()

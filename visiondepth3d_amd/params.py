@@ -1,0 +1,62 @@
+"""Map the reference's Python call signatures onto the C-ABI parameter structs (pure host logic).
+
+``render_kwargs_to_params`` accepts the keyword names of ``render_sbs_3d``
+(core/render_3d.py:933-985) and reproduces which of them the reference actually forwards:
+``depth_pop_*``, ``fg_pop_multiplier``, ``bg_push_multiplier``, ``subject_lock_strength`` are accepted
+and IGNORED (the loop passes literals, :1299-1305), and ``parallax_balance`` is never forwarded
+(:1284-1331), so the pixel_shift_cuda default 0.8 applies.
+"""
+from __future__ import annotations
+
+import inspect
+
+from ._abi import RenderParams, ShiftParams
+from .geometry import make_render_params, plan_geometry
+
+# defaults of render_sbs_3d's keyword parameters (core/render_3d.py:949-984)
+RENDER_DEFAULTS = dict(
+    feather_strength=0.0, blur_ksize=1, use_ffmpeg=False, selected_ffmpeg_codec=None, crf_value=23,
+    use_subject_tracking=False, use_floating_window=False, max_pixel_shift_percent=0.02, progress=None,
+    progress_label=None, suspend_flag=None, cancel_flag=None, auto_crop_black_bars=False, parallax_balance=0.8,
+    preserve_original_aspect=False, zero_parallax_strength=0.0, enable_edge_masking=True, enable_feathering=True,
+    skip_blank_frames=False, original_video_width=None, original_video_height=None, convergence_strength=0.0,
+    enable_dynamic_convergence=True, ipd_factor=1.0, depth_pop_gamma=0.85, depth_pop_mid=0.50, depth_stretch_lo=0.05,
+    depth_stretch_hi=0.95, fg_pop_multiplier=1.20, bg_push_multiplier=1.10, subject_lock_strength=1.00,
+    color_saturation=1.0, color_contrast=1.0, color_brightness=0.0, start_s=None, end_s=None,
+)
+
+
+def shift_params_from_kwargs(fg_shift, mg_shift, bg_shift, **kw) -> ShiftParams:
+    """pixel_shift_cuda(..., **kw) -> vd3d_shift_params (unknown keywords raise TypeError like Python would)."""
+    kw = dict(kw)
+    kw.pop("return_shift_map", None)
+    kw.pop("dof_strength", None)  # accepted and unused by pixel_shift_cuda (:579)
+    return ShiftParams.defaults(fg_shift, mg_shift, bg_shift, **kw)
+
+
+def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, mg_shift, bg_shift,
+                            sharpness_factor, output_format, dof_strength, target_ratio=16 / 9,
+                            **kw) -> RenderParams:
+    unknown = set(kw) - set(RENDER_DEFAULTS) - {"output_width", "input_path", "depth_path", "output_path",
+                                                "selected_codec", "fps", "selected_aspect_ratio", "aspect_ratios"}
+    if unknown:
+        raise TypeError(f"render_sbs_3d() got unexpected keyword argument(s) {sorted(unknown)}")
+    o = dict(RENDER_DEFAULTS)
+    o.update(kw)
+    if o["auto_crop_black_bars"]:
+        raise NotImplementedError("auto_crop_black_bars (detect_black_bars, core/render_3d.py:293-316) is not built yet")
+    if o["skip_blank_frames"]:
+        raise NotImplementedError("skip_blank_frames needs the ffmpeg blackdetect side-channel (out of scope)")
+    geom = plan_geometry(src_w, src_h, output_height, output_format, target_ratio, o["preserve_original_aspect"],
+                         o["original_video_width"], o["original_video_height"])
+    shift = ShiftParams.defaults(
+        fg_shift, mg_shift, bg_shift,
+        blur_ksize=o["blur_ksize"], feather_strength=o["feather_strength"],
+        use_subject_tracking=o["use_subject_tracking"], enable_floating_window=o["use_floating_window"],
+        max_pixel_shift_percent=o["max_pixel_shift_percent"], zero_parallax_strength=o["zero_parallax_strength"],
+        enable_edge_masking=o["enable_edge_masking"], enable_feathering=o["enable_feathering"],
+        convergence_strength=o["convergence_strength"], enable_dynamic_convergence=o["enable_dynamic_convergence"])
+    p = make_render_params(geom, shift, ipd_factor=o["ipd_factor"], dof_strength=dof_strength,
+                           sharpness_factor=sharpness_factor, color_saturation=o["color_saturation"],
+                           color_contrast=o["color_contrast"], color_brightness=o["color_brightness"])
+    return p
