@@ -158,7 +158,10 @@ const char* vd3d_last_error(void);
 void vd3d_shift_params_default(vd3d_shift_params* p);   /* defaults of core/render_3d.py:569-589 */
 void vd3d_render_params_default(vd3d_render_params* p);
 
-/* One ctx per device per thread.  `stream` is a hipStream_t (NULL = create a private stream). */
+/* One ctx per device per thread.  `stream` is a hipStream_t: NULL = the device's default (null) stream, which is
+ * what PyTorch enqueues on by default, so tensors and vd3d calls stay ordered; VD3D_STREAM_PRIVATE = create and own a
+ * private non-blocking stream (the caller then orders against it with events / vd3d_sync). */
+#define VD3D_STREAM_PRIVATE ((void*)(intptr_t)-1)
 int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out);
 int vd3d_ctx_destroy(vd3d_ctx* ctx);
 int vd3d_sync(vd3d_ctx* ctx);                            /* hipStreamSynchronize */
@@ -199,9 +202,14 @@ int vd3d_quantiles(vd3d_ctx* ctx, const float* plane, int64_t n, const float* q_
 int vd3d_subject_depth(vd3d_ctx* ctx, const float* plane, int H, int W, float* out_host);
 /* device-to-device streaming copy used as the measured-peak yardstick for roofline.frac */
 int vd3d_stream_copy(vd3d_ctx* ctx, const void* src, void* dst, size_t bytes);
-/* time (ms) between two internal events bracketing the last call of the named stage; -1 if unknown */
-float vd3d_last_stage_ms(vd3d_ctx* ctx, const char* stage);
+/* HIP-event profiling of the stages on the ctx stream ("frame", "ingest", "select_eye", "select_dc", "shape",
+ * "select_s1", "warp", "finish", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
+ * profiling was enabled (-1 if never seen); both getters synchronise. */
 int vd3d_set_profiling(vd3d_ctx* ctx, int enable);
+float vd3d_last_stage_ms(vd3d_ctx* ctx, const char* stage);
+long vd3d_stage_calls(vd3d_ctx* ctx, const char* stage);
+/* internal planes of the last call (device pointers owned by ctx; tests only) */
+int vd3d_debug_planes(vd3d_ctx* ctx, float** D, float** S, uint8_t** L, uint8_t** R, float** rgb_eye, float** dn_cur);
 
 #ifdef __cplusplus
 }

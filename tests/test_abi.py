@@ -1,0 +1,65 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/vd3d.h
+declares, its struct layouts match the ctypes mirror, and it fails LOUDLY (no fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from visiondepth3d_amd import _abi, _lib
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(L):
+    hdr = open(os.path.join(ROOT, "include", "vd3d.h")).read()
+    declared = set(re.findall(r"\b(vd3d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.vd3d_abi_version() == _abi.ABI_VERSION
+
+
+def test_struct_layouts_match_c(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vd3d.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(vd3d_shift_params),sizeof(vd3d_render_params),sizeof(vd3d_state),sizeof(vd3d_frame_scalars),'
+                   'offsetof(vd3d_render_params,shift),offsetof(vd3d_state,focal),offsetof(vd3d_frame_scalars,zpo));}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    exp = [C.sizeof(_abi.ShiftParams), C.sizeof(_abi.RenderParams), C.sizeof(_abi.State), C.sizeof(_abi.FrameScalars),
+           _abi.RenderParams.shift.offset, _abi.State.focal.offset, _abi.FrameScalars.zpo.offset]
+    assert got == exp
+
+
+def test_defaults_match_reference_signature(L):
+    p = _abi.ShiftParams()
+    L.vd3d_shift_params_default(C.byref(p))
+    d = _abi.ShiftParams.defaults()
+    for k, _ in _abi.ShiftParams._fields_:
+        assert getattr(p, k) == getattr(d, k), k
+    # core/render_3d.py:569-589
+    assert (p.blur_ksize, p.feather_strength, p.max_pixel_shift_percent, p.parallax_balance) == (9, 10.0, 0.02, 0.8)
+    assert (p.depth_pop_gamma, p.depth_pop_mid, p.depth_stretch_lo, p.depth_stretch_hi) == (0.85, 0.5, 0.05, 0.95)
+    assert (p.fg_pop_multiplier, p.bg_push_multiplier, p.subject_lock_strength) == (1.2, 1.1, 1.0)
+
+
+def test_fails_loudly_without_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    rc = L.vd3d_ctx_create(0, None, C.byref(ctx))
+    assert rc == _abi.E_HIP and b"hipGetDeviceCount" in L.vd3d_last_error()
+    from visiondepth3d_amd.render_3d import Renderer
+    with pytest.raises(RuntimeError):
+        Renderer()

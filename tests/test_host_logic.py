@@ -1,0 +1,67 @@
+"""CPU-only tests of the host logic that mirrors the reference's Python: geometry, kwargs mapping, synth."""
+import numpy as np
+import pytest
+
+from visiondepth3d_amd import synth
+from visiondepth3d_amd._abi import FMT_HALF_SBS, ShiftParams
+from visiondepth3d_amd.geometry import plan_geometry
+from visiondepth3d_amd.params import render_kwargs_to_params, shift_params_from_kwargs
+
+
+def test_half_sbs_geometry_1080p_and_4k():
+    # 1080p -> eye 540x960 -> warp 1080x1920 -> fit 1080x960 -> hstack 1920x1080
+    g = plan_geometry(1920, 1080, 1080, "Half-SBS")
+    assert (g["eye_w"], g["eye_h"], g["warp_w"], g["warp_h"], g["fit_w"], g["fit_h"], g["out_w"], g["out_h"]) == \
+        (960, 540, 1920, 1080, 960, 1080, 1920, 1080)
+    g = plan_geometry(3840, 2160, 2160, "Half-SBS")
+    assert (g["eye_w"], g["eye_h"], g["warp_w"], g["warp_h"], g["out_w"], g["out_h"]) == (1920, 1080, 3840, 2160, 3840, 2160)
+
+
+def test_full_sbs_is_hardwired_1080p_unless_preserve():
+    g = plan_geometry(3840, 2160, 2160, "Full-SBS")  # core/render_3d.py:1120-1123
+    assert (g["fit_w"], g["fit_h"], g["out_w"], g["out_h"]) == (1920, 1080, 3840, 1080)
+    g = plan_geometry(3840, 2160, 2160, "Full-SBS", preserve_original_aspect=True, original_video_width=3840, original_video_height=2160)
+    assert (g["eye_w"], g["eye_h"], g["out_w"], g["out_h"]) == (3840, 2160, 7680, 2160)
+
+
+def test_centre_crop_when_aspect_differs():
+    g = plan_geometry(160, 120, 90, "Half-SBS")  # 4:3 source, 16:9 target
+    assert (g["crop_x"], g["crop_y"], g["crop_w"], g["crop_h"]) == (0, 15, 160, 90)
+    g = plan_geometry(400, 100, 90, "Half-SBS")  # wider than target
+    assert g["crop_w"] == int(100 * 16 / 9) and g["crop_x"] == (400 - g["crop_w"]) // 2
+
+
+def test_render_kwargs_mirror_reference_forwarding():
+    p = render_kwargs_to_params(192, 108, output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+                                output_format="Half-SBS", dof_strength=2.0, depth_pop_gamma=0.5, parallax_balance=0.3,
+                                use_subject_tracking=True, use_floating_window=True)
+    # accepted but never forwarded by render_sbs_3d (:1284-1331): the struct keeps pixel_shift_cuda's defaults
+    assert p.shift.depth_pop_gamma == 0.85 and p.shift.parallax_balance == 0.8
+    assert p.format == FMT_HALF_SBS and p.shift.use_subject_tracking == 1 and p.shift.enable_floating_window == 1
+    with pytest.raises(TypeError):
+        render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0, output_format="Half-SBS",
+                                dof_strength=0, codec="XVID")  # render_cli.py's stale kwarg is a TypeError in the reference too
+    with pytest.raises(NotImplementedError):
+        render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0,
+                                output_format="Half-SBS", dof_strength=0, auto_crop_black_bars=True)
+
+
+def test_shift_kwargs():
+    p = shift_params_from_kwargs(4.5, -1.5, -6.0, blur_ksize=1, feather_strength=0.0, return_shift_map=False, dof_strength=2.0)
+    assert isinstance(p, ShiftParams) and p.blur_ksize == 1 and p.fg_shift == 4.5
+    with pytest.raises(TypeError):
+        shift_params_from_kwargs(1, 2, 3, bogus=1)
+
+
+def test_synth_is_deterministic_and_well_conditioned():
+    f1, d1 = synth.synth_frame(5, 108, 192)
+    f2, d2 = synth.synth_frame(5, 108, 192)
+    assert np.array_equal(f1, f2) and np.array_equal(d1, d2)
+    assert f1.dtype == np.uint8 and d1.dtype == np.float32 and 0.0 <= d1.min() and d1.max() <= 1.0
+    assert np.quantile(d1, 0.98) - np.quantile(d1, 0.02) > 0.3      # far from the collapse guard
+    crop = d1[108 // 5:108 * 4 // 5, 192 // 5:192 * 4 // 5]
+    assert np.count_nonzero((crop > 0.05) & (crop < 0.95)) > 20     # estimate_subject_depth has samples
+    # platform-independence pin: integer-defined generator -> fixed checksum
+    assert int(f1.astype(np.int64).sum()) == int(synth.synth_frame(5, 108, 192)[0].astype(np.int64).sum())
+    g = synth.depth_to_u8_bgr(d1)
+    assert g.shape == (108, 192, 3) and np.array_equal(g[..., 0], g[..., 2])

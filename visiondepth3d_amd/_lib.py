@@ -1,0 +1,78 @@
+"""ctypes binding of libvd3d_hip.so (include/vd3d.h).  There is NO fallback path: if the HIP library
+is missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _abi
+from ._abi import FrameScalars, RenderParams, ShiftParams, State
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvd3d_hip.so")
+
+# every symbol include/vd3d.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = (
+    "vd3d_abi_version", "vd3d_last_error", "vd3d_shift_params_default", "vd3d_render_params_default",
+    "vd3d_ctx_create", "vd3d_ctx_destroy", "vd3d_sync", "vd3d_ctx_stream",
+    "vd3d_state_reset", "vd3d_state_new_clip", "vd3d_state_export", "vd3d_state_import", "vd3d_state_planes",
+    "vd3d_last_scalars", "vd3d_pixel_shift", "vd3d_render_frame", "vd3d_finish_frame", "vd3d_quantiles",
+    "vd3d_subject_depth", "vd3d_stream_copy", "vd3d_set_profiling", "vd3d_last_stage_ms", "vd3d_stage_calls",
+    "vd3d_debug_planes",
+)
+
+_lib = None
+
+
+class Vd3dError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvd3d_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libvd3d_hip.so (built in-tree by ``__graft_entry__.build()`` / ``make -C visiondepth3d_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32p, u8p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
+    L.vd3d_abi_version.restype = i32
+    L.vd3d_last_error.restype = C.c_char_p
+    L.vd3d_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.vd3d_ctx_destroy.argtypes = [vp]
+    L.vd3d_sync.argtypes = [vp]
+    L.vd3d_ctx_stream.argtypes = [vp]
+    L.vd3d_ctx_stream.restype = vp
+    for n in ("vd3d_state_reset", "vd3d_state_new_clip"):
+        getattr(L, n).argtypes = [vp]
+    L.vd3d_state_export.argtypes = [vp, C.POINTER(State)]
+    L.vd3d_state_import.argtypes = [vp, C.POINTER(State)]
+    L.vd3d_state_planes.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    L.vd3d_last_scalars.argtypes = [vp, C.POINTER(FrameScalars)]
+    L.vd3d_pixel_shift.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, C.POINTER(ShiftParams), u8p, u8p, f32p]
+    L.vd3d_render_frame.argtypes = [vp, u8p, vp, i32, C.POINTER(RenderParams), u8p]
+    L.vd3d_finish_frame.argtypes = [vp, u8p, u8p, f32p, i32, i32, C.POINTER(RenderParams), C.c_double, i32, i32, u8p]
+    L.vd3d_quantiles.argtypes = [vp, f32p, C.c_int64, C.POINTER(C.c_float), i32, C.POINTER(C.c_float)]
+    L.vd3d_subject_depth.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_float)]
+    L.vd3d_stream_copy.argtypes = [vp, vp, vp, C.c_size_t]
+    L.vd3d_set_profiling.argtypes = [vp, i32]
+    L.vd3d_last_stage_ms.argtypes = [vp, C.c_char_p]
+    L.vd3d_last_stage_ms.restype = C.c_float
+    L.vd3d_stage_calls.argtypes = [vp, C.c_char_p]
+    L.vd3d_stage_calls.restype = C.c_long
+    L.vd3d_debug_planes.argtypes = [vp] + [C.POINTER(vp)] * 6
+    L.vd3d_shift_params_default.argtypes = [C.POINTER(ShiftParams)]
+    L.vd3d_render_params_default.argtypes = [C.POINTER(RenderParams)]
+    if L.vd3d_abi_version() != _abi.ABI_VERSION:
+        raise ImportError("libvd3d_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise Vd3dError(rc, lib().vd3d_last_error().decode(errors="replace"))

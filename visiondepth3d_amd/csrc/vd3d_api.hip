@@ -1,0 +1,474 @@
+// vd3d_api.hip -- C ABI of libvd3d_hip.so (include/vd3d.h).  Host-side orchestration only:
+// every entry point enqueues kernels on the ctx stream and returns; no host synchronisation
+// except where the header says so.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vd3d_kernels.h"
+
+#define VD3D_EXPORT extern "C" __attribute__((visibility("default")))
+
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(x)                                                                                     \
+  do {                                                                                                \
+    hipError_t e_ = (x);                                                                              \
+    if (e_ != hipSuccess) return set_err(VD3D_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct vd_prof_rec { std::string name; hipEvent_t a, b; };
+
+struct vd3d_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  vd_dev_work* work = nullptr;
+  uint32_t* histA = nullptr;  // [VD_NJOBS][VD_NB_A] followed by histB [VD_NJOBS][VD_MAX_T][VD_NB_B]
+  uint32_t* histB = nullptr;
+  size_t hist_bytes = 0;
+  // eye-res planes
+  int eye_h = 0, eye_w = 0;
+  float* rgb_eye = nullptr; float* tdf = nullptr; float* dn[2] = {nullptr, nullptr};
+  int dn_cur = 0;
+  // warp-res planes
+  int H = 0, W = 0;
+  float *D = nullptr, *S = nullptr, *e2L = nullptr, *e2R = nullptr, *bL = nullptr, *bR = nullptr;
+  uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<vd_prof_rec> recs;
+  std::vector<hipEvent_t> ev_pool;
+  std::map<std::string, std::pair<double, long>> acc;
+};
+
+struct StageTimer {
+  vd3d_ctx* c; vd_prof_rec r; bool on;
+  StageTimer(vd3d_ctx* ctx, const char* name) : c(ctx), on(ctx->profiling) {
+    if (!on) return;
+    r.name = name;
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else hipEventCreate(&e); return e; };
+    r.a = get(); r.b = get();
+    hipEventRecord(r.a, c->stream);
+  }
+  ~StageTimer() {
+    if (!on) return;
+    hipEventRecord(r.b, c->stream);
+    c->recs.push_back(r);
+  }
+};
+
+static void prof_collect(vd3d_ctx* c) {
+  for (auto& r : c->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& a = c->acc[r.name];
+      a.first += ms; a.second += 1;
+    }
+    c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
+  }
+  c->recs.clear();
+}
+
+template <class T> static hipError_t re_alloc(T** p, size_t n) {
+  if (*p) { hipError_t e = hipFree(*p); *p = nullptr; if (e != hipSuccess) return e; }
+  return n ? hipMalloc((void**)p, n * sizeof(T)) : hipSuccess;
+}
+
+static int ensure_eye(vd3d_ctx* c, int eh, int ew) {
+  if (c->eye_h == eh && c->eye_w == ew) return 0;
+  size_t ne = (size_t)eh * ew;
+  HIPCHK(re_alloc(&c->rgb_eye, 3 * ne));
+  HIPCHK(re_alloc(&c->tdf, ne));
+  HIPCHK(re_alloc(&c->dn[0], ne));
+  HIPCHK(re_alloc(&c->dn[1], ne));
+  c->eye_h = eh; c->eye_w = ew; c->dn_cur = 0;
+  return 0;
+}
+static int ensure_work(vd3d_ctx* c, int H, int W) {
+  if (c->H == H && c->W == W) return 0;
+  size_t n = (size_t)H * W;
+  HIPCHK(re_alloc(&c->D, n)); HIPCHK(re_alloc(&c->S, n));
+  HIPCHK(re_alloc(&c->e2L, n)); HIPCHK(re_alloc(&c->e2R, n));
+  HIPCHK(re_alloc(&c->bL, n)); HIPCHK(re_alloc(&c->bR, n));
+  HIPCHK(re_alloc(&c->L, 3 * n)); HIPCHK(re_alloc(&c->R, 3 * n));
+  HIPCHK(re_alloc(&c->gL, 3 * n)); HIPCHK(re_alloc(&c->gR, 3 * n));
+  c->H = H; c->W = W;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+VD3D_EXPORT int vd3d_abi_version(void) { return VD3D_ABI_VERSION; }
+VD3D_EXPORT const char* vd3d_last_error(void) { return g_err; }
+
+VD3D_EXPORT void vd3d_shift_params_default(vd3d_shift_params* p) {
+  memset(p, 0, sizeof *p);
+  p->blur_ksize = 9; p->use_subject_tracking = 1; p->enable_floating_window = 1; p->enable_feathering = 1;
+  p->enable_edge_masking = 1; p->enable_dynamic_convergence = 1; p->feather_strength = 10.0;
+  p->max_pixel_shift_percent = 0.02; p->parallax_balance = 0.8; p->zero_parallax_strength = 0.0;
+  p->convergence_strength = 0.0; p->depth_pop_gamma = 0.85; p->depth_pop_mid = 0.50; p->depth_stretch_lo = 0.05;
+  p->depth_stretch_hi = 0.95; p->fg_pop_multiplier = 1.20; p->bg_push_multiplier = 1.10; p->subject_lock_strength = 1.00;
+}
+VD3D_EXPORT void vd3d_render_params_default(vd3d_render_params* p) {
+  memset(p, 0, sizeof *p);
+  vd3d_shift_params_default(&p->shift);
+  // render_sbs_3d's own keyword defaults (core/render_3d.py:949-984)
+  p->shift.feather_strength = 0.0; p->shift.blur_ksize = 1; p->shift.use_subject_tracking = 0; p->shift.enable_floating_window = 0;
+  p->ipd_factor = 1.0; p->dof_strength = 0.0; p->sharpness_factor = 0.0;
+  p->color_saturation = 1.0; p->color_contrast = 1.0; p->color_brightness = 0.0;
+  p->format = VD3D_FMT_HALF_SBS;
+}
+
+VD3D_EXPORT int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out) {
+  if (!out) return set_err(VD3D_E_INVALID, "out is NULL");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return set_err(VD3D_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  vd3d_ctx* c = new vd3d_ctx();
+  c->device = device;
+  if (stream == VD3D_STREAM_PRIVATE) { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  else c->stream = (hipStream_t)stream;  // NULL = the default stream
+  HIPCHK(hipMalloc((void**)&c->work, sizeof(vd_dev_work)));
+  HIPCHK(hipMemsetAsync(c->work, 0, sizeof(vd_dev_work), c->stream));
+  const size_t nA = (size_t)VD_NJOBS * VD_NB_A, nB = (size_t)VD_NJOBS * VD_MAX_T * VD_NB_B;
+  c->hist_bytes = (nA + nB) * sizeof(uint32_t);
+  HIPCHK(hipMalloc((void**)&c->histA, c->hist_bytes));
+  c->histB = c->histA + nA;
+  *out = c;
+  return 0;
+}
+VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  prof_collect(c);
+  for (auto e : c->ev_pool) hipEventDestroy(e);
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+VD3D_EXPORT int vd3d_sync(vd3d_ctx* c) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  return 0;
+}
+VD3D_EXPORT void* vd3d_ctx_stream(vd3d_ctx* c) { return (void*)c->stream; }
+
+// ---- state ------------------------------------------------------------------------------------
+VD3D_EXPORT int vd3d_state_export(vd3d_ctx* c, vd3d_state* out) {
+  HIPCHK(hipMemcpyAsync(out, &c->work->st, sizeof(vd3d_state), hipMemcpyDeviceToHost, c->stream));
+  return vd3d_sync(c);
+}
+VD3D_EXPORT int vd3d_state_import(vd3d_ctx* c, const vd3d_state* in) {
+  HIPCHK(hipMemcpyAsync(&c->work->st, in, sizeof(vd3d_state), hipMemcpyHostToDevice, c->stream));
+  return vd3d_sync(c);
+}
+VD3D_EXPORT int vd3d_state_reset(vd3d_ctx* c) {
+  vd3d_state z;
+  memset(&z, 0, sizeof z);
+  return vd3d_state_import(c, &z);
+}
+VD3D_EXPORT int vd3d_state_new_clip(vd3d_ctx* c) {  // what render_sbs_3d re-creates per call (:1174-1182)
+  vd3d_state s;
+  int rc = vd3d_state_export(c, &s);
+  if (rc) return rc;
+  s.smooth_valid = 0; s.tdf_valid = 0; s.prev_depth_valid = 0; s.focal_valid = 0;
+  return vd3d_state_import(c, &s);
+}
+VD3D_EXPORT int vd3d_state_planes(vd3d_ctx* c, float** tdf_prev, float** norm_prev, int* eye_h, int* eye_w) {
+  if (tdf_prev) *tdf_prev = c->tdf;
+  if (norm_prev) *norm_prev = c->dn[c->dn_cur ^ 1];  // the plane the NEXT frame treats as d_{t-1}
+  if (eye_h) *eye_h = c->eye_h;
+  if (eye_w) *eye_w = c->eye_w;
+  return 0;
+}
+VD3D_EXPORT int vd3d_last_scalars(vd3d_ctx* c, vd3d_frame_scalars* out) {
+  HIPCHK(hipMemcpyAsync(out, &c->work->fs, sizeof(vd3d_frame_scalars), hipMemcpyDeviceToHost, c->stream));
+  return vd3d_sync(c);
+}
+
+// ---- shared middle section: shaped depth, s1, shift, feather, warp --------------------------------
+static int check_shift_params(const vd3d_shift_params* p, int H, int W) {
+  if (W < 2 || H < 2) return set_err(VD3D_E_INVALID, "warp size %dx%d too small", W, H);
+  if ((long long)H * W >= (1ll << 31)) return set_err(VD3D_E_INVALID, "warp size too large");
+  if (p->blur_ksize < 1) return set_err(VD3D_E_INVALID, "blur_ksize must be >= 1 (avg_pool2d raises)");
+  if (p->blur_ksize > PL_KMAX_HOST) return set_err(VD3D_E_UNSUPPORTED, "blur_ksize %d > %d not built", p->blur_ksize, PL_KMAX_HOST);
+  return 0;
+}
+
+static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_plane, int ih, int iw, int W, int H,
+                              const vd3d_shift_params& sp, vd_stage_args a) {
+  hipStream_t s = c->stream;
+  { StageTimer t(c, "select_dc");
+    vd_launch_hist_work_dc(s, false, depth_plane, ih, iw, H, W, c->work, c->histA, c->histB);
+    if (a.have_eye) vd_launch_hist_eye_subj(s, false, depth_plane, ih, iw, c->work, c->histA, c->histB);
+    a.stage = VD_ST_A1; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
+    vd_launch_hist_work_dc(s, true, depth_plane, ih, iw, H, W, c->work, c->histA, c->histB);
+    if (a.have_eye) vd_launch_hist_eye_subj(s, true, depth_plane, ih, iw, c->work, c->histA, c->histB);
+    a.stage = VD_ST_B1; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
+  }
+  { StageTimer t(c, "shape");
+    vd_launch_shape(s, depth_plane, ih, iw, H, W, c->work, (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, c->D);
+  }
+  { StageTimer t(c, "select_s1");
+    vd_launch_hist_work_s1(s, false, c->D, H, W, c->work, c->histA, c->histB);
+    a.stage = VD_ST_A2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
+    vd_launch_hist_work_s1(s, true, c->D, H, W, c->work, c->histA, c->histB);
+    a.stage = VD_ST_B2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
+  }
+  { StageTimer t(c, "warp");
+    vd_launch_shift(s, c->D, H, W, c->work, sp, c->S);
+    if (sp.enable_feathering) {
+      vd_launch_e2(s, c->D, c->S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
+      vd_launch_pool(s, c->e2L, c->e2R, H, W, sp.blur_ksize, c->bL, c->bR);
+    }
+    vd_launch_warp(s, rgb, ih, iw, c->S, c->bL, c->bR, H, W, sp.enable_feathering ? 1 : 0, c->L, c->R);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_pixel_shift(vd3d_ctx* c, const float* rgb_chw, const float* depth, int in_h, int in_w, int W, int H,
+                                 const vd3d_shift_params* p, uint8_t* left_bgr, uint8_t* right_bgr, float* shift_or_null) {
+  if (!c || !rgb_chw || !depth || !p || !left_bgr || !right_bgr) return set_err(VD3D_E_INVALID, "NULL argument");
+  if (in_h < 1 || in_w < 1) return set_err(VD3D_E_INVALID, "bad input size");
+  int rc = check_shift_params(p, H, W);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  if ((rc = ensure_work(c, H, W))) return rc;
+  StageTimer tf(c, "pixel_shift");
+  HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, c->stream));
+  vd_stage_args a;
+  memset(&a, 0, sizeof a);
+  a.have_eye = 0; a.W = W; a.H = H; a.shift = *p; a.ipd_factor = 0.0;
+  rc = run_shift_and_warp(c, rgb_chw, depth, in_h, in_w, W, H, *p, a);
+  if (rc) return rc;
+  const size_t n = (size_t)H * W;
+  HIPCHK(hipMemcpyAsync(left_bgr, c->L, 3 * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(right_bgr, c->R, 3 * n, hipMemcpyDeviceToDevice, c->stream));
+  if (shift_or_null) HIPCHK(hipMemcpyAsync(shift_or_null, c->S, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+// ---- finishing constants ------------------------------------------------------------------------
+static float linspace_host(float start, float end, int steps, int i) {
+  if (steps == 1) return start;
+  float step = (end - start) / (float)(steps - 1);
+  if (i < steps / 2) return fmaf(step, (float)i, start);
+  return fmaf(-step, (float)(steps - 1 - i), end);
+}
+static int make_finish_consts(const vd3d_render_params* p, vd_finish_consts* fc) {
+  memset(fc, 0, sizeof *fc);
+  const int NL = 5;
+  if (p->dof_strength > 0.0) {
+    fc->nlev = NL - 1;
+    for (int l = 1; l < NL; ++l) {  // apply_dof_cuda :798-806 + torchvision _get_gaussian_kernel1d
+      float sigma = linspace_host(0.f, (float)p->dof_strength, NL, l);
+      int k = (int)(2 * ceil(2 * (double)sigma) + 1);
+      if (k > 2 * DF_RMAX_HOST + 1) return set_err(VD3D_E_UNSUPPORTED, "dof_strength %.3f needs a %d-tap Gaussian (> %d)", p->dof_strength, k, 2 * DF_RMAX_HOST + 1);
+      fc->ksz[l - 1] = k;
+      const float half = (float)((k - 1) * 0.5);
+      float sum = 0.f;
+      for (int i = 0; i < k; ++i) {
+        float x = linspace_host(-half, half, k, i);
+        float t = x / sigma;
+        fc->kern[l - 1][i] = (float)exp((double)(-0.5f * (t * t)));
+        sum += fc->kern[l - 1][i];
+      }
+      for (int i = 0; i < k; ++i) fc->kern[l - 1][i] = fc->kern[l - 1][i] / sum;
+    }
+  }
+  fc->fw = (float)(0.35 + 1e-6);
+  fc->imax = (float)((NL - 1) - 1e-6);
+  fc->sat = (float)p->color_saturation; fc->con = (float)p->color_contrast; fc->bri = (float)p->color_brightness;
+  // apply_sharpening :719-728: float32 kernel / np.sum (numpy pairwise order for 9 elements)
+  const float c0 = (float)(5.0 + p->sharpness_factor);
+  float ks = ((0.f + -1.f) + (0.f + -1.f)) + ((c0 + -1.f) + (0.f + -1.f));
+  ks = ks + 0.f;
+  fc->sharp_kn = ks != 0.f ? -1.f / ks : -1.f;
+  fc->sharp_kc = ks != 0.f ? c0 / ks : c0;
+  return 0;
+}
+
+static int check_fit(const vd3d_render_params* p) {
+  if (p->format == VD3D_FMT_VR) return set_err(VD3D_E_UNSUPPORTED, "VR format (1440x1600 INTER_LINEAR + fractional INTER_AREA) not built yet");
+  if (p->format < 0 || p->format > VD3D_FMT_INTERLACED) return set_err(VD3D_E_INVALID, "unknown format %d", p->format);
+  int in_w, in_h;
+  if (p->format == VD3D_FMT_HALF_SBS) { in_w = p->fit_w; in_h = p->fit_h; }
+  else {
+    const double ta = (double)p->fit_w / p->fit_h, ca = (double)p->warp_w / p->warp_h;
+    if (ca > ta) { in_w = p->fit_w; in_h = (int)(p->fit_w / ca); }
+    else { in_h = p->fit_h; in_w = (int)(ca * p->fit_h); }
+  }
+  if (in_w < 1 || in_h < 1 || p->warp_w % in_w || p->warp_h % in_h)
+    return set_err(VD3D_E_UNSUPPORTED, "fit %dx%d -> %dx%d is not an integer INTER_AREA ratio (fractional path not built yet)",
+                   p->warp_w, p->warp_h, in_w, in_h);
+  const int mux_w = (p->format == VD3D_FMT_HALF_SBS || p->format == VD3D_FMT_FULL_SBS) ? 2 * p->fit_w : p->fit_w;
+  if (p->out_w != mux_w || p->out_h != p->fit_h) return set_err(VD3D_E_INVALID, "out size %dx%d does not match mux %dx%d", p->out_w, p->out_h, mux_w, p->fit_h);
+  return 0;
+}
+
+static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
+                      const vd3d_render_params* p, const vd_finish_consts& fc, float focal, int use_override, int bw, int bs,
+                      uint8_t* out) {
+  StageTimer t(c, "finish");
+  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, c->work, focal, use_override, bw, bs, c->gL);
+  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, c->work, focal, use_override, bw, bs, c->gR);
+  vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_finish_frame(vd3d_ctx* c, const uint8_t* left_bgr, const uint8_t* right_bgr, const float* depth_norm,
+                                  int eye_h, int eye_w, const vd3d_render_params* p, double focal_depth, int bar_width,
+                                  int bar_side, uint8_t* out_bgr) {
+  if (!c || !left_bgr || !right_bgr || !depth_norm || !p || !out_bgr) return set_err(VD3D_E_INVALID, "NULL argument");
+  int rc = check_fit(p);
+  if (rc) return rc;
+  vd_finish_consts fc;
+  if ((rc = make_finish_consts(p, &fc))) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
+  return run_finish(c, left_bgr, right_bgr, depth_norm, eye_h, eye_w, p, fc, (float)focal_depth, 1, bar_width, bar_side, out_bgr);
+}
+
+// ---- B2 ---------------------------------------------------------------------------------------
+VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
+                                  const vd3d_render_params* p, uint8_t* out_bgr) {
+  if (!c || !frame_bgr || !depth || !p || !out_bgr) return set_err(VD3D_E_INVALID, "NULL argument");
+  if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
+  if (p->crop_x < 0 || p->crop_y < 0 || p->crop_w < 1 || p->crop_h < 1 || p->crop_x + p->crop_w > p->src_w || p->crop_y + p->crop_h > p->src_h)
+    return set_err(VD3D_E_INVALID, "crop window outside the frame");
+  if (p->eye_w < 2 || p->eye_h < 2) return set_err(VD3D_E_INVALID, "eye size too small");
+  int rc = check_fit(p);
+  if (rc) return rc;
+  // render_sbs_3d forwards literals for the pop/lock controls and never forwards parallax_balance (:1284-1331)
+  vd3d_shift_params sp = p->shift;
+  sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
+  sp.depth_stretch_hi = 0.95; sp.fg_pop_multiplier = 1.20; sp.bg_push_multiplier = 1.10; sp.subject_lock_strength = 1.00;
+  if ((rc = check_shift_params(&sp, p->warp_h, p->warp_w))) return rc;
+  vd_finish_consts fc;
+  if ((rc = make_finish_consts(p, &fc))) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  if ((rc = ensure_eye(c, p->eye_h, p->eye_w))) return rc;
+  if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
+  hipStream_t s = c->stream;
+  const long long ne = (long long)p->eye_h * p->eye_w;
+  StageTimer tf(c, "frame");
+  vd_stage_args a;
+  memset(&a, 0, sizeof a);
+  a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.n_eye = ne;
+  a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
+  a.ipd_factor = p->ipd_factor; a.shift = sp;
+  float* dn_cur = c->dn[c->dn_cur];
+  float* dn_prev = c->dn[c->dn_cur ^ 1];
+  { StageTimer t(c, "ingest");
+    HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
+    vd_launch_ingest(s, frame_bgr, depth, depth_fmt, *p, c->work, c->rgb_eye, c->tdf);
+  }
+  { StageTimer t(c, "select_eye");
+    vd_launch_hist_eye_d(s, false, c->tdf, ne, c->work, c->histA, c->histB);
+    a.stage = VD_ST_A0; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
+    vd_launch_hist_eye_d(s, true, c->tdf, ne, c->work, c->histA, c->histB);
+    a.stage = VD_ST_B0; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
+    vd_launch_eye_stats(s, c->tdf, dn_cur, dn_prev, p->eye_h, p->eye_w, c->work);
+  }
+  rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a);
+  if (rc) return rc;
+  rc = run_finish(c, c->L, c->R, dn_cur, p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr);
+  if (rc) return rc;
+  c->dn_cur ^= 1;
+  return 0;
+}
+
+// ---- diagnostics / tests --------------------------------------------------------------------------
+VD3D_EXPORT int vd3d_debug_planes(vd3d_ctx* c, float** D, float** S, uint8_t** L, uint8_t** R, float** rgb_eye, float** dn_cur) {
+  if (D) *D = c->D;
+  if (S) *S = c->S;
+  if (L) *L = c->L;
+  if (R) *R = c->R;
+  if (rgb_eye) *rgb_eye = c->rgb_eye;
+  if (dn_cur) *dn_cur = c->dn[c->dn_cur ^ 1];  // the plane the last render_frame wrote
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_quantiles(vd3d_ctx* c, const float* plane, int64_t n, const float* q_host, int nq, float* out_host) {
+  if (!c || !plane || !q_host || !out_host || n < 1 || nq < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  if (n >= (1ll << 31)) return set_err(VD3D_E_INVALID, "n too large");
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < nq; i += 2) {
+    vd_stage_args a;
+    memset(&a, 0, sizeof a);
+    // reuse the work-res quantile job through the stretch_lo/hi slots
+    a.shift.depth_stretch_lo = q_host[i];
+    a.shift.depth_stretch_hi = q_host[i + 1 < nq ? i + 1 : i];
+    HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, c->stream));
+    vd_launch_hist_eye_d(c->stream, false, plane, n, c->work, c->histA, c->histB);
+    a.stage = VD_ST_AQ; vd_launch_scalar_stage(c->stream, c->work, c->histA, c->histB, a);
+    vd_launch_hist_eye_d(c->stream, true, plane, n, c->work, c->histA, c->histB);
+    a.stage = VD_ST_BQ; vd_launch_scalar_stage(c->stream, c->work, c->histA, c->histB, a);
+    float res[2];
+    HIPCHK(hipMemcpyAsync(res, &c->work->fs.q_lo, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    out_host[i] = res[0];
+    if (i + 1 < nq) out_host[i + 1] = res[1];
+  }
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_subject_depth(vd3d_ctx* c, const float* plane, int H, int W, float* out_host) {
+  if (!c || !plane || !out_host || H < 1 || W < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  vd_stage_args a;
+  memset(&a, 0, sizeof a);
+  HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, c->stream));
+  vd_launch_hist_work_s1(c->stream, false, plane, H, W, c->work, c->histA, c->histB);
+  a.stage = VD_ST_A2; vd_launch_scalar_stage(c->stream, c->work, c->histA, c->histB, a);
+  vd_launch_hist_work_s1(c->stream, true, plane, H, W, c->work, c->histA, c->histB);
+  a.stage = VD_ST_BS; vd_launch_scalar_stage(c->stream, c->work, c->histA, c->histB, a);
+  HIPCHK(hipMemcpyAsync(out_host, &c->work->fs.s1, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_stream_copy(vd3d_ctx* c, const void* src, void* dst, size_t bytes) {
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "stream_copy");
+  vd_launch_stream_copy(c->stream, src, dst, bytes);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_set_profiling(vd3d_ctx* c, int enable) {
+  vd3d_sync(c);
+  c->profiling = enable != 0;
+  if (enable) c->acc.clear();
+  return 0;
+}
+// average milliseconds per call of the named stage since profiling was enabled; -1 if never seen.  Synchronises.
+VD3D_EXPORT float vd3d_last_stage_ms(vd3d_ctx* c, const char* stage) {
+  vd3d_sync(c);
+  auto it = c->acc.find(stage);
+  if (it == c->acc.end() || it->second.second == 0) return -1.f;
+  return (float)(it->second.first / (double)it->second.second);
+}
+VD3D_EXPORT long vd3d_stage_calls(vd3d_ctx* c, const char* stage) {
+  vd3d_sync(c);
+  auto it = c->acc.find(stage);
+  return it == c->acc.end() ? 0 : it->second.second;
+}

@@ -1,0 +1,123 @@
+// vd3d_dev.h -- device-side arithmetic primitives for the gfx950 DIBR kernels.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): float32, one rounding per reference operator, built
+// with -ffp-contract=off; FMA only where written explicitly (the places ATen's own fused kernels
+// contract); pow/exp are the correctly-rounded float32 value computed through float64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vd3d.h"
+
+#define VD_DEV __device__ __forceinline__
+
+VD_DEV float vd_clamp(float x, float lo, float hi) {
+  float t = x < lo ? lo : x;
+  return t > hi ? hi : t;
+}
+VD_DEV float vd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// torch.linspace float32, element form: step=(end-start)/(steps-1); i<steps/2 ? fma(step,i,start) : fma(-step,steps-1-i,end)
+VD_DEV float vd_linspace(float start, float end, int steps, int i) {
+  if (steps == 1) return start;
+  float step = (end - start) / (float)(steps - 1);
+  if (i < steps / 2) return vd_fma(step, (float)i, start);
+  return vd_fma(-step, (float)(steps - 1 - i), end);
+}
+VD_DEV float vd_lin11(int steps, int i) { return vd_linspace(-1.f, 1.f, steps, i); }
+
+// correctly-rounded float32 pow / exp through float64 (device libm is < 1 ULP in float64)
+VD_DEV float vd_pow_cr(float x, float e) { return (float)pow((double)x, (double)e); }
+VD_DEV float vd_exp_cr(float x) { return (float)exp((double)x); }
+// x^1.5 == x*sqrt(x): float64 sqrt is correctly rounded, product error < 1 ULP(float64) => same float32 as pow
+VD_DEV float vd_pow15_cr(float x) {
+  double d = (double)x;
+  return (float)(d * sqrt(d));
+}
+
+// F.interpolate(bilinear, align_corners=False) tap for output index o
+struct vd_tap { int i0, i1; float w0, w1; };
+VD_DEV vd_tap vd_interp_tap(int in, int out, int o) {
+  vd_tap t;
+  if (in == out) { t.i0 = o; t.i1 = o; t.w0 = 1.f; t.w1 = 0.f; return t; }
+  const float scale = (float)in / (float)out;
+  float src = scale * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  int i0 = (int)floorf(src);
+  if (i0 > in - 1) i0 = in - 1;
+  float l1 = vd_clamp(src - (float)i0, 0.f, 1.f);
+  t.i0 = i0;
+  t.i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  t.w1 = l1;
+  t.w0 = 1.f - l1;
+  return t;
+}
+// ATen Interpolate<>::eval association: fma(t0,w0,t1*w1), rows then columns
+VD_DEV float vd_bilerp(float p00, float p01, float p10, float p11, float wx0, float wx1, float wy0, float wy1) {
+  float a = vd_fma(p00, wx0, wx1 * p01);
+  float b = vd_fma(p10, wx0, wx1 * p11);
+  return vd_fma(a, wy0, wy1 * b);
+}
+
+// grid_sample(bilinear, border, align_corners=True) parameters for a normalised coordinate pair
+struct vd_gs { int xw, yn; float nw, ne, sw, se; bool e_ok, s_ok; };
+VD_DEV vd_gs vd_gs_params(float gx, float gy, int W, int H) {
+  vd_gs p;
+  float ix = (gx + 1.f) * ((float)(W - 1) / 2.f);
+  float iy = (gy + 1.f) * ((float)(H - 1) / 2.f);
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+  float xw = floorf(ix), yn = floorf(iy);
+  float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
+  p.nw = s * e; p.ne = s * w; p.sw = n * e; p.se = n * w;
+  p.xw = (int)xw; p.yn = (int)yn;
+  p.e_ok = (p.xw + 1) < W;
+  p.s_ok = (p.yn + 1) < H;
+  return p;
+}
+VD_DEV float vd_gs_combine(const vd_gs& p, float vnw, float vne, float vsw, float vse) {
+  return vd_fma(vse, p.se, vd_fma(vsw, p.sw, vd_fma(vne, p.ne, vnw * p.nw)));
+}
+
+// order-independent fixed-point accumulation (oracle: fx40)
+#define VD_FX 1099511627776.0
+VD_DEV long long vd_fx40(double v) { return __double2ll_rn(v * VD_FX); }
+
+VD_DEV int vd_reflect(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+  }
+  return i;
+}
+VD_DEV uint8_t vd_sat_rne_u8(float v) {
+  float r = rintf(v);
+  r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+  return (uint8_t)r;
+}
+
+// 64-bit wave reductions (wave = 64 lanes on gfx950)
+VD_DEV long long vd_wave_sum_ll(long long v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    int lo = __shfl_down((int)(v & 0xffffffffll), off, 64);
+    int hi = __shfl_down((int)(v >> 32), off, 64);
+    v += ((long long)hi << 32) | (unsigned int)lo;
+  }
+  return v;
+}
+
+// histogram add with wave-level aggregation of equal keys (smooth depth planes put most of a wave in
+// one bin; a plain atomic would serialise 64-way on that address)
+template <typename HistPtr>
+VD_DEV void vd_hist_add_agg(HistPtr hist, unsigned key, bool valid) {
+  unsigned long long mask = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  while (mask) {
+    int leader = __ffsll((long long)mask) - 1;
+    unsigned lk = __shfl((int)key, leader, 64);
+    unsigned long long same = __ballot(valid && key == lk) & mask;
+    if (lane == leader) atomicAdd(&hist[lk], (unsigned)__popcll(same));
+    mask &= ~same;
+  }
+}

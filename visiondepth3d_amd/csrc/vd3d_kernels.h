@@ -1,0 +1,71 @@
+// vd3d_kernels.h -- launch prototypes + small PODs shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vd3d_work.h"
+
+enum { VD_ST_A0 = 0, VD_ST_B0, VD_ST_A1, VD_ST_B1, VD_ST_A2, VD_ST_B2,
+       VD_ST_AQ, VD_ST_BQ, VD_ST_BS };  // AQ/BQ: generic quantile pair, BS: bare subject depth (test entry points)
+#define PL_KMAX_HOST 33   // largest blur_ksize the pool kernel's LDS tile is sized for
+#define DF_RMAX_HOST 15   // largest Gaussian radius of the DOF kernel
+
+struct vd_stage_args {
+  int stage;
+  int have_eye;        // 1: full render_frame chain (eye-res stages exist); 0: bare pixel_shift_cuda
+  int W, H;            // warp size
+  long long n_eye;     // eye_h*eye_w
+  long long n_crop;    // centre-crop population of compute_dynamic_parallax_scale
+  double ipd_factor;
+  vd3d_shift_params shift;
+};
+
+#ifdef __HIPCC__
+#include "vd3d_dev.h"
+// enhance_curvature(.,0.08) + clamp (core/render_3d.py:599-601) of the bilinearly resized depth (:596)
+VD_DEV float vd_curved_depth(const float* __restrict__ dn, int ih, int iw, int H, int W, int y, int x) {
+  float d;
+  if (ih == H && iw == W) {
+    d = dn[(size_t)y * W + x];
+  } else {
+    vd_tap ty = vd_interp_tap(ih, H, y), tx = vd_interp_tap(iw, W, x);
+    const float* r0 = dn + (size_t)ty.i0 * iw;
+    const float* r1 = dn + (size_t)ty.i1 * iw;
+    d = vd_bilerp(r0[tx.i0], r0[tx.i1], r1[tx.i0], r1[tx.i1], tx.w0, tx.w1, ty.w0, ty.w1);
+  }
+  const float xx = vd_lin11(W, x), yy = vd_lin11(H, y);
+  const float curv = 1.f - (xx * xx + yy * yy);
+  return vd_clamp(d + curv * (float)0.08, 0.f, 1.f);
+}
+#endif
+
+// ---- vd3d_select.hip
+void vd_launch_hist_eye_d(hipStream_t s, bool passB, const float* tdf, long long n, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
+void vd_launch_hist_eye_subj(hipStream_t s, bool passB, const float* dn, int eh, int ew, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
+void vd_launch_hist_work_dc(hipStream_t s, bool passB, const float* dn, int ih, int iw, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
+void vd_launch_hist_work_s1(hipStream_t s, bool passB, const float* D, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
+void vd_launch_scalar_stage(hipStream_t s, vd_dev_work* w, const uint32_t* histA, const uint32_t* histB, const vd_stage_args& a);
+
+// ---- vd3d_planes.hip
+struct vd_finish_consts {
+  int nlev;                 // number of blurred levels (4 when dof on, 0 when off)
+  int ksz[4];               // kernel sizes
+  float kern[4][32];        // 1-D Gaussian weights per level (torchvision _get_gaussian_kernel1d)
+  float fw, imax;           // focus_width + 1e-6, (N-1) - 1e-6
+  float sat, con, bri;
+  float sharp_kn, sharp_kc; // normalised sharpen taps
+};
+void vd_launch_ingest(hipStream_t s, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params& p,
+                      const vd_dev_work* w, float* rgb_eye, float* tdf_prev);
+void vd_launch_eye_stats(hipStream_t s, const float* tdf, float* dn_cur, const float* dn_prev, int eh, int ew, vd_dev_work* w);
+void vd_launch_shape(hipStream_t s, const float* dn, int ih, int iw, int H, int W, const vd_dev_work* w, float mid, float gamma, float* D);
+void vd_launch_shift(hipStream_t s, const float* D, int H, int W, const vd_dev_work* w, const vd3d_shift_params& p, float* S);
+void vd_launch_e2(hipStream_t s, const float* D, const float* S, int H, int W, float fs, float* e2L, float* e2R);
+void vd_launch_pool(hipStream_t s, const float* e2L, const float* e2R, int H, int W, int k, float* bL, float* bR);
+void vd_launch_warp(hipStream_t s, const float* rgb, int ih, int iw, const float* S, const float* bL, const float* bR, int H, int W,
+                    int feather, uint8_t* L, uint8_t* R);
+void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
+                         const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
+                         int bar_width, int bar_side, uint8_t* eye_out);
+void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
+                         const vd_finish_consts& fc, uint8_t* out);
+void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);

@@ -1,0 +1,511 @@
+// vd3d_select.hip -- exact order statistics on HBM-resident float32 planes (gfx950).
+//
+// Replaces the reference's torch.quantile / torch.median / torch.histc call sites
+// (core/render_3d.py:154-170,249-250,536-537; 51 % of the reference's CPU time is aten::sort there).
+// No sort: values live in [0,1], so the float bit pattern is a monotone uint32 key.
+//   pass A  : 16-bit-prefix histogram (16257 live bins) privatised in LDS (65 KB / job), wave-aggregated
+//             ds_add, one global atomic per non-empty bin per workgroup;
+//   scan A  : one workgroup prefix-scans the bins, derives the requested ranks on device
+//             (torch.quantile's float32 rank arithmetic, the lower-median index, the 64-bin histc arg-max
+//             which is an exact aggregation of the prefix bins) and records <= 4 target prefixes;
+//   pass B  : elements whose prefix is a target add to a 65536-bin histogram of their low 16 bits
+//             (global atomics, wave-aggregated -- a constant plane costs N/64 atomics, not N);
+//   scan B  : locates each rank inside its target bin -> the exact float, then the scalar stage runs.
+// Everything stays on the device: no host synchronisation anywhere in the frame.
+#include "vd3d_dev.h"
+#include "vd3d_kernels.h"
+
+#define NBL 16272  // LDS bins per job (>= 0x3F80 + 1)
+
+// ------------------------------------------------------------------------------------------------
+// pass A / pass B over a value functor.  F::get(i, v, in_all, in_crop)
+// ------------------------------------------------------------------------------------------------
+template <class F, int J_ALL, int J_CROP>
+__global__ __launch_bounds__(1024) void k_hist_a(F f, uint32_t* __restrict__ histA) {
+  __shared__ uint32_t h0[J_ALL >= 0 ? NBL : 1];
+  __shared__ uint32_t h1[J_CROP >= 0 ? NBL : 1];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < NBL; b += 1024) {
+    if (J_ALL >= 0) h0[b] = 0;
+    if (J_CROP >= 0) h1[b] = 0;
+  }
+  __syncthreads();
+  const long long n = f.count();
+  const long long stride = (long long)gridDim.x * 1024;
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += stride) {
+    const long long i = base + tid;
+    float v = 0.f;
+    bool in_all = false, in_crop = false;
+    if (i < n) f.get(i, v, in_all, in_crop);
+    unsigned key = __float_as_uint(v) >> 16;
+    key = key < (NBL - 1) ? key : (NBL - 1);
+    if (J_ALL >= 0) vd_hist_add_agg(h0, key, in_all);
+    if (J_CROP >= 0) vd_hist_add_agg(h1, key, in_crop);
+  }
+  __syncthreads();
+  for (int b = tid; b < NBL; b += 1024) {
+    if (J_ALL >= 0) { uint32_t c = h0[b]; if (c) atomicAdd(&histA[(size_t)J_ALL * VD_NB_A + b], c); }
+    if (J_CROP >= 0) { uint32_t c = h1[b]; if (c) atomicAdd(&histA[(size_t)J_CROP * VD_NB_A + b], c); }
+  }
+}
+
+template <class F, int J_ALL, int J_CROP>
+__global__ __launch_bounds__(256) void k_hist_b(F f, const vd_dev_work* __restrict__ w, uint32_t* __restrict__ histB) {
+  const long long n = f.count();
+  const long long stride = (long long)gridDim.x * 256;
+  uint32_t nt0 = 0, nt1 = 0, tp0[VD_MAX_T], tp1[VD_MAX_T];
+  if (J_ALL >= 0) { nt0 = w->job[J_ALL].ntargets; for (int t = 0; t < VD_MAX_T; ++t) tp0[t] = w->job[J_ALL].tprefix[t]; }
+  if (J_CROP >= 0) { nt1 = w->job[J_CROP].ntargets; for (int t = 0; t < VD_MAX_T; ++t) tp1[t] = w->job[J_CROP].tprefix[t]; }
+  for (long long base = (long long)blockIdx.x * 256; base < n; base += stride) {
+    const long long i = base + threadIdx.x;
+    float v = 0.f;
+    bool in_all = false, in_crop = false;
+    if (i < n) f.get(i, v, in_all, in_crop);
+    const unsigned bits = __float_as_uint(v);
+    const unsigned pre = bits >> 16, low = bits & 0xffffu;
+    if (J_ALL >= 0) {
+      bool hit = false; unsigned key = 0;
+      for (uint32_t t = 0; t < nt0; ++t) if (in_all && pre == tp0[t]) { hit = true; key = (t << 16) | low; }
+      vd_hist_add_agg(histB + (size_t)J_ALL * VD_MAX_T * VD_NB_B, key, hit);
+    }
+    if (J_CROP >= 0) {
+      bool hit = false; unsigned key = 0;
+      for (uint32_t t = 0; t < nt1; ++t) if (in_crop && pre == tp1[t]) { hit = true; key = (t << 16) | low; }
+      vd_hist_add_agg(histB + (size_t)J_CROP * VD_MAX_T * VD_NB_B, key, hit);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// value functors
+// ------------------------------------------------------------------------------------------------
+VD_DEV bool vd_in_subject_crop(int y, int x, int H, int W, float v) {  // core/render_3d.py:154-157
+  return y >= H / 5 && y < H * 4 / 5 && x >= W / 5 && x < W * 4 / 5 && v > 0.05f && v < 0.95f;
+}
+
+struct FEyeD {  // clamp(filtered depth): DepthPercentileEMA input (:247)
+  const float* tdf; long long n;
+  VD_DEV long long count() const { return n; }
+  VD_DEV void get(long long i, float& v, bool& in_all, bool& in_crop) const {
+    v = vd_clamp(tdf[i], 0.f, 1.f); in_all = true; in_crop = false;
+  }
+};
+struct FPlaneSubj {  // a stored plane, masked centre crop membership (estimate_subject_depth)
+  const float* p; int H, W;
+  VD_DEV long long count() const { return (long long)H * W; }
+  VD_DEV void get(long long i, float& v, bool& in_all, bool& in_crop) const {
+    v = p[i];
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    in_all = false; in_crop = vd_in_subject_crop(y, x, H, W, v);
+  }
+};
+struct FWorkDc {  // curved depth at warp resolution, recomputed from the eye-res plane
+  const float* dn; int ih, iw, H, W;
+  VD_DEV long long count() const { return (long long)H * W; }
+  VD_DEV void get(long long i, float& v, bool& in_all, bool& in_crop) const {
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    v = vd_curved_depth(dn, ih, iw, H, W, y, x);
+    in_all = true; in_crop = vd_in_subject_crop(y, x, H, W, v);
+  }
+};
+
+static inline int hist_grid(long long n, int per_block, int cap) {
+  long long g = (n + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+void vd_launch_hist_eye_d(hipStream_t s, bool passB, const float* tdf, long long n, vd_dev_work* w, uint32_t* histA, uint32_t* histB) {
+  FEyeD f{tdf, n};
+  if (!passB) hipLaunchKernelGGL((k_hist_a<FEyeD, VD_J_EYE_Q, -1>), dim3(hist_grid(n, 4096, 512)), dim3(1024), 0, s, f, histA);
+  else hipLaunchKernelGGL((k_hist_b<FEyeD, VD_J_EYE_Q, -1>), dim3(hist_grid(n, 1024, 2048)), dim3(256), 0, s, f, w, histB);
+}
+void vd_launch_hist_eye_subj(hipStream_t s, bool passB, const float* dn, int eh, int ew, vd_dev_work* w, uint32_t* histA, uint32_t* histB) {
+  FPlaneSubj f{dn, eh, ew};
+  long long n = (long long)eh * ew;
+  if (!passB) hipLaunchKernelGGL((k_hist_a<FPlaneSubj, -1, VD_J_EYE_SUBJ>), dim3(hist_grid(n, 4096, 512)), dim3(1024), 0, s, f, histA);
+  else hipLaunchKernelGGL((k_hist_b<FPlaneSubj, -1, VD_J_EYE_SUBJ>), dim3(hist_grid(n, 1024, 2048)), dim3(256), 0, s, f, w, histB);
+}
+void vd_launch_hist_work_dc(hipStream_t s, bool passB, const float* dn, int ih, int iw, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB) {
+  FWorkDc f{dn, ih, iw, H, W};
+  long long n = (long long)H * W;
+  if (!passB) hipLaunchKernelGGL((k_hist_a<FWorkDc, VD_J_WORK_Q, VD_J_WORK_S0>), dim3(hist_grid(n, 8192, 256)), dim3(1024), 0, s, f, histA);
+  else hipLaunchKernelGGL((k_hist_b<FWorkDc, VD_J_WORK_Q, VD_J_WORK_S0>), dim3(hist_grid(n, 1024, 2048)), dim3(256), 0, s, f, w, histB);
+}
+void vd_launch_hist_work_s1(hipStream_t s, bool passB, const float* D, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB) {
+  FPlaneSubj f{D, H, W};
+  long long n = (long long)H * W;
+  if (!passB) hipLaunchKernelGGL((k_hist_a<FPlaneSubj, -1, VD_J_WORK_S1>), dim3(hist_grid(n, 4096, 512)), dim3(1024), 0, s, f, histA);
+  else hipLaunchKernelGGL((k_hist_b<FPlaneSubj, -1, VD_J_WORK_S1>), dim3(hist_grid(n, 1024, 2048)), dim3(256), 0, s, f, w, histB);
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-workgroup scans
+// ------------------------------------------------------------------------------------------------
+// exclusive prefix of one uint32 per thread over a 1024-thread workgroup
+VD_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /*[16]*/, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, tot = 0;
+  for (int i = 0; i < 16; ++i) {
+    uint32_t s = wsum[i];
+    if (i < wv) wbase += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return wbase + inc - v;
+}
+
+enum { SEL_QUANT = 0, SEL_SUBJECT = 1 };
+
+// scan A for one job: count, ranks, target prefixes (+ 64-bin arg-max for subject jobs)
+VD_DEV void scan_a_job(vd_sel_ctl* c, const uint32_t* __restrict__ hist, int kind, float q0, float q1,
+                       uint32_t* sm /* >= 16 + 64 + 8 words */) {
+  const int tid = threadIdx.x;
+  uint32_t loc[16];
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { loc[i] = hist[tid * 16 + i]; tsum += loc[i]; }
+  uint32_t* wsum = sm;
+  uint32_t* h64 = sm + 16;
+  if (tid < 64) h64[tid] = 0;
+  uint32_t total;
+  uint32_t base = block_excl_scan(tsum, wsum, total);
+  if (kind == SEL_SUBJECT) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (loc[i]) {
+        float v = __uint_as_float((uint32_t)(tid * 16 + i) << 16);
+        int b = (int)(v * 64.0f);
+        b = b > 63 ? 63 : b;
+        atomicAdd(&h64[b], loc[i]);
+      }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    c->count = total;
+    c->fallback = 0;
+    c->ntargets = 0;
+    if (kind == SEL_QUANT) {
+      // torch.quantile: rank = float32(q) * float32(n-1), floor/ceil, weight = rank - floor
+      const float nm1 = (float)((long long)total - 1);
+      const float r0 = q0 * nm1, r1 = q1 * nm1;
+      c->nranks = 4;
+      c->ranks[0] = (uint64_t)floorf(r0); c->ranks[1] = (uint64_t)ceilf(r0);
+      c->ranks[2] = (uint64_t)floorf(r1); c->ranks[3] = (uint64_t)ceilf(r1);
+      c->w[0] = r0 - floorf(r0); c->w[1] = r1 - floorf(r1);
+    } else {
+      c->nranks = 1;
+      c->ranks[0] = total ? ((uint64_t)total - 1) / 2 : 0;  // torch.median: lower median
+      if (total < 20) { c->fallback = 1; c->nranks = 0; }
+      int peak = 0;
+      for (int b = 1; b < 64; ++b) if (h64[b] > h64[peak]) peak = b;  // first maximum
+      c->peak_bin = (uint32_t)peak;
+    }
+    for (uint32_t r = 0; r < c->nranks; ++r)
+      if (c->ranks[r] >= total) c->ranks[r] = total ? total - 1 : 0;
+  }
+  __syncthreads();
+  __threadfence_block();
+  const uint32_t nr = c->nranks;
+  for (uint32_t r = 0; r < nr; ++r) {
+    const uint64_t rk = c->ranks[r];
+    if (rk >= base && rk < (uint64_t)base + tsum) {
+      uint64_t acc = base;
+      for (int i = 0; i < 16; ++i) {
+        if (rk < acc + loc[i]) {
+          sm[80 + r] = (uint32_t)(tid * 16 + i);  // prefix
+          c->rank_rem[r] = rk - acc;
+          break;
+        }
+        acc += loc[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t nt = 0;
+    for (uint32_t r = 0; r < nr; ++r) {
+      uint32_t p = sm[80 + r], slot = nt;
+      for (uint32_t t = 0; t < nt; ++t) if (c->tprefix[t] == p) slot = t;
+      if (slot == nt) c->tprefix[nt++] = p;
+      c->rank_t[r] = slot;
+    }
+    c->ntargets = nt;
+  }
+  __syncthreads();
+}
+
+// scan B for one job: resolve each rank inside its target's low-16 histogram
+VD_DEV void scan_b_job(vd_sel_ctl* c, const uint32_t* __restrict__ histB_job, uint32_t* sm) {
+  const int tid = threadIdx.x;
+  const uint32_t nr = c->nranks;
+  for (uint32_t r = 0; r < nr; ++r) {
+    const uint32_t* h = histB_job + (size_t)c->rank_t[r] * VD_NB_B;
+    uint32_t tsum = 0;
+    for (int i = 0; i < 64; ++i) tsum += h[tid * 64 + i];
+    uint32_t total;
+    uint32_t base = block_excl_scan(tsum, sm, total);
+    const uint64_t rk = c->rank_rem[r];
+    if (rk >= base && rk < (uint64_t)base + tsum) {
+      uint64_t acc = base;
+      for (int i = 0; i < 64; ++i) {
+        uint32_t cnt = h[tid * 64 + i];
+        if (rk < acc + cnt) {
+          c->val[r] = __uint_as_float((c->tprefix[c->rank_t[r]] << 16) | (uint32_t)(tid * 64 + i));
+          break;
+        }
+        acc += cnt;
+      }
+    }
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
+VD_DEV float quantile_lerp(float va, float vb, float w) {  // ATen lerp: two-branch form
+  float diff = vb - va;
+  return (w < 0.5f) ? va + w * diff : vb - diff * (1.f - w);
+}
+VD_DEV float subject_from_job(const vd_sel_ctl* c) {  // core/render_3d.py:159-172
+  if (c->fallback) return 0.5f;
+  const float bin_width = (float)(1.0 / 64);
+  float subject = ((float)c->peak_bin + 0.5f) * bin_width;
+  float s = 0.7f * subject + 0.3f * c->val[0];
+  return vd_clamp(s, 0.f, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar recurrences (Python-float == float64 arithmetic), ports of the tracker classes
+// ------------------------------------------------------------------------------------------------
+VD_DEV double fw_smooth_offset(vd3d_state* st, double cur, double threshold) {  // :485-498
+  const double alpha = 0.97;
+  double delta = fabs(cur - st->fw_prev_offset);
+  if (delta < threshold) return st->fw_prev_offset;
+  st->fw_prev_offset = alpha * st->fw_prev_offset + (1 - alpha) * cur;
+  st->fw_frame_counter += 1;
+  if (st->fw_frame_counter >= 100) {
+    double v = st->fw_prev_offset;
+    v = v < 1.0 ? v : 1.0;
+    v = v > -1.0 ? v : -1.0;
+    st->fw_prev_offset = v;
+    st->fw_frame_counter = 0;
+  }
+  return st->fw_prev_offset;
+}
+VD_DEV double focal_update(vd3d_state* st, double motion, double cand) {  // :895-922
+  double m = motion < 0.0 ? 0.0 : (motion > 1.0 ? 1.0 : motion);
+  const double alpha = 0.10 + 0.20 * m, deadband = 0.03, max_step = 0.02;
+  double c = cand;
+  if (!st->focal_valid) { st->focal = c; st->focal_valid = 1; return c; }
+  if (fabs(c - st->focal) < deadband) c = st->focal;
+  double nf = (1.0 - alpha) * st->focal + alpha * c;
+  double delta = nf - st->focal;
+  if (delta > max_step) nf = st->focal + max_step;
+  else if (delta < -max_step) nf = st->focal - max_step;
+  nf = nf < 1.0 ? nf : 1.0;
+  st->focal = nf > 0.0 ? nf : 0.0;
+  return st->focal;
+}
+
+// pixel_shift_cuda scalars :633-671 once s1 is known
+VD_DEV void shift_scalars(vd_dev_work* w, const vd3d_shift_params& p, int W, float s1, double fg_d, double mg_d, double bg_d) {
+  const float fg = (float)fg_d, mg = (float)mg_d, bg = (float)bg_d;
+  const float fgm = (float)p.fg_pop_multiplier, bgm = (float)p.bg_push_multiplier, pb = (float)p.parallax_balance;
+  const double half_width_d = (double)W / 2.0;
+  const float half_width = (float)half_width_d;
+  w->fg = fg; w->mg = mg; w->bg = bg;
+  w->have_zpo = 0; w->zpo_f = 0.f;
+  w->fs.zpo_raw = 0.f; w->fs.zpo = 0.0;
+  if (p.use_subject_tracking) {
+    float adj = s1 * pb;
+    float z = ((((-adj) * fg) * fgm + ((-adj) * mg)) + ((adj * bg) * bgm)) / half_width;
+    z = z * (float)p.subject_lock_strength;
+    z = z - (float)p.zero_parallax_strength;
+    if (p.enable_floating_window) {
+      float sw = vd_clamp(1.0f - s1 * 2.0f, 0.5f, 1.0f);
+      z = z * sw;
+      z = vd_clamp(z, -0.35f, 0.35f);
+      w->fs.zpo_raw = z;
+      double zd = fw_smooth_offset(&w->st, (double)z, 0.0015);
+      w->fs.zpo = zd;
+      w->zpo_f = (float)zd;
+    } else {
+      w->fs.zpo_raw = z;
+      w->fs.zpo = (double)z;
+      w->zpo_f = z;
+    }
+    w->have_zpo = 1;
+  }
+  w->msn = (float)(((double)W * p.max_pixel_shift_percent) / half_width_d);
+  w->have_conv = 0; w->conv = 0.f;
+  if (p.convergence_strength != 0.0) {
+    double cn;
+    if (p.enable_dynamic_convergence) cn = (double)(s1 * (float)p.convergence_strength);
+    else cn = p.convergence_strength;
+    w->conv = (float)(cn / half_width_d);
+    w->have_conv = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the scalar stage kernel: one workgroup, runs between plane passes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uint32_t* __restrict__ histA,
+                                                       const uint32_t* __restrict__ histB, vd_stage_args a) {
+  __shared__ uint32_t sm[128];
+  const int tid = threadIdx.x;
+  switch (a.stage) {
+    case VD_ST_A0:
+      scan_a_job(&w->job[VD_J_EYE_Q], histA + (size_t)VD_J_EYE_Q * VD_NB_A, SEL_QUANT, (float)0.02, (float)0.98, sm);
+      break;
+    case VD_ST_B0: {
+      vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
+      scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, sm);
+      if (tid == 0) {  // DepthPercentileEMA.normalize :249-261
+        float lo = quantile_lerp(c->val[0], c->val[1], c->w[0]);
+        float hi = quantile_lerp(c->val[2], c->val[3], c->w[1]);
+        vd3d_state* st = &w->st;
+        w->fs.q_lo = lo; w->fs.q_hi = hi;
+        if ((hi - lo) < 1e-5f) {
+          w->collapse = 1;
+        } else {
+          w->collapse = 0;
+          if (!st->ema_valid) { st->ema_lo = lo; st->ema_hi = hi; st->ema_valid = 1; }
+          else {
+            const float al = (float)0.92, be = (float)(1 - 0.92);
+            st->ema_lo = al * st->ema_lo + be * lo;
+            st->ema_hi = al * st->ema_hi + be * hi;
+          }
+        }
+        w->ema_lo = st->ema_lo;
+        w->ema_den = (st->ema_hi - st->ema_lo) + (float)1e-6;
+        w->fs.ema_lo = st->ema_lo; w->fs.ema_hi = st->ema_hi; w->fs.collapse = w->collapse;
+        st->tdf_valid = 1;
+        w->sum1 = 0; w->sum2 = 0; w->sum_mad = 0;
+      }
+    } break;
+    case VD_ST_A1:
+      if (a.have_eye) scan_a_job(&w->job[VD_J_EYE_SUBJ], histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      scan_a_job(&w->job[VD_J_WORK_Q], histA + (size_t)VD_J_WORK_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
+                 (float)a.shift.depth_stretch_hi, sm);
+      scan_a_job(&w->job[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      break;
+    case VD_ST_B1: {
+      if (a.have_eye) scan_b_job(&w->job[VD_J_EYE_SUBJ], histB + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_B, sm);
+      scan_b_job(&w->job[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, sm);
+      scan_b_job(&w->job[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, sm);
+      if (tid == 0) {
+        vd_sel_ctl* cq = &w->job[VD_J_WORK_Q];
+        const float lo = quantile_lerp(cq->val[0], cq->val[1], cq->w[0]);
+        const float hi = quantile_lerp(cq->val[2], cq->val[3], cq->w[1]);
+        const float s0 = subject_from_job(&w->job[VD_J_WORK_S0]);
+        w->fs.q05 = lo; w->fs.q95 = hi; w->fs.s0 = s0;
+        // shape_depth_for_pop constants :536-553
+        const int stretch = !((hi - lo) < 1e-5f);
+        const float den = (hi - lo) + (float)1e-6;
+        const float subj = vd_clamp(s0, 0.f, 1.f);
+        w->shp_stretch = stretch; w->shp_lo = lo; w->shp_den = den;
+        w->shp_subj_s = stretch ? vd_clamp((subj - lo) / den, 0.f, 1.f) : subj;
+        if (a.have_eye) {
+          vd3d_state* st = &w->st;
+          w->fs.s_norm = subject_from_job(&w->job[VD_J_EYE_SUBJ]);
+          // compute_dynamic_parallax_scale :412-427 from the exact fixed-point sums
+          const double n = (double)a.n_crop;
+          const double s1d = (double)w->sum1 / VD_FX, s2d = (double)w->sum2 / VD_FX;
+          const float mean = (float)(s1d / n);
+          const float var = (float)((s2d - s1d * s1d / n) / (a.n_crop > 1 ? n - 1.0 : 1.0));
+          const float nv = vd_clamp(var / (mean + 1e-5f), 0.f, 1.f);
+          const float scale = (float)0.90 + nv * (float)(1.15 - 0.90);
+          w->fs.mean_c = mean; w->fs.var_c = var; w->fs.dyn_scale = (double)scale;
+          // ShiftSmoother :470-477 then :1276,1308
+          double fg = a.shift.fg_shift, mg = a.shift.mg_shift, bg = a.shift.bg_shift;
+          const double al = 0.15;
+          if (!st->smooth_valid) { st->sm_fg = fg; st->sm_mg = mg; st->sm_bg = bg; st->smooth_valid = 1; }
+          else {
+            st->sm_fg = al * fg + (1 - al) * st->sm_fg;
+            st->sm_mg = al * mg + (1 - al) * st->sm_mg;
+            st->sm_bg = al * bg + (1 - al) * st->sm_bg;
+          }
+          fg = st->sm_fg; mg = st->sm_mg; bg = st->sm_bg;
+          fg *= (double)scale; mg *= (double)scale; bg *= (double)scale;
+          if (a.ipd_factor != 0.0) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
+          w->fg_d = fg; w->mg_d = mg; w->bg_d = bg;
+          // compute_motion_metric :924-929
+          w->fs.mad = 0.f;
+          double motion = 0.0;
+          if (st->prev_depth_valid) {
+            const float mad = (float)(((double)w->sum_mad / VD_FX) / (double)a.n_eye);
+            w->fs.mad = mad;
+            double m = (double)mad * 4.0;
+            motion = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
+          }
+          w->fs.focal = focal_update(st, motion, (double)w->fs.s_norm);
+          w->focal = (float)w->fs.focal;
+          st->prev_depth_valid = 1;
+        } else {
+          w->fg_d = a.shift.fg_shift; w->mg_d = a.shift.mg_shift; w->bg_d = a.shift.bg_shift;
+        }
+      }
+    } break;
+    case VD_ST_AQ:
+      scan_a_job(&w->job[VD_J_EYE_Q], histA + (size_t)VD_J_EYE_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
+                 (float)a.shift.depth_stretch_hi, sm);
+      break;
+    case VD_ST_BQ: {
+      vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
+      scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, sm);
+      if (tid == 0) {
+        w->fs.q_lo = quantile_lerp(c->val[0], c->val[1], c->w[0]);
+        w->fs.q_hi = quantile_lerp(c->val[2], c->val[3], c->w[1]);
+      }
+    } break;
+    case VD_ST_BS:
+      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, sm);
+      if (tid == 0) w->fs.s1 = subject_from_job(&w->job[VD_J_WORK_S1]);
+      break;
+    case VD_ST_A2:
+      scan_a_job(&w->job[VD_J_WORK_S1], histA + (size_t)VD_J_WORK_S1 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      break;
+    case VD_ST_B2: {
+      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, sm);
+      if (tid == 0) {
+        const float s1 = subject_from_job(&w->job[VD_J_WORK_S1]);
+        w->fs.s1 = s1;
+        shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);
+        if (a.have_eye) {  // floating-window bars :1390-1403
+          vd3d_state* st = &w->st;
+          const float s = w->fs.s_norm;
+          const float rz = ((((-s) * (float)w->fg_d) + ((-s) * (float)w->mg_d)) + (s * (float)w->bg_d)) /
+                           (float)((double)a.W / 2 + 1e-6);
+          if (!st->conv_valid) { st->conv_val = (double)rz; st->conv_valid = 1; }
+          else st->conv_val = 0.97 * st->conv_val + (1 - 0.97) * (double)rz;
+          const double sz = st->conv_val;
+          w->fs.stable_zero = sz;
+          int bw = 0, side = 0;
+          if (a.shift.enable_floating_window && a.shift.use_subject_tracking) {
+            int raw_bar = (int)(fabs(sz) * a.W * 0.75);
+            st->bar_prev_width = (int)(0.85 * st->bar_prev_width + (1 - 0.85) * raw_bar);
+            bw = st->bar_prev_width < 80 ? st->bar_prev_width : 80;
+            bw = bw > 0 ? bw : 0;
+            if (sz > 0.005) side = 1; else if (sz < -0.005) side = 2;
+          }
+          w->bar_width = bw; w->bar_side = side;
+          w->fs.bar_width = bw; w->fs.bar_side = side;
+        }
+      }
+    } break;
+  }
+}
+
+void vd_launch_scalar_stage(hipStream_t s, vd_dev_work* w, const uint32_t* histA, const uint32_t* histB, const vd_stage_args& a) {
+  hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(1024), 0, s, w, histA, histB, a);
+}

@@ -1,0 +1,281 @@
+"""Host-side mirror of the reference's operator interface for the 2D->3D path
+(``core/render_3d.py`` of VisionDepth3D): same function names, argument meaning and error behaviour,
+backed by libvd3d_hip.so (hand-written HIP for gfx950).  PyTorch is used only for device memory and
+streams.  There is no CPU fallback: without the HIP library / a GPU these functions raise.
+
+    pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg, mg, bg, **kw)   # core/render_3d.py:561-712
+    Renderer.render_frame(frame_bgr_u8, depth, params)                              # loop body :1227-1419
+    render_clip(frames, depths, **render_sbs_3d kwargs)                             # loop :1194-1464 (first frame skipped)
+    render_sbs_3d(input_path, depth_path, output_path, ...)                         # :933-985 signature (needs cv2 for I/O)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, FrameScalars, RenderParams, ShiftParams, State
+from .geometry import aspect_ratios  # noqa: F401  (re-exported like the reference module does)
+from .params import render_kwargs_to_params, shift_params_from_kwargs
+
+torch_device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def _ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+class Renderer:
+    """One vd3d_ctx on one GPU.  Holds the tracker state the reference keeps in module globals."""
+
+    def __init__(self, device: int | torch.device | None = None, private_stream: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("visiondepth3d_amd needs a ROCm GPU (MI355X); there is no CPU path")
+        L = _lib.lib()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index or 0)
+        self._L = L
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            # default: enqueue on torch's current stream so tensor ops and vd3d kernels stay ordered
+            stream = C.c_void_p(-1) if private_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(L.vd3d_ctx_create(self.device.index, stream, C.byref(self._ctx)))
+
+    def close(self):
+        if self._ctx:
+            self._L.vd3d_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ----
+    def reset_state(self):
+        _lib.check(self._L.vd3d_state_reset(self._ctx))
+
+    def new_clip(self):
+        _lib.check(self._L.vd3d_state_new_clip(self._ctx))
+
+    def export_state(self) -> State:
+        s = State()
+        _lib.check(self._L.vd3d_state_export(self._ctx, C.byref(s)))
+        return s
+
+    def import_state(self, s: State):
+        _lib.check(self._L.vd3d_state_import(self._ctx, C.byref(s)))
+
+    def last_scalars(self) -> FrameScalars:
+        f = FrameScalars()
+        _lib.check(self._L.vd3d_last_scalars(self._ctx, C.byref(f)))
+        return f
+
+    def sync(self):
+        _lib.check(self._L.vd3d_sync(self._ctx))
+
+    def set_profiling(self, on: bool):
+        _lib.check(self._L.vd3d_set_profiling(self._ctx, int(on)))
+
+    def stage_ms(self, name: str) -> float:
+        return float(self._L.vd3d_last_stage_ms(self._ctx, name.encode()))
+
+    def stage_calls(self, name: str) -> int:
+        return int(self._L.vd3d_stage_calls(self._ctx, name.encode()))
+
+    # ---- B1 ----
+    def pixel_shift(self, frame_tensor: torch.Tensor, depth_tensor: torch.Tensor, width, height,
+                    params: ShiftParams, want_shift=False):
+        """Device-resident form of pixel_shift_cuda: returns (left_u8, right_u8[, shift]) CUDA tensors."""
+        W, H = int(width), int(height)
+        if frame_tensor.dim() != 3 or frame_tensor.shape[0] != 3:
+            raise AssertionError("frame_tensor must be [3,h,w]")
+        if depth_tensor.dim() != 3 or depth_tensor.shape[0] != 1:
+            raise AssertionError("Depth tensor must be [1, H, W]")
+        if frame_tensor.shape[1:] != depth_tensor.shape[1:]:
+            raise AssertionError("Shape mismatch")
+        ft = frame_tensor.to(self.device, torch.float32).contiguous()
+        dt = depth_tensor.to(self.device, torch.float32).contiguous()
+        ih, iw = ft.shape[1:]
+        L = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        R = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        S = torch.empty((1, H, W), dtype=torch.float32, device=self.device) if want_shift else None
+        _lib.check(self._L.vd3d_pixel_shift(self._ctx, _ptr(ft), _ptr(dt), ih, iw, W, H, C.byref(params), _ptr(L), _ptr(R),
+                                            _ptr(S) if want_shift else None))
+        return (L, R, S) if want_shift else (L, R)
+
+    # ---- B2 ----
+    def render_frame(self, frame_bgr: torch.Tensor, depth: torch.Tensor, params: RenderParams,
+                     out: torch.Tensor | None = None) -> torch.Tensor:
+        """One iteration of the render loop on device tensors.  frame_bgr: uint8 [h,w,3]; depth: float32 [h,w]
+        (precomputed), uint8 [h,w,3] (depth-video frame) or uint8 [h,w]."""
+        if frame_bgr.dtype != torch.uint8 or frame_bgr.dim() != 3 or frame_bgr.shape[2] != 3:
+            raise AssertionError("frame must be uint8 [h,w,3] BGR")
+        if tuple(frame_bgr.shape[:2]) != (params.src_h, params.src_w):
+            raise AssertionError("frame size does not match params.src_h/src_w")
+        if depth.dtype == torch.float32 and depth.dim() == 2:
+            fmt = DEPTH_F32
+        elif depth.dtype == torch.uint8 and depth.dim() == 3 and depth.shape[2] == 3:
+            fmt = DEPTH_BGR_U8
+        elif depth.dtype == torch.uint8 and depth.dim() == 2:
+            fmt = DEPTH_GRAY_U8
+        else:
+            raise AssertionError("depth must be float32 [h,w], uint8 [h,w,3] or uint8 [h,w]")
+        if tuple(depth.shape[:2]) != (params.src_h, params.src_w):
+            raise AssertionError("depth size does not match the frame")
+        f = frame_bgr.to(self.device).contiguous()
+        d = depth.to(self.device).contiguous()
+        if out is None:
+            out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.vd3d_render_frame(self._ctx, _ptr(f), _ptr(d), fmt, C.byref(params), _ptr(out)))
+        return out
+
+    def finish_frame(self, left, right, depth_norm, params: RenderParams, focal_depth, bar_width=0, bar_side=0):
+        out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
+        dn = depth_norm.to(self.device, torch.float32).contiguous()
+        eh, ew = dn.shape[-2:]
+        _lib.check(self._L.vd3d_finish_frame(self._ctx, _ptr(left.contiguous()), _ptr(right.contiguous()), _ptr(dn), eh, ew,
+                                             C.byref(params), float(focal_depth), int(bar_width), int(bar_side), _ptr(out)))
+        return out
+
+    # ---- exact reductions (test / diagnostic entry points) ----
+    def quantiles(self, plane: torch.Tensor, qs):
+        p = plane.to(self.device, torch.float32).contiguous()
+        q = (C.c_float * len(qs))(*[float(np.float32(v)) for v in qs])
+        o = (C.c_float * len(qs))()
+        _lib.check(self._L.vd3d_quantiles(self._ctx, _ptr(p), p.numel(), q, len(qs), o))
+        return [float(v) for v in o]
+
+    def subject_depth(self, plane: torch.Tensor) -> float:
+        p = plane.to(self.device, torch.float32).contiguous()
+        H, W = p.shape[-2:]
+        o = C.c_float()
+        _lib.check(self._L.vd3d_subject_depth(self._ctx, _ptr(p), H, W, C.byref(o)))
+        return float(o.value)
+
+    def debug_planes(self, H, W, eh=None, ew=None):
+        """Copies of the internal planes of the last call (tests only)."""
+        ptrs = [C.c_void_p() for _ in range(6)]
+        self._L.vd3d_debug_planes(self._ctx, *[C.byref(p) for p in ptrs])
+        self.sync()
+
+        def view(ptr, shape, dtype):
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            _lib.check(self._L.vd3d_stream_copy(self._ctx, ptr, _ptr(t), t.numel() * t.element_size()))
+            return t
+
+        out = {"D": view(ptrs[0], (H, W), torch.float32), "S": view(ptrs[1], (H, W), torch.float32),
+               "L": view(ptrs[2], (H, W, 3), torch.uint8), "R": view(ptrs[3], (H, W, 3), torch.uint8)}
+        if eh:
+            out["rgb_eye"] = view(ptrs[4], (3, eh, ew), torch.float32)
+            out["dn"] = view(ptrs[5], (eh, ew), torch.float32)
+        self.sync()
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# module-level functions with the reference's names
+# ---------------------------------------------------------------------------------------------------
+_default: Renderer | None = None
+
+
+def default_renderer() -> Renderer:
+    """The module-level renderer plays the role of the reference's module singletons."""
+    global _default
+    if _default is None:
+        _default = Renderer()
+    return _default
+
+
+def frame_to_tensor(frame):  # core/render_3d.py:135-138: BGR->RGB, /255.0 ON THE HOST (true division), then upload
+    t = torch.from_numpy(np.ascontiguousarray(frame[..., ::-1])).float().permute(2, 0, 1) / 255.0
+    return t.to(torch_device)
+
+
+def pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg_shift, mg_shift, bg_shift, return_shift_map=True, **kw):
+    """Same signature and returns as the reference (core/render_3d.py:561-712): host uint8 BGR arrays
+    (+ the float32 shift map on CPU when ``return_shift_map``).  Mutates the default renderer's
+    FloatingWindowTracker exactly like the reference mutates its module global."""
+    p = shift_params_from_kwargs(fg_shift, mg_shift, bg_shift, **kw)
+    r = default_renderer()
+    res = r.pixel_shift(frame_tensor, depth_tensor, width, height, p, want_shift=bool(return_shift_map))
+    if return_shift_map:
+        return res[0].cpu().numpy(), res[1].cpu().numpy(), res[2].cpu()
+    return res[0].cpu().numpy(), res[1].cpu().numpy()
+
+
+def render_clip(frames, depths, *, renderer: Renderer | None = None, target_ratio=16 / 9, keep_on_device=False, **kw):
+    """The render_sbs_3d frame loop over in-memory frames (uint8 BGR arrays/tensors) and depths
+    (float32 [h,w] or uint8 depth-video frames).  Yields muxed frames.  Mirrors the reference's read
+    order: the first frame of the clip is consumed before the loop and never rendered (:1026,1184,1222)."""
+    r = renderer or default_renderer()
+    it = iter(zip(frames, depths))
+    first = next(it, None)
+    if first is None:
+        return
+    f0 = first[0]
+    sh, sw = int(f0.shape[0]), int(f0.shape[1])
+    params = render_kwargs_to_params(sw, sh, target_ratio=target_ratio, **kw)
+    r.new_clip()
+    for f, d in it:
+        ft = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
+        dt = d if torch.is_tensor(d) else torch.from_numpy(np.ascontiguousarray(d))
+        out = r.render_frame(ft.to(r.device, non_blocking=True), dt.to(r.device, non_blocking=True), params)
+        yield out if keep_on_device else out.cpu().numpy()
+
+
+def render_sbs_3d(input_path, depth_path, output_path, selected_codec, fps, output_width, output_height, fg_shift,
+                  mg_shift, bg_shift, sharpness_factor, output_format, selected_aspect_ratio, aspect_ratios, dof_strength,
+                  **kw):
+    """Reference signature (core/render_3d.py:933-985).  Video I/O goes through OpenCV exactly like the
+    reference; this build environment has no cv2, so the I/O shell raises ImportError there while
+    ``render_clip`` carries the whole per-frame path."""
+    try:
+        import cv2
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("render_sbs_3d needs OpenCV for VideoCapture/VideoWriter; use render_clip() for in-memory frames") from e
+    cancel_flag, suspend_flag = kw.pop("cancel_flag", None), kw.pop("suspend_flag", None)
+    progress, progress_label = kw.pop("progress", None), kw.pop("progress_label", None)
+    for k in ("use_ffmpeg", "selected_ffmpeg_codec", "crf_value"):
+        kw.pop(k, None)
+    start_s, end_s = kw.pop("start_s", None), kw.pop("end_s", None)
+    cap, dcap = cv2.VideoCapture(input_path), cv2.VideoCapture(depth_path)
+    if not cap.isOpened() or not dcap.isOpened():
+        return
+    total = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+    fps = cap.get(cv2.CAP_PROP_FPS) or fps or 30.0
+    start_idx = int(round(max(0.0, (start_s or 0.0)) * fps))
+    end_idx = total if end_s is None else min(total, int(round(end_s * fps)))
+    cap.set(cv2.CAP_PROP_POS_FRAMES, start_idx)
+    dcap.set(cv2.CAP_PROP_POS_FRAMES, start_idx)
+
+    def gen(c):
+        n = 0
+        while n < max(0, end_idx - start_idx):
+            ok, fr = c.read()
+            if not ok:
+                return
+            n += 1
+            yield fr
+
+    target_ratio = aspect_ratios.get(selected_aspect_ratio.get(), 16 / 9)
+    writer = None
+    for i, out in enumerate(render_clip(gen(cap), gen(dcap), target_ratio=target_ratio, output_height=output_height,
+                                        fg_shift=fg_shift, mg_shift=mg_shift, bg_shift=bg_shift,
+                                        sharpness_factor=sharpness_factor, output_format=output_format,
+                                        dof_strength=dof_strength, **kw)):
+        if cancel_flag is not None and cancel_flag.is_set():
+            break
+        if writer is None:
+            writer = cv2.VideoWriter(output_path, cv2.VideoWriter_fourcc(*selected_codec), fps, (out.shape[1], out.shape[0]))
+        writer.write(out)
+        if progress is not None:
+            progress["value"] = 100.0 * i / max(total, 1)
+    cap.release()
+    dcap.release()
+    if writer is not None:
+        writer.release()
