@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo-pairs/s of the depth -> DIBR hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
+
+A "step" is one pass of the hot path over one batch of B synthetic frames already resident in HBM:
+depth inference (workloads with a depth net) -> 8-bit depth hand-off -> the per-frame DIBR chain
+(ingest, exact order statistics, shaping, warp + feather, DOF, grade, sharpen, Half-SBS mux) -> muxed
+frames in HBM.  Default workload = BASELINE.json configs[1] (1080p, Depth-Anything-V2-Small + DIBR).
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; frames are sharded by clip
+(every rank renders its own clip with its own tracker state: no data-path collective), the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is reported.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (src_h, src_w, depth model or None, description)
+    "1080p-dav2s-dibr": (1080, 1920, "depth-anything-v2-small", "BASELINE configs[1]: 1080p, DA-V2-Small inference + DIBR, Half-SBS"),
+    "1080p-dibr": (1080, 1920, None, "1080p, precomputed f32 depth, DIBR only, Half-SBS"),
+    "4k-dibr": (2160, 3840, None, "BASELINE configs[2]: 4K, precomputed f32 depth, DIBR warp+DOF only (HBM roofline run)"),
+    "4k-dav2b-dibr": (2160, 3840, "depth-anything-v2-base", "BASELINE configs[3] per-GPU slice: 4K, DA-V2-Base + DIBR"),
+}
+RENDER_KW = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
+                 feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)  # render_cli.py:24-33
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(sh, sw, seconds_budget=20.0):
+    """The CPU oracle (kind "port", 1 core) on a bounded sample of the same frames; DIBR chain only."""
+    from oracle import oracle as O
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
+    ro = O.RenderOracle(p)
+    ro.new_clip()
+    n, t_used = 0, 0.0
+    while n < 2 or (t_used < seconds_budget and n < 30):
+        f, d = synth.synth_frame(n, sh, sw)
+        t0 = time.perf_counter()
+        ro.render(f, d, 0)
+        t_used += time.perf_counter() - t0
+        n += 1
+        if t_used > seconds_budget:
+            break
+    return {"value": round(n / t_used, 4), "unit": "stereo-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames {sw}x{sh} Half-SBS through oracle/vd3d_oracle.c (DIBR chain only, precomputed depth; "
+                      f"the oracle has no depth net), {t_used:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="1080p-dav2s-dibr", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8, help="frames per step")
+    ap.add_argument("--clip", type=int, default=8, help="distinct synthetic frames resident in HBM (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    from visiondepth3d_amd.render_3d import Renderer
+
+    sh, sw, model_name, desc = WORKLOADS[args.workload]
+    p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
+    r = Renderer(local_rank)
+    r.new_clip()
+    B = args.batch
+
+    # synthetic clip resident in HBM (each rank renders its own clip: frame indices offset by rank)
+    frames_np, depths_np = synth.synth_clip(args.clip, sh, sw, start=rank * 1000)
+    frames = torch.stack([torch.from_numpy(f) for f in frames_np]).cuda()          # [C,h,w,3] u8
+    depths = torch.stack([torch.from_numpy(d) for d in depths_np]).cuda()          # [C,h,w] f32
+    outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
+
+    pipe = None
+    if model_name:
+        from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
+        pipe = DepthPipe(model_name, device="cuda", dtype=torch.bfloat16)
+
+    def step(i):
+        idx = [(i * B + j) % args.clip for j in range(B)]
+        fb = frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
+        if pipe is not None:
+            pred = pipe.infer_bgr_u8(fb)                 # [B,h,w] f32 on device
+            dgray = depth_to_u8(pred)                    # the reference's 8-bit depth hand-off (a24), no disk hop
+            for j in range(B):
+                r.render_frame(fb[j], dgray[j], p, out=outs[j])
+        else:
+            for j in range(B):
+                r.render_frame(fb[j], depths[idx[j]], p, out=outs[j])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    if not args.no_profile:
+        r.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stage_ms = {}
+    if not args.no_profile:
+        for name in ("frame", "ingest", "select_eye", "select_dc", "shape", "select_s1", "warp", "finish"):
+            stage_ms[name] = round(r.stage_ms(name), 5)
+        r.set_profiling(False)
+
+    # measured streaming-copy yardstick: device-to-device copy of 1 GiB through the same library
+    copy_gbs = None
+    if rank == 0:
+        nbytes = 1 << 30
+        a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        for _ in range(3):
+            r._L.vd3d_stream_copy(r._ctx, a.data_ptr(), b.data_ptr(), nbytes)
+        r.set_profiling(True)
+        for _ in range(10):
+            r._L.vd3d_stream_copy(r._ctx, a.data_ptr(), b.data_ptr(), nbytes)
+        ms = r.stage_ms("stream_copy")
+        r.set_profiling(False)
+        copy_gbs = 2 * nbytes / (ms * 1e-3) / 1e9
+        del a, b
+
+    if rank == 0:
+        frames_total = world * args.steps * B
+        value = frames_total / dt
+        N = p.warp_h * p.warp_w
+        res = {
+            "metric": "stereo-pairs/sec end-to-end (depth+warp+fill+mux)",
+            "value": round(value, 3), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 DIBR kernels (u8 in/out)" + (" + bf16 depth net" if pipe is not None else ""),
+            "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)",
+            "config": {"workload": args.workload, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
+                       "frames_per_step": B, "depth_model": model_name, "sharding": "one clip per GPU, no data-path collective",
+                       "params": "render_cli.py defaults + dof_strength 2.0"},
+        }
+        if stage_ms:
+            warp_ms = stage_ms["warp"]
+            alg_bytes = 13 * N  # warp kernel W1 = read RGB 3N + read depth 4N + write two u8 eyes 6N per stereo pair
+            achieved = alg_bytes / (warp_ms * 1e-3) / 1e9 if warp_ms > 0 else None
+            res["roofline"] = {"bound": "hbm", "kernel": "warp stage (shift + feather mask + warp kernels)", "achieved": round(achieved, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                               "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": warp_ms,
+                               "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
+                               "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None}
+            res["stage_ms"] = stage_ms
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sh, sw)
+        print(json.dumps(res), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

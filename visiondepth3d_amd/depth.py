@@ -1,0 +1,162 @@
+"""Depth-model callable (boundary B3, core/render_depth.py:1106-1119) on PyTorch-ROCm.
+
+The reference wraps ``transformers.pipeline("depth-estimation")`` in
+``pipe(images: list[PIL], inference_size=None) -> list[{"predicted_depth": Tensor}]``.  This module
+keeps that protocol (``DepthPipe.__call__``) and adds a device-resident fast path
+(``DepthPipe.infer_bgr_u8``) that consumes uint8 BGR frames already in HBM and returns depth planes in HBM,
+so the 2D->3D stage can start without the reference's host round trip and 8-bit depth video on disk
+(core/render_depth.py:1907-1935) -- while still reproducing that hand-off's per-frame min-max -> uint8
+truncation (``depth_to_u8``, a24) so the DIBR stage sees the same quantised values.
+
+MFMA work (DINOv2 GEMMs / attention, DPT convs) goes through PyTorch-ROCm (hipBLASLt / MIOpen / SDPA): per
+BASELINE.json:north_star the depth net is NOT hand-written.  No network and no checkpoints exist in this
+environment, so weights are deterministic synthetic tensors (NumPy PCG64 keyed by parameter name).
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# Depth-Anything-V2 family (HF configs of depth-anything/Depth-Anything-V2-{Small,Base,Large}-hf)
+MODEL_ZOO = {
+    "depth-anything-v2-small": dict(hidden=384, layers=12, heads=6, out_indices=[9, 10, 11, 12],
+                                    neck=[48, 96, 192, 384], fusion=64, head=32),
+    "depth-anything-v2-base": dict(hidden=768, layers=12, heads=12, out_indices=[9, 10, 11, 12],
+                                   neck=[96, 192, 384, 768], fusion=128, head=32),
+    "depth-anything-v2-large": dict(hidden=1024, layers=24, heads=16, out_indices=[21, 22, 23, 24],
+                                    neck=[256, 512, 1024, 1024], fusion=256, head=32),
+}
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def build_config(name: str):
+    from transformers import DepthAnythingConfig, Dinov2Config
+    z = MODEL_ZOO[name]
+    bc = Dinov2Config(hidden_size=z["hidden"], num_hidden_layers=z["layers"], num_attention_heads=z["heads"], patch_size=14,
+                      image_size=518, out_indices=z["out_indices"], reshape_hidden_states=False, apply_layernorm=True)
+    return DepthAnythingConfig(backbone_config=bc, neck_hidden_sizes=z["neck"], fusion_hidden_size=z["fusion"],
+                               head_hidden_size=z["head"], reassemble_factors=[4, 2, 1, 0.5], patch_size=14)
+
+
+@torch.no_grad()
+def synthetic_weights_(model: torch.nn.Module, seed: int = 0) -> None:
+    """Deterministic, platform-stable weights: PCG64 keyed by crc32(parameter name) ^ seed."""
+    for name, p in model.named_parameters():
+        rng = np.random.Generator(np.random.PCG64((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF))
+        if p.ndim >= 2 and "position_embeddings" not in name and "token" not in name:
+            fan_in = int(np.prod(p.shape[1:]))
+            a = float(np.sqrt(3.0 / max(fan_in, 1)))  # unit-gain uniform
+            v = rng.uniform(-a, a, size=tuple(p.shape)).astype(np.float32)
+        elif name.endswith("bias"):
+            v = rng.uniform(-0.02, 0.02, size=tuple(p.shape)).astype(np.float32)
+        elif "lambda" in name or "layer_scale" in name:
+            v = np.full(tuple(p.shape), 0.2, np.float32)
+        elif p.ndim == 1:
+            v = (1.0 + rng.uniform(-0.05, 0.05, size=tuple(p.shape))).astype(np.float32)
+        else:
+            v = rng.uniform(-0.02, 0.02, size=tuple(p.shape)).astype(np.float32)
+        p.copy_(torch.from_numpy(v).to(p.dtype))
+
+
+def dpt_resize_target(h: int, w: int, size: int = 518, multiple: int = 14):
+    """DPTImageProcessor.get_resize_output_image_size (keep_aspect_ratio, ensure_multiple_of=14): 1080x1920 -> 518x924."""
+    sh, sw = size / h, size / w
+    if abs(1 - sw) < abs(1 - sh):
+        sh = sw
+    else:
+        sw = sh
+
+    def snap(v):
+        return max(int(round(v / multiple)) * multiple, multiple)
+
+    return snap(sh * h), snap(sw * w)
+
+
+def depth_to_u8(pred: torch.Tensor, invert: bool = False) -> torch.Tensor:
+    """convert_depth_to_grayscale (core/render_depth.py:585-611) per frame, on device: min-max normalise,
+    ``(norm*255).astype(uint8)`` truncation; invalid / flat frames -> zeros; optional ``255 - u8`` (:1914-1916)."""
+    p = pred.float()
+    flat = p.flatten(1)
+    mn, mx = flat.min(dim=1).values, flat.max(dim=1).values
+    bad = torch.isnan(mn) | torch.isnan(mx) | ((mx - mn) < 1e-6)
+    norm = (p - mn[:, None, None]) / (mx - mn + 1e-6)[:, None, None]
+    u8 = (norm * 255).clamp(0, 255).to(torch.uint8)
+    u8 = torch.where(bad[:, None, None], torch.zeros_like(u8), u8)
+    return 255 - u8 if invert else u8
+
+
+class DepthPipe:
+    """``pipe(images, inference_size=None) -> [{"predicted_depth": Tensor[h, w]}]`` (reference protocol) plus a
+    device-resident batch path."""
+
+    def __init__(self, name: str = "depth-anything-v2-small", device="cuda", dtype=torch.bfloat16, seed: int = 0,
+                 channels_last: bool = True):
+        from transformers import DepthAnythingForDepthEstimation
+        self.name, self.device, self.dtype = name, torch.device(device), dtype
+        cfg = build_config(name)
+        model = DepthAnythingForDepthEstimation(cfg).eval()
+        synthetic_weights_(model, seed)
+        self.model = model.to(self.device, dtype)
+        if channels_last and self.device.type == "cuda":
+            self.model = self.model.to(memory_format=torch.channels_last)
+        self.mean = torch.tensor(IMAGENET_MEAN, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
+        self.std = torch.tensor(IMAGENET_STD, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
+        self.n_params = sum(p.numel() for p in self.model.parameters())
+
+    @torch.no_grad()
+    def infer_bgr_u8(self, frames_bgr: torch.Tensor, inference_size=None) -> torch.Tensor:
+        """uint8 [B,H,W,3] BGR frames in HBM -> float32 [B,H,W] predicted depth at the frame size (the
+        depth-estimation pipeline's post-process: bicubic, align_corners=False)."""
+        B, H, W, _ = frames_bgr.shape
+        x = frames_bgr.to(self.device).flip(-1).permute(0, 3, 1, 2).float()  # RGB, NCHW
+        if inference_size is not None:  # hf_batch_safe_pipe: img.resize(inference_size, BICUBIC) first (:1113-1116)
+            x = F.interpolate(x, size=(int(inference_size[1]), int(inference_size[0])), mode="bicubic", antialias=True,
+                              align_corners=False).clamp_(0, 255)
+        th, tw = dpt_resize_target(x.shape[2], x.shape[3])
+        x = F.interpolate(x, size=(th, tw), mode="bicubic", antialias=True, align_corners=False)
+        x = ((x / 255.0) - self.mean) / self.std
+        x = x.to(self.dtype)
+        if self.device.type == "cuda":
+            x = x.contiguous(memory_format=torch.channels_last)
+        pred = self.model(pixel_values=x).predicted_depth  # [B, th, tw]
+        pred = F.interpolate(pred.float().unsqueeze(1), size=(H, W), mode="bicubic", align_corners=False).squeeze(1)
+        return pred
+
+    def __call__(self, images, inference_size=None):
+        """Reference protocol: list of PIL images (or HxWx3 uint8 RGB arrays) -> list of dicts."""
+        single = not isinstance(images, (list, tuple))
+        imgs = [images] if single else list(images)
+        outs = []
+        for im in imgs:
+            a = np.asarray(im.convert("RGB") if hasattr(im, "convert") else im)
+            bgr = torch.from_numpy(np.ascontiguousarray(a[..., ::-1]))[None]
+            outs.append({"predicted_depth": self.infer_bgr_u8(bgr, inference_size)[0]})
+        return outs
+
+    def flops_per_frame(self, h: int, w: int) -> float:
+        """Dense-GEMM flop estimate for MFMA accounting: 2*params_linear*tokens + 4*T^2*d per layer
+        for the backbone, measured conv flops for the DPT head via a counting hook."""
+        th, tw = dpt_resize_target(h, w)
+        T = (th // 14) * (tw // 14) + 1
+        z = MODEL_ZOO[self.name]
+        d, L = z["hidden"], z["layers"]
+        lin = L * (4 * d * d + 8 * d * d)  # qkv+proj, mlp 4x
+        backbone = 2.0 * lin * T + 4.0 * T * T * d * L
+        total = [0.0]
+
+        def hook(mod, inp, out):
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                k = mod.kernel_size[0] * mod.kernel_size[1]
+                total[0] += 2.0 * out.numel() / out.shape[0] * (mod.in_channels // mod.groups) * k
+
+        hs = [m.register_forward_hook(hook) for m in self.model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
+        with torch.no_grad():
+            x = torch.zeros(1, 3, th, tw, device=self.device, dtype=self.dtype)
+            self.model(pixel_values=x)
+        for hnd in hs:
+            hnd.remove()
+        return backbone + total[0]
