@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -49,6 +50,7 @@ struct vd3d_ctx {
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
   // profiling
   bool profiling = false;
+  bool use_fused = true;   // VD3D_UNFUSED=1 selects the one-stage-per-kernel v0 path (A/B and debugging)
   std::vector<vd_prof_rec> recs;
   std::vector<hipEvent_t> ev_pool;
   std::map<std::string, std::pair<double, long>> acc;
@@ -139,11 +141,12 @@ VD3D_EXPORT int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out) {
   HIPCHK(hipSetDevice(device));
   vd3d_ctx* c = new vd3d_ctx();
   c->device = device;
+  { const char* e = getenv("VD3D_UNFUSED"); c->use_fused = !(e && e[0] == '1'); }
   if (stream == VD3D_STREAM_PRIVATE) { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
   else c->stream = (hipStream_t)stream;  // NULL = the default stream
   HIPCHK(hipMalloc((void**)&c->work, sizeof(vd_dev_work)));
   HIPCHK(hipMemsetAsync(c->work, 0, sizeof(vd_dev_work), c->stream));
-  const size_t nA = (size_t)VD_NJOBS * VD_NB_A, nB = (size_t)VD_NJOBS * VD_MAX_T * VD_NB_B;
+  const size_t nA = (size_t)VD_NJOBS * VD_NB_A, nB = (size_t)VD_NJOBS * VD_MAX_T * (VD_NB_B + VD_NB_BC);
   c->hist_bytes = (nA + nB) * sizeof(uint32_t);
   HIPCHK(hipMalloc((void**)&c->histA, c->hist_bytes));
   c->histB = c->histA + nA;
@@ -233,11 +236,15 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
   }
   { StageTimer t(c, "warp");
     vd_launch_shift(s, c->D, H, W, c->work, sp, c->S);
+    if (c->use_fused && vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R)) {
+      // fused path taken
+    } else {
     if (sp.enable_feathering) {
       vd_launch_e2(s, c->D, c->S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
       vd_launch_pool(s, c->e2L, c->e2R, H, W, sp.blur_ksize, c->bL, c->bR);
     }
     vd_launch_warp(s, rgb, ih, iw, c->S, c->bL, c->bR, H, W, sp.enable_feathering ? 1 : 0, c->L, c->R);
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -72,17 +72,20 @@ __global__ __launch_bounds__(256) void k_eye_stats(const float* __restrict__ tdf
     }
     if (have_prev) sm += vd_fx40((double)fabsf(v - dn_prev[i]));
   }
+  __shared__ long long part[3][4];
   s1 = vd_wave_sum_ll(s1); s2 = vd_wave_sum_ll(s2); sm = vd_wave_sum_ll(sm);
-  if ((threadIdx.x & 63) == 0) {
-    if (s1) atomicAdd((unsigned long long*)&w->sum1, (unsigned long long)s1);
-    if (s2) atomicAdd((unsigned long long*)&w->sum2, (unsigned long long)s2);
-    if (sm) atomicAdd((unsigned long long*)&w->sum_mad, (unsigned long long)sm);
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s1; part[1][threadIdx.x >> 6] = s2; part[2][threadIdx.x >> 6] = sm; }
+  __syncthreads();
+  if (threadIdx.x < 3) {  // one atomic per sum per workgroup (integer: order-independent)
+    const long long v = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+    long long* dst = threadIdx.x == 0 ? &w->sum1 : (threadIdx.x == 1 ? &w->sum2 : &w->sum_mad);
+    if (v) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
   }
 }
 void vd_launch_eye_stats(hipStream_t s, const float* tdf, float* dn_cur, const float* dn_prev, int eh, int ew, vd_dev_work* w) {
   long long n = (long long)eh * ew;
-  int g = (int)((n + 256 * 4 - 1) / (256 * 4));
-  g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
+  int g = (int)((n + 256 * 8 - 1) / (256 * 8));
+  g = g > 1024 ? 1024 : (g < 1 ? 1 : g);
   hipLaunchKernelGGL(k_eye_stats, dim3(g), dim3(256), 0, s, tdf, dn_cur, dn_prev, eh, ew, w);
 }
 

@@ -49,6 +49,10 @@ __global__ __launch_bounds__(1024) void k_hist_a(F f, uint32_t* __restrict__ his
   }
 }
 
+// coarse (low16>>8) counts live behind the fine arena: histBC = histB + VD_NJOBS*VD_MAX_T*VD_NB_B, [job][target][256]
+VD_DEV uint32_t* vd_histbc(uint32_t* histB) { return histB + (size_t)VD_NJOBS * VD_MAX_T * VD_NB_B; }
+VD_DEV const uint32_t* vd_histbc(const uint32_t* histB) { return histB + (size_t)VD_NJOBS * VD_MAX_T * VD_NB_B; }
+
 template <class F, int J_ALL, int J_CROP>
 __global__ __launch_bounds__(256) void k_hist_b(F f, const vd_dev_work* __restrict__ w, uint32_t* __restrict__ histB) {
   const long long n = f.count();
@@ -67,11 +71,13 @@ __global__ __launch_bounds__(256) void k_hist_b(F f, const vd_dev_work* __restri
       bool hit = false; unsigned key = 0;
       for (uint32_t t = 0; t < nt0; ++t) if (in_all && pre == tp0[t]) { hit = true; key = (t << 16) | low; }
       vd_hist_add_agg(histB + (size_t)J_ALL * VD_MAX_T * VD_NB_B, key, hit);
+      vd_hist_add_agg(vd_histbc(histB) + (size_t)J_ALL * VD_MAX_T * VD_NB_BC, key >> 8, hit);
     }
     if (J_CROP >= 0) {
       bool hit = false; unsigned key = 0;
       for (uint32_t t = 0; t < nt1; ++t) if (in_crop && pre == tp1[t]) { hit = true; key = (t << 16) | low; }
       vd_hist_add_agg(histB + (size_t)J_CROP * VD_MAX_T * VD_NB_B, key, hit);
+      vd_hist_add_agg(vd_histbc(histB) + (size_t)J_CROP * VD_MAX_T * VD_NB_BC, key >> 8, hit);
     }
   }
 }
@@ -171,8 +177,15 @@ VD_DEV void scan_a_job(vd_sel_ctl* c, const uint32_t* __restrict__ hist, int kin
   const int tid = threadIdx.x;
   uint32_t loc[16];
   uint32_t tsum = 0;
+  {
+    const uint4* hv = reinterpret_cast<const uint4*>(hist) + tid * 4;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { loc[i] = hist[tid * 16 + i]; tsum += loc[i]; }
+    for (int i = 0; i < 4; ++i) {
+      const uint4 q = hv[i];
+      loc[4 * i] = q.x; loc[4 * i + 1] = q.y; loc[4 * i + 2] = q.z; loc[4 * i + 3] = q.w;
+      tsum += q.x + q.y + q.z + q.w;
+    }
+  }
   uint32_t* wsum = sm;
   uint32_t* h64 = sm + 16;
   if (tid < 64) h64[tid] = 0;
@@ -243,27 +256,37 @@ VD_DEV void scan_a_job(vd_sel_ctl* c, const uint32_t* __restrict__ hist, int kin
   __syncthreads();
 }
 
-// scan B for one job: resolve each rank inside its target's low-16 histogram
-VD_DEV void scan_b_job(vd_sel_ctl* c, const uint32_t* __restrict__ histB_job, uint32_t* sm) {
-  const int tid = threadIdx.x;
+// scan B for one job: resolve each rank inside its target's low-16 histogram through the coarse level.
+// The 1024 threads split into 4 groups of 256; group r resolves rank r (all ranks in parallel).
+VD_DEV void scan_b_job(vd_sel_ctl* c, const uint32_t* __restrict__ histB_job, const uint32_t* __restrict__ histBC_job,
+                       uint32_t* sm /* >= 4*(4+1) words */) {
+  const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wv = t >> 6;
   const uint32_t nr = c->nranks;
-  for (uint32_t r = 0; r < nr; ++r) {
-    const uint32_t* h = histB_job + (size_t)c->rank_t[r] * VD_NB_B;
-    uint32_t tsum = 0;
-    for (int i = 0; i < 64; ++i) tsum += h[tid * 64 + i];
-    uint32_t total;
-    uint32_t base = block_excl_scan(tsum, sm, total);
-    const uint64_t rk = c->rank_rem[r];
-    if (rk >= base && rk < (uint64_t)base + tsum) {
-      uint64_t acc = base;
-      for (int i = 0; i < 64; ++i) {
-        uint32_t cnt = h[tid * 64 + i];
-        if (rk < acc + cnt) {
-          c->val[r] = __uint_as_float((c->tprefix[c->rank_t[r]] << 16) | (uint32_t)(tid * 64 + i));
-          break;
-        }
-        acc += cnt;
-      }
+  uint32_t* gs = sm + grp * 8;  // per group: [0..3] wave sums, [4] coarse bin, [5] remaining rank
+  for (int level = 0; level < 2; ++level) {
+    uint32_t v = 0;
+    uint64_t rk = 0;
+    if ((uint32_t)grp < nr) {
+      const uint32_t slot = c->rank_t[grp];
+      if (level == 0) { v = histBC_job[(size_t)slot * VD_NB_BC + t]; rk = c->rank_rem[grp]; }
+      else { v = histB_job[(size_t)slot * VD_NB_B + gs[4] * 256u + t]; rk = gs[5]; }
+    }
+    // exclusive scan over the 256 threads of the group (4 waves)
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t u = (uint32_t)__shfl_up((int)inc, off, 64);
+      if (lane >= off) inc += u;
+    }
+    __syncthreads();  // previous level's reads of gs[] are done
+    if (lane == 63) gs[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < wv; ++i) base += gs[i];
+    base += inc - v;
+    __syncthreads();
+    if ((uint32_t)grp < nr && rk >= base && rk < (uint64_t)base + v) {
+      if (level == 0) { gs[4] = (uint32_t)t; gs[5] = (uint32_t)(rk - base); }
+      else c->val[grp] = __uint_as_float((c->tprefix[c->rank_t[grp]] << 16) | (gs[4] << 8) | (uint32_t)t);
     }
     __syncthreads();
   }
@@ -369,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
       break;
     case VD_ST_B0: {
       vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
-      scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, sm);
+      scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {  // DepthPercentileEMA.normalize :249-261
         float lo = quantile_lerp(c->val[0], c->val[1], c->w[0]);
         float hi = quantile_lerp(c->val[2], c->val[3], c->w[1]);
@@ -400,9 +423,9 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
       scan_a_job(&w->job[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
       break;
     case VD_ST_B1: {
-      if (a.have_eye) scan_b_job(&w->job[VD_J_EYE_SUBJ], histB + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_B, sm);
-      scan_b_job(&w->job[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, sm);
-      scan_b_job(&w->job[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, sm);
+      if (a.have_eye) scan_b_job(&w->job[VD_J_EYE_SUBJ], histB + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_BC, sm);
+      scan_b_job(&w->job[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_BC, sm);
+      scan_b_job(&w->job[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
         vd_sel_ctl* cq = &w->job[VD_J_WORK_Q];
         const float lo = quantile_lerp(cq->val[0], cq->val[1], cq->w[0]);
@@ -462,21 +485,21 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
       break;
     case VD_ST_BQ: {
       vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
-      scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, sm);
+      scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
         w->fs.q_lo = quantile_lerp(c->val[0], c->val[1], c->w[0]);
         w->fs.q_hi = quantile_lerp(c->val[2], c->val[3], c->w[1]);
       }
     } break;
     case VD_ST_BS:
-      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, sm);
+      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) w->fs.s1 = subject_from_job(&w->job[VD_J_WORK_S1]);
       break;
     case VD_ST_A2:
       scan_a_job(&w->job[VD_J_WORK_S1], histA + (size_t)VD_J_WORK_S1 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
       break;
     case VD_ST_B2: {
-      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, sm);
+      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
         const float s1 = subject_from_job(&w->job[VD_J_WORK_S1]);
         w->fs.s1 = s1;

@@ -6,6 +6,7 @@
 
 #define VD_NB_A 16384u  // float bit-pattern prefix (top 16 bits) bins; values in [0,1] use 0..0x3F80
 #define VD_NB_B 65536u  // low 16 bits
+#define VD_NB_BC 256u   // coarse level of the low-16 histogram (low16 >> 8): scan B walks 256 + 256 bins, not 65536
 #define VD_MAX_T 4      // distinct target prefixes per select job
 #define VD_NJOBS 5
 
