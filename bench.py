@@ -7,8 +7,11 @@ A "step" is one pass of the hot path over one batch of B synthetic frames alread
 depth inference (workloads with a depth net) -> 8-bit depth hand-off -> the per-frame DIBR chain
 (ingest, exact order statistics, shaping, warp + feather, DOF, grade, sharpen, Half-SBS mux) -> muxed
 frames in HBM.  Default workload = BASELINE.json configs[1] (1080p, Depth-Anything-V2-Small + DIBR).
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; frames are sharded by clip
-(every rank renders its own clip with its own tracker state: no data-path collective), the timed region is
+For N > 1 the driver launches one rank per GPU with torch.distributed.run and the frames of ONE clip are sharded
+round-robin (frame t -> rank t % N, visiondepth3d_amd/sharded.py): each rank runs depth inference and the pixel
+kernels for its own frames; the only data-path collective is an RCCL all-gather of the uint8 depth planes, after
+which every rank advances the (sequential) temporal-tracker state over all frames with vd3d_advance_state, so
+the output is bit-identical to the 1-GPU render.  Weak scaling: B frames per rank per step.  The timed region is
 bracketed by barrier + synchronize and the MAX over ranks is reported.
 """
 from __future__ import annotations
@@ -106,17 +109,32 @@ def main():
         from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
         pipe = DepthPipe(model_name, device="cuda", dtype=torch.bfloat16)
 
+    gathered = torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") if world > 1 else None
+    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and world > 1 else None
+
     def step(i):
+        # this rank's B frames of the step; global frame order inside a step: (j, g) for j in range(B) for g in range(world)
         idx = [(i * B + j) % args.clip for j in range(B)]
         fb = frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
         if pipe is not None:
             pred = pipe.infer_bgr_u8(fb)                 # [B,h,w] f32 on device
-            dgray = depth_to_u8(pred)                    # the reference's 8-bit depth hand-off (a24), no disk hop
-            for j in range(B):
-                r.render_frame(fb[j], dgray[j], p, out=outs[j])
+            dloc = depth_to_u8(pred)                     # the reference's 8-bit depth hand-off (a24), no disk hop
         else:
+            dloc = None
+        if world == 1:
             for j in range(B):
-                r.render_frame(fb[j], depths[idx[j]], p, out=outs[j])
+                r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs[j])
+            return
+        if dloc is None:
+            dloc = depths_u8[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else depths_u8[idx]
+        dist.all_gather_into_tensor(gathered, dloc.contiguous())   # the one data-path collective: [world*B, h, w] uint8
+        for j in range(B):
+            for g in range(world):
+                d = gathered[g * B + j]
+                if g == rank:
+                    r.render_frame(fb[j], d, p, out=outs[j])
+                else:
+                    r.advance_state(d, p)
 
     def fence():
         torch.cuda.synchronize()
@@ -172,7 +190,8 @@ def main():
             "dtype": "f32 DIBR kernels (u8 in/out)" + (" + bf16 depth net" if pipe is not None else ""),
             "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)",
             "config": {"workload": args.workload, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
-                       "frames_per_step": B, "depth_model": model_name, "sharding": "one clip per GPU, no data-path collective",
+                       "frames_per_step": B, "depth_model": model_name,
+                       "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes + vd3d_advance_state (bit-identical to 1 GPU)",
                        "params": "render_cli.py defaults + dof_strength 2.0"},
         }
         if stage_ms:

@@ -189,6 +189,11 @@ int vd3d_pixel_shift(vd3d_ctx* ctx, const float* rgb_chw, const float* depth, in
 int vd3d_render_frame(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
                       const vd3d_render_params* p, uint8_t* out_bgr);
 
+/* Advance all temporal state (TemporalDepthFilter / percentile EMA / trackers) over one frame exactly as
+ * vd3d_render_frame does, without rendering pixels; needs only the depth.  Frame sharding across GPUs:
+ * every rank advances over all frames, and renders only its own. */
+int vd3d_advance_state(vd3d_ctx* ctx, const void* depth, int depth_fmt, const vd3d_render_params* p);
+
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux
  * (core/render_3d.py:1340-1419) on two u8 eyes. depth_norm is the eye-res normalised depth. */

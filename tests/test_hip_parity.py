@@ -218,6 +218,38 @@ def test_render_frame_f32_depth_and_collapse(R, oracle):
         assert np.array_equal(got, exp), (i, u8_diff_stats(got, exp))
 
 
+def test_frame_sharding_two_contexts_equals_sequential(R, oracle):
+    """vd3d_advance_state: two contexts playing rank 0 / rank 1 of a frame-sharded clip reproduce the sequential
+    render bit for bit and end in the same tracker state; orchestration itself is covered on CPU/gloo."""
+    from visiondepth3d_amd.render_3d import Renderer
+    from visiondepth3d_amd.sharded import FrameShardedRenderer, HipBackend
+    g = load_golden("render_loop.npz")
+    sh, sw, n, kw = golden_json(g, "cases_json")["half_sbs_cli"]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
+    p = render_kwargs_to_params(sw, sh, **kw)
+    R.reset_state(); R.new_clip()
+    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
+    st_seq = R.export_state().as_dict()
+    ranks = [Renderer(0), Renderer(0)]
+    for rr in ranks:
+        rr.reset_state(); rr.new_clip()
+    for t, (f, d) in enumerate(zip(frames, gray)):
+        for g_, rr in enumerate(ranks):
+            if t % 2 == g_:
+                out = rr.render_frame(T(f), T(d), p).cpu().numpy()
+                assert np.array_equal(out, seq[t]), t
+            else:
+                rr.advance_state(T(d), p)
+    assert ranks[0].export_state().as_dict() == ranks[1].export_state().as_dict() == st_seq
+    sr = FrameShardedRenderer(HipBackend(ranks[0], p), 0, 1)
+    ranks[0].reset_state()
+    got = [o.cpu().numpy() for _, o in sr.render_clip(n, lambda t: T(frames[t]), lambda t: T(gray[t]))]
+    assert all(np.array_equal(a, b) for a, b in zip(got, seq))
+    for rr in ranks:
+        rr.close()
+
+
 # ------------------------------------------------------------------------------------------ full-size
 @pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840)])
 def test_full_size_properties(R, oracle, hw):

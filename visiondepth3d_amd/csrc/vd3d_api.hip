@@ -215,7 +215,7 @@ static int check_shift_params(const vd3d_shift_params* p, int H, int W) {
 }
 
 static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_plane, int ih, int iw, int W, int H,
-                              const vd3d_shift_params& sp, vd_stage_args a) {
+                              const vd3d_shift_params& sp, vd_stage_args a, bool state_only = false) {
   hipStream_t s = c->stream;
   { StageTimer t(c, "select_dc");
     vd_launch_hist_work_dc(s, false, depth_plane, ih, iw, H, W, c->work, c->histA, c->histB);
@@ -234,7 +234,7 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     vd_launch_hist_work_s1(s, true, c->D, H, W, c->work, c->histA, c->histB);
     a.stage = VD_ST_B2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
   }
-  { StageTimer t(c, "warp");
+  if (!state_only) { StageTimer t(c, "warp");
     vd_launch_shift(s, c->D, H, W, c->work, sp, c->S);
     if (c->use_fused && vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R)) {
       // fused path taken
@@ -355,9 +355,9 @@ VD3D_EXPORT int vd3d_finish_frame(vd3d_ctx* c, const uint8_t* left_bgr, const ui
 }
 
 // ---- B2 ---------------------------------------------------------------------------------------
-VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
-                                  const vd3d_render_params* p, uint8_t* out_bgr) {
-  if (!c || !frame_bgr || !depth || !p || !out_bgr) return set_err(VD3D_E_INVALID, "NULL argument");
+static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
+                             const vd3d_render_params* p, uint8_t* out_bgr, bool state_only) {
+  if (!c || !depth || !p || (!state_only && (!frame_bgr || !out_bgr))) return set_err(VD3D_E_INVALID, "NULL argument");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
   if (p->crop_x < 0 || p->crop_y < 0 || p->crop_w < 1 || p->crop_h < 1 || p->crop_x + p->crop_w > p->src_w || p->crop_y + p->crop_h > p->src_h)
     return set_err(VD3D_E_INVALID, "crop window outside the frame");
@@ -376,7 +376,7 @@ VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const v
   if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
   hipStream_t s = c->stream;
   const long long ne = (long long)p->eye_h * p->eye_w;
-  StageTimer tf(c, "frame");
+  StageTimer tf(c, state_only ? "advance" : "frame");
   vd_stage_args a;
   memset(&a, 0, sizeof a);
   a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.n_eye = ne;
@@ -395,12 +395,26 @@ VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const v
     a.stage = VD_ST_B0; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
     vd_launch_eye_stats(s, c->tdf, dn_cur, dn_prev, p->eye_h, p->eye_w, c->work);
   }
-  rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a);
+  rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, state_only);
   if (rc) return rc;
-  rc = run_finish(c, c->L, c->R, dn_cur, p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr);
-  if (rc) return rc;
+  if (!state_only) {
+    rc = run_finish(c, c->L, c->R, dn_cur, p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr);
+    if (rc) return rc;
+  }
   c->dn_cur ^= 1;
   return 0;
+}
+
+VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
+                                  const vd3d_render_params* p, uint8_t* out_bgr) {
+  return render_frame_impl(c, frame_bgr, depth, depth_fmt, p, out_bgr, false);
+}
+
+// Advance every temporal tracker (planes + scalars) exactly as vd3d_render_frame would for this frame, WITHOUT producing
+// pixels: only the depth is needed.  This is what lets frames of one clip be sharded across GPUs with bit-identical
+// results: every rank advances the state over all frames and renders the pixels of its own frames.
+VD3D_EXPORT int vd3d_advance_state(vd3d_ctx* c, const void* depth, int depth_fmt, const vd3d_render_params* p) {
+  return render_frame_impl(c, nullptr, depth, depth_fmt, p, nullptr, true);
 }
 
 // ---- diagnostics / tests --------------------------------------------------------------------------

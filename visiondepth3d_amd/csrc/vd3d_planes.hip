@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ fram
   const size_t i10 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i0 + p.crop_x);
   const size_t i11 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i1 + p.crop_x);
   const size_t ne = (size_t)p.eye_h * p.eye_w, o = (size_t)ey * p.eye_w + ex;
+  if (frame)
 #pragma unroll
   for (int c = 0; c < 3; ++c) {  // output plane c = R,G,B ; source byte 2-c
     const int sc = 2 - c;

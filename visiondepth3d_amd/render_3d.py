@@ -134,6 +134,19 @@ class Renderer:
         _lib.check(self._L.vd3d_render_frame(self._ctx, _ptr(f), _ptr(d), fmt, C.byref(params), _ptr(out)))
         return out
 
+    def advance_state(self, depth: torch.Tensor, params: RenderParams) -> None:
+        """Advance the temporal state over one frame without rendering it (frame sharding)."""
+        if depth.dtype == torch.float32 and depth.dim() == 2:
+            fmt = DEPTH_F32
+        elif depth.dtype == torch.uint8 and depth.dim() == 3 and depth.shape[2] == 3:
+            fmt = DEPTH_BGR_U8
+        elif depth.dtype == torch.uint8 and depth.dim() == 2:
+            fmt = DEPTH_GRAY_U8
+        else:
+            raise AssertionError("depth must be float32 [h,w], uint8 [h,w,3] or uint8 [h,w]")
+        d = depth.to(self.device).contiguous()
+        _lib.check(self._L.vd3d_advance_state(self._ctx, _ptr(d), fmt, C.byref(params)))
+
     def finish_frame(self, left, right, depth_norm, params: RenderParams, focal_depth, bar_width=0, bar_side=0):
         out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
         dn = depth_norm.to(self.device, torch.float32).contiguous()

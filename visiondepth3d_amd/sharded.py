@@ -1,0 +1,103 @@
+"""Frame sharding of ONE clip across GPUs, bit-identical to the sequential render.
+
+The reference's per-frame path carries sequential temporal state (a plane EMA, a percentile EMA and several
+non-linear scalar trackers, core/render_3d.py:220-286,463-511,895-922), so frames cannot simply be dealt out.
+What CAN be dealt out is the expensive part -- depth inference and the pixel work (warp, DOF, sharpen, mux):
+
+  round r, world G:  rank g owns frame t = r*G + g
+    1. every rank runs depth inference for ITS frame                                   (parallel, MFMA-bound)
+    2. ONE collective: all-gather of the uint8 depth planes (h*w bytes per frame; 2 MB @1080p) over RCCL/xGMI
+       -- skipped entirely when the depth video already exists on every rank
+    3. for t in the round, in order: the owner calls render_frame (state advance + pixels),
+       every other rank calls advance_state (state advance only: eye-res reductions + scalar stage, no pixels)
+
+Every rank therefore walks the identical state trajectory (the HIP reductions are integer / fixed-point, hence
+deterministic across GPUs) and the muxed frames equal the single-GPU render bit for bit.  The only data-path
+collective is the depth all-gather; payload per frame is the plane the reference would have written to its
+depth video anyway.
+
+The runner is backend-agnostic (``render_frame`` / ``advance_state`` / ``new_clip``) so the orchestration is
+covered by world_size-2 gloo tests on CPU with the oracle as backend (tests/test_sharded_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class HipBackend:
+    """Adapter over visiondepth3d_amd.render_3d.Renderer."""
+
+    def __init__(self, renderer, params):
+        self.r, self.p = renderer, params
+        self.device = renderer.device
+
+    def new_clip(self):
+        self.r.new_clip()
+
+    def render_frame(self, frame, depth):
+        return self.r.render_frame(frame, depth, self.p)
+
+    def advance_state(self, depth):
+        self.r.advance_state(depth, self.p)
+
+
+class FrameShardedRenderer:
+    def __init__(self, backend, rank: int | None = None, world: int | None = None, group=None):
+        self.b = backend
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+
+    def new_clip(self):
+        self.b.new_clip()
+
+    def owner(self, t: int) -> int:
+        return t % self.world
+
+    def render_round(self, n_valid: int, frame=None, depth_local: Optional[torch.Tensor] = None,
+                     depth_all: Optional[torch.Tensor] = None):
+        """One round of up to ``world`` consecutive frames (``n_valid`` of them exist).  ``frame``/``depth_local`` are
+        this rank's frame and its depth (None if rank >= n_valid).  Pass ``depth_all`` [world,h,w(,3)] when every
+        rank already has all depth planes (precomputed depth video) to skip the collective.  Returns this rank's
+        muxed frame or None."""
+        G = self.world
+        if depth_all is None:
+            if G == 1:
+                depth_all = depth_local[None]
+            else:
+                assert depth_local is not None, "every rank contributes a (possibly dummy) depth plane to the all-gather"
+                shp = tuple(depth_local.shape)
+                flat = torch.empty((G * shp[0],) + shp[1:], dtype=depth_local.dtype, device=depth_local.device)
+                dist.all_gather_into_tensor(flat, depth_local.contiguous(), group=self.group)  # concatenation along dim 0
+                depth_all = flat.view((G,) + shp)
+        out = None
+        for g in range(min(n_valid, G)):
+            if g == self.rank:
+                out = self.b.render_frame(frame, depth_all[g])
+            else:
+                self.b.advance_state(depth_all[g])
+        return out
+
+    def render_clip(self, n_frames: int, get_frame: Callable[[int], torch.Tensor],
+                    get_depth: Callable[[int], torch.Tensor], depth_everywhere: bool = False) -> Iterable:
+        """Render frames 0..n_frames-1 of a clip (the caller has already dropped the reference's skipped first frame).
+        ``get_frame(t)`` / ``get_depth(t)`` are called only for frames this rank needs.  Yields (t, muxed frame) for
+        the frames this rank owns."""
+        G = self.world
+        self.new_clip()
+        for r0 in range(0, n_frames, G):
+            n_valid = min(G, n_frames - r0)
+            t = r0 + self.rank
+            mine = self.rank < n_valid
+            frame = get_frame(t) if mine else None
+            if depth_everywhere:
+                d_all = torch.stack([get_depth(r0 + g) for g in range(n_valid)])
+                out = self.render_round(n_valid, frame, None, d_all)
+            else:
+                d_loc = get_depth(t) if mine else torch.zeros_like(get_depth(r0))  # dummy contribution past the clip end
+                out = self.render_round(n_valid, frame, d_loc)
+            if mine:
+                yield t, out
