@@ -117,8 +117,8 @@ def main():
         idx = [(i * B + j) % args.clip for j in range(B)]
         fb = frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
         if pipe is not None:
-            pred = pipe.infer_bgr_u8(fb)                 # [B,h,w] f32 on device
-            dloc = depth_to_u8(pred)                     # the reference's 8-bit depth hand-off (a24), no disk hop
+            pred = pipe.infer_bgr_u8(fb, raw=True)       # [B,518,924] f32 on device
+            dloc = r.depth_handoff(pred, sh, sw)         # the reference's 8-bit depth hand-off (a24) fused on device, no disk hop
         else:
             dloc = None
         if world == 1:

@@ -194,6 +194,11 @@ int vd3d_render_frame(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth
  * every rank advances over all frames, and renders only its own. */
 int vd3d_advance_state(vd3d_ctx* ctx, const void* depth, int depth_fmt, const vd3d_render_params* p);
 
+/* ---- depth hand-off (a24): transformers' bicubic post-process to (H,W) + convert_depth_to_grayscale
+ * (core/render_depth.py:585-611,1914-1916) for a batch of B predictions [B][ph][pw] float32 -> uint8 [B][H][W].
+ * Replaces the reference's 8-bit depth video on disk while keeping its quantisation. */
+int vd3d_depth_handoff(vd3d_ctx* ctx, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint8_t* out_gray);
+
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux
  * (core/render_3d.py:1340-1419) on two u8 eyes. depth_norm is the eye-res normalised depth. */

@@ -218,6 +218,15 @@ def format_output(L, R, fmt):
     return out
 
 
+def depth_handoff(pred, H, W, invert=False):
+    """a24: bicubic post-process to (H, W) + per-frame min-max -> uint8 (truncation)."""
+    pred, pp = _f(pred)
+    ph, pw = pred.shape[-2:]
+    out = np.empty((H, W), np.uint8)
+    lib().vo_depth_handoff(pp, ph, pw, int(H), int(W), int(bool(invert)), out.ctypes.data_as(_u8p))
+    return out
+
+
 # ------------------------------------------------------------------------------ composite
 def pixel_shift(rgb_chw, depth, W, H, params: ShiftParams, state: State | None = None,
                 want_shift=False, want_dshaped=False):

@@ -76,6 +76,30 @@ def test_subject_depth_edge_cases(R, oracle):
     assert R.subject_depth(T(p)) == oracle.subject_depth(p)
 
 
+def test_depth_handoff_bit_exact_vs_oracle_and_close_to_torch(R, oracle):
+    """a24: HIP == oracle exactly; both within 1 LSB (rare) of torch's bicubic + numpy min-max/truncate."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    pred = (torch.randn(3, 74, 132, generator=g) * 3 + 5).float()
+    pred[2] = 1.25  # flat prediction -> the reference writes zeros
+    H, W = 216, 384
+    got = R.depth_handoff(pred.cuda(), H, W).cpu().numpy()
+    inv = R.depth_handoff(pred.cuda(), H, W, invert=True).cpu().numpy()
+    for b in range(3):
+        exp = oracle.depth_handoff(pred[b].numpy(), H, W)
+        assert np.array_equal(got[b], exp), b
+        assert np.array_equal(inv[b], 255 - exp), b
+    ref = F.interpolate(pred[:2, None], size=(H, W), mode="bicubic", align_corners=False)[:, 0].numpy()
+    for b in range(2):
+        mn, mx = ref[b].min(), ref[b].max()
+        u8 = (((ref[b] - mn) / (mx - mn + np.float32(1e-6))) * 255).astype(np.uint8)
+        mx_d, frac, _ = u8_diff_stats(got[b], u8)
+        assert mx_d <= 1 and frac < 1e-3
+    same = R.depth_handoff(pred.cuda(), 74, 132).cpu().numpy()  # identity size: no resampling
+    assert np.array_equal(same[0], oracle.depth_handoff(pred[0].numpy(), 74, 132))
+    assert not same[2].any()  # exactly flat prediction (max - min < 1e-6) -> the reference writes zeros (:603-606)
+
+
 # ------------------------------------------------------------------------------------------ B1
 def _shift_cases():
     g = load_golden("pixel_shift_cases.npz")

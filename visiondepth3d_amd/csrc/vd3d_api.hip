@@ -48,6 +48,7 @@ struct vd3d_ctx {
   int H = 0, W = 0;
   float *D = nullptr, *S = nullptr, *e2L = nullptr, *e2R = nullptr, *bL = nullptr, *bR = nullptr;
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
+  uint32_t* mm = nullptr; int mm_cap = 0;   // depth hand-off min/max keys [B][3]
   // profiling
   bool profiling = false;
   bool use_fused = true;   // VD3D_UNFUSED=1 selects the one-stage-per-kernel v0 path (A/B and debugging)
@@ -159,7 +160,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -464,6 +465,17 @@ VD3D_EXPORT int vd3d_subject_depth(vd3d_ctx* c, const float* plane, int H, int W
   a.stage = VD_ST_BS; vd_launch_scalar_stage(c->stream, c->work, c->histA, c->histB, a);
   HIPCHK(hipMemcpyAsync(out_host, &c->work->fs.s1, sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// a24: depth-net prediction [B][ph][pw] float32 -> uint8 depth planes [B][H][W] (bicubic post-process + per-frame min-max)
+VD3D_EXPORT int vd3d_depth_handoff(vd3d_ctx* c, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint8_t* out_gray) {
+  if (!c || !pred || !out_gray || B < 1 || ph < 1 || pw < 1 || H < 1 || W < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (B > c->mm_cap) { HIPCHK(re_alloc(&c->mm, (size_t)3 * B)); c->mm_cap = B; }
+  StageTimer t(c, "handoff");
+  vd_launch_depth_handoff(c->stream, pred, B, ph, pw, H, W, invert ? 1 : 0, c->mm, out_gray);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

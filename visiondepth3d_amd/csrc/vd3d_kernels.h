@@ -71,3 +71,7 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
                          const vd_finish_consts& fc, uint8_t* out);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
+
+// ---- vd3d_handoff.hip
+void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint32_t* mm,
+                             uint8_t* out);

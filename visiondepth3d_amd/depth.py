@@ -106,11 +106,29 @@ class DepthPipe:
         self.mean = torch.tensor(IMAGENET_MEAN, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
         self.std = torch.tensor(IMAGENET_STD, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
         self.n_params = sum(p.numel() for p in self.model.parameters())
+        self._cache_position_embeddings()
+
+    def _cache_position_embeddings(self):
+        """DINOv2 re-interpolates its position embedding (bicubic 37x37 -> patch grid) on EVERY forward; for a fixed
+        frame size the result is a constant, and ATen's bicubic kernel loops the 384-1024 channels serially per output
+        pixel (measured 2.9 ms per forward on MI355X, 14 % of the step).  Memoise it per (height, width)."""
+        emb = self.model.backbone.embeddings
+        orig = emb.interpolate_pos_encoding
+        cache = {}
+
+        def cached(embeddings, height, width):
+            key = (int(height), int(width), embeddings.dtype, embeddings.shape[1])
+            if key not in cache:
+                cache[key] = orig(embeddings, height, width).detach()
+            return cache[key]
+
+        emb.interpolate_pos_encoding = cached
 
     @torch.no_grad()
-    def infer_bgr_u8(self, frames_bgr: torch.Tensor, inference_size=None) -> torch.Tensor:
+    def infer_bgr_u8(self, frames_bgr: torch.Tensor, inference_size=None, raw: bool = False) -> torch.Tensor:
         """uint8 [B,H,W,3] BGR frames in HBM -> float32 [B,H,W] predicted depth at the frame size (the
-        depth-estimation pipeline's post-process: bicubic, align_corners=False)."""
+        depth-estimation pipeline's post-process: bicubic, align_corners=False).  ``raw=True`` returns the model-resolution
+        prediction [B,th,tw] instead, for the fused HIP hand-off (Renderer.depth_handoff)."""
         B, H, W, _ = frames_bgr.shape
         x = frames_bgr.to(self.device).flip(-1).permute(0, 3, 1, 2).float()  # RGB, NCHW
         if inference_size is not None:  # hf_batch_safe_pipe: img.resize(inference_size, BICUBIC) first (:1113-1116)
@@ -123,6 +141,8 @@ class DepthPipe:
         if self.device.type == "cuda":
             x = x.contiguous(memory_format=torch.channels_last)
         pred = self.model(pixel_values=x).predicted_depth  # [B, th, tw]
+        if raw:
+            return pred.float()
         pred = F.interpolate(pred.float().unsqueeze(1), size=(H, W), mode="bicubic", align_corners=False).squeeze(1)
         return pred
 

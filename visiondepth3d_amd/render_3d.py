@@ -147,6 +147,17 @@ class Renderer:
         d = depth.to(self.device).contiguous()
         _lib.check(self._L.vd3d_advance_state(self._ctx, _ptr(d), fmt, C.byref(params)))
 
+    def depth_handoff(self, pred: torch.Tensor, H: int, W: int, invert: bool = False, out: torch.Tensor | None = None):
+        """a24 on device: predictions float32 [B,ph,pw] -> uint8 depth planes [B,H,W] (bicubic + per-frame min-max)."""
+        p = pred.to(self.device, torch.float32).contiguous()
+        if p.dim() == 2:
+            p = p[None]
+        B, ph, pw = p.shape
+        if out is None:
+            out = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.vd3d_depth_handoff(self._ctx, _ptr(p), B, ph, pw, int(H), int(W), int(bool(invert)), _ptr(out)))
+        return out
+
     def finish_frame(self, left, right, depth_norm, params: RenderParams, focal_depth, bar_width=0, bar_side=0):
         out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
         dn = depth_norm.to(self.device, torch.float32).contiguous()
