@@ -64,13 +64,15 @@ def cpu_baseline(sh, sw, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="1080p-dav2s-dibr", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=8, help="frames per step")
-    ap.add_argument("--clip", type=int, default=8, help="distinct synthetic frames resident in HBM (cycled)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per step")
+    ap.add_argument("--clip", type=int, default=16, help="distinct synthetic frames resident in HBM (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     args = ap.parse_args()
 
     import torch
@@ -94,7 +96,10 @@ def main():
 
     sh, sw, model_name, desc = WORKLOADS[args.workload]
     p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
-    r = Renderer(local_rank)
+    overlap = (not args.no_overlap) and WORKLOADS[args.workload][2] is not None
+    r = Renderer(local_rank, private_stream=overlap)   # DIBR chain: ~25 small dependent launches per frame
+    rh = Renderer(local_rank) if overlap else r        # depth hand-off stays on the depth net's (torch) stream
+    dibr_stream = r.stream if overlap else None
     r.new_clip()
     B = args.batch
 
@@ -109,32 +114,45 @@ def main():
         from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
         pipe = DepthPipe(model_name, device="cuda", dtype=torch.bfloat16)
 
-    gathered = torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") if world > 1 else None
+    NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
+    gathered = [torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if world > 1 else None
+    dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
+    done = [torch.cuda.Event() for _ in range(NBUF)]
     depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and world > 1 else None
 
     def step(i):
         # this rank's B frames of the step; global frame order inside a step: (j, g) for j in range(B) for g in range(world)
         idx = [(i * B + j) % args.clip for j in range(B)]
         fb = frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
+        k = i % NBUF
+        if overlap:
+            torch.cuda.current_stream().wait_event(done[k])  # hand-off buffer k is free again (no-op until first recorded)
         if pipe is not None:
             pred = pipe.infer_bgr_u8(fb, raw=True)       # [B,518,924] f32 on device
-            dloc = r.depth_handoff(pred, sh, sw)         # the reference's 8-bit depth hand-off (a24) fused on device, no disk hop
+            dloc = rh.depth_handoff(pred, sh, sw, out=dbuf[k])  # the reference's 8-bit depth hand-off (a24), fused, no disk hop
         else:
             dloc = None
+        if world > 1:
+            if dloc is None:
+                dloc = depths_u8[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else depths_u8[idx]
+            dist.all_gather_into_tensor(gathered[k], dloc.contiguous())   # the one data-path collective: [world*B,h,w] u8
+        if overlap:  # hand the batch to the DIBR stream; this (torch) stream goes on to the next batch's depth inference
+            ev = torch.cuda.Event()
+            ev.record()
+            dibr_stream.wait_event(ev)
         if world == 1:
             for j in range(B):
                 r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs[j])
-            return
-        if dloc is None:
-            dloc = depths_u8[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else depths_u8[idx]
-        dist.all_gather_into_tensor(gathered, dloc.contiguous())   # the one data-path collective: [world*B, h, w] uint8
-        for j in range(B):
-            for g in range(world):
-                d = gathered[g * B + j]
-                if g == rank:
-                    r.render_frame(fb[j], d, p, out=outs[j])
-                else:
-                    r.advance_state(d, p)
+        else:
+            for j in range(B):
+                for g in range(world):
+                    d = gathered[k][g * B + j]
+                    if g == rank:
+                        r.render_frame(fb[j], d, p, out=outs[j])
+                    else:
+                        r.advance_state(d, p)
+        if overlap:
+            done[k].record(dibr_stream)
 
     def fence():
         torch.cuda.synchronize()

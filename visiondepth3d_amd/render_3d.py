@@ -44,6 +44,14 @@ class Renderer:
             stream = C.c_void_p(-1) if private_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             _lib.check(L.vd3d_ctx_create(self.device.index, stream, C.byref(self._ctx)))
 
+    @property
+    def stream(self) -> "torch.cuda.Stream":
+        """The HIP stream this renderer enqueues on, as a torch stream object (for events / record_stream)."""
+        ptr = self._L.vd3d_ctx_stream(self._ctx)
+        if not ptr:
+            return torch.cuda.default_stream(self.device)
+        return torch.cuda.ExternalStream(int(ptr), device=self.device)
+
     def close(self):
         if self._ctx:
             self._L.vd3d_ctx_destroy(self._ctx)
