@@ -335,6 +335,10 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
                       const vd3d_render_params* p, const vd_finish_consts& fc, float focal, int use_override, int bw, int bs,
                       uint8_t* out) {
   StageTimer t(c, "finish");
+  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, c->work, focal, use_override, bw, bs, out)) {
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, c->work, focal, use_override, bw, bs, c->gL);
   vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, c->work, focal, use_override, bw, bs, c->gR);
   vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);

@@ -75,3 +75,8 @@ void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t byt
 // ---- vd3d_handoff.hip
 void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint32_t* mm,
                              uint8_t* out);
+
+// ---- vd3d_finish.hip
+bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
+                            const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
+                            int use_override, int bar_w, int bar_s, uint8_t* out);
