@@ -213,7 +213,7 @@ int vd3d_subject_depth(vd3d_ctx* ctx, const float* plane, int H, int W, float* o
 /* device-to-device streaming copy used as the measured-peak yardstick for roofline.frac */
 int vd3d_stream_copy(vd3d_ctx* ctx, const void* src, void* dst, size_t bytes);
 /* HIP-event profiling of the stages on the ctx stream ("frame", "ingest", "select_eye", "select_dc", "shape",
- * "select_s1", "warp", "finish", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
+ * "select_s1", "warp" (= "shift" + "w1", the fused warp kernel alone), "finish", "handoff", "advance", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
  * profiling was enabled (-1 if never seen); both getters synchronise. */
 int vd3d_set_profiling(vd3d_ctx* ctx, int enable);
 float vd3d_last_stage_ms(vd3d_ctx* ctx, const char* stage);

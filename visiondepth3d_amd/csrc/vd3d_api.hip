@@ -236,8 +236,10 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     a.stage = VD_ST_B2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
   }
   if (!state_only) { StageTimer t(c, "warp");
-    vd_launch_shift(s, c->D, H, W, c->work, sp, c->S);
-    if (c->use_fused && vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R)) {
+    { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
+    bool fused = false;
+    if (c->use_fused) { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R); }
+    if (fused) {
       // fused path taken
     } else {
     if (sp.enable_feathering) {

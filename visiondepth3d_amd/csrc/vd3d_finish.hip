@@ -79,7 +79,9 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
                                                         const vd_dev_work* __restrict__ w, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
   __shared__ __attribute__((aligned(16))) float hb[3][FF_IH][FF_GW];
-  __shared__ uint32_t gb[FF_GH][FF_GW];
+  __shared__ uint32_t gb[FF_GH][FF_GW + 1];   // odd pitch: the epilogue's column walks stay conflict-free
+  __shared__ float lut[256];                  // v / 255.0f (true division), computed once per workgroup
+  __shared__ int lvl_mask;                    // levels any pixel of this tile needs
   const int eye = blockIdx.z;
   const uint8_t* __restrict__ src = eye == 0 ? eyeL : eyeR;
   const int H = a.H, W = a.W;
@@ -88,13 +90,16 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
   const int ix0 = gx0 - FF_R, iy0 = gy0 - FF_R;    // input tile origin
   const int tid = threadIdx.x;
 
+  if (tid < 256) lut[tid] = (float)tid / 255.0f;
+  if (tid == 0) lvl_mask = 0;
+  __syncthreads();
   for (int t = tid; t < FF_IH * FF_IW; t += FF_NT) {
     const int ty = t / FF_IW, tx = t - ty * FF_IW;
     const int y = vd_reflect(iy0 + ty, H), x = vd_reflect(ix0 + tx, W);
     const uint8_t* px = src + ((size_t)y * W + x) * 3;
-    tile[0][ty][tx] = (float)px[2] / 255.0f;
-    tile[1][ty][tx] = (float)px[1] / 255.0f;
-    tile[2][ty][tx] = (float)px[0] / 255.0f;
+    tile[0][ty][tx] = lut[px[2]];
+    tile[1][ty][tx] = lut[px[1]];
+    tile[2][ty][tx] = lut[px[0]];
   }
   // per-strip setup (threads 0..323 own one 4-pixel strip of the graded region)
   const bool strip = tid < FF_GH * FF_NS;
@@ -123,8 +128,12 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       lo[q] = l; alpha[q] = bi - (float)l;
       lmin = min(lmin, l); lmax = max(lmax, l + 1);
     }
+    int m = 0;
+    for (int l = max(lmin, 1); l <= lmax; ++l) m |= 1 << l;
+    if (m) atomicOr(&lvl_mask, m);
   }
   __syncthreads();
+  const int need_mask = lvl_mask;
   float vlo[3][4], vhi[3][4];
   if (strip) {
 #pragma unroll
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
     }
   }
   for (int l = 0; l < fc.nlev; ++l) {  // level l+1 of the reference's stack
+    if (!(need_mask >> (l + 1) & 1)) continue;  // no pixel of this tile blends with this level (workgroup-uniform)
     const int off = FF_R - fc.ksz[l] / 2;
     const bool need = strip && l + 1 >= lmin && l + 1 <= lmax;
     switch (off) {  // compile-time tap count => all register indexing is static
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
   const float kn = fc.sharp_kn, kc = fc.sharp_kc;
   const float scale = 1.f / (float)(a.fx * a.fy);
   for (int t = tid; t < oh * (ow / 4); t += FF_NT) {
-    const int ty = t / (ow / 4), tq = t - ty * (ow / 4);
+    const int tq = t / oh, ty = t - tq * oh;   // row-fastest: lanes walk a column of the odd-pitch gb tile
     const int oy = oy0 + ty;
     if (oy >= a.in_h) continue;
     uint32_t pack[3] = {0, 0, 0};

@@ -285,6 +285,7 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   if (resize) {
     a.er_max = (int)ceil((WF_TH + 2) * (double)a.scale_h) + 3;
     a.ec_max = (int)ceil((WF_TW + 2 * a.bound + 3) * (double)a.scale_w) + 3;
+    a.ec_max |= 1;                       // odd row pitch: the 4-rows-per-wave gathers of phase D land on distinct banks
     if (a.ec_max > iw) a.ec_max = iw;
     fl += (size_t)3 * a.er_max * a.ec_max;
   }

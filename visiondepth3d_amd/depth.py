@@ -38,7 +38,8 @@ def build_config(name: str):
     z = MODEL_ZOO[name]
     bc = Dinov2Config(hidden_size=z["hidden"], num_hidden_layers=z["layers"], num_attention_heads=z["heads"], patch_size=14,
                       image_size=518, out_indices=z["out_indices"], reshape_hidden_states=False, apply_layernorm=True)
-    return DepthAnythingConfig(backbone_config=bc, neck_hidden_sizes=z["neck"], fusion_hidden_size=z["fusion"],
+    return DepthAnythingConfig(backbone_config=bc, reassemble_hidden_size=z["hidden"], neck_hidden_sizes=z["neck"],
+                               fusion_hidden_size=z["fusion"],
                                head_hidden_size=z["head"], reassemble_factors=[4, 2, 1, 0.5], patch_size=14)
 
 
