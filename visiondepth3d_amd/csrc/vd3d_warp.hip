@@ -4,13 +4,13 @@
 // (core/render_3d.py:684-712): warped-depth gradient mask -> k x k separable window average -> RGB warp of both
 // eyes -> feather blend -> tensor_to_frame truncation, with NO intermediate planes in HBM.
 //
-// Per 64x32 output tile (512 threads, 4 consecutive pixels of one row per thread in the last phase):
-//   stage   D tile (TH+k+2) x (TW+k+2*bound+2) and S tile (TH+k) x (TW+k): coalesced row loads into LDS
-//   phase A warped depth of both eyes on the (TH+k) x (TW+k) halo: 1-D-ish bilinear gathers FROM LDS
-//   (the eye-res RGB tile was requested from HBM before phase A into registers and lands in the dead D tile)
+// Per 64x32 output tile (512 threads, 2 workgroups per CU):
+//   phase A warped depth of both eyes on the (TH+k) x (TW+k) halo: S loads then D gathers (L2), fixed unroll for ILP
+//   (the eye-res RGB tile is requested from HBM before phase A into registers and lands in LDS afterwards)
 //   phase B e2 = clamp(|grad WD| * fs, 0, 1)            phase C horizontal k-sums (ascending x)
 //   phase D vertical k-sums -> b, RGB samples = nested bilinear (resize of :595 inside the grid_sample of :697)
-//           read from the LDS eye tile, blend, truncate, 12-byte packed stores per eye.
+//           read from the LDS eye tile, one row per wave (row-uniform taps; exact skip of the south samples when the
+//           sample row is integral), blend, truncate, shuffle-packed 12-byte stores per 4 lanes.
 // Arithmetic is identical to the unfused v0 kernels (same helpers, same association) => bit-exact vs the oracle.
 //
 // Algorithmic HBM bytes per stereo pair: read RGB 3N (eye-res f32 x3 at N/4) + D 4N + S 4N, write 6N.
@@ -108,9 +108,13 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
               const vd_gs g = vd_gs_params(eye == 0 ? gx + sv[j] : gx - sv[j], gy, W, H);
               const float* r0 = D + (size_t)g.yn * W + g.xw;
               const float vnw = r0[0], vne = g.e_ok ? r0[1] : 0.f;
-              float vsw = 0.f, vse = 0.f;
-              if (g.s_ok) { vsw = r0[W]; vse = g.e_ok ? r0[W + 1] : 0.f; }
-              const float v = vd_gs_combine(g, vnw, vne, vsw, vse);
+              float v;
+              if (g.s_ok && (g.sw != 0.f || g.se != 0.f)) {
+                const float vsw = r0[W], vse = g.e_ok ? r0[W + 1] : 0.f;
+                v = vd_gs_combine(g, vnw, vne, vsw, vse);
+              } else {
+                v = vd_fma(vne, g.ne, vnw * g.nw);   // sw = se = 0 exactly: the south samples add +0
+              }
               if (eye == 0) vl = v; else vr = v;
             }
           }
@@ -166,29 +170,31 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     }
   }
   __syncthreads();
-  // phase D: each thread owns 4 consecutive pixels of one row
+  // phase D: one wave = 64 consecutive pixels of ONE row per iteration, so everything that depends on y only
+  // (sample rows yn / yn+1, their resize taps, the vertical weights) is wave-uniform.  ~70 % of rows have an exactly
+  // integral sample row (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 -> skipped
+  // (bit-exact: fma(v, 0, acc) == acc for finite v).
   const float* hs = wd;
   const float div = (float)(k * k);
   const size_t ni = (size_t)a.ih * a.iw;
-  const int ty = tid / (WF_TW / 4), tq = tid - ty * (WF_TW / 4);
-  const int y = y0 + ty;
-  if (y >= H) return;
-  uint32_t packL[3] = {0, 0, 0}, packR[3] = {0, 0, 0};
-  const float gy = vd_lin11(H, y);
-  const vd_tap tyo = wf_tap(a.ih, H, a.scale_h, y);
-  // rows yn / yn+1 depend on y only (not on x, not on the eye): hoisted out of the pixel loop
-  const int yn_row = vd_gs_params(0.f, gy, W, H).yn;
-  const vd_tap ty0 = wf_tap(a.ih, H, a.scale_h, yn_row), ty1 = wf_tap(a.ih, H, a.scale_h, min(yn_row + 1, H - 1));
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int tx = tq * 4 + q, x = x0 + tx;
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int ty = wv; ty < WF_TH; ty += WF_NT / 64) {
+    const int y = y0 + ty;
+    if (y >= H) break;
+    const float gy = vd_lin11(H, y);
+    const vd_gs grow = vd_gs_params(0.f, gy, W, H);      // row part: yn, s_ok and whether n == 0
+    const bool south = grow.s_ok && (grow.sw != 0.f || grow.se != 0.f);   // n != 0 (e + w == 1, so not both products vanish)
+    const vd_tap tyo = wf_tap(a.ih, H, a.scale_h, y);
+    const vd_tap ty0 = wf_tap(a.ih, H, a.scale_h, grow.yn), ty1 = wf_tap(a.ih, H, a.scale_h, min(grow.yn + 1, H - 1));
+    const int x = x0 + lane;
+    uint32_t pL = 0, pR = 0;
     if (x < W) {
       const size_t o = (size_t)y * W + x;
       float b[2] = {0.f, 0.f};
       if (a.feather) {
 #pragma unroll
         for (int eye = 0; eye < 2; ++eye) {
-          const float* col = hs + eye * eh * WF_TW + ty * WF_TW + tx;
+          const float* col = hs + eye * eh * WF_TW + ty * WF_TW + lane;
           float sacc = 0.f;
           for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
           b[eye] = sacc / div;
@@ -197,7 +203,6 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       const float s = S[o];
       const float gx0 = vd_lin11(W, x);
       const vd_gs gl = vd_gs_params(gx0 + s, gy, W, H), gr = vd_gs_params(gx0 - s, gy, W, H);
-      uint8_t px[2][3];
       if (RESIZE) {
         const vd_tap txo = wf_tap(a.iw, W, a.scale_w, x);
         const vd_tap tl0 = wf_tap(a.iw, W, a.scale_w, gl.xw), tl1 = wf_tap(a.iw, W, a.scale_w, min(gl.xw + 1, W - 1));
@@ -218,11 +223,17 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
             const vd_tap& xb = eye == 0 ? tl1 : tr1;
             const float vnw = smp(ty0, xa);
             const float vne = g.e_ok ? smp(ty0, xb) : 0.f;
-            float vsw = 0.f, vse = 0.f;
-            if (g.s_ok) { vsw = smp(ty1, xa); vse = g.e_ok ? smp(ty1, xb) : 0.f; }
-            float v = vd_gs_combine(g, vnw, vne, vsw, vse);
+            float v;
+            if (south) {
+              const float vsw = smp(ty1, xa);
+              const float vse = g.e_ok ? smp(ty1, xb) : 0.f;
+              v = vd_gs_combine(g, vnw, vne, vsw, vse);
+            } else {
+              v = vd_fma(vne, g.ne, vnw * g.nw);   // == vd_gs_combine with sw = se = 0 (or no south row)
+            }
             if (a.feather) v = vd_clamp(v * (1.0f - b[eye]) + orig * b[eye], 0.f, 1.f);
-            px[eye][2 - c] = (uint8_t)(v * 255.0f);
+            const uint32_t u = (uint32_t)(uint8_t)(v * 255.0f);
+            if (eye == 0) pL |= u << (8 * (2 - c)); else pR |= u << (8 * (2 - c));
           }
         }
       } else {
@@ -235,35 +246,40 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
             const vd_gs& g = eye == 0 ? gl : gr;
             const float* r0 = pl + (size_t)g.yn * W;
             const float vnw = r0[g.xw], vne = g.e_ok ? r0[g.xw + 1] : 0.f;
-            float vsw = 0.f, vse = 0.f;
-            if (g.s_ok) { vsw = r0[W + g.xw]; vse = g.e_ok ? r0[W + g.xw + 1] : 0.f; }
-            float v = vd_gs_combine(g, vnw, vne, vsw, vse);
+            float v;
+            if (south) {
+              const float vsw = r0[W + g.xw], vse = g.e_ok ? r0[W + g.xw + 1] : 0.f;
+              v = vd_gs_combine(g, vnw, vne, vsw, vse);
+            } else {
+              v = vd_fma(vne, g.ne, vnw * g.nw);
+            }
             if (a.feather) v = vd_clamp(v * (1.0f - b[eye]) + orig * b[eye], 0.f, 1.f);
-            px[eye][2 - c] = (uint8_t)(v * 255.0f);
+            const uint32_t u = (uint32_t)(uint8_t)(v * 255.0f);
+            if (eye == 0) pL |= u << (8 * (2 - c)); else pR |= u << (8 * (2 - c));
           }
         }
       }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {  // byte 3q+c of the 12-byte group
-        const int bi = 3 * q + c;
-        packL[bi >> 2] |= (uint32_t)px[0][c] << (8 * (bi & 3));
-        packR[bi >> 2] |= (uint32_t)px[1][c] << (8 * (bi & 3));
-      }
     }
-  }
-  const int xq = x0 + tq * 4;
-  if (xq + 3 < W && (((size_t)y * W + xq) * 3) % 4 == 0) {
-    uint32_t* pl = reinterpret_cast<uint32_t*>(L + ((size_t)y * W + xq) * 3);
-    uint32_t* pr = reinterpret_cast<uint32_t*>(R + ((size_t)y * W + xq) * 3);
-    pl[0] = packL[0]; pl[1] = packL[1]; pl[2] = packL[2];
-    pr[0] = packR[0]; pr[1] = packR[1]; pr[2] = packR[2];
-  } else {
-    for (int q = 0; q < 4 && xq + q < W; ++q)
-      for (int c = 0; c < 3; ++c) {
-        const int bi = 3 * q + c;
-        L[((size_t)y * W + xq + q) * 3 + c] = (uint8_t)(packL[bi >> 2] >> (8 * (bi & 3)));
-        R[((size_t)y * W + xq + q) * 3 + c] = (uint8_t)(packR[bi >> 2] >> (8 * (bi & 3)));
+    // pack 4 lanes x 3 bytes into 3 dwords (lanes 4j, 4j+1, 4j+2 store) : pX = B | G<<8 | R<<16
+    const uint32_t nL = (uint32_t)__shfl_down((int)pL, 1, 64), nR = (uint32_t)__shfl_down((int)pR, 1, 64);
+    const int q = lane & 3;
+    const int xq = x0 + (lane & ~3);
+    const bool full = (xq + 3 < W) && ((((size_t)y * W + xq) * 3) % 4 == 0);
+    if (full) {
+      if (q < 3) {
+        uint32_t dL, dR;
+        if (q == 0) { dL = pL | (nL << 24); dR = pR | (nR << 24); }
+        else if (q == 1) { dL = (pL >> 8) | (nL << 16); dR = (pR >> 8) | (nR << 16); }
+        else { dL = (pL >> 16) | (nL << 8); dR = (pR >> 16) | (nR << 8); }
+        reinterpret_cast<uint32_t*>(L + ((size_t)y * W + xq) * 3)[q] = dL;
+        reinterpret_cast<uint32_t*>(R + ((size_t)y * W + xq) * 3)[q] = dR;
       }
+    } else if (x < W) {
+      uint8_t* ol = L + ((size_t)y * W + x) * 3;
+      uint8_t* orr = R + ((size_t)y * W + x) * 3;
+      ol[0] = (uint8_t)pL; ol[1] = (uint8_t)(pL >> 8); ol[2] = (uint8_t)(pL >> 16);
+      orr[0] = (uint8_t)pR; orr[1] = (uint8_t)(pR >> 8); orr[2] = (uint8_t)(pR >> 16);
+    }
   }
 }
 
