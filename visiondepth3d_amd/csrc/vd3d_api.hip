@@ -46,6 +46,7 @@ struct vd3d_ctx {
   int dn_cur = 0;
   // warp-res planes
   int H = 0, W = 0;
+  float *dc = nullptr;   // curved depth plane (fused chain)
   float *D = nullptr, *S = nullptr, *e2L = nullptr, *e2R = nullptr, *bL = nullptr, *bR = nullptr;
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
   uint32_t* mm = nullptr; int mm_cap = 0;   // depth hand-off min/max keys [B][3]
@@ -103,7 +104,7 @@ static int ensure_eye(vd3d_ctx* c, int eh, int ew) {
 static int ensure_work(vd3d_ctx* c, int H, int W) {
   if (c->H == H && c->W == W) return 0;
   size_t n = (size_t)H * W;
-  HIPCHK(re_alloc(&c->D, n)); HIPCHK(re_alloc(&c->S, n));
+  HIPCHK(re_alloc(&c->D, n)); HIPCHK(re_alloc(&c->S, n)); HIPCHK(re_alloc(&c->dc, n));
   HIPCHK(re_alloc(&c->e2L, n)); HIPCHK(re_alloc(&c->e2R, n));
   HIPCHK(re_alloc(&c->bL, n)); HIPCHK(re_alloc(&c->bR, n));
   HIPCHK(re_alloc(&c->L, 3 * n)); HIPCHK(re_alloc(&c->R, 3 * n));
@@ -160,7 +161,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -218,6 +219,12 @@ static int check_shift_params(const vd3d_shift_params* p, int H, int W) {
 static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_plane, int ih, int iw, int W, int H,
                               const vd3d_shift_params& sp, vd_stage_args a, bool state_only = false) {
   hipStream_t s = c->stream;
+  if (c->use_fused) {
+    StageTimer t(c, "select_dc");   // fused chain: stage1 (A1), b1 (B1), shape (+A2), b2 (B2)
+    vd_launch_chain_work(s, a.have_eye, a.have_eye ? c->tdf : depth_plane, a.have_eye ? const_cast<float*>(depth_plane) : nullptr,
+                         a.have_eye ? c->dn[c->dn_cur ^ 1] : nullptr, ih, iw, H, W, c->work, (float)sp.depth_pop_mid,
+                         (float)sp.depth_pop_gamma, c->dc, c->D, c->histA, c->histB, a);
+  } else {
   { StageTimer t(c, "select_dc");
     vd_launch_hist_work_dc(s, false, depth_plane, ih, iw, H, W, c->work, c->histA, c->histB);
     if (a.have_eye) vd_launch_hist_eye_subj(s, false, depth_plane, ih, iw, c->work, c->histA, c->histB);
@@ -234,6 +241,7 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     a.stage = VD_ST_A2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
     vd_launch_hist_work_s1(s, true, c->D, H, W, c->work, c->histA, c->histB);
     a.stage = VD_ST_B2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
+  }
   }
   if (!state_only) { StageTimer t(c, "warp");
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
@@ -387,10 +395,16 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   vd_stage_args a;
   memset(&a, 0, sizeof a);
   a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.n_eye = ne;
+  { const char* e = getenv("VD3D_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a.ipd_factor = p->ipd_factor; a.shift = sp;
   float* dn_cur = c->dn[c->dn_cur];
   float* dn_prev = c->dn[c->dn_cur ^ 1];
+  if (c->use_fused) {
+    StageTimer t(c, "select_eye");   // fused chain: ingest (+A0), b0 (B0); eye stats ride on the next launch
+    HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
+    vd_launch_chain_eye(s, frame_bgr, depth, depth_fmt, *p, c->work, c->rgb_eye, c->tdf, c->histA, c->histB, a);
+  } else {
   { StageTimer t(c, "ingest");
     HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
     vd_launch_ingest(s, frame_bgr, depth, depth_fmt, *p, c->work, c->rgb_eye, c->tdf);
@@ -401,6 +415,7 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
     vd_launch_hist_eye_d(s, true, c->tdf, ne, c->work, c->histA, c->histB);
     a.stage = VD_ST_B0; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
     vd_launch_eye_stats(s, c->tdf, dn_cur, dn_prev, p->eye_h, p->eye_w, c->work);
+  }
   }
   rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, state_only);
   if (rc) return rc;

@@ -25,7 +25,12 @@ VD_DEV float vd_linspace(float start, float end, int steps, int i) {
   return vd_fma(-step, (float)(steps - 1 - i), end);
 }
 VD_DEV float vd_lin11(int steps, int i) { return vd_linspace(-1.f, 1.f, steps, i); }
-
+// same value with the (loop-invariant) step hoisted: step = (1 - (-1)) / (float)(steps - 1)
+VD_DEV float vd_lin11_step(float step, int steps, int i) {
+  if (steps == 1) return -1.f;
+  if (i < steps / 2) return vd_fma(step, (float)i, -1.f);
+  return vd_fma(-step, (float)(steps - 1 - i), 1.f);
+}
 // correctly-rounded float32 pow / exp through float64 (device libm is < 1 ULP in float64)
 VD_DEV float vd_pow_cr(float x, float e) { return (float)pow((double)x, (double)e); }
 VD_DEV float vd_exp_cr(float x) { return (float)exp((double)x); }
@@ -52,6 +57,18 @@ VD_DEV vd_tap vd_interp_tap(int in, int out, int o) {
   t.w0 = 1.f - l1;
   return t;
 }
+VD_DEV vd_tap vd_interp_tap_s(int in, int out, float scale, int o) {  // vd_interp_tap with scale = (float)in/(float)out hoisted
+  vd_tap t;
+  if (in == out) { t.i0 = o; t.i1 = o; t.w0 = 1.f; t.w1 = 0.f; return t; }
+  float src = scale * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  int i0 = (int)floorf(src);
+  if (i0 > in - 1) i0 = in - 1;
+  float l1 = vd_clamp(src - (float)i0, 0.f, 1.f);
+  t.i0 = i0; t.i1 = i0 + (i0 < in - 1 ? 1 : 0); t.w1 = l1; t.w0 = 1.f - l1;
+  return t;
+}
+
 // ATen Interpolate<>::eval association: fma(t0,w0,t1*w1), rows then columns
 VD_DEV float vd_bilerp(float p00, float p01, float p10, float p11, float wx0, float wx1, float wy0, float wy1) {
   float a = vd_fma(p00, wx0, wx1 * p01);
@@ -120,4 +137,11 @@ VD_DEV void vd_hist_add_agg(HistPtr hist, unsigned key, bool valid) {
     if (lane == leader) atomicAdd(&hist[lk], (unsigned)__popcll(same));
     mask &= ~same;
   }
+}
+
+// LDS histogram add: a plain returnless ds_add_u32.  Same-address lanes serialise at ~1 lane/clk inside the LDS, so
+// even a fully uniform wave costs ~64 cycles -- cheaper than one round of the ballot/shuffle aggregation above, which
+// is therefore reserved for GLOBAL atomics (pass B), where every conflicting lane would be a separate L2 operation.
+VD_DEV void vd_lds_hist_add(uint32_t* hist, unsigned key, bool valid) {
+  if (valid) atomicAdd(&hist[key], 1u);
 }

@@ -16,6 +16,7 @@ struct vd_stage_args {
   long long n_eye;     // eye_h*eye_w
   long long n_crop;    // centre-crop population of compute_dynamic_parallax_scale
   double ipd_factor;
+  int dbg;             // development probes: bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket + fences
   vd3d_shift_params shift;
 };
 
@@ -36,7 +37,48 @@ VD_DEV float vd_curved_depth(const float* __restrict__ dn, int ih, int iw, int H
   const float curv = 1.f - (xx * xx + yy * yy);
   return vd_clamp(d + curv * (float)0.08, 0.f, 1.f);
 }
+
+// frame_to_tensor / depth_to_tensor (:135-143) + centre crop (:1236-1248) + resize to the eye size (:1262-1263) for one
+// eye-res pixel, and the TemporalDepthFilter update (:225-229) of that pixel in place.  Returns the new filtered value.
+VD_DEV float vd_depth_at(const void* depth, int fmt, size_t idx) {
+  if (fmt == VD3D_DEPTH_F32) return ((const float*)depth)[idx];
+  if (fmt == VD3D_DEPTH_GRAY_U8) return (float)((const uint8_t*)depth)[idx] / 255.0f;
+  const uint8_t* p = (const uint8_t*)depth + idx * 3;  // cv2.COLOR_BGR2GRAY fixed point
+  int g = (p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14;
+  return (float)g / 255.0f;
+}
+VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt, const vd3d_render_params& p,
+                             int tdf_valid, float* __restrict__ rgb_eye, float* __restrict__ tdf, int ey, int ex) {
+  const vd_tap ty = vd_interp_tap(p.crop_h, p.eye_h, ey), tx = vd_interp_tap(p.crop_w, p.eye_w, ex);
+  const size_t i00 = (size_t)(ty.i0 + p.crop_y) * p.src_w + (tx.i0 + p.crop_x);
+  const size_t i01 = (size_t)(ty.i0 + p.crop_y) * p.src_w + (tx.i1 + p.crop_x);
+  const size_t i10 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i0 + p.crop_x);
+  const size_t i11 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i1 + p.crop_x);
+  const size_t ne = (size_t)p.eye_h * p.eye_w, o = (size_t)ey * p.eye_w + ex;
+  if (frame) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // output plane c = R,G,B ; source byte 2-c
+      const int sc = 2 - c;
+      float p00 = (float)frame[i00 * 3 + sc] / 255.0f, p01 = (float)frame[i01 * 3 + sc] / 255.0f;
+      float p10 = (float)frame[i10 * 3 + sc] / 255.0f, p11 = (float)frame[i11 * 3 + sc] / 255.0f;
+      rgb_eye[c * ne + o] = vd_bilerp(p00, p01, p10, p11, tx.w0, tx.w1, ty.w0, ty.w1);
+    }
+  }
+  const float cur = vd_bilerp(vd_depth_at(depth, fmt, i00), vd_depth_at(depth, fmt, i01), vd_depth_at(depth, fmt, i10),
+                              vd_depth_at(depth, fmt, i11), tx.w0, tx.w1, ty.w0, ty.w1);
+  const float prev = tdf_valid ? tdf[o] : cur;
+  const float nv = 0.5f * prev + (float)(1 - 0.5) * cur;
+  tdf[o] = nv;
+  return nv;
+}
 #endif
+
+// ---- vd3d_select.hip (fused chain)
+void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w,
+                         float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a);
+void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
+                          vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
+                          const vd_stage_args& a);
 
 // ---- vd3d_select.hip
 void vd_launch_hist_eye_d(hipStream_t s, bool passB, const float* tdf, long long n, vd_dev_work* w, uint32_t* histA, uint32_t* histB);

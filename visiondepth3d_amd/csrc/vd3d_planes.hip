@@ -12,38 +12,13 @@
 // ------------------------------------------------------------------------------------------------
 // ingest: uint8 frame + depth -> eye-res float planes, temporal filter in place
 // ------------------------------------------------------------------------------------------------
-VD_DEV float depth_at(const void* depth, int fmt, size_t idx) {
-  if (fmt == VD3D_DEPTH_F32) return ((const float*)depth)[idx];
-  if (fmt == VD3D_DEPTH_GRAY_U8) return (float)((const uint8_t*)depth)[idx] / 255.0f;
-  const uint8_t* p = (const uint8_t*)depth + idx * 3;  // cv2.COLOR_BGR2GRAY fixed point
-  int g = (p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14;
-  return (float)g / 255.0f;
-}
-
 __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt,
                                                 vd3d_render_params p, const vd_dev_work* __restrict__ w,
                                                 float* __restrict__ rgb_eye, float* __restrict__ tdf) {
   const int ex = blockIdx.x * 32 + (threadIdx.x & 31);
   const int ey = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (ex >= p.eye_w || ey >= p.eye_h) return;
-  const vd_tap ty = vd_interp_tap(p.crop_h, p.eye_h, ey), tx = vd_interp_tap(p.crop_w, p.eye_w, ex);
-  const size_t i00 = (size_t)(ty.i0 + p.crop_y) * p.src_w + (tx.i0 + p.crop_x);
-  const size_t i01 = (size_t)(ty.i0 + p.crop_y) * p.src_w + (tx.i1 + p.crop_x);
-  const size_t i10 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i0 + p.crop_x);
-  const size_t i11 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i1 + p.crop_x);
-  const size_t ne = (size_t)p.eye_h * p.eye_w, o = (size_t)ey * p.eye_w + ex;
-  if (frame)
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {  // output plane c = R,G,B ; source byte 2-c
-    const int sc = 2 - c;
-    float p00 = (float)frame[i00 * 3 + sc] / 255.0f, p01 = (float)frame[i01 * 3 + sc] / 255.0f;
-    float p10 = (float)frame[i10 * 3 + sc] / 255.0f, p11 = (float)frame[i11 * 3 + sc] / 255.0f;
-    rgb_eye[c * ne + o] = vd_bilerp(p00, p01, p10, p11, tx.w0, tx.w1, ty.w0, ty.w1);
-  }
-  float cur = vd_bilerp(depth_at(depth, fmt, i00), depth_at(depth, fmt, i01), depth_at(depth, fmt, i10),
-                        depth_at(depth, fmt, i11), tx.w0, tx.w1, ty.w0, ty.w1);
-  const float prev = w->st.tdf_valid ? tdf[o] : cur;
-  tdf[o] = 0.5f * prev + (float)(1 - 0.5) * cur;
+  vd_ingest_pixel(frame, depth, fmt, p, w->st.tdf_valid, rgb_eye, tdf, ey, ex);
 }
 
 void vd_launch_ingest(hipStream_t s, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params& p,
@@ -65,7 +40,7 @@ __global__ __launch_bounds__(256) void k_eye_stats(const float* __restrict__ tdf
     const float d = vd_clamp(tdf[i], 0.f, 1.f);
     const float v = collapse ? d : vd_clamp((d - lo) / den, 0.f, 1.f);
     dn_cur[i] = v;
-    const int y = (int)(i / ew), x = (int)(i - (long long)y * ew);
+    const int y = (int)((unsigned)i / (unsigned)ew), x = (int)((unsigned)i - (unsigned)y * (unsigned)ew);
     if (y >= eh / 4 && y < eh * 3 / 4 && x >= ew / 4 && x < ew * 3 / 4) {
       const double dv = (double)v;
       s1 += vd_fx40(dv);

@@ -39,8 +39,8 @@ __global__ __launch_bounds__(1024) void k_hist_a(F f, uint32_t* __restrict__ his
     if (i < n) f.get(i, v, in_all, in_crop);
     unsigned key = __float_as_uint(v) >> 16;
     key = key < (NBL - 1) ? key : (NBL - 1);
-    if (J_ALL >= 0) vd_hist_add_agg(h0, key, in_all);
-    if (J_CROP >= 0) vd_hist_add_agg(h1, key, in_crop);
+    if (J_ALL >= 0) vd_lds_hist_add(h0, key, in_all);
+    if (J_CROP >= 0) vd_lds_hist_add(h1, key, in_crop);
   }
   __syncthreads();
   for (int b = tid; b < NBL; b += 1024) {
@@ -101,7 +101,7 @@ struct FPlaneSubj {  // a stored plane, masked centre crop membership (estimate_
   VD_DEV long long count() const { return (long long)H * W; }
   VD_DEV void get(long long i, float& v, bool& in_all, bool& in_crop) const {
     v = p[i];
-    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    const int y = (int)((unsigned)i / (unsigned)W), x = (int)((unsigned)i - (unsigned)y * (unsigned)W);
     in_all = false; in_crop = vd_in_subject_crop(y, x, H, W, v);
   }
 };
@@ -109,7 +109,7 @@ struct FWorkDc {  // curved depth at warp resolution, recomputed from the eye-re
   const float* dn; int ih, iw, H, W;
   VD_DEV long long count() const { return (long long)H * W; }
   VD_DEV void get(long long i, float& v, bool& in_all, bool& in_crop) const {
-    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    const int y = (int)((unsigned)i / (unsigned)W), x = (int)((unsigned)i - (unsigned)y * (unsigned)W);
     v = vd_curved_depth(dn, ih, iw, H, W, y, x);
     in_all = true; in_crop = vd_in_subject_crop(y, x, H, W, v);
   }
@@ -382,16 +382,23 @@ VD_DEV void shift_scalars(vd_dev_work* w, const vd3d_shift_params& p, int W, flo
 // ------------------------------------------------------------------------------------------------
 // the scalar stage kernel: one workgroup, runs between plane passes
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uint32_t* __restrict__ histA,
-                                                       const uint32_t* __restrict__ histB, vd_stage_args a) {
-  __shared__ uint32_t sm[128];
+VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32_t* histB, const vd_stage_args& a, uint32_t* sm) {
   const int tid = threadIdx.x;
+  // The select control blocks live in LDS for the duration of the stage: the scans' rank/target bookkeeping is a chain
+  // of dependent single-thread accesses, ~1 us each against global memory (measured: 15 us per stage before).
+  __shared__ vd_sel_ctl lcs[VD_NJOBS];
+  {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(&w->job[0]);
+    uint32_t* l = reinterpret_cast<uint32_t*>(&lcs[0]);
+    for (int i = tid; i < (int)(sizeof(lcs) / 4); i += blockDim.x) l[i] = g[i];
+  }
+  __syncthreads();
   switch (a.stage) {
     case VD_ST_A0:
-      scan_a_job(&w->job[VD_J_EYE_Q], histA + (size_t)VD_J_EYE_Q * VD_NB_A, SEL_QUANT, (float)0.02, (float)0.98, sm);
+      scan_a_job(&lcs[VD_J_EYE_Q], histA + (size_t)VD_J_EYE_Q * VD_NB_A, SEL_QUANT, (float)0.02, (float)0.98, sm);
       break;
     case VD_ST_B0: {
-      vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
+      vd_sel_ctl* c = &lcs[VD_J_EYE_Q];
       scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {  // DepthPercentileEMA.normalize :249-261
         float lo = quantile_lerp(c->val[0], c->val[1], c->w[0]);
@@ -417,20 +424,20 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
       }
     } break;
     case VD_ST_A1:
-      if (a.have_eye) scan_a_job(&w->job[VD_J_EYE_SUBJ], histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
-      scan_a_job(&w->job[VD_J_WORK_Q], histA + (size_t)VD_J_WORK_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
+      if (a.have_eye) scan_a_job(&lcs[VD_J_EYE_SUBJ], histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      scan_a_job(&lcs[VD_J_WORK_Q], histA + (size_t)VD_J_WORK_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
                  (float)a.shift.depth_stretch_hi, sm);
-      scan_a_job(&w->job[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      scan_a_job(&lcs[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
       break;
     case VD_ST_B1: {
-      if (a.have_eye) scan_b_job(&w->job[VD_J_EYE_SUBJ], histB + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_BC, sm);
-      scan_b_job(&w->job[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_BC, sm);
-      scan_b_job(&w->job[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_BC, sm);
+      if (a.have_eye) scan_b_job(&lcs[VD_J_EYE_SUBJ], histB + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_BC, sm);
+      scan_b_job(&lcs[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_BC, sm);
+      scan_b_job(&lcs[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
-        vd_sel_ctl* cq = &w->job[VD_J_WORK_Q];
+        vd_sel_ctl* cq = &lcs[VD_J_WORK_Q];
         const float lo = quantile_lerp(cq->val[0], cq->val[1], cq->w[0]);
         const float hi = quantile_lerp(cq->val[2], cq->val[3], cq->w[1]);
-        const float s0 = subject_from_job(&w->job[VD_J_WORK_S0]);
+        const float s0 = subject_from_job(&lcs[VD_J_WORK_S0]);
         w->fs.q05 = lo; w->fs.q95 = hi; w->fs.s0 = s0;
         // shape_depth_for_pop constants :536-553
         const int stretch = !((hi - lo) < 1e-5f);
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
         w->shp_subj_s = stretch ? vd_clamp((subj - lo) / den, 0.f, 1.f) : subj;
         if (a.have_eye) {
           vd3d_state* st = &w->st;
-          w->fs.s_norm = subject_from_job(&w->job[VD_J_EYE_SUBJ]);
+          w->fs.s_norm = subject_from_job(&lcs[VD_J_EYE_SUBJ]);
           // compute_dynamic_parallax_scale :412-427 from the exact fixed-point sums
           const double n = (double)a.n_crop;
           const double s1d = (double)w->sum1 / VD_FX, s2d = (double)w->sum2 / VD_FX;
@@ -480,11 +487,11 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
       }
     } break;
     case VD_ST_AQ:
-      scan_a_job(&w->job[VD_J_EYE_Q], histA + (size_t)VD_J_EYE_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
+      scan_a_job(&lcs[VD_J_EYE_Q], histA + (size_t)VD_J_EYE_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
                  (float)a.shift.depth_stretch_hi, sm);
       break;
     case VD_ST_BQ: {
-      vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
+      vd_sel_ctl* c = &lcs[VD_J_EYE_Q];
       scan_b_job(c, histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
         w->fs.q_lo = quantile_lerp(c->val[0], c->val[1], c->w[0]);
@@ -492,16 +499,16 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
       }
     } break;
     case VD_ST_BS:
-      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
-      if (tid == 0) w->fs.s1 = subject_from_job(&w->job[VD_J_WORK_S1]);
+      scan_b_job(&lcs[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
+      if (tid == 0) w->fs.s1 = subject_from_job(&lcs[VD_J_WORK_S1]);
       break;
     case VD_ST_A2:
-      scan_a_job(&w->job[VD_J_WORK_S1], histA + (size_t)VD_J_WORK_S1 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      scan_a_job(&lcs[VD_J_WORK_S1], histA + (size_t)VD_J_WORK_S1 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
       break;
     case VD_ST_B2: {
-      scan_b_job(&w->job[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
+      scan_b_job(&lcs[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
-        const float s1 = subject_from_job(&w->job[VD_J_WORK_S1]);
+        const float s1 = subject_from_job(&lcs[VD_J_WORK_S1]);
         w->fs.s1 = s1;
         shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);
         if (a.have_eye) {  // floating-window bars :1390-1403
@@ -527,8 +534,316 @@ __global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uin
       }
     } break;
   }
+  __syncthreads();
+  {
+    uint32_t* g = reinterpret_cast<uint32_t*>(&w->job[0]);
+    const uint32_t* l = reinterpret_cast<const uint32_t*>(&lcs[0]);
+    for (int i = tid; i < (int)(sizeof(lcs) / 4); i += blockDim.x) g[i] = l[i];
+  }
+}
+
+
+__global__ __launch_bounds__(1024) void k_scalar_stage(vd_dev_work* w, const uint32_t* __restrict__ histA,
+                                                       const uint32_t* __restrict__ histB, vd_stage_args a) {
+  __shared__ uint32_t sm[128];
+  run_scalar_stage(w, histA, histB, a, sm);
 }
 
 void vd_launch_scalar_stage(hipStream_t s, vd_dev_work* w, const uint32_t* histA, const uint32_t* histB, const vd_stage_args& a) {
   hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(1024), 0, s, w, histA, histB, a);
+}
+
+
+// ================================================================================================
+// Fused select chain (default path): pass-A histograms ride on the producer kernels, eye-res and warp-res work share
+// one launch, and the scan + scalar stage that used to be a separate 1-workgroup launch is executed by the LAST
+// workgroup to finish (agent-scope release -> ticket -> acquire, cdna_hip_programming.md Guideline 16).
+// Per frame: 6 launches instead of 17 for everything up to the shift plane.
+// ================================================================================================
+// last-arrival ticket: returns true (workgroup-uniformly) in exactly one workgroup, after every other workgroup's
+// global writes/atomics are visible to it.
+VD_DEV bool last_workgroup(uint32_t* counter, uint32_t* sflag, int dbg = 0) {
+  if (dbg & 2) return false;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores / returnless atomics have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ROCm 7.2 may drop the wait after buffer_wbl2: restate it
+    const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t last = (t == gridDim.x - 1) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next frame
+    }
+    *sflag = last;
+  }
+  __syncthreads();
+  return *sflag != 0u;
+}
+
+VD_DEV void lds_hist_flush(const uint32_t* h, uint32_t* g) {
+  for (int b = threadIdx.x; b < NBL; b += blockDim.x) { const uint32_t c = h[b]; if (c) atomicAdd(&g[b], c); }
+}
+VD_DEV unsigned key_a(float v) { unsigned k = __float_as_uint(v) >> 16; return k < (NBL - 1) ? k : (NBL - 1); }
+
+// K1: ingest (+ TemporalDepthFilter) + pass A of J0; last workgroup: scan A0
+__global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt,
+                                                       vd3d_render_params p, vd_dev_work* w, float* __restrict__ rgb_eye,
+                                                       float* __restrict__ tdf, uint32_t* histA, const uint32_t* histB,
+                                                       vd_stage_args a) {
+  __shared__ uint32_t h0[NBL];
+  __shared__ uint32_t sm[128];
+  for (int b = threadIdx.x; b < NBL; b += 1024) h0[b] = 0;
+  __syncthreads();
+  const long long n = (long long)p.eye_h * p.eye_w;
+  const int tdf_valid = w->st.tdf_valid;
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+    const long long i = base + threadIdx.x;
+    float v = 0.f;
+    if (i < n) {
+      const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
+      v = vd_ingest_pixel(frame, depth, fmt, p, tdf_valid, rgb_eye, tdf, ey, ex);
+    }
+    vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
+  }
+  __syncthreads();
+  lds_hist_flush(h0, histA + (size_t)VD_J_EYE_Q * VD_NB_A);
+  if (last_workgroup(&w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A0; run_scalar_stage(w, histA, histB, a, sm); }
+}
+
+// K2: pass B of J0; last workgroup: scan B0 + DepthPercentileEMA
+__global__ __launch_bounds__(1024) void k_chain_b0(const float* __restrict__ tdf, long long n, vd_dev_work* w, const uint32_t* histA,
+                                                   uint32_t* histB, vd_stage_args a) {
+  __shared__ uint32_t sm[128];
+  const vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
+  const uint32_t nt = c->ntargets;
+  uint32_t tp[VD_MAX_T];
+  for (int t = 0; t < VD_MAX_T; ++t) tp[t] = c->tprefix[t];
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+    const long long i = base + threadIdx.x;
+    const unsigned bits = i < n ? __float_as_uint(vd_clamp(tdf[i], 0.f, 1.f)) : 0u;
+    bool hit = false; unsigned key = 0;
+    for (uint32_t t = 0; t < nt; ++t) if (i < n && (bits >> 16) == tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
+    vd_hist_add_agg(histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, key, hit);
+    vd_hist_add_agg(vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, key >> 8, hit);
+  }
+  if (last_workgroup(&w->ticket[1], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B0; run_scalar_stage(w, histA, histB, a, sm); }
+}
+
+// curved depth at warp resolution straight from the filtered plane (normalisation recomputed per tap, so this
+// does not depend on the dn plane another workgroup of the same launch is writing) or from a given plane (B1 API)
+struct FWorkSrc {
+  const float* src; int ih, iw, H, W, norm, collapse; float lo, den;
+  float scale_h, scale_w, step_x, step_y;   // hoisted loop invariants (same float32 expressions as vd_interp_tap / vd_lin11)
+  VD_DEV float tap(size_t idx) const {
+    float d = src[idx];
+    if (!norm) return d;
+    d = vd_clamp(d, 0.f, 1.f);
+    return collapse ? d : vd_clamp((d - lo) / den, 0.f, 1.f);
+  }
+  VD_DEV float at(int y, int x) const {
+    float d;
+    if (ih == H && iw == W) d = tap((size_t)y * W + x);
+    else {
+      const vd_tap ty = vd_interp_tap_s(ih, H, scale_h, y), tx = vd_interp_tap_s(iw, W, scale_w, x);
+      d = vd_bilerp(tap((size_t)ty.i0 * iw + tx.i0), tap((size_t)ty.i0 * iw + tx.i1), tap((size_t)ty.i1 * iw + tx.i0),
+                    tap((size_t)ty.i1 * iw + tx.i1), tx.w0, tx.w1, ty.w0, ty.w1);
+    }
+    const float xx = vd_lin11_step(step_x, W, x), yy = vd_lin11_step(step_y, H, y);
+    const float curv = 1.f - (xx * xx + yy * yy);
+    return vd_clamp(d + curv * (float)0.08, 0.f, 1.f);
+  }
+};
+
+// K3: [eye workgroups] normalise + centre-crop sums + MAD + pass A of J1   |   [work workgroups] pass A of J2 + J3
+//     last workgroup: scan A1.   n_eye_wg = 0 for the bare pixel_shift_cuda entry point.
+__global__ __launch_bounds__(1024) void k_chain_stage1(const float* __restrict__ tdf, float* __restrict__ dn_cur,
+                                                       const float* __restrict__ dn_prev, int eh, int ew, int n_eye_wg,
+                                                       FWorkSrc f, float* __restrict__ dc, vd_dev_work* w, uint32_t* histA,
+                                                       const uint32_t* histB, vd_stage_args a) {
+  __shared__ uint32_t h0[NBL];
+  __shared__ uint32_t h1[NBL];
+  __shared__ uint32_t sm[128];
+  __shared__ long long part[3][16];
+  if (f.norm) { f.lo = w->ema_lo; f.den = w->ema_den; f.collapse = w->collapse; }  // device scalars from stage B0
+  for (int b = threadIdx.x; b < NBL; b += 1024) { h0[b] = 0; h1[b] = 0; }
+  __syncthreads();
+  if ((int)blockIdx.x < n_eye_wg) {
+    const long long n = (long long)eh * ew;
+    const float lo = w->ema_lo, den = w->ema_den;
+    const int collapse = w->collapse, have_prev = w->st.prev_depth_valid;
+    long long s1 = 0, s2 = 0, sd = 0;
+    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)n_eye_wg * 1024) {
+      const long long i = base + threadIdx.x;
+      float v = 0.f; bool in_crop = false;
+      if (i < n) {
+        const float d = vd_clamp(tdf[i], 0.f, 1.f);
+        v = collapse ? d : vd_clamp((d - lo) / den, 0.f, 1.f);
+        dn_cur[i] = v;
+        const int y = (int)((unsigned)i / (unsigned)ew), x = (int)((unsigned)i - (unsigned)y * (unsigned)ew);
+        if (y >= eh / 4 && y < eh * 3 / 4 && x >= ew / 4 && x < ew * 3 / 4) {
+          const double dv = (double)v;
+          s1 += vd_fx40(dv); s2 += vd_fx40(dv * dv);
+        }
+        if (have_prev) sd += vd_fx40((double)fabsf(v - dn_prev[i]));
+        in_crop = vd_in_subject_crop(y, x, eh, ew, v);
+      }
+      vd_lds_hist_add(h1, key_a(v), in_crop);
+    }
+    s1 = vd_wave_sum_ll(s1); s2 = vd_wave_sum_ll(s2); sd = vd_wave_sum_ll(sd);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s1; part[1][threadIdx.x >> 6] = s2; part[2][threadIdx.x >> 6] = sd; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      long long v = 0;
+      for (int i = 0; i < 16; ++i) v += part[threadIdx.x][i];
+      long long* dst = threadIdx.x == 0 ? &w->sum1 : (threadIdx.x == 1 ? &w->sum2 : &w->sum_mad);
+      if (v) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
+    }
+    lds_hist_flush(h1, histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A);
+  } else {
+    const long long n = (long long)f.H * f.W;
+    const int nwg = (int)gridDim.x - n_eye_wg, wg = (int)blockIdx.x - n_eye_wg;
+    for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
+      const long long i = base + threadIdx.x;
+      float v = 0.f; bool in_crop = false;
+      if (i < n) {
+        const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W);
+        v = f.at(y, x);
+        dc[i] = v;   // curved depth plane: pass B and the shape kernel stream it instead of re-deriving it from 4 taps
+        in_crop = vd_in_subject_crop(y, x, f.H, f.W, v);
+      }
+      const unsigned key = key_a(v);
+      vd_lds_hist_add(h0, key, i < n);
+      vd_lds_hist_add(h1, key, in_crop);
+    }
+    __syncthreads();
+    lds_hist_flush(h0, histA + (size_t)VD_J_WORK_Q * VD_NB_A);
+    lds_hist_flush(h1, histA + (size_t)VD_J_WORK_S0 * VD_NB_A);
+  }
+  if (last_workgroup(&w->ticket[2], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A1; run_scalar_stage(w, histA, histB, a, sm); }
+}
+
+struct vd_targets { uint32_t nt, tp[VD_MAX_T]; };
+VD_DEV vd_targets load_targets(const vd_sel_ctl* c) {
+  vd_targets t; t.nt = c->ntargets;
+  for (int i = 0; i < VD_MAX_T; ++i) t.tp[i] = c->tprefix[i];
+  return t;
+}
+VD_DEV void hist_b_add(uint32_t* histB, int job, const vd_targets& c, float v, bool member) {
+  const unsigned bits = __float_as_uint(v);
+  bool hit = false; unsigned key = 0;
+  for (uint32_t t = 0; t < c.nt; ++t) if (member && (bits >> 16) == c.tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
+  vd_hist_add_agg(histB + (size_t)job * VD_MAX_T * VD_NB_B, key, hit);
+  vd_hist_add_agg(vd_histbc(histB) + (size_t)job * VD_MAX_T * VD_NB_BC, key >> 8, hit);
+}
+
+// K4: [eye] pass B of J1 on the stored dn plane | [work] pass B of J2 + J3 ; last workgroup: scan B1 + its scalar stage
+__global__ __launch_bounds__(1024) void k_chain_b1(const float* __restrict__ dn_cur, int eh, int ew, int n_eye_wg, FWorkSrc f,
+                                                   const float* __restrict__ dc, vd_dev_work* w, const uint32_t* histA,
+                                                   uint32_t* histB, vd_stage_args a) {
+  __shared__ uint32_t sm[128];
+  const vd_targets t_eye = load_targets(&w->job[VD_J_EYE_SUBJ]), t_q = load_targets(&w->job[VD_J_WORK_Q]),
+                   t_s0 = load_targets(&w->job[VD_J_WORK_S0]);
+  if ((int)blockIdx.x < n_eye_wg) {
+    const long long n = (long long)eh * ew;
+    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)n_eye_wg * 1024) {
+      const long long i = base + threadIdx.x;
+      float v = 0.f; bool in_crop = false;
+      if (i < n) { v = dn_cur[i]; const int y = (int)((unsigned)i / (unsigned)ew), x = (int)((unsigned)i - (unsigned)y * (unsigned)ew); in_crop = vd_in_subject_crop(y, x, eh, ew, v); }
+      hist_b_add(histB, VD_J_EYE_SUBJ, t_eye, v, in_crop);
+    }
+  } else {
+    const long long n = (long long)f.H * f.W;
+    const int nwg = (int)gridDim.x - n_eye_wg, wg = (int)blockIdx.x - n_eye_wg;
+    for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
+      const long long i = base + threadIdx.x;
+      float v = 0.f; bool in_crop = false;
+      if (i < n) { const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W); v = dc[i]; in_crop = vd_in_subject_crop(y, x, f.H, f.W, v); }
+      hist_b_add(histB, VD_J_WORK_Q, t_q, v, i < n);
+      hist_b_add(histB, VD_J_WORK_S0, t_s0, v, in_crop);
+    }
+  }
+  if (last_workgroup(&w->ticket[3], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B1; run_scalar_stage(w, histA, histB, a, sm); }
+}
+
+// K5: shape_depth_for_pop -> D plane + pass A of J4 ; last workgroup: scan A2
+__global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* __restrict__ dc, vd_dev_work* w, float mid, float gamma,
+                                                      float* __restrict__ D,
+                                                      uint32_t* histA, const uint32_t* histB, vd_stage_args a) {
+  __shared__ uint32_t h1[NBL];
+  __shared__ uint32_t sm[128];
+  for (int b = threadIdx.x; b < NBL; b += 1024) h1[b] = 0;
+  __syncthreads();
+  const long long n = (long long)f.H * f.W;
+  const int stretch = w->shp_stretch;
+  const float lo = w->shp_lo, den = w->shp_den, subj_s = w->shp_subj_s;
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+    const long long i = base + threadIdx.x;
+    float v = 0.f; bool in_crop = false;
+    if (i < n) {
+      const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W);
+      const float d = dc[i];
+      const float ds = stretch ? vd_clamp((d - lo) / den, 0.f, 1.f) : d;
+      const float centered = (ds - subj_s) + mid;
+      const float t = centered - mid;
+      const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+      v = vd_clamp(sgn * vd_pow_cr(fabsf(t), gamma) + mid, 0.f, 1.f);
+      D[i] = v;
+      in_crop = vd_in_subject_crop(y, x, f.H, f.W, v);
+    }
+    vd_lds_hist_add(h1, key_a(v), in_crop);
+  }
+  __syncthreads();
+  lds_hist_flush(h1, histA + (size_t)VD_J_WORK_S1 * VD_NB_A);
+  if (last_workgroup(&w->ticket[4], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A2; run_scalar_stage(w, histA, histB, a, sm); }
+}
+
+// K6: pass B of J4 on the D plane ; last workgroup: scan B2 + tracker recurrences
+__global__ __launch_bounds__(1024) void k_chain_b2(const float* __restrict__ D, int H, int W, vd_dev_work* w, const uint32_t* histA,
+                                                   uint32_t* histB, vd_stage_args a) {
+  __shared__ uint32_t sm[128];
+  const long long n = (long long)H * W;
+  const vd_targets t_s1 = load_targets(&w->job[VD_J_WORK_S1]);
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+    const long long i = base + threadIdx.x;
+    float v = 0.f; bool in_crop = false;
+    if (i < n) { v = D[i]; const int y = (int)((unsigned)i / (unsigned)W), x = (int)((unsigned)i - (unsigned)y * (unsigned)W); in_crop = vd_in_subject_crop(y, x, H, W, v); }
+    hist_b_add(histB, VD_J_WORK_S1, t_s1, v, in_crop);
+  }
+  if (last_workgroup(&w->ticket[5], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B2; run_scalar_stage(w, histA, histB, a, sm); }
+}
+
+static inline int chain_grid(long long n, int per_wg, int cap) {
+  long long g = (n + per_wg - 1) / per_wg;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w,
+                         float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a) {
+  const long long ne = (long long)p.eye_h * p.eye_w;
+  hipLaunchKernelGGL(k_chain_ingest, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, frame, depth, fmt, p, w, rgb_eye, tdf, histA,
+                     histB, a);
+  hipLaunchKernelGGL(k_chain_b0, dim3(chain_grid(ne, 4096, 256)), dim3(1024), 0, s, tdf, ne, w, histA, histB, a);
+}
+
+// src = the filtered plane (render path: have_eye) or the caller's depth plane (bare pixel_shift_cuda)
+void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
+                          vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
+                          const vd_stage_args& a) {
+  FWorkSrc f;
+  f.src = src; f.ih = ih; f.iw = iw; f.H = H; f.W = W; f.norm = have_eye ? 1 : 0; f.collapse = 0; f.lo = 0.f; f.den = 1.f;
+  f.scale_h = (float)ih / (float)H; f.scale_w = (float)iw / (float)W;
+  f.step_x = W > 1 ? (1.f - (-1.f)) / (float)(W - 1) : 0.f; f.step_y = H > 1 ? (1.f - (-1.f)) / (float)(H - 1) : 0.f;
+  const long long ne = (long long)ih * iw, n = (long long)H * W;
+  const int eye_wg = have_eye ? chain_grid(ne, 4096, 128) : 0;
+  const int work_wg = chain_grid(n, 8192, 256);     // K3: 130 KB of LDS histograms -> one resident workgroup per CU
+  const int eye_wg_b = eye_wg;
+  const int work_wg_b = chain_grid(n, 4096, 512);   // K4: streams the stored curved-depth plane (each workgroup pays one release fence)
+  // K3's warp-res workgroups must not read the dn plane its eye-res workgroups are writing: they read the filtered plane
+  // and apply the (device-scalar) normalisation per tap; K4/K5 read the stored plane, complete by then.
+  hipLaunchKernelGGL(k_chain_stage1, dim3(eye_wg + work_wg), dim3(1024), 0, s, src, dn_cur, dn_prev, ih, iw, eye_wg, f, dc, w, histA, histB, a);
+  f.src = have_eye ? dn_cur : src; f.norm = 0;
+  hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b), dim3(1024), 0, s, dn_cur, ih, iw, eye_wg_b, f, dc, w, histA, histB, a);
+  hipLaunchKernelGGL(k_chain_shape, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, f, dc, w, mid, gamma, D, histA, histB, a);
+  hipLaunchKernelGGL(k_chain_b2, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, D, H, W, w, histA, histB, a);
 }

@@ -37,6 +37,7 @@ struct vd_dev_work {
   vd3d_state st;
   vd3d_frame_scalars fs;
   vd_sel_ctl job[VD_NJOBS];
+  uint32_t ticket[8];             // last-workgroup arrival counters of the fused chain kernels (self re-arming)
   long long sum1, sum2, sum_mad;  // 2^-40 fixed-point sums (centre crop of the normalised depth; |d_t - d_{t-1}|)
   // constants derived by the scalar stages, consumed by the plane kernels
   float ema_lo, ema_den;
