@@ -8,10 +8,10 @@ depth inference (workloads with a depth net) -> 8-bit depth hand-off -> the per-
 (ingest, exact order statistics, shaping, warp + feather, DOF, grade, sharpen, Half-SBS mux) -> muxed
 frames in HBM.  Default workload = BASELINE.json configs[1] (1080p, Depth-Anything-V2-Small + DIBR).
 For N > 1 the driver launches one rank per GPU with torch.distributed.run and the frames of ONE clip are sharded
-round-robin (frame t -> rank t % N, visiondepth3d_amd/sharded.py): each rank runs depth inference and the pixel
-kernels for its own frames; the only data-path collective is an RCCL all-gather of the uint8 depth planes, after
-which every rank advances the (sequential) temporal-tracker state over all frames with vd3d_advance_state, so
-the output is bit-identical to the 1-GPU render.  Weak scaling: B frames per rank per step.  The timed region is
+round-robin (frame t -> rank t % N, visiondepth3d_amd/sharded.py StepShardedRenderer): each rank runs depth inference
+and the pixel kernels for its own frames; the data-path collectives are an RCCL all-gather of the uint8 depth planes
+and an all-gather of one float (s1) per frame; every rank runs the cheap eye-res chain for all frames and replays the
+tracker, so the output is bit-identical to the 1-GPU render.  Weak scaling: B frames per rank per step.  The timed region is
 bracketed by barrier + synchronize and the MAX over ranks is reported.
 """
 from __future__ import annotations
@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--clip", type=int, default=16, help="distinct synthetic frames resident in HBM (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
+    ap.add_argument("--sharded", action="store_true", help="use the three-phase sharding protocol even at N=1 (it is the N>1 path)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     args = ap.parse_args()
@@ -109,6 +110,11 @@ def main():
     depths = torch.stack([torch.from_numpy(d) for d in depths_np]).cuda()          # [C,h,w] f32
     outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
 
+    shr = None
+    if world > 1 or args.sharded:
+        from visiondepth3d_amd.sharded import StepShardedRenderer
+        shr = StepShardedRenderer(r, p, rank, world, B)
+
     pipe = None
     if model_name:
         from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
@@ -118,7 +124,7 @@ def main():
     gathered = [torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if world > 1 else None
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     done = [torch.cuda.Event() for _ in range(NBUF)]
-    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and world > 1 else None
+    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded) else None
 
     def step(i):
         # this rank's B frames of the step; global frame order inside a step: (j, g) for j in range(B) for g in range(world)
@@ -132,25 +138,25 @@ def main():
             dloc = rh.depth_handoff(pred, sh, sw, out=dbuf[k])  # the reference's 8-bit depth hand-off (a24), fused, no disk hop
         else:
             dloc = None
+        if shr is not None and dloc is None:
+            dloc = depths_u8[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else depths_u8[idx]
         if world > 1:
-            if dloc is None:
-                dloc = depths_u8[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else depths_u8[idx]
-            dist.all_gather_into_tensor(gathered[k], dloc.contiguous())   # the one data-path collective: [world*B,h,w] u8
+            dist.all_gather_into_tensor(gathered[k], dloc.contiguous())   # data-path collective 1: uint8 depth planes [world*B,h,w]
         if overlap:  # hand the batch to the DIBR stream; this (torch) stream goes on to the next batch's depth inference
             ev = torch.cuda.Event()
             ev.record()
             dibr_stream.wait_event(ev)
-        if world == 1:
+        if shr is None:
             for j in range(B):
                 r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs[j])
-        else:
-            for j in range(B):
-                for g in range(world):
-                    d = gathered[k][g * B + j]
-                    if g == rank:
-                        r.render_frame(fb[j], d, p, out=outs[j])
-                    else:
-                        r.advance_state(d, p)
+        else:  # three-phase sharding: pass 1 over all world*B frames, s1 exchange (collective 2: B floats per rank), replay, pixels
+            shr.pass1(fb, gathered[k] if world > 1 else dloc)
+            if overlap:
+                with torch.cuda.stream(dibr_stream):
+                    s1_all = shr.gather(shr.s1_local)
+            else:
+                s1_all = shr.gather(shr.s1_local)
+            shr.finish(s1_all, outs)
         if overlap:
             done[k].record(dibr_stream)
 
@@ -209,7 +215,8 @@ def main():
             "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)",
             "config": {"workload": args.workload, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
                        "frames_per_step": B, "depth_model": model_name,
-                       "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes + vd3d_advance_state (bit-identical to 1 GPU)",
+                       "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes, eye-res chain on every rank, all-gather of s1, "
+                                   "tracker replay, pixel pass on the owner (bit-identical to 1 GPU)",
                        "params": "render_cli.py defaults + dof_strength 2.0"},
         }
         if stage_ms:

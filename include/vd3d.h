@@ -194,6 +194,19 @@ int vd3d_render_frame(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth
  * every rank advances over all frames, and renders only its own. */
 int vd3d_advance_state(vd3d_ctx* ctx, const void* depth, int depth_fmt, const vd3d_render_params* p);
 
+/* ---- frame sharding, three-phase protocol (one clip over G GPUs, bit-identical to 1 GPU) -------------
+ * A "step" is a window of n <= 512 consecutive frames dealt round-robin to the ranks.  Every rank calls
+ *   vd3d_shard_pass1 for EVERY frame of the step in order (slot >= 0 for its own frames, -1 for foreign ones: only the
+ *     depth plane is needed there and only the cheap eye-res chain runs, so all eye-res trackers advance identically),
+ *   exchanges the measured s1 of its frames (one float per frame; all-gather over RCCL),
+ *   vd3d_shard_pass2 to replay the FloatingWindowTracker over the whole step from the gathered s1 values,
+ *   vd3d_shard_pixels for each of its own frames (shift plane, warp, DOF, grade, sharpen, mux). */
+int vd3d_shard_begin(vd3d_ctx* ctx, const vd3d_render_params* p, int n_slots);
+int vd3d_shard_pass1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void* depth, int depth_fmt,
+                     const vd3d_render_params* p, int step_idx, int slot, float* s1_out_dev);
+int vd3d_shard_pass2(vd3d_ctx* ctx, const float* s1_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);
+int vd3d_shard_pixels(vd3d_ctx* ctx, int slot, const vd3d_render_params* p, uint8_t* out_bgr);
+
 /* ---- depth hand-off (a24): transformers' bicubic post-process to (H,W) + convert_depth_to_grayscale
  * (core/render_depth.py:585-611,1914-1916) for a batch of B predictions [B][ph][pw] float32 -> uint8 [B][H][W].
  * Replaces the reference's 8-bit depth video on disk while keeping its quantisation. */

@@ -103,3 +103,68 @@ def test_single_rank_degenerates_to_sequential(oracle):
     ro.new_clip()
     for t in range(NF):
         assert np.array_equal(got[t], ro.render(frames[t], gray[t], 2))
+
+
+# ---------------------------------------------------------------------------------------------------
+# three-phase protocol (StepShardedRenderer): orchestration + collectives on gloo with a recording fake backend
+# ---------------------------------------------------------------------------------------------------
+class _FakeRenderer:
+    """Implements the shard_* surface of Renderer on CPU tensors and records what the protocol asked of it."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.calls = []
+        self.replayed = None
+
+    def shard_begin(self, params, n_slots):
+        self.n_slots = n_slots
+
+    def shard_pass1(self, frame, depth, params, step_idx, slot=-1, s1_out=None):
+        key = int(depth[0, 0])            # the depth plane encodes the global frame index
+        self.calls.append((step_idx, slot, key, frame is not None))
+        if slot >= 0:
+            assert frame is not None and int(frame[0, 0, 0]) == key
+            s1_out[0] = 1000.0 + key      # "measurement" of the owned frame
+
+    def shard_pass2(self, s1_all, own_slots, params):
+        self.replayed = (s1_all.clone(), list(own_slots))
+
+    def shard_pixels(self, slot, params, out=None):
+        return torch.tensor([slot])
+
+
+def _proto_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from visiondepth3d_amd.sharded import StepShardedRenderer
+        B = 3
+        fr = _FakeRenderer()
+        sr = StepShardedRenderer(fr, None, rank, world, B)
+        # global frame t = j*world + g carries the value t in its depth plane and frame
+        depth_local = torch.stack([torch.full((4, 5), j * world + rank, dtype=torch.uint8) for j in range(B)])
+        frames_local = [torch.full((4, 5, 3), j * world + rank, dtype=torch.uint8) for j in range(B)]
+        outs = sr.render_step(frames_local, depth_local)
+        s1_all, own = fr.replayed
+        torch.save({"calls": fr.calls, "s1": s1_all, "own": own, "outs": [int(o) for o in outs]}, os.path.join(outdir, f"p{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_phase_protocol_world2(tmp_path):
+    world, B = 2, 3
+    mp.spawn(_proto_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        rec = torch.load(tmp_path / f"p{rank}.pt")
+        # pass 1 visited every frame of the step exactly once, in frame order, owning exactly its round-robin share
+        assert [c[0] for c in rec["calls"]] == list(range(world * B))
+        assert [c[2] for c in rec["calls"]] == list(range(world * B))          # depth plane of frame t really is frame t's
+        for t, (idx, slot, key, has_frame) in enumerate(rec["calls"]):
+            assert (slot >= 0) == (t % world == rank) == has_frame
+            if slot >= 0:
+                assert slot == t // world
+        # the replay saw every frame's s1 in FRAME order on every rank (all-gather is rank-major: needs the transpose)
+        assert rec["s1"].tolist() == [1000.0 + t for t in range(world * B)]
+        assert rec["own"] == [(t // world if t % world == rank else -1) for t in range(world * B)]
+        assert rec["outs"] == list(range(B))

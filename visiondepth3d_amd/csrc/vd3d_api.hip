@@ -49,7 +49,12 @@ struct vd3d_ctx {
   float *dc = nullptr;   // curved depth plane (fused chain)
   float *D = nullptr, *S = nullptr, *e2L = nullptr, *e2R = nullptr, *bL = nullptr, *bR = nullptr;
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
-  uint32_t* mm = nullptr; int mm_cap = 0;   // depth hand-off min/max keys [B][3]
+  uint32_t* mm = nullptr; int mm_cap = 0;
+  // frame sharding (three-phase protocol): per-slot planes of the frames this rank owns inside the current step
+  int n_slots = 0, slot_eh = 0, slot_ew = 0, slot_H = 0, slot_W = 0;
+  std::vector<float*> slot_rgb, slot_dn, slot_D;
+  vd_dev_work* slot_work = nullptr;
+  int* own_slot_dev = nullptr; int* own_slot_pin = nullptr;   // depth hand-off min/max keys [B][3]
   // profiling
   bool profiling = false;
   bool use_fused = true;   // VD3D_UNFUSED=1 selects the one-stage-per-kernel v0 path (A/B and debugging)
@@ -343,14 +348,15 @@ static int check_fit(const vd3d_render_params* p) {
 
 static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                       const vd3d_render_params* p, const vd_finish_consts& fc, float focal, int use_override, int bw, int bs,
-                      uint8_t* out) {
+                      uint8_t* out, const vd_dev_work* wk = nullptr) {
   StageTimer t(c, "finish");
-  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, c->work, focal, use_override, bw, bs, out)) {
+  if (!wk) wk = c->work;
+  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out)) {
     HIPCHK(hipGetLastError());
     return 0;
   }
-  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, c->work, focal, use_override, bw, bs, c->gL);
-  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, c->work, focal, use_override, bw, bs, c->gR);
+  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL);
+  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR);
   vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
   HIPCHK(hipGetLastError());
   return 0;
@@ -371,7 +377,8 @@ VD3D_EXPORT int vd3d_finish_frame(vd3d_ctx* c, const uint8_t* left_bgr, const ui
 
 // ---- B2 ---------------------------------------------------------------------------------------
 static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
-                             const vd3d_render_params* p, uint8_t* out_bgr, bool state_only) {
+                             const vd3d_render_params* p, uint8_t* out_bgr, bool state_only, int shard = 0, int step_idx = 0,
+                             int slot = -1, float* s1_out = nullptr) {
   if (!c || !depth || !p || (!state_only && (!frame_bgr || !out_bgr))) return set_err(VD3D_E_INVALID, "NULL argument");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
   if (p->crop_x < 0 || p->crop_y < 0 || p->crop_w < 1 || p->crop_h < 1 || p->crop_x + p->crop_w > p->src_w || p->crop_y + p->crop_h > p->src_h)
@@ -396,6 +403,9 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   memset(&a, 0, sizeof a);
   a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.n_eye = ne;
   { const char* e = getenv("VD3D_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.shard = shard; a.shard_idx = step_idx; a.s1_out = s1_out;
+  float* const save_D = c->D; float* const save_rgb = c->rgb_eye;
+  if (shard == 1) { c->D = c->slot_D[slot]; c->rgb_eye = c->slot_rgb[slot]; }
   a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a.ipd_factor = p->ipd_factor; a.shift = sp;
   float* dn_cur = c->dn[c->dn_cur];
@@ -418,7 +428,12 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   }
   }
   rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, state_only);
+  c->D = save_D; c->rgb_eye = save_rgb;
   if (rc) return rc;
+  if (shard == 1) {  // keep what the deferred pixel pass needs: this frame's normalised depth and all per-frame constants
+    HIPCHK(hipMemcpyAsync(c->slot_dn[slot], dn_cur, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(&c->slot_work[slot], c->work, sizeof(vd_dev_work), hipMemcpyDeviceToDevice, s));
+  }
   if (!state_only) {
     rc = run_finish(c, c->L, c->R, dn_cur, p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr);
     if (rc) return rc;
@@ -437,6 +452,88 @@ VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const v
 // results: every rank advances the state over all frames and renders the pixels of its own frames.
 VD3D_EXPORT int vd3d_advance_state(vd3d_ctx* c, const void* depth, int depth_fmt, const vd3d_render_params* p) {
   return render_frame_impl(c, nullptr, depth, depth_fmt, p, nullptr, true);
+}
+
+// ---- frame sharding, three-phase protocol (visiondepth3d_amd/sharded.py) ----------------------------------
+VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n_slots) {
+  if (!c || !p || n_slots < 1 || n_slots > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+  if (!c->use_fused) return set_err(VD3D_E_UNSUPPORTED, "frame sharding needs the fused chain (unset VD3D_UNFUSED)");
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure_eye(c, p->eye_h, p->eye_w))) return rc;
+  if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
+  const bool same = c->n_slots >= n_slots && c->slot_eh == p->eye_h && c->slot_ew == p->eye_w && c->slot_H == p->warp_h && c->slot_W == p->warp_w;
+  if (same) return 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto q : c->slot_rgb) hipFree(q);
+  for (auto q : c->slot_dn) hipFree(q);
+  for (auto q : c->slot_D) hipFree(q);
+  c->slot_rgb.clear(); c->slot_dn.clear(); c->slot_D.clear();
+  const size_t ne = (size_t)p->eye_h * p->eye_w, n = (size_t)p->warp_h * p->warp_w;
+  for (int i = 0; i < n_slots; ++i) {
+    float *a = nullptr, *b = nullptr, *d = nullptr;
+    HIPCHK(hipMalloc((void**)&a, 3 * ne * sizeof(float))); HIPCHK(hipMalloc((void**)&b, ne * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&d, n * sizeof(float)));
+    c->slot_rgb.push_back(a); c->slot_dn.push_back(b); c->slot_D.push_back(d);
+  }
+  HIPCHK(re_alloc(&c->slot_work, (size_t)n_slots));
+  c->n_slots = n_slots; c->slot_eh = p->eye_h; c->slot_ew = p->eye_w; c->slot_H = p->warp_h; c->slot_W = p->warp_w;
+  return 0;
+}
+// phase 1, called for EVERY frame of the step in order.  slot >= 0: this rank owns the frame (frame_bgr required): full
+// measurement incl. the warp-res select, s1 written to *s1_out_dev, planes kept in the slot.  slot < 0: foreign frame
+// (only the depth is needed): eye-res chain only, so all eye-res trackers advance identically on every rank.
+VD3D_EXPORT int vd3d_shard_pass1(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
+                                 const vd3d_render_params* p, int step_idx, int slot, float* s1_out_dev) {
+  if (!c || step_idx < 0 || step_idx >= VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad step index");
+  if (slot >= c->n_slots) return set_err(VD3D_E_INVALID, "slot %d out of range (vd3d_shard_begin)", slot);
+  if (slot >= 0 && (!frame_bgr || !s1_out_dev)) return set_err(VD3D_E_INVALID, "own frame needs the frame and an s1 destination");
+  return render_frame_impl(c, slot >= 0 ? frame_bgr : nullptr, depth, depth_fmt, p, nullptr, true, slot >= 0 ? 1 : 2, step_idx, slot, s1_out_dev);
+}
+// phase 2: replay the FloatingWindowTracker over the n frames of the step from the exchanged s1 values (device array in
+// frame order); own_slot_host[t] = slot of frame t on this rank or -1.
+VD3D_EXPORT int vd3d_shard_pass2(vd3d_ctx* c, const float* s1_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p) {
+  if (!c || !s1_all_dev || !own_slot_host || !p || n < 1 || n > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  vd3d_shift_params sp = p->shift;
+  sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
+  sp.depth_stretch_hi = 0.95; sp.fg_pop_multiplier = 1.20; sp.bg_push_multiplier = 1.10; sp.subject_lock_strength = 1.00;
+  vd_stage_args a;
+  memset(&a, 0, sizeof a);
+  a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.shift = sp;
+  StageTimer t(c, "replay");
+  vd_launch_shard_replay(c->stream, c->work, s1_all_dev, own_slot_host, n, c->slot_work, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// phase 3: shift plane, fused warp and finishing kernels of one owned frame from its slot -> muxed frame
+VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_params* p, uint8_t* out_bgr) {
+  if (!c || !p || !out_bgr || slot < 0 || slot >= c->n_slots) return set_err(VD3D_E_INVALID, "bad argument");
+  int rc = check_fit(p);
+  if (rc) return rc;
+  vd3d_shift_params sp = p->shift;
+  sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
+  sp.depth_stretch_hi = 0.95; sp.fg_pop_multiplier = 1.20; sp.bg_push_multiplier = 1.10; sp.subject_lock_strength = 1.00;
+  vd_finish_consts fc;
+  if ((rc = make_finish_consts(p, &fc))) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int H = p->warp_h, W = p->warp_w;
+  const vd_dev_work* wk = &c->slot_work[slot];
+  { StageTimer t(c, "warp");
+    { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, c->S); }
+    bool fused;
+    { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], c->S, H, W, sp, c->L, c->R); }
+    if (!fused) {
+      if (sp.enable_feathering) {
+        vd_launch_e2(s, c->slot_D[slot], c->S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
+        vd_launch_pool(s, c->e2L, c->e2R, H, W, sp.blur_ksize, c->bL, c->bR);
+      }
+      vd_launch_warp(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->S, c->bL, c->bR, H, W, sp.enable_feathering ? 1 : 0, c->L, c->R);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return run_finish(c, c->L, c->R, c->slot_dn[slot], p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr, wk);
 }
 
 // ---- diagnostics / tests --------------------------------------------------------------------------

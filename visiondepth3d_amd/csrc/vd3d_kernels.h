@@ -5,7 +5,7 @@
 #include "vd3d_work.h"
 
 enum { VD_ST_A0 = 0, VD_ST_B0, VD_ST_A1, VD_ST_B1, VD_ST_A2, VD_ST_B2,
-       VD_ST_AQ, VD_ST_BQ, VD_ST_BS };  // AQ/BQ: generic quantile pair, BS: bare subject depth (test entry points)
+       VD_ST_AQ, VD_ST_BQ, VD_ST_BS, VD_ST_B2_LITE };  // AQ/BQ: generic quantile pair, BS: bare subject depth (test entry points)
 #define PL_KMAX_HOST 33   // largest blur_ksize the pool kernel's LDS tile is sized for
 #define DF_RMAX_HOST 15   // largest Gaussian radius of the DOF kernel
 
@@ -16,6 +16,9 @@ struct vd_stage_args {
   long long n_eye;     // eye_h*eye_w
   long long n_crop;    // centre-crop population of compute_dynamic_parallax_scale
   double ipd_factor;
+  int shard;           // frame sharding: 0 = normal frame, 1 = own frame (s1 measured, tracker deferred), 2 = foreign frame
+  int shard_idx;       // frame index inside the sharded step
+  float* s1_out;       // shard == 1: where the measured s1 goes (device)
   int dbg;             // development probes: bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket + fences
   vd3d_shift_params shift;
 };
@@ -78,7 +81,7 @@ void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth,
                          float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a);
 void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
                           vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
-                          const vd_stage_args& a);
+                          const vd_stage_args& a);   // a.shard == 2 (foreign frame): eye-res part only, no warp-res select
 
 // ---- vd3d_select.hip
 void vd_launch_hist_eye_d(hipStream_t s, bool passB, const float* tdf, long long n, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
@@ -122,3 +125,7 @@ void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, in
 bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
                             int use_override, int bar_w, int bar_s, uint8_t* out);
+
+// ---- frame sharding (vd3d_select.hip)
+void vd_launch_shard_replay(hipStream_t s, vd_dev_work* w, const float* s1_all, const int* own_slot, int n, vd_dev_work* slot_work,
+                            const vd_stage_args& a);

@@ -425,14 +425,18 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
     } break;
     case VD_ST_A1:
       if (a.have_eye) scan_a_job(&lcs[VD_J_EYE_SUBJ], histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
-      scan_a_job(&lcs[VD_J_WORK_Q], histA + (size_t)VD_J_WORK_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
-                 (float)a.shift.depth_stretch_hi, sm);
-      scan_a_job(&lcs[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      if (a.shard != 2) {
+        scan_a_job(&lcs[VD_J_WORK_Q], histA + (size_t)VD_J_WORK_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
+                   (float)a.shift.depth_stretch_hi, sm);
+        scan_a_job(&lcs[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
+      }
       break;
     case VD_ST_B1: {
       if (a.have_eye) scan_b_job(&lcs[VD_J_EYE_SUBJ], histB + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_BC, sm);
-      scan_b_job(&lcs[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_BC, sm);
-      scan_b_job(&lcs[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_BC, sm);
+      if (a.shard != 2) {
+        scan_b_job(&lcs[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_BC, sm);
+        scan_b_job(&lcs[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_BC, sm);
+      }
       if (tid == 0) {
         vd_sel_ctl* cq = &lcs[VD_J_WORK_Q];
         const float lo = quantile_lerp(cq->val[0], cq->val[1], cq->w[0]);
@@ -469,6 +473,9 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           fg *= (double)scale; mg *= (double)scale; bg *= (double)scale;
           if (a.ipd_factor != 0.0) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
           w->fg_d = fg; w->mg_d = mg; w->bg_d = bg;
+          if (a.shard && a.shard_idx >= 0 && a.shard_idx < VD_MAX_STEP) {
+            w->step_fg[a.shard_idx] = fg; w->step_mg[a.shard_idx] = mg; w->step_bg[a.shard_idx] = bg;
+          }
           // compute_motion_metric :924-929
           w->fs.mad = 0.f;
           double motion = 0.0;
@@ -505,12 +512,17 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
     case VD_ST_A2:
       scan_a_job(&lcs[VD_J_WORK_S1], histA + (size_t)VD_J_WORK_S1 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
       break;
-    case VD_ST_B2: {
-      scan_b_job(&lcs[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
+    case VD_ST_B2:
+    case VD_ST_B2_LITE: {
+      if (a.stage == VD_ST_B2)
+        scan_b_job(&lcs[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
-        const float s1 = subject_from_job(&lcs[VD_J_WORK_S1]);
-        w->fs.s1 = s1;
-        shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);
+        if (a.stage == VD_ST_B2) {
+          const float s1 = subject_from_job(&lcs[VD_J_WORK_S1]);
+          w->fs.s1 = s1;
+          if (a.shard == 1) { if (a.s1_out) *a.s1_out = s1; }  // sharded: the FloatingWindowTracker is replayed after the exchange
+          else shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);
+        }
         if (a.have_eye) {  // floating-window bars :1390-1403
           vd3d_state* st = &w->st;
           const float s = w->fs.s_norm;
@@ -836,14 +848,46 @@ void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* 
   f.step_x = W > 1 ? (1.f - (-1.f)) / (float)(W - 1) : 0.f; f.step_y = H > 1 ? (1.f - (-1.f)) / (float)(H - 1) : 0.f;
   const long long ne = (long long)ih * iw, n = (long long)H * W;
   const int eye_wg = have_eye ? chain_grid(ne, 4096, 128) : 0;
-  const int work_wg = chain_grid(n, 8192, 256);     // K3: 130 KB of LDS histograms -> one resident workgroup per CU
+  const bool foreign = a.shard == 2;                // sharded foreign frame: eye-res part only
+  const int work_wg = foreign ? 0 : chain_grid(n, 8192, 256);     // K3: 130 KB of LDS histograms -> one resident workgroup per CU
   const int eye_wg_b = eye_wg;
-  const int work_wg_b = chain_grid(n, 4096, 512);   // K4: streams the stored curved-depth plane (each workgroup pays one release fence)
+  const int work_wg_b = foreign ? 0 : chain_grid(n, 4096, 512);   // K4: streams the stored curved-depth plane (one release fence per workgroup)
   // K3's warp-res workgroups must not read the dn plane its eye-res workgroups are writing: they read the filtered plane
   // and apply the (device-scalar) normalisation per tap; K4/K5 read the stored plane, complete by then.
   hipLaunchKernelGGL(k_chain_stage1, dim3(eye_wg + work_wg), dim3(1024), 0, s, src, dn_cur, dn_prev, ih, iw, eye_wg, f, dc, w, histA, histB, a);
   f.src = have_eye ? dn_cur : src; f.norm = 0;
   hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b), dim3(1024), 0, s, dn_cur, ih, iw, eye_wg_b, f, dc, w, histA, histB, a);
+  if (foreign) {  // no shaped depth, no s1: only the bar/convergence recurrences of stage B2
+    vd_stage_args b = a;
+    b.stage = VD_ST_B2_LITE;
+    hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(1024), 0, s, w, histA, histB, b);
+    return;
+  }
   hipLaunchKernelGGL(k_chain_shape, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, f, dc, w, mid, gamma, D, histA, histB, a);
   hipLaunchKernelGGL(k_chain_b2, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, D, H, W, w, histA, histB, a);
+}
+
+// Tracker replay of a sharded step: the FloatingWindowTracker (and everything shift_scalars derives from s1) is advanced over
+// ALL frames of the step in order from the exchanged s1 values; own frames get their final constants patched into their slot.
+struct vd_own_slots { short v[VD_MAX_STEP]; };  // passed by value in the kernel arguments (1 KB): no staging copy, no sync
+__global__ void k_shard_replay(vd_dev_work* w, const float* __restrict__ s1_all, vd_own_slots own, int n,
+                               vd_dev_work* slot_work, vd_stage_args a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int t = 0; t < n; ++t) {
+    shift_scalars(w, a.shift, a.W, s1_all[t], w->step_fg[t], w->step_mg[t], w->step_bg[t]);
+    const int sl = own.v[t];
+    if (sl >= 0) {
+      vd_dev_work* d = &slot_work[sl];
+      d->fg = w->fg; d->mg = w->mg; d->bg = w->bg;
+      d->zpo_f = w->zpo_f; d->have_zpo = w->have_zpo; d->msn = w->msn; d->conv = w->conv; d->have_conv = w->have_conv;
+      d->fs.s1 = s1_all[t]; d->fs.zpo_raw = w->fs.zpo_raw; d->fs.zpo = w->fs.zpo;
+      d->st = w->st;  // snapshot for diagnostics (vd3d_last_scalars on a slot is not exposed; kept for debugging)
+    }
+  }
+}
+void vd_launch_shard_replay(hipStream_t s, vd_dev_work* w, const float* s1_all, const int* own_slot_host, int n, vd_dev_work* slot_work,
+                            const vd_stage_args& a) {
+  vd_own_slots own;
+  for (int t = 0; t < VD_MAX_STEP; ++t) own.v[t] = (short)(t < n ? own_slot_host[t] : -1);
+  hipLaunchKernelGGL(k_shard_replay, dim3(1), dim3(64), 0, s, w, s1_all, own, n, slot_work, a);
 }

@@ -9,6 +9,7 @@
 #define VD_NB_BC 256u   // coarse level of the low-16 histogram (low16 >> 8): scan B walks 256 + 256 bins, not 65536
 #define VD_MAX_T 4      // distinct target prefixes per select job
 #define VD_NJOBS 5
+#define VD_MAX_STEP 512  // frames per sharded step (world * frames-per-rank)
 
 // select jobs
 enum {
@@ -53,4 +54,6 @@ struct vd_dev_work {
   int32_t have_conv;
   float focal;
   int32_t bar_width, bar_side;
+  // per-frame layer shifts of the current sharded step (after smoother * dyn_scale * ipd): inputs of the tracker replay
+  double step_fg[VD_MAX_STEP], step_mg[VD_MAX_STEP], step_bg[VD_MAX_STEP];
 };

@@ -155,6 +155,37 @@ class Renderer:
         d = depth.to(self.device).contiguous()
         _lib.check(self._L.vd3d_advance_state(self._ctx, _ptr(d), fmt, C.byref(params)))
 
+    # ---- frame sharding, three-phase protocol (include/vd3d.h; orchestrated by visiondepth3d_amd.sharded) ----
+    def _depth_fmt(self, depth):
+        if depth.dtype == torch.float32 and depth.dim() == 2:
+            return DEPTH_F32
+        if depth.dtype == torch.uint8 and depth.dim() == 3 and depth.shape[2] == 3:
+            return DEPTH_BGR_U8
+        if depth.dtype == torch.uint8 and depth.dim() == 2:
+            return DEPTH_GRAY_U8
+        raise AssertionError("depth must be float32 [h,w], uint8 [h,w,3] or uint8 [h,w]")
+
+    def shard_begin(self, params: RenderParams, n_slots: int):
+        _lib.check(self._L.vd3d_shard_begin(self._ctx, C.byref(params), int(n_slots)))
+
+    def shard_pass1(self, frame, depth, params: RenderParams, step_idx: int, slot: int = -1, s1_out: torch.Tensor | None = None):
+        d = depth.to(self.device).contiguous()
+        f = frame.to(self.device).contiguous() if frame is not None else None
+        _lib.check(self._L.vd3d_shard_pass1(self._ctx, _ptr(f) if f is not None else None, _ptr(d), self._depth_fmt(d), C.byref(params),
+                                            int(step_idx), int(slot), _ptr(s1_out) if s1_out is not None else None))
+
+    def shard_pass2(self, s1_all: torch.Tensor, own_slots, params: RenderParams):
+        n = len(own_slots)
+        arr = (C.c_int * n)(*[int(v) for v in own_slots])
+        s1 = s1_all.to(self.device, torch.float32).contiguous()
+        _lib.check(self._L.vd3d_shard_pass2(self._ctx, _ptr(s1), arr, n, C.byref(params)))
+
+    def shard_pixels(self, slot: int, params: RenderParams, out: torch.Tensor | None = None):
+        if out is None:
+            out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.vd3d_shard_pixels(self._ctx, int(slot), C.byref(params), _ptr(out)))
+        return out
+
     def depth_handoff(self, pred: torch.Tensor, H: int, W: int, invert: bool = False, out: torch.Tensor | None = None):
         """a24 on device: predictions float32 [B,ph,pw] -> uint8 depth planes [B,H,W] (bicubic + per-frame min-max)."""
         p = pred.to(self.device, torch.float32).contiguous()

@@ -101,3 +101,63 @@ class FrameShardedRenderer:
                 out = self.render_round(n_valid, frame, d_loc)
             if mine:
                 yield t, out
+
+
+class StepShardedRenderer:
+    """Three-phase frame sharding (include/vd3d.h "frame sharding"): the scaling path used by bench.py for N > 1.
+
+    A step is a window of ``world * B`` consecutive frames; global order inside the step is t = j * world + g
+    (j-th local frame of rank g), i.e. frames are dealt round-robin.  Per step and rank:
+
+      0. (caller) depth inference for the B local frames, all-gather of the uint8 depth planes  -> depth_all [world*B,h,w]
+      1. pass 1 over ALL world*B frames in order: own frames -> full measurement (warp-res select, s1) with planes kept
+         in a slot; foreign frames -> eye-res chain only (~5x cheaper than a full state advance)
+      2. all-gather of the measured s1 (B floats per rank), tracker replay over the step (one tiny kernel)
+      3. pixel pass (shift plane, fused warp, fused finish) for the B own frames
+
+    Every rank runs the identical eye-res chain and the identical replay, so all tracker state is bit-identical across
+    ranks and the muxed frames equal the sequential 1-GPU render (tests/test_hip_parity.py emulates two ranks with two
+    contexts on one GPU and compares bit for bit).
+    """
+
+    def __init__(self, renderer, params, rank: int, world: int, frames_per_rank: int, group=None):
+        self.r, self.p, self.rank, self.world, self.B, self.group = renderer, params, rank, world, frames_per_rank, group
+        if world * frames_per_rank > 512:
+            raise ValueError("a sharded step holds at most 512 frames")
+        renderer.shard_begin(params, frames_per_rank)
+        self.s1_local = torch.zeros(frames_per_rank, dtype=torch.float32, device=renderer.device)
+        self.own_slots = [(t // world if t % world == rank else -1) for t in range(world * frames_per_rank)]
+
+    def gather(self, local: torch.Tensor) -> torch.Tensor:
+        """all-gather along dim 0: [B, ...] per rank -> [world*B, ...] laid out rank-major."""
+        if self.world == 1:
+            return local
+        shp = tuple(local.shape)
+        out = torch.empty((self.world * shp[0],) + shp[1:], dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        return out
+
+    def pass1(self, frames_local, depth_all: torch.Tensor):
+        G, B = self.world, self.B
+        for j in range(B):
+            for g in range(G):
+                t = j * G + g
+                d = depth_all[g * B + j]
+                if g == self.rank:
+                    self.r.shard_pass1(frames_local[j], d, self.p, t, slot=j, s1_out=self.s1_local[j:j + 1])
+                else:
+                    self.r.shard_pass1(None, d, self.p, t, slot=-1)
+
+    def finish(self, s1_gathered: torch.Tensor, outs=None):
+        G, B = self.world, self.B
+        s1_t = s1_gathered.view(G, B).t().contiguous().view(-1) if G > 1 else s1_gathered   # rank-major -> frame order
+        self.r.shard_pass2(s1_t, self.own_slots, self.p)
+        res = []
+        for j in range(B):
+            res.append(self.r.shard_pixels(j, self.p, out=None if outs is None else outs[j]))
+        return res
+
+    def render_step(self, frames_local, depth_local: torch.Tensor, outs=None):
+        depth_all = self.gather(depth_local)
+        self.pass1(frames_local, depth_all)
+        return self.finish(self.gather(self.s1_local), outs)
