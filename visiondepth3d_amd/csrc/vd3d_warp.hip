@@ -55,7 +55,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   const int ew = WF_TW + k - 1, eh = WF_TH + k - 1;  // e2 region
   float* wd = lds;                                   // [2][wh*ww]   (later hs [2][eh*WF_TW])
   float* e2 = lds + 2 * wh * ww;                     // [2][eh*ew]
-  float* tile = e2 + 2 * eh * ew;                    // [3][er][ec]
+  float* tile = a.feather ? e2 + 2 * eh * ew : lds;  // [3][er][ec] (the feather buffers are not allocated when feathering is off)
   const int tid = threadIdx.x;
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
 
