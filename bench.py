@@ -234,11 +234,18 @@ def main():
                                "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                                "traffic": traffic, "traffic_source": traffic_src,
-                               "note": "measured VALU-issue-bound (1143 VALU wave-instr/pixel, 62% VALU busy; profiles/r01_pmc_4k_dibr.md), "
-                                       "not HBM-bound: the reference's nested bilinear arithmetic is kept exact",
+                               "note": "measured VALU-issue-bound (~1100 VALU lane-instr/pixel = ~98% of the SIMD issue cycles of the launch; "
+                                       "profiles/r01_pmc_4k_dibr.md), not HBM-bound: the reference's nested bilinear arithmetic is kept exact",
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": warp_ms,
                                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                                "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None}
+            fin_ms = stage_ms.get("finish", -1)
+            if fin_ms > 0:  # E1 (fused DOF/grade/sharpen/fit/mux): 6N eyes in + N eye-res depth + 3N Half-SBS out
+                e1_bytes = 10 * N
+                e1 = e1_bytes / (fin_ms * 1e-3) / 1e9
+                res["roofline_e1"] = {"bound": "hbm", "kernel": "k_finish_fused (E1)", "achieved": round(e1, 2), "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": round(e1 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": e1_bytes,
+                                      "avg_launch_ms": fin_ms}
             res["stage_ms"] = stage_ms
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sh, sw)

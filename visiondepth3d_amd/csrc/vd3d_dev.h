@@ -40,6 +40,39 @@ VD_DEV float vd_pow15_cr(float x) {
   return (float)(d * sqrt(d));
 }
 
+// packed-f32 vector types: hipcc lowers arithmetic on these to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (2 lanes-worth of
+// IEEE float32 work per VALU issue slot on gfx950); each element is rounded exactly like the scalar operator.
+typedef float vd_f2 __attribute__((ext_vector_type(2)));
+typedef float vd_f4 __attribute__((ext_vector_type(4)));
+VD_DEV float vd_vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+VD_DEV vd_f2 vd_vfma(vd_f2 a, vd_f2 b, vd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+VD_DEV vd_f4 vd_vfma(vd_f4 a, vd_f4 b, vd_f4 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// (float)v / 255.0f for an integer v in [0,255] without the division: one Newton residual step makes the product
+// correctly rounded; verified exhaustively for all 256 inputs (tests/test_host_logic.py restates the check).
+VD_DEV float vd_u8_unit(float x) {
+  const float rc = 1.0f / 255.0f;
+  const float q0 = x * rc;
+  return vd_fma(vd_fma(-q0, 255.0f, x), rc, q0);
+}
+
+// DOF Gaussian tap sum: the kernel is exactly symmetric, taps are paired outermost-first and
+// accumulated with fused multiply-adds:  acc = w0*(v0+v[K-1]); acc = fma(w_t, v_t+v[K-1-t], acc) ...; acc = fma(w_r, v_r, acc)
+template <int K, typename V>
+VD_DEV V vd_gauss_sym(const float* __restrict__ kw, const V* v) {
+  constexpr int r = K / 2;
+  V acc = kw[0] * (v[0] + v[K - 1]);
+#pragma unroll
+  for (int t = 1; t < r; ++t) acc = vd_vfma((V)(kw[t]), v[t] + v[K - 1 - t], acc);
+  return vd_vfma((V)(kw[r]), v[r], acc);
+}
+VD_DEV float vd_gauss_sym_rt(const float* __restrict__ kw, int k, const float* v, int stride) {  // run-time tap count
+  const int r = k / 2;
+  float acc = kw[0] * (v[0] + v[(k - 1) * stride]);
+  for (int t = 1; t < r; ++t) acc = vd_fma(kw[t], v[t * stride] + v[(k - 1 - t) * stride], acc);
+  return vd_fma(kw[r], v[r * stride], acc);
+}
+
 // F.interpolate(bilinear, align_corners=False) tap for output index o
 struct vd_tap { int i0, i1; float w0, w1; };
 VD_DEV vd_tap vd_interp_tap(int in, int out, int o) {

@@ -3,12 +3,16 @@
 // (core/render_3d.py:1340-1419).  Replaces k_dof_grade x2 + k_sharp_mux and their two graded planes (-12N B of HBM).
 //
 // Per 64x16 tile of sharpened pixels (384 threads, blockIdx.z = eye):
-//   load    (16+2+8) x (64+8+8) reflect-padded u8 tile -> /255 -> float planes in LDS (row pitch 80 floats, 16 B aligned)
-//   level l H-pass: one task = (channel,row,4-pixel strip): 3x ds_read_b128 window, k-tap sums in the reference order,
-//           one ds_write_b128;   V-pass: one thread = one strip of the 18x72 graded region, k x ds_read_b128
-//   blend the two levels each pixel needs, grade, truncate, side bars -> packed BGR0 dwords in LDS
-//   epilogue: 3x3 sharpen (5 dword reads give all 3 channels), integer-ratio box average, 12-byte packed stores
-// Arithmetic identical to k_dof_grade / k_sharp_mux (and the oracle): same association, no contraction.
+//   load    (16+2+8) x (64+8+8) reflect-padded u8 tile -> v/255 (exact 3-op form) -> float planes in LDS, TWO ROWS
+//           INTERLEAVED per element (tile2[c][row/2][x][row&1]) so that a ds_read_b128 yields two aligned (row,row+1) pairs
+//   level l H-pass: one task = (channel, row pair, 4-pixel strip): 6x ds_read_b128, symmetric-pair FMA tap sums on
+//           (row,row+1) float2 vectors => v_pk_add/fma_f32, two row-major ds_write_b128
+//           V-pass: one thread = one strip of the 18x72 graded region, k x ds_read_b128, float4 => v_pk_* again
+//   blend the two levels each pixel needs, grade, truncate, side bars -> packed BGR0 dwords in LDS (one b128 per strip)
+//   epilogue: 3x3 sharpen on float4 (4 pixels per lane), integer-ratio box average, 12-byte packed stores;
+//           interior tiles with fit (1,1) / (2,1) take the vector path, everything else the generic per-pixel one.
+// Arithmetic identical to k_dof_grade / k_sharp_mux and the oracle (same association, explicit FMAs only in the
+// Gaussian tap sums, vd_gauss_sym).
 // Fast path conditions (else the unfused kernels run): Gaussian taps <= 9 (dof_strength <= 2), fit factors in {1,2,4},
 // format in {Half-SBS, Full-SBS, Passive Interlaced}.
 #include "vd3d_dev.h"
@@ -21,7 +25,9 @@
 #define FF_GH (FF_TH + 2)           // graded region height (1-pixel halo)
 #define FF_IW (FF_GW + 2 * FF_R)    // input tile width  = 80
 #define FF_IH (FF_GH + 2 * FF_R)    // input tile height = 26
+#define FF_RP (FF_IH / 2)           // row pairs = 13
 #define FF_NS (FF_GW / 4)           // strips per row = 18
+#define FF_GP 76                    // pitch of the graded dword tile (multiple of 4: b128 rows)
 #define FF_NT 384
 
 struct vd_ff_args {
@@ -31,39 +37,39 @@ struct vd_ff_args {
   float focal;
 };
 
-// one Gaussian level: K = 9 - 2*OFF taps.  H-pass over (channel,row,strip) tasks, then V-pass for the strips that need it.
+typedef float (*ff_tile_t)[FF_RP][FF_IW][2];
+typedef float (*ff_hb_t)[FF_IH][FF_GW];
+#define FF_T2(tile, c, row, x) tile[c][(row) >> 1][x][(row) & 1]
+
+// one Gaussian level: K = 9 - 2*OFF taps.  H-pass over (channel,row pair,strip) tasks, then V-pass for the strips that need it.
 template <int OFF>
-VD_DEV void ff_level(float (*tile)[FF_IH][FF_IW], float (*hb)[FF_IH][FF_GW], const float* __restrict__ kern, int tid, bool need,
-                     int sy, int ss, int level, const int lo[4], float vlo[3][4], float vhi[3][4]) {
+VD_DEV void ff_level(ff_tile_t tile, ff_hb_t hb, const float* __restrict__ kern, int tid, bool need,
+                     int sy, int ss, int level, const int lo[4], vd_f4 vlo[3], vd_f4 vhi[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
   float kw[K];
 #pragma unroll
   for (int t = 0; t < K; ++t) kw[t] = kern[t];
-  for (int t = tid; t < 3 * FF_IH * FF_NS; t += FF_NT) {
-    const int c = t / (FF_IH * FF_NS), rem = t - c * FF_IH * FF_NS, row = rem / FF_NS, s = rem - row * FF_NS;
-    const float4* wp = reinterpret_cast<const float4*>(&tile[c][row][4 * s]);
-    const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-    const float win[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-    float o[4];
+  for (int t = tid; t < 3 * FF_RP * FF_NS; t += FF_NT) {
+    const int c = t / (FF_RP * FF_NS), rem = t - c * FF_RP * FF_NS, rp = rem / FF_NS, s = rem - rp * FF_NS;
+    const vd_f4* wp = reinterpret_cast<const vd_f4*>(&tile[c][rp][4 * s][0]);
+    vd_f2 win[12];   // win[i] = (row 2rp, row 2rp+1) at column 4s+i
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float sacc = 0.f;
+    for (int i = 0; i < 6; ++i) { const vd_f4 q = wp[i]; win[2 * i] = q.xy; win[2 * i + 1] = q.zw; }
+    vd_f2 o[4];
 #pragma unroll
-      for (int tt = 0; tt < K; ++tt) sacc += kw[tt] * win[j + OFF + tt];
-      o[j] = sacc;
-    }
-    *reinterpret_cast<float4*>(&hb[c][row][4 * s]) = make_float4(o[0], o[1], o[2], o[3]);
+    for (int j = 0; j < 4; ++j) o[j] = vd_gauss_sym<K, vd_f2>(kw, &win[j + OFF]);
+    vd_f4 r0 = {o[0].x, o[1].x, o[2].x, o[3].x}, r1 = {o[0].y, o[1].y, o[2].y, o[3].y};
+    *reinterpret_cast<vd_f4*>(&hb[c][2 * rp][4 * s]) = r0;
+    *reinterpret_cast<vd_f4*>(&hb[c][2 * rp + 1][4 * s]) = r1;
   }
   __syncthreads();
   if (need) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      vd_f4 v[K];
 #pragma unroll
-      for (int tt = 0; tt < K; ++tt) {
-        const float4 v = *reinterpret_cast<const float4*>(&hb[c][sy + OFF + tt][4 * ss]);
-        o[0] += kw[tt] * v.x; o[1] += kw[tt] * v.y; o[2] += kw[tt] * v.z; o[3] += kw[tt] * v.w;
-      }
+      for (int tt = 0; tt < K; ++tt) v[tt] = *reinterpret_cast<const vd_f4*>(&hb[c][sy + OFF + tt][4 * ss]);
+      const vd_f4 o = vd_gauss_sym<K, vd_f4>(kw, v);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (level == lo[q]) vlo[c][q] = o[q];
@@ -74,13 +80,38 @@ VD_DEV void ff_level(float (*tile)[FF_IH][FF_IW], float (*hb)[FF_IH][FF_GW], con
   __syncthreads();
 }
 
+VD_DEV float ff_byte(uint32_t v, int sh) { return (float)((v >> sh) & 0xffu); }   // v_cvt_f32_ubyteN
+
+// 3x3 sharpen (:717-732) of 4 consecutive pixels of one row of the graded dword tile (interior: no reflection needed)
+VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, float kc, int s[3][4]) {
+  const uint4 U = *reinterpret_cast<const uint4*>(&gb[gy - 1][gc]);
+  const uint4 C = *reinterpret_cast<const uint4*>(&gb[gy][gc]);
+  const uint4 D = *reinterpret_cast<const uint4*>(&gb[gy + 1][gc]);
+  const uint32_t lf = gb[gy][gc - 1], rt = gb[gy][gc + 4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sh = 8 * c;
+    const vd_f4 u = {ff_byte(U.x, sh), ff_byte(U.y, sh), ff_byte(U.z, sh), ff_byte(U.w, sh)};
+    const vd_f4 d = {ff_byte(D.x, sh), ff_byte(D.y, sh), ff_byte(D.z, sh), ff_byte(D.w, sh)};
+    const vd_f4 m = {ff_byte(C.x, sh), ff_byte(C.y, sh), ff_byte(C.z, sh), ff_byte(C.w, sh)};
+    const vd_f4 l = {ff_byte(lf, sh), m.x, m.y, m.z}, r = {m.y, m.z, m.w, ff_byte(rt, sh)};
+    // 0 + kn*u + kn*l + kc*m + kn*r + kn*d in that order; the leading "0 +" only decides the sign of an all-zero sum
+    vd_f4 acc = kn * u;
+    acc = acc + kn * l;
+    acc = acc + kc * m;
+    acc = acc + kn * r;
+    acc = acc + kn * d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[c][q] = (int)vd_sat_rne_u8(acc[q]);
+  }
+}
+
 __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
                                                         const vd_dev_work* __restrict__ w, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
+  __shared__ __attribute__((aligned(16))) float tile[3][FF_RP][FF_IW][2];
   __shared__ __attribute__((aligned(16))) float hb[3][FF_IH][FF_GW];
-  __shared__ uint32_t gb[FF_GH][FF_GW + 1];   // odd pitch: the epilogue's column walks stay conflict-free
-  __shared__ float lut[256];                  // v / 255.0f (true division), computed once per workgroup
+  __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
   __shared__ int lvl_mask;                    // levels any pixel of this tile needs
   const int eye = blockIdx.z;
   const uint8_t* __restrict__ src = eye == 0 ? eyeL : eyeR;
@@ -90,24 +121,48 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
   const int ix0 = gx0 - FF_R, iy0 = gy0 - FF_R;    // input tile origin
   const int tid = threadIdx.x;
 
-  if (tid < 256) lut[tid] = (float)tid / 255.0f;
   if (tid == 0) lvl_mask = 0;
-  __syncthreads();
-  for (int t = tid; t < FF_IH * FF_IW; t += FF_NT) {
-    const int ty = t / FF_IW, tx = t - ty * FF_IW;
-    const int y = vd_reflect(iy0 + ty, H), x = vd_reflect(ix0 + tx, W);
-    const uint8_t* px = src + ((size_t)y * W + x) * 3;
-    tile[0][ty][tx] = lut[px[2]];
-    tile[1][ty][tx] = lut[px[1]];
-    tile[2][ty][tx] = lut[px[0]];
+  const bool in_interior = ix0 >= 0 && ix0 + FF_IW <= W && iy0 >= 0 && iy0 + FF_IH <= H && (W & 3) == 0 &&
+                           (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+  if (in_interior) {
+    // one task = 4 pixels x 2 rows: 2 x 3 dword loads (12 B = 4 BGR pixels), six ds_write_b128
+    for (int t = tid; t < FF_RP * (FF_IW / 4); t += FF_NT) {
+      const int rp = t / (FF_IW / 4), g = t - rp * (FF_IW / 4);
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(src + ((size_t)(iy0 + 2 * rp) * W + ix0 + 4 * g) * 3);
+      const uint32_t* p1 = p0 + (size_t)W * 3 / 4;
+      const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+      // byte k of the 12-byte group: pixel k/3, channel BGR[k%3]
+#define FF_B(d0, d1, d2, k) ff_byte((k) < 4 ? d0 : ((k) < 8 ? d1 : d2), 8 * ((k) & 3))
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {   // plane 0 = R (byte 2), 1 = G (byte 1), 2 = B (byte 0)
+        const int bo = 2 - c;
+        const vd_f4 lo4 = {vd_u8_unit(FF_B(a0, a1, a2, 0 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 0 + bo)),
+                           vd_u8_unit(FF_B(a0, a1, a2, 3 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 3 + bo))};
+        const vd_f4 hi4 = {vd_u8_unit(FF_B(a0, a1, a2, 6 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 6 + bo)),
+                           vd_u8_unit(FF_B(a0, a1, a2, 9 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 9 + bo))};
+        *reinterpret_cast<vd_f4*>(&tile[c][rp][4 * g][0]) = lo4;
+        *reinterpret_cast<vd_f4*>(&tile[c][rp][4 * g + 2][0]) = hi4;
+      }
+#undef FF_B
+    }
+  } else {
+    for (int t = tid; t < FF_IH * FF_IW; t += FF_NT) {
+      const int ty = t / FF_IW, tx = t - ty * FF_IW;
+      const int y = vd_reflect(iy0 + ty, H), x = vd_reflect(ix0 + tx, W);
+      const uint8_t* px = src + ((size_t)y * W + x) * 3;
+      FF_T2(tile, 0, ty, tx) = vd_u8_unit((float)px[2]);
+      FF_T2(tile, 1, ty, tx) = vd_u8_unit((float)px[1]);
+      FF_T2(tile, 2, ty, tx) = vd_u8_unit((float)px[0]);
+    }
   }
   // per-strip setup (threads 0..323 own one 4-pixel strip of the graded region)
   const bool strip = tid < FF_GH * FF_NS;
   const int sy = tid / FF_NS, ss = tid - sy * FF_NS;   // graded row, strip index
   const int gy = gy0 + sy, gxs = gx0 + 4 * ss;
   int lo[4] = {0, 0, 0, 0};
-  float alpha[4] = {0.f, 0.f, 0.f, 0.f};
+  vd_f4 alpha = {0.f, 0.f, 0.f, 0.f};
   int lmin = 9, lmax = -1;
+  __syncthreads();   // lvl_mask = 0 visible before the atomicOr below; tile complete
   if (strip && fc.nlev) {
     const float focal = a.use_override ? a.focal : w->focal;
 #pragma unroll
@@ -132,18 +187,17 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
     for (int l = max(lmin, 1); l <= lmax; ++l) m |= 1 << l;
     if (m) atomicOr(&lvl_mask, m);
   }
-  __syncthreads();
-  const int need_mask = lvl_mask;
-  float vlo[3][4], vhi[3][4];
+  vd_f4 vlo[3], vhi[3];
   if (strip) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float4 v = *reinterpret_cast<const float4*>(&tile[c][sy + FF_R][4 * ss + FF_R]);
-      vlo[c][0] = v.x; vlo[c][1] = v.y; vlo[c][2] = v.z; vlo[c][3] = v.w;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) vhi[c][q] = vlo[c][q];
+      for (int q = 0; q < 4; ++q) vlo[c][q] = FF_T2(tile, c, sy + FF_R, 4 * ss + FF_R + q);
+      vhi[c] = vlo[c];
     }
   }
+  __syncthreads();
+  const int need_mask = lvl_mask;
   for (int l = 0; l < fc.nlev; ++l) {  // level l+1 of the reference's stack
     if (!(need_mask >> (l + 1) & 1)) continue;  // no pixel of this tile blends with this level (workgroup-uniform)
     const int off = FF_R - fc.ksz[l] / 2;
@@ -155,41 +209,90 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       default: ff_level<3>(tile, hb, fc.kern[l], tid, need, sy, ss, l + 1, lo, vlo, vhi); break;
     }
   }
-  if (strip) {  // blend, grade (:750-767), truncate, side bars (:885-892)
+  if (strip) {  // blend, grade (:750-767), truncate, side bars (:885-892); float4 = the strip's 4 pixels
     const int bar_w = a.use_override ? a.bar_w : w->bar_width, bar_s = a.use_override ? a.bar_s : w->bar_side;
+    vd_f4 rgbv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      vd_f4 v = vlo[c];
+      if (fc.nlev) {
+        v = (1.0f - alpha) * vlo[c] + alpha * vhi[c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = vd_clamp(v[q], 0.f, 1.f);
+      }
+      rgbv[c] = v;
+    }
+    const vd_f4 luma = ((float)0.2126 * rgbv[0] + (float)0.7152 * rgbv[1]) + (float)0.0722 * rgbv[2];
+    uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      vd_f4 v = luma + (rgbv[c] - luma) * fc.sat;
+      v = 0.5f + (v - 0.5f) * fc.con;
+      v = v + fc.bri;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float vc = vd_clamp(v[q], 0.f, 1.f);
+        pk[q] |= (uint32_t)(uint8_t)(vc * 255.0f) << (8 * (2 - c));  // byte 0 = B, 1 = G, 2 = R
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float rgbv[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float v = vlo[c][q];
-        if (fc.nlev) v = vd_clamp((1.0f - alpha[q]) * vlo[c][q] + alpha[q] * vhi[c][q], 0.f, 1.f);
-        rgbv[c] = v;
-      }
-      const float luma = ((float)0.2126 * rgbv[0] + (float)0.7152 * rgbv[1]) + (float)0.0722 * rgbv[2];
       const int x = gxs + q;
       const bool masked = bar_w > 0 && ((bar_s == 2 && x < bar_w) || (bar_s == 1 && x >= W - bar_w));
-      uint32_t pk = 0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float v = luma + (rgbv[c] - luma) * fc.sat;
-        v = 0.5f + (v - 0.5f) * fc.con;
-        v = v + fc.bri;
-        v = vd_clamp(v, 0.f, 1.f);
-        const uint32_t u = masked ? 0u : (uint32_t)(uint8_t)(v * 255.0f);
-        pk |= u << (8 * (2 - c));  // byte 0 = B, 1 = G, 2 = R
-      }
-      gb[sy][4 * ss + q] = pk;
+      if (masked) pk[q] = 0u;
     }
+    *reinterpret_cast<uint4*>(&gb[sy][4 * ss]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
   __syncthreads();
-  // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux; one task = 4 consecutive output pixels
+  // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux
   const int ow = FF_TW / a.fx, oh = FF_TH / a.fy;      // output pixels produced by this tile
   const int ox0 = x0 / a.fx, oy0 = y0 / a.fy;
   const float kn = fc.sharp_kn, kc = fc.sharp_kc;
+  const bool out_interior = x0 >= 1 && x0 + FF_TW <= W - 1 && y0 >= 1 && y0 + FF_TH <= H - 1 && a.fy == 1 &&
+                            (a.fx == 1 || a.fx == 2) && ox0 + ow <= a.in_w && oy0 + oh <= a.in_h;
+  if (out_interior) {
+    // one task = 4 consecutive OUTPUT pixels of one row = fx groups of 4 sharpened pixels; 12-byte packed store
+    const int ngrp = ow / 4;                          // 16 (fx = 1) or 8 (fx = 2)
+    for (int t = tid; t < FF_TH * ngrp; t += FF_NT) {
+      const int ty = t / ngrp, m = t - ty * ngrp;
+      const int oy = oy0 + ty;
+      if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
+      uint32_t pack[3] = {0, 0, 0};
+      if (a.fx == 1) {
+        int s[3][4];
+        ff_sharp4(gb, ty + 1, 4 + 4 * m, kn, kc, s);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { const int bi = 3 * q + c; pack[bi >> 2] |= (uint32_t)s[c][q] << (8 * (bi & 3)); }
+      } else {
+        int s0[3][4], s1[3][4];
+        ff_sharp4(gb, ty + 1, 4 + 8 * m, kn, kc, s0);
+        ff_sharp4(gb, ty + 1, 8 + 8 * m, kn, kc, s1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int sum = q < 2 ? s0[c][2 * q] + s0[c][2 * q + 1] : s1[c][2 * q - 4] + s1[c][2 * q - 3];
+            const uint32_t v = vd_sat_rne_u8((float)sum * 0.5f);
+            const int bi = 3 * q + c;
+            pack[bi >> 2] |= v << (8 * (bi & 3));
+          }
+      }
+      const int oxq = ox0 + 4 * m + a.xo + ((a.format == VD3D_FMT_INTERLACED) ? 0 : eye * a.fit_w);
+      uint8_t* o = out + ((size_t)(oy + a.yo) * a.out_w + oxq) * 3;
+      if ((reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+        o32[0] = pack[0]; o32[1] = pack[1]; o32[2] = pack[2];
+      } else {
+        for (int bi = 0; bi < 12; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
+      }
+    }
+    return;
+  }
   const float scale = 1.f / (float)(a.fx * a.fy);
   for (int t = tid; t < oh * (ow / 4); t += FF_NT) {
-    const int tq = t / oh, ty = t - tq * oh;   // row-fastest: lanes walk a column of the odd-pitch gb tile
+    const int tq = t / oh, ty = t - tq * oh;
     const int oy = oy0 + ty;
     if (oy >= a.in_h) continue;
     uint32_t pack[3] = {0, 0, 0};

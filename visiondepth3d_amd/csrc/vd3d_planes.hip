@@ -350,17 +350,14 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
       const int c = t / (th * DF_TW), rem = t - c * th * DF_TW;
       const int hy = rem / DF_TW, hx = rem - hy * DF_TW;
       const float* row = tile + (size_t)c * th * tw + hy * tw + hx + R - r;
-      float s = 0.f;
-      for (int j = 0; j < k; ++j) s += fc.kern[l][j] * row[j];
-      hb[t] = s;
+      hb[t] = vd_gauss_sym_rt(fc.kern[l], k, row, 1);
     }
     __syncthreads();
     if (l + 1 == lo || l + 1 == lo + 1) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float* col = hb + (size_t)c * th * DF_TW + (ty + R - r) * DF_TW + tx;
-        float s = 0.f;
-        for (int i = 0; i < k; ++i) s += fc.kern[l][i] * col[i * DF_TW];
+        const float s = vd_gauss_sym_rt(fc.kern[l], k, col, DF_TW);
         if (l + 1 == lo) vlo[c] = s; else vhi[c] = s;
       }
     }
