@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VD3D_ABI_VERSION 1
+#define VD3D_ABI_VERSION 2
 
 typedef enum vd3d_status {
   VD3D_OK = 0,
@@ -98,12 +98,15 @@ typedef struct vd3d_render_params {
   int32_t fit_w, fit_h;          /* per_eye_w/h: size each eye is fitted to before muxing (:1409-1417) */
   int32_t out_w, out_h;          /* muxed frame size */
   int32_t format;                /* vd3d_format */
+  int32_t auto_crop_black_bars;  /* :1230-1234: detect_black_bars + crop per frame, then the aspect crop of :1236-1248 is
+                                    re-derived per frame ON DEVICE from target_ratio (crop_x/y/w/h are then ignored) */
   /* sliders */
   vd3d_shift_params shift;       /* fg/mg/bg are the UNSCALED slider values; dyn_scale/ipd are applied per frame */
   double ipd_factor;             /* :1283,1308 */
   double dof_strength;           /* max_sigma of apply_dof_cuda; 0 disables (:1340) */
   double sharpness_factor;       /* apply_sharpening factor (:1406) */
   double color_saturation, color_contrast, color_brightness; /* apply_color_grade (:1362-1365) */
+  double target_ratio;           /* aspect_ratios[selected_aspect_ratio] (:1072); used when auto_crop_black_bars */
 } vd3d_render_params;
 
 /*
@@ -147,6 +150,7 @@ typedef struct vd3d_frame_scalars {
   int32_t bar_width;
   int32_t bar_side;              /* 0 none, 1 = mask right columns, 2 = mask left columns */
   int32_t collapse;              /* DepthPercentileEMA "hi-lo<1e-5" guard taken */
+  int32_t crop_top, crop_bottom; /* detect_black_bars result of this frame (0,0 when auto crop is off) */
   int32_t reserved;
 } vd3d_frame_scalars;
 
@@ -223,6 +227,9 @@ int vd3d_finish_frame(vd3d_ctx* ctx, const uint8_t* left_bgr, const uint8_t* rig
 int vd3d_quantiles(vd3d_ctx* ctx, const float* plane, int64_t n, const float* q_host, int nq, float* out_host);
 /* estimate_subject_depth, core/render_3d.py:145-172 (synchronises; test/diagnostic entry) */
 int vd3d_subject_depth(vd3d_ctx* ctx, const float* plane, int H, int W, float* out_host);
+/* detect_black_bars, core/render_3d.py:293-316, on a device-resident uint8 BGR frame (synchronises; test/diagnostic
+ * entry -- vd3d_render_frame runs the same kernel asynchronously when auto_crop_black_bars is set) */
+int vd3d_detect_black_bars(vd3d_ctx* ctx, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host);
 /* device-to-device streaming copy used as the measured-peak yardstick for roofline.frac */
 int vd3d_stream_copy(vd3d_ctx* ctx, const void* src, void* dst, size_t bytes);
 /* HIP-event profiling of the stages on the ctx stream ("frame", "ingest", "select_eye", "select_dc", "shape",

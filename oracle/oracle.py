@@ -198,6 +198,24 @@ def resize_area_int(img, dw, dh):
     return out
 
 
+def resize_area(img, dw, dh):
+    """cv2.resize(img, (dw, dh), interpolation=cv2.INTER_AREA), any down-scale ratio."""
+    img, pi = _u(img)
+    out = np.empty((dh, dw, 3), np.uint8)
+    rc = lib().vo_resize_area(pi, img.shape[0], img.shape[1], out.ctypes.data_as(_u8p), dh, dw)
+    if rc:
+        raise NotImplementedError("oracle: INTER_AREA up-scale")
+    return out
+
+
+def detect_black_bars(frame_bgr):
+    """detect_black_bars(frame_to_tensor(frame_bgr)) -> (top, bottom)."""
+    img, pi = _u(frame_bgr)
+    t, b = C.c_int(), C.c_int()
+    lib().vo_detect_black_bars(pi, img.shape[0], img.shape[1], C.byref(t), C.byref(b))
+    return t.value, b.value
+
+
 def pad_to_aspect(img, tw, th):
     img, pi = _u(img)
     out = np.empty((th, tw, 3), np.uint8)
@@ -211,7 +229,7 @@ def format_output(L, R, fmt):
     L, pl = _u(L)
     R, pr = _u(R)
     h, w = L.shape[:2]
-    out = np.empty((h, 2 * w, 3) if fmt in (0, 1) else (h, w, 3), np.uint8)
+    out = np.empty((h, 2 * w, 3) if fmt in (0, 1, 2) else (h, w, 3), np.uint8)
     rc = lib().vo_format_output(pl, pr, h, w, int(fmt), out.ctypes.data_as(_u8p))
     if rc:
         raise NotImplementedError(f"oracle: format {fmt}")

@@ -297,8 +297,81 @@ def gen_loops():
     save("render_loop.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 5. round-1 widening: fractional INTER_AREA (VR / non-preserve Full-SBS fit), black-bar auto crop
+# ------------------------------------------------------------------------------------------
+LOOP_CASES2 = {
+    # VR: eye 1440x810 -> warp 1920x1080 -> pad_to_aspect_ratio(1440,1600) = INTER_AREA 4/3 + letterbox; frames are
+    # 2880x1600, only bands are stored (rows 393..441 = top edge of the picture, rows 1200..1210 = bottom edge)
+    "vr_1080": (405, 720, 3, dict(output_format="VR", output_height=1080, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0,
+                                sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0, blur_ksize=9,
+                                use_subject_tracking=True, use_floating_window=True), [(393, 441), (1200, 1210)]),
+    # letterboxed source (bars: 10 rows top, 14 rows bottom, value <= 9), auto crop + 2.0 -> 16:9 column crop
+    "autocrop_letterbox": (120, 192, 5, dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5,
+                                             bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0,
+                                             blur_ksize=9, use_subject_tracking=True, use_floating_window=True,
+                                             auto_crop_black_bars=True), None),
+}
+
+
+def run_loop2(name):
+    sh, sw, n, kw, _ = LOOP_CASES2[name]
+    if name == "autocrop_letterbox":
+        frames, depth_bgr = synth.letterbox_clip(n, sh, sw, 10, 14)
+    else:
+        frames, depths = synth.synth_clip(n, sh, sw)
+        depth_bgr = [synth.depth_to_u8_bgr(d) for d in depths]
+    ref_stubs._Clip.clips["in.mp4"] = frames
+    ref_stubs._Clip.clips["depth.mp4"] = depth_bgr
+    rl.reset_state()
+    args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0,
+                output_width=sw, selected_aspect_ratio=_Aspect("Default (16:9)"), aspect_ratios=r.aspect_ratios,
+                suspend_flag=threading.Event(), cancel_flag=threading.Event())
+    args.update(kw)
+    with contextlib.redirect_stdout(io.StringIO()) as so:
+        r.render_sbs_3d(**args)
+    if "crashed" in so.getvalue():
+        raise RuntimeError(so.getvalue())
+    return ref_stubs._Clip.written["out.avi"], so.getvalue()
+
+
+def gen_widen():
+    import cv2
+    out = {}
+    # helper level: fractional / mixed INTER_AREA and pad_to_aspect_ratio at small sizes
+    bgr = synth.synth_frame(3, 72, 128)[0]
+    for nm, (dw, dh) in {"area_4_3": (96, 54), "area_3_2": (85, 48), "area_2p5": (51, 28), "area_mixed": (64, 54),
+                         "area_1p07": (120, 67)}.items():
+        out[nm] = cv2.resize(bgr, (dw, dh), interpolation=cv2.INTER_AREA)
+    out["pad_frac_wide"] = r.pad_to_aspect_ratio(bgr, 96, 60)     # 4/3 down + vertical bars
+    out["pad_frac_tall"] = r.pad_to_aspect_ratio(bgr, 100, 48)    # 3/2 down + horizontal bars
+    out["fmt__VR_identity"] = r.format_3d_output(np.zeros((1600, 1440, 3), np.uint8) + 7, np.zeros((1600, 1440, 3), np.uint8) + 9, "VR")[::200, ::240]
+    # detect_black_bars on the letterboxed frames
+    lf, _ = synth.letterbox_clip(4, 120, 192, 10, 14)
+    out["bars"] = np.array([r.detect_black_bars(r.frame_to_tensor(f)) for f in lf], dtype=np.int32)
+    out["bars_none"] = np.array(r.detect_black_bars(r.frame_to_tensor(np.zeros((40, 64, 3), np.uint8) + 200)), dtype=np.int32)
+    out["bars_all_black"] = np.array(r.detect_black_bars(r.frame_to_tensor(np.zeros((40, 64, 3), np.uint8) + 4)), dtype=np.int32)
+    for name, (sh, sw, n, kw, bands) in LOOP_CASES2.items():
+        written, log = run_loop2(name)
+        fr = np.stack(written)
+        print(f"  loop {name}: {len(written)} frames of {written[0].shape}")
+        out[f"{name}__shape"] = np.array(fr.shape, dtype=np.int64)
+        if bands is None:
+            out[f"{name}__frames"] = fr
+        else:
+            for (a, b) in bands:
+                out[f"{name}__rows_{a}_{b}"] = fr[:, a:b]
+            out[f"{name}__colsum"] = fr.astype(np.int64).sum(axis=(1, 3))   # per-frame per-column sums (coarse full-frame check)
+        if name == "autocrop_letterbox":
+            out[f"{name}__log"] = np.frombuffer(log.encode(), dtype=np.uint8)
+    out["cases_json"] = np.frombuffer(json.dumps({k: list(v) for k, v in LOOP_CASES2.items()}).encode(), dtype=np.uint8)
+    save("widen.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen"]
+    if "widen" in which:
+        gen_widen()
     if "kat" in which:
         gen_kat()
     if "shift" in which:

@@ -116,7 +116,7 @@ def _resize_area(src, dw, dh):
     sh, sw = src.shape[:2]
     if (sw, sh) == (dw, dh):
         return src.copy()
-    sx, sy = sw / dw, sh / dh
+    sx, sy = 1.0 / (dw / sw), 1.0 / (dh / sh)   # hal::resize: scale = 1./inv_scale, inv_scale = (double)dsize/ssize
     isx, isy = int(round(sx)), int(round(sy))
     if sx >= 1 and sy >= 1 and abs(sx - isx) < 2.2e-16 * 4 and abs(sy - isy) < 2.2e-16 * 4:
         # integer-ratio fast path: int sums * float(1/area) -> saturate_cast

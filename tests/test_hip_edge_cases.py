@@ -129,7 +129,10 @@ def test_finish_frame_padded_canvas_and_unsupported_ratio(R, oracle):
     got = R.finish_frame(T(L_), T(R_), T(dn), p, 0.5, 0, 0).cpu().numpy()
     assert np.array_equal(got, exp)
     assert not got[:9].any() and not got[63:].any()           # black bars of the canvas
-    p.fit_w, p.fit_h, p.out_w, p.out_h = 100, 72, 200, 72      # fractional INTER_AREA: valid in the reference, not built -> loud
+    p.fit_w, p.fit_h, p.out_w, p.out_h = 100, 72, 200, 72      # fractional INTER_AREA (1.28): generic area-table path
+    got = R.finish_frame(T(L_), T(R_), T(dn), p, 0.5, 0, 0).cpu().numpy()
+    assert np.array_equal(got, oracle.finish_frame(L_, R_, dn, p, 0.5, 0, 0))
+    p.fit_w, p.fit_h, p.out_w, p.out_h = 200, 72, 400, 72      # INTER_AREA up-scale (OpenCV's linear area mode): not built -> loud
     with pytest.raises(Vd3dError) as e:
         R.finish_frame(T(L_), T(R_), T(dn), p, 0.5, 0, 0)
     assert e.value.code == -4
@@ -159,10 +162,10 @@ def test_degenerate_depth_planes(R, oracle):
 
 def test_unsupported_features_fail_loudly():
     with pytest.raises(NotImplementedError):
-        render_kwargs_to_params(96, 54, output_height=54, auto_crop_black_bars=True, output_format="Half-SBS", **{k: v for k, v in BASE.items()})
+        render_kwargs_to_params(96, 54, output_height=54, skip_blank_frames=True, output_format="Half-SBS", **{k: v for k, v in BASE.items()})
     from visiondepth3d_amd.render_3d import Renderer
     r = Renderer(0)
-    p = render_kwargs_to_params(96, 54, **dict(BASE, output_format="VR", output_height=54))
+    p = render_kwargs_to_params(96, 54, **dict(BASE, output_format="VR", output_height=54))   # 96x54 warp -> 1440x810: up-scale
     with pytest.raises(Vd3dError) as e:
         r.render_frame(torch.zeros(54, 96, 3, dtype=torch.uint8).cuda(), torch.zeros(54, 96).cuda(), p)
     assert e.value.code == -4

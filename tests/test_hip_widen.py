@@ -1,0 +1,136 @@
+"""GPU parity tests (-m gpu) for the round-1 widening rows: black-bar auto crop (core/render_3d.py:293-326,1230-1248),
+fractional / mixed INTER_AREA inside pad_to_aspect_ratio (:101-131) and the VR format (:846-849).
+HIP (through the C ABI) vs the CPU oracle: bit-exact; vs the reference goldens (tests/golden/widen.npz): the B2 bars."""
+import numpy as np
+import pytest
+
+from conftest import golden_json, load_golden, u8_diff_stats
+from visiondepth3d_amd import synth
+from visiondepth3d_amd._lib import Vd3dError
+from visiondepth3d_amd.params import render_kwargs_to_params
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def R():
+    from visiondepth3d_amd.render_3d import Renderer
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_detect_black_bars_vs_oracle_and_golden(R, oracle):
+    g = load_golden("widen.npz")
+    lf, _ = synth.letterbox_clip(4, 120, 192, 10, 14)
+    got = [R.detect_black_bars(T(f)) for f in lf]
+    assert got == [oracle.detect_black_bars(f) for f in lf]
+    assert np.array_equal(np.array(got, np.int32), g["bars"])
+    rng = np.random.default_rng(5)
+    cases = {
+        "no_bars": np.zeros((40, 64, 3), np.uint8) + 200,
+        "all_black": np.zeros((40, 64, 3), np.uint8) + 4,
+        "threshold_edge": np.zeros((9, 50, 3), np.uint8) + 10,       # gray 10 everywhere: mean == 10 is NOT > 10
+        "one_bright_pixel": np.zeros((9, 50, 3), np.uint8) + 10,
+        "noise_dark": rng.integers(0, 22, (37, 131, 3)).astype(np.uint8),   # row means straddle the threshold
+        "single_row": rng.integers(0, 255, (1, 17, 3)).astype(np.uint8),
+        "wide_4k_row": rng.integers(0, 40, (6, 3840, 3)).astype(np.uint8),
+    }
+    cases["one_bright_pixel"] = cases["one_bright_pixel"].copy()
+    cases["one_bright_pixel"][4, 7] = 255
+    for name, f in cases.items():
+        assert R.detect_black_bars(T(f)) == oracle.detect_black_bars(f), name
+
+
+def _loop(R, oracle, frames, depth_bgr, p):
+    R.reset_state(); R.new_clip()
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    got, exp = [], []
+    for f, d in list(zip(frames, depth_bgr))[1:]:
+        got.append(R.render_frame(T(f), T(d), p).cpu().numpy())
+        exp.append(ro.render(f, d, 1))
+        a, b = R.last_scalars().as_dict(), ro.last.as_dict()
+        assert a == b, {k: (a[k], b[k]) for k in a if a[k] != b[k]}
+    return np.stack(got), np.stack(exp)
+
+
+def test_autocrop_loop_bit_exact(R, oracle):
+    g = load_golden("widen.npz")
+    sh, sw, n, kw, _ = golden_json(g, "cases_json")["autocrop_letterbox"]
+    frames, depth_bgr = synth.letterbox_clip(n, sh, sw, 10, 14)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    got, exp = _loop(R, oracle, frames, depth_bgr, p)
+    assert np.array_equal(got, exp), u8_diff_stats(got, exp)
+    mx, frac, frac_gt1 = u8_diff_stats(got, g["autocrop_letterbox__frames"])
+    assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2
+    # a later clip WITHOUT auto crop on the same context reports (0, 0) again and uses the static crop
+    kw2 = dict(kw); kw2["auto_crop_black_bars"] = False
+    p2 = render_kwargs_to_params(sw, sh, **kw2)
+    got2, exp2 = _loop(R, oracle, frames, depth_bgr, p2)
+    assert np.array_equal(got2, exp2) and not np.array_equal(got2, got)
+    assert R.last_scalars().crop_top == 0 and R.last_scalars().crop_bottom == 0
+
+
+@pytest.mark.parametrize("fmt", ["Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph"])
+def test_autocrop_other_formats_and_unfused(R, oracle, fmt, monkeypatch):
+    frames, depth_bgr = synth.letterbox_clip(3, 96, 160, 7, 9)
+    p = render_kwargs_to_params(160, 96, output_format=fmt, output_height=90, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                sharpness_factor=0.2, dof_strength=1.0, auto_crop_black_bars=True, preserve_original_aspect=True,
+                                original_video_width=160, original_video_height=90)
+    got, exp = _loop(R, oracle, frames, depth_bgr, p)
+    assert np.array_equal(got, exp), u8_diff_stats(got, exp)
+
+
+def test_autocrop_needs_the_frame(R):
+    p = render_kwargs_to_params(192, 120, output_format="Half-SBS", output_height=108, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                sharpness_factor=0.2, dof_strength=0.0, auto_crop_black_bars=True)
+    d = T(np.zeros((120, 192), np.float32))
+    with pytest.raises(Vd3dError):
+        R.advance_state(d, p)       # depth-only state advance cannot detect bars: loud, not silently uncropped
+
+
+def test_fractional_fit_finish_vs_oracle(R, oracle):
+    """finish stage with fractional / mixed INTER_AREA ratios and pad offsets (small canvases, every format that pads)."""
+    rng = np.random.default_rng(11)
+    H, W = 72, 128
+    L = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    Rr = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+    dn = rng.random((H, W)).astype(np.float32)
+    for fmt, (fw, fh) in [("Full-SBS", (96, 60)), ("Full-SBS", (100, 48)), ("Passive Interlaced", (85, 50)),
+                          ("Red-Cyan Anaglyph", (51, 40)), ("Full-SBS", (120, 70))]:
+        p = render_kwargs_to_params(W, H, output_format=fmt, output_height=H, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                    sharpness_factor=0.2, dof_strength=2.0, preserve_original_aspect=True,
+                                    original_video_width=W, original_video_height=H)
+        p.fit_w, p.fit_h = fw, fh
+        p.out_w = 2 * fw if fmt == "Full-SBS" else fw
+        p.out_h = fh
+        got = R.finish_frame(T(L), T(Rr), T(dn), p, 0.4, bar_width=5, bar_side=1).cpu().numpy()
+        exp = oracle.finish_frame(L, Rr, dn, p, 0.4, 5, 1)
+        assert np.array_equal(got, exp), (fmt, fw, fh, u8_diff_stats(got, exp))
+
+
+def test_vr_loop_bit_exact_and_golden(R, oracle):
+    g = load_golden("widen.npz")
+    sh, sw, n, kw, bands = golden_json(g, "cases_json")["vr_1080"]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    got, exp = _loop(R, oracle, frames, [synth.depth_to_u8_bgr(d) for d in depths], p)
+    assert got.shape == (2, 1600, 2880, 3)
+    assert np.array_equal(got, exp), u8_diff_stats(got, exp)
+    for (a, b) in bands:
+        mx, frac, frac_gt1 = u8_diff_stats(got[:, a:b], g[f"vr_1080__rows_{a}_{b}"])
+        assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2, (a, b, mx, frac, frac_gt1)
+
+
+def test_upscaling_inter_area_is_refused(R):
+    p = render_kwargs_to_params(128, 72, output_format="Full-SBS", output_height=72, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                sharpness_factor=0.2, dof_strength=0.0)     # fixed 1920x1080 eyes from a 128x72 warp
+    with pytest.raises(Vd3dError):
+        R.render_frame(T(np.zeros((72, 128, 3), np.uint8)), T(np.zeros((72, 128), np.float32)), p)

@@ -43,7 +43,10 @@ def test_render_kwargs_mirror_reference_forwarding():
                                 dof_strength=0, codec="XVID")  # render_cli.py's stale kwarg is a TypeError in the reference too
     with pytest.raises(NotImplementedError):
         render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0,
-                                output_format="Half-SBS", dof_strength=0, auto_crop_black_bars=True)
+                                output_format="Half-SBS", dof_strength=0, skip_blank_frames=True)
+    pa = render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0,
+                                 output_format="Half-SBS", dof_strength=0, auto_crop_black_bars=True, target_ratio=2.39)
+    assert pa.auto_crop_black_bars == 1 and pa.target_ratio == 2.39 and p.auto_crop_black_bars == 0
 
 
 def test_shift_kwargs():

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FMT_HALF_SBS, FMT_FULL_SBS, FMT_VR, FMT_ANAGLYPH, FMT_INTERLACED = range(5)
 FORMAT_IDS = {
@@ -67,12 +67,13 @@ class RenderParams(C.Structure):
         ("warp_w", C.c_int32), ("warp_h", C.c_int32),
         ("fit_w", C.c_int32), ("fit_h", C.c_int32),
         ("out_w", C.c_int32), ("out_h", C.c_int32),
-        ("format", C.c_int32),
+        ("format", C.c_int32), ("auto_crop_black_bars", C.c_int32),
         ("shift", ShiftParams),
         ("ipd_factor", C.c_double),
         ("dof_strength", C.c_double),
         ("sharpness_factor", C.c_double),
         ("color_saturation", C.c_double), ("color_contrast", C.c_double), ("color_brightness", C.c_double),
+        ("target_ratio", C.c_double),
     ]
 
 
@@ -99,7 +100,8 @@ class FrameScalars(C.Structure):
         ("s_norm", C.c_float), ("mad", C.c_float),
         ("s0", C.c_float), ("q05", C.c_float), ("q95", C.c_float), ("s1", C.c_float),
         ("zpo_raw", C.c_float), ("zpo", C.c_double), ("focal", C.c_double), ("stable_zero", C.c_double),
-        ("bar_width", C.c_int32), ("bar_side", C.c_int32), ("collapse", C.c_int32), ("reserved", C.c_int32),
+        ("bar_width", C.c_int32), ("bar_side", C.c_int32), ("collapse", C.c_int32),
+        ("crop_top", C.c_int32), ("crop_bottom", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self):

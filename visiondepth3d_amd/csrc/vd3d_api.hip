@@ -50,6 +50,8 @@ struct vd3d_ctx {
   float *D = nullptr, *S = nullptr, *e2L = nullptr, *e2R = nullptr, *bL = nullptr, *bR = nullptr;
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
   uint32_t* mm = nullptr; int mm_cap = 0;
+  uint32_t* rowflag = nullptr; int rowflag_cap = 0;   // k_autocrop: one flag per source row
+  bool crop_scalars_dirty = false;                    // fs.crop_top/bottom hold a previous auto-crop result
   // frame sharding (three-phase protocol): per-slot planes of the frames this rank owns inside the current step
   int n_slots = 0, slot_eh = 0, slot_ew = 0, slot_H = 0, slot_W = 0;
   std::vector<float*> slot_rgb, slot_dn, slot_D;
@@ -166,7 +168,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -328,8 +330,11 @@ static int make_finish_consts(const vd3d_render_params* p, vd_finish_consts* fc)
   return 0;
 }
 
+#define VD_AREA_MAXT_HOST 12
 static int check_fit(const vd3d_render_params* p) {
-  if (p->format == VD3D_FMT_VR) return set_err(VD3D_E_UNSUPPORTED, "VR format (1440x1600 INTER_LINEAR + fractional INTER_AREA) not built yet");
+  // VR: format_3d_output's cv2.resize(eye,(1440,1600)) is the identity only for the 1440x1600 eyes render_sbs_3d makes (:1104,1127)
+  if (p->format == VD3D_FMT_VR && (p->fit_w != 1440 || p->fit_h != 1600))
+    return set_err(VD3D_E_UNSUPPORTED, "VR with a %dx%d eye canvas would need format_3d_output's INTER_LINEAR resize (not built)", p->fit_w, p->fit_h);
   if (p->format < 0 || p->format > VD3D_FMT_INTERLACED) return set_err(VD3D_E_INVALID, "unknown format %d", p->format);
   int in_w, in_h;
   if (p->format == VD3D_FMT_HALF_SBS) { in_w = p->fit_w; in_h = p->fit_h; }
@@ -338,10 +343,12 @@ static int check_fit(const vd3d_render_params* p) {
     if (ca > ta) { in_w = p->fit_w; in_h = (int)(p->fit_w / ca); }
     else { in_h = p->fit_h; in_w = (int)(ca * p->fit_h); }
   }
-  if (in_w < 1 || in_h < 1 || p->warp_w % in_w || p->warp_h % in_h)
-    return set_err(VD3D_E_UNSUPPORTED, "fit %dx%d -> %dx%d is not an integer INTER_AREA ratio (fractional path not built yet)",
+  if (in_w < 1 || in_h < 1 || in_w > p->warp_w || in_h > p->warp_h)
+    return set_err(VD3D_E_UNSUPPORTED, "fit %dx%d -> %dx%d up-scales: OpenCV's INTER_AREA switches to its linear area mode there (not built)",
                    p->warp_w, p->warp_h, in_w, in_h);
-  const int mux_w = (p->format == VD3D_FMT_HALF_SBS || p->format == VD3D_FMT_FULL_SBS) ? 2 * p->fit_w : p->fit_w;
+  if ((p->warp_w % in_w || p->warp_h % in_h) && ((double)p->warp_w / in_w > VD_AREA_MAXT_HOST - 2 || (double)p->warp_h / in_h > VD_AREA_MAXT_HOST - 2))
+    return set_err(VD3D_E_UNSUPPORTED, "fractional INTER_AREA ratio above %d not built", VD_AREA_MAXT_HOST - 2);
+  const int mux_w = (p->format == VD3D_FMT_HALF_SBS || p->format == VD3D_FMT_FULL_SBS || p->format == VD3D_FMT_VR) ? 2 * p->fit_w : p->fit_w;
   if (p->out_w != mux_w || p->out_h != p->fit_h) return set_err(VD3D_E_INVALID, "out size %dx%d does not match mux %dx%d", p->out_w, p->out_h, mux_w, p->fit_h);
   return 0;
 }
@@ -381,8 +388,14 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
                              int slot = -1, float* s1_out = nullptr) {
   if (!c || !depth || !p || (!state_only && (!frame_bgr || !out_bgr))) return set_err(VD3D_E_INVALID, "NULL argument");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
-  if (p->crop_x < 0 || p->crop_y < 0 || p->crop_w < 1 || p->crop_h < 1 || p->crop_x + p->crop_w > p->src_w || p->crop_y + p->crop_h > p->src_h)
+  if (!p->auto_crop_black_bars &&
+      (p->crop_x < 0 || p->crop_y < 0 || p->crop_w < 1 || p->crop_h < 1 || p->crop_x + p->crop_w > p->src_w || p->crop_y + p->crop_h > p->src_h))
     return set_err(VD3D_E_INVALID, "crop window outside the frame");
+  if (p->auto_crop_black_bars) {
+    if (!frame_bgr) return set_err(VD3D_E_UNSUPPORTED, "auto_crop_black_bars needs the frame of EVERY step (detect_black_bars runs on the "
+                                   "RGB frame): frame-sharded steps and depth-only state advances cannot derive the crop");
+    if (!(p->target_ratio > 0.0) || p->src_w < 1 || p->src_h < 1) return set_err(VD3D_E_INVALID, "auto_crop_black_bars needs target_ratio > 0");
+  }
   if (p->eye_w < 2 || p->eye_h < 2) return set_err(VD3D_E_INVALID, "eye size too small");
   int rc = check_fit(p);
   if (rc) return rc;
@@ -410,6 +423,14 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   a.ipd_factor = p->ipd_factor; a.shift = sp;
   float* dn_cur = c->dn[c->dn_cur];
   float* dn_prev = c->dn[c->dn_cur ^ 1];
+  if (p->auto_crop_black_bars) {   // :1230-1248 decided on device, no host round trip
+    if (p->src_h > c->rowflag_cap) { HIPCHK(re_alloc(&c->rowflag, (size_t)p->src_h)); c->rowflag_cap = p->src_h; }
+    vd_launch_autocrop(s, frame_bgr, p->src_h, p->src_w, p->target_ratio, c->rowflag, c->work);
+    c->crop_scalars_dirty = true;
+  } else if (c->crop_scalars_dirty) {
+    HIPCHK(hipMemsetAsync(&c->work->fs.crop_top, 0, 2 * sizeof(int32_t), s));
+    c->crop_scalars_dirty = false;
+  }
   if (c->use_fused) {
     StageTimer t(c, "select_eye");   // fused chain: ingest (+A0), b0 (B0); eye stats ride on the next launch
     HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
@@ -594,6 +615,19 @@ VD3D_EXPORT int vd3d_depth_handoff(vd3d_ctx* c, const float* pred, int B, int ph
   StageTimer t(c, "handoff");
   vd_launch_depth_handoff(c->stream, pred, B, ph, pw, H, W, invert ? 1 : 0, c->mm, out_gray);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
+  if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (h > c->rowflag_cap) { HIPCHK(re_alloc(&c->rowflag, (size_t)h)); c->rowflag_cap = h; }
+  vd_launch_autocrop(c->stream, frame_bgr, h, w, 16.0 / 9.0, c->rowflag, c->work);
+  c->crop_scalars_dirty = true;
+  int32_t tb[2];
+  HIPCHK(hipMemcpyAsync(tb, &c->work->fs.crop_top, sizeof tb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *top_host = tb[0]; *bottom_host = tb[1];
   return 0;
 }
 

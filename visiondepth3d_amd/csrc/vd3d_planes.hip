@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ fram
   const int ex = blockIdx.x * 32 + (threadIdx.x & 31);
   const int ey = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (ex >= p.eye_w || ey >= p.eye_h) return;
+  if (p.auto_crop_black_bars) { p.crop_x = w->acrop[0]; p.crop_y = w->acrop[1]; p.crop_w = w->acrop[2]; p.crop_h = w->acrop[3]; }
   vd_ingest_pixel(frame, depth, fmt, p, w->st.tdf_valid, rgb_eye, tdf, ey, ex);
 }
 
@@ -414,7 +415,27 @@ struct vd_mux_geom {
   int xo, yo;          // its offset
   int fx, fy;          // integer down-scale factors
   int out_w, out_h, format;
+  int frac;            // non-integer (or mixed) INTER_AREA ratio: generic area table path
+  double sx, sy;       // OpenCV's scale = 1./((double)dsize/ssize)
 };
+// computeResizeAreaTab (OpenCV resize.cpp) for ONE destination index: consecutive source indices s0..s0+n-1 with weights a[].
+#define VD_AREA_MAXT 12
+VD_DEV int vd_area_taps(int ssize, double scale, int d, int* s0, float* a) {
+  const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+  const double cell = scale < (double)ssize - fsx1 ? scale : (double)ssize - fsx1;
+  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+  sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+  sx1 = sx1 < sx2 ? sx1 : sx2;
+  int n = 0;
+  *s0 = sx1;
+  if (sx1 - fsx1 > 1e-3) { *s0 = sx1 - 1; a[n++] = (float)((sx1 - fsx1) / cell); }
+  for (int sx = sx1; sx < sx2 && n < VD_AREA_MAXT; ++sx) a[n++] = (float)(1.0 / cell);
+  if (fsx2 - sx2 > 1e-3 && n < VD_AREA_MAXT) {
+    double t = fsx2 - sx2; t = t < 1.0 ? t : 1.0; t = t < cell ? t : cell;
+    a[n++] = (float)(t / cell);
+  }
+  return n;
+}
 __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, vd_mux_geom m,
                                                    float kn, float kc, uint8_t* __restrict__ out) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -429,7 +450,18 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       uint8_t v = 0;
-      if (inside) {
+      if (inside && m.frac) {  // ResizeArea_<uchar,float>: per source row sum_k S*alpha (float32), then sum_j row*beta
+        float ax[VD_AREA_MAXT], ay[VD_AREA_MAXT];
+        int x0s, y0s;
+        const int nx = vd_area_taps(m.W, m.sx, ix, &x0s, ax), ny = vd_area_taps(m.H, m.sy, iy, &y0s, ay);
+        float acc = 0.f;
+        for (int j = 0; j < ny; ++j) {
+          float h = 0.f;
+          for (int k = 0; k < nx; ++k) h = h + (float)sharp_at(g, m.H, m.W, y0s + j, x0s + k, c, kn, kc) * ax[k];
+          acc = acc + h * ay[j];
+        }
+        v = vd_sat_rne_u8(acc);
+      } else if (inside) {
         if (m.fx == 1 && m.fy == 1) v = sharp_at(g, m.H, m.W, iy, ix, c, kn, kc);
         else {
           int sum = 0;
@@ -442,7 +474,7 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
       px[eye][c] = v;
     }
   }
-  if (m.format == VD3D_FMT_HALF_SBS || m.format == VD3D_FMT_FULL_SBS) {
+  if (m.format == VD3D_FMT_HALF_SBS || m.format == VD3D_FMT_FULL_SBS || m.format == VD3D_FMT_VR) {
     uint8_t* o0 = out + ((size_t)y * m.out_w + x) * 3;
     uint8_t* o1 = out + ((size_t)y * m.out_w + x + m.fit_w) * 3;
 #pragma unroll
@@ -477,6 +509,8 @@ void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
     m.xo = (p.fit_w - m.in_w) / 2; m.yo = (p.fit_h - m.in_h) / 2;
   }
   m.fx = m.in_w > 0 ? p.warp_w / m.in_w : 1; m.fy = m.in_h > 0 ? p.warp_h / m.in_h : 1;
+  m.sx = 1.0 / ((double)m.in_w / p.warp_w); m.sy = 1.0 / ((double)m.in_h / p.warp_h);
+  m.frac = (p.warp_w % m.in_w || p.warp_h % m.in_h) ? 1 : 0;
   hipLaunchKernelGGL(k_sharp_mux, dim3((p.fit_w + 63) / 64, (p.fit_h + 3) / 4), dim3(256), 0, s, gL, gR, m, fc.sharp_kn, fc.sharp_kc, out);
 }
 

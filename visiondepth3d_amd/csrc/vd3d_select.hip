@@ -598,6 +598,53 @@ VD_DEV void lds_hist_flush(const uint32_t* h, uint32_t* g) {
 }
 VD_DEV unsigned key_a(float v) { unsigned k = __float_as_uint(v) >> 16; return k < (NBL - 1) ? k : (NBL - 1); }
 
+// K0 (only when auto_crop_black_bars): detect_black_bars (:293-316) + crop_black_bars_torch (:318-326) + the aspect crop of
+// :1236-1248, decided on device.  One wave per source row: integer sum of the cv2 RGB2GRAY of the frame after the
+// reference's float32 round trip ((v/255)*255 truncated); row is "content" iff sum > 10*w (== np.mean(row) > 10).
+// Last workgroup: first / last content row -> top / bottom -> crop rectangle in vd_dev_work::acrop.
+__global__ __launch_bounds__(256) void k_autocrop(const uint8_t* __restrict__ frame, int h, int wd, double target_ratio,
+                                                  uint32_t* __restrict__ rowflag, vd_dev_work* w) {
+  __shared__ uint32_t sflag;
+  __shared__ int s_first, s_last;
+  const int lane = threadIdx.x & 63;
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (y < h) {
+    unsigned sum = 0;
+    for (int x = lane; x < wd; x += 64) {
+      const uint8_t* px = frame + ((size_t)y * wd + x) * 3;
+      const unsigned b = (unsigned)(uint8_t)(vd_u8_unit((float)px[0]) * 255.0f), g = (unsigned)(uint8_t)(vd_u8_unit((float)px[1]) * 255.0f),
+                     r = (unsigned)(uint8_t)(vd_u8_unit((float)px[2]) * 255.0f);
+      sum += (r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += (unsigned)__shfl_down((int)sum, off, 64);
+    if (lane == 0) rowflag[y] = sum > 10u * (unsigned)wd ? 1u : 0u;
+  }
+  if (!last_workgroup(&w->ticket[6], &sflag)) return;
+  if (threadIdx.x == 0) { s_first = h; s_last = -1; }
+  __syncthreads();
+  int first = h, last = -1;
+  for (int r = threadIdx.x; r < h; r += 256)
+    if (rowflag[r]) { first = min(first, r); last = max(last, r); }
+  if (first < h) { atomicMin(&s_first, first); atomicMax(&s_last, last); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int top = s_last < 0 ? 0 : s_first, bottom = s_last < 0 ? 0 : h - s_last - 1;
+    int y0 = 0, hh = h;
+    if (top + bottom < h) { y0 = top; hh = h - top - bottom; }
+    int cx = 0, cy = y0, cw = wd, ch = hh;
+    const double cr = (double)wd / (double)hh;
+    if (fabs(cr - target_ratio) > 0.01) {
+      if (cr > target_ratio) { const int nw = (int)((double)hh * target_ratio); cx = (wd - nw) / 2; cw = nw; }
+      else { const int nh = (int)((double)wd / target_ratio); cy = y0 + (hh - nh) / 2; ch = nh; }
+    }
+    w->acrop[0] = cx; w->acrop[1] = cy; w->acrop[2] = cw; w->acrop[3] = ch;
+    w->fs.crop_top = top; w->fs.crop_bottom = bottom;
+  }
+}
+void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w) {
+  hipLaunchKernelGGL(k_autocrop, dim3((h + 3) / 4), dim3(256), 0, s, frame, h, wd, target_ratio, rowflag, w);
+}
+
 // K1: ingest (+ TemporalDepthFilter) + pass A of J0; last workgroup: scan A0
 __global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt,
                                                        vd3d_render_params p, vd_dev_work* w, float* __restrict__ rgb_eye,
@@ -609,6 +656,7 @@ __global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict
   __syncthreads();
   const long long n = (long long)p.eye_h * p.eye_w;
   const int tdf_valid = w->st.tdf_valid;
+  if (p.auto_crop_black_bars) { p.crop_x = w->acrop[0]; p.crop_y = w->acrop[1]; p.crop_w = w->acrop[2]; p.crop_h = w->acrop[3]; }
   for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
     const long long i = base + threadIdx.x;
     float v = 0.f;

@@ -43,8 +43,6 @@ def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, 
         raise TypeError(f"render_sbs_3d() got unexpected keyword argument(s) {sorted(unknown)}")
     o = dict(RENDER_DEFAULTS)
     o.update(kw)
-    if o["auto_crop_black_bars"]:
-        raise NotImplementedError("auto_crop_black_bars (detect_black_bars, core/render_3d.py:293-316) is not built yet")
     if o["skip_blank_frames"]:
         raise NotImplementedError("skip_blank_frames needs the ffmpeg blackdetect side-channel (out of scope)")
     geom = plan_geometry(src_w, src_h, output_height, output_format, target_ratio, o["preserve_original_aspect"],
@@ -59,4 +57,6 @@ def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, 
     p = make_render_params(geom, shift, ipd_factor=o["ipd_factor"], dof_strength=dof_strength,
                            sharpness_factor=sharpness_factor, color_saturation=o["color_saturation"],
                            color_contrast=o["color_contrast"], color_brightness=o["color_brightness"])
+    p.auto_crop_black_bars = 1 if o["auto_crop_black_bars"] else 0   # :1230-1234, crop decided per frame on device
+    p.target_ratio = float(target_ratio)
     return p

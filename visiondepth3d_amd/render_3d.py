@@ -220,6 +220,13 @@ class Renderer:
         _lib.check(self._L.vd3d_subject_depth(self._ctx, _ptr(p), H, W, C.byref(o)))
         return float(o.value)
 
+    def detect_black_bars(self, frame_bgr: torch.Tensor):
+        """detect_black_bars(frame_to_tensor(frame)) (core/render_3d.py:293-316) on a uint8 BGR frame -> (top, bottom)."""
+        f = frame_bgr.to(self.device, torch.uint8).contiguous()
+        t, b = C.c_int(), C.c_int()
+        _lib.check(self._L.vd3d_detect_black_bars(self._ctx, _ptr(f), f.shape[0], f.shape[1], C.byref(t), C.byref(b)))
+        return t.value, b.value
+
     def debug_planes(self, H, W, eh=None, ew=None):
         """Copies of the internal planes of the last call (tests only)."""
         ptrs = [C.c_void_p() for _ in range(6)]

@@ -93,3 +93,24 @@ def synth_clip(n: int, h: int, w: int, start: int = 0):
         frames.append(f)
         depths.append(d)
     return frames, depths
+
+
+def letterbox_clip(n: int, sh: int, sw: int, top: int, bottom: int):
+    """synth clip with dark bars painted over it (auto_crop_black_bars fixtures): bar pixels = (3*x + y + 5*t) % 10, so
+    bar-row means stay <= 9 < the detector's threshold 10; frame 2 additionally has a dark first content row (the detected
+    top moves by one on that frame).  Returns (frames_bgr_u8, depth_bgr_u8) lists."""
+    frames, depths = synth_clip(n, sh, sw)
+    y, x = np.mgrid[0:sh, 0:sw]
+    out_f, out_d = [], []
+    for t, (f, d) in enumerate(zip(frames, depths)):
+        f = f.copy()
+        bar = ((3 * x + y + 5 * t) % 10).astype(np.uint8)
+        m = (y < top) | (y >= sh - bottom)
+        f[m] = bar[m][:, None]
+        if t == 2:
+            f[top] = 7
+        db = depth_to_u8_bgr(d).copy()
+        db[m] = 0
+        out_f.append(f)
+        out_d.append(db)
+    return out_f, out_d
