@@ -118,7 +118,7 @@ def main():
     pipe = None
     if model_name:
         from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
-        pipe = DepthPipe(model_name, device="cuda", dtype=torch.bfloat16)
+        pipe = DepthPipe(model_name, device="cuda", dtype=torch.bfloat16, renderer=rh)   # fused image-processor front end
 
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
     gathered = [torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if world > 1 else None

@@ -216,6 +216,12 @@ int vd3d_shard_pixels(vd3d_ctx* ctx, int slot, const vd3d_render_params* p, uint
  * Replaces the reference's 8-bit depth video on disk while keeping its quantisation. */
 int vd3d_depth_handoff(vd3d_ctx* ctx, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint8_t* out_gray);
 
+/* ---- depth-net input preparation (a25, core/render_depth.py:1106-1119 -> DPTImageProcessor): B uint8 BGR frames
+ * [B][H][W][3] -> antialiased bicubic resize to (th,tw), 1/255, (x-mean)/std, RGB, bfloat16, NHWC [B][th][tw][3].
+ * Returns VD3D_E_UNSUPPORTED when the down-scale factor exceeds the kernel's tap budget (scale > ~5.5). */
+int vd3d_depth_preprocess(vd3d_ctx* ctx, const uint8_t* frames_bgr, int B, int H, int W, int th, int tw,
+                          const float* mean3_host, const float* std3_host, void* out_bf16_nhwc);
+
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux
  * (core/render_3d.py:1340-1419) on two u8 eyes. depth_norm is the eye-res normalised depth. */

@@ -1,0 +1,57 @@
+"""GPU test (-m gpu) of the fused depth-net input preparation (vd3d_depth_preprocess, boundary B3 / SURVEY a25) against
+the plain PyTorch float32 statement of the same operator chain (antialiased bicubic resize -> 1/255 -> ImageNet
+normalise).  Floating-point kernel: tolerance = bf16 rounding of the result (1/2 ulp = 2^-9 relative) plus the float32
+association noise of the 2-D filter sums."""
+import numpy as np
+import pytest
+
+from visiondepth3d_amd import synth
+from visiondepth3d_amd.depth import IMAGENET_MEAN, IMAGENET_STD, dpt_resize_target
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _ref(frames_u8, th, tw):
+    import torch.nn.functional as F
+    x = frames_u8.flip(-1).permute(0, 3, 1, 2).float()
+    x = F.interpolate(x, size=(th, tw), mode="bicubic", antialias=True, align_corners=False)
+    mean = torch.tensor(IMAGENET_MEAN, device=x.device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=x.device).view(1, 3, 1, 1)
+    return ((x / 255.0) - mean) / std
+
+
+@pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840), (270, 480), (518, 924), (101, 333)])
+def test_depth_preprocess_matches_torch(hw):
+    from visiondepth3d_amd.render_3d import Renderer
+    H, W = hw
+    r = Renderer(0)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(i, H, W)[0] for i in range(2)])).cuda()
+    th, tw = dpt_resize_target(H, W)
+    got = r.depth_preprocess(frames, th, tw, IMAGENET_MEAN, IMAGENET_STD)
+    assert got.shape == (2, 3, th, tw) and got.dtype == torch.bfloat16
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    ref = _ref(frames, th, tw)
+    err = (got.float() - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 2e-3       # bf16 half-ulp (2^-9) with margin + filter-sum noise near zero
+    assert bool((err <= tol).all()), float((err - tol).max())
+    same = (got == ref.to(torch.bfloat16)).float().mean().item()
+    assert same > 0.98, same                  # almost every element is the SAME bf16 value as the rounded torch result
+    r.close()
+
+
+def test_depth_pipe_uses_fused_front_end():
+    """DepthPipe(renderer=...) runs the fused launch and produces (almost) the same prediction as the ATen front end."""
+    from visiondepth3d_amd.depth import DepthPipe
+    from visiondepth3d_amd.render_3d import Renderer
+    r = Renderer(0)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(i, 270, 480)[0] for i in range(2)])).cuda()
+    pa = DepthPipe("depth-anything-v2-small", device="cuda")
+    pb = DepthPipe("depth-anything-v2-small", device="cuda", renderer=r)
+    a = pa.infer_bgr_u8(frames, raw=True)
+    r.set_profiling(True)
+    b = pb.infer_bgr_u8(frames, raw=True)
+    assert r.stage_calls("depth_prep") == 1
+    rel = ((a - b).abs().mean() / a.abs().mean()).item()
+    assert rel < 2e-2, rel                    # bf16 network: inputs differ in a few last bf16 bits
+    r.close()

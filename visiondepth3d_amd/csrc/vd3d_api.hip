@@ -618,6 +618,18 @@ VD3D_EXPORT int vd3d_depth_handoff(vd3d_ctx* c, const float* pred, int B, int ph
   return 0;
 }
 
+VD3D_EXPORT int vd3d_depth_preprocess(vd3d_ctx* c, const uint8_t* frames_bgr, int B, int H, int W, int th, int tw,
+                                      const float* mean3_host, const float* std3_host, void* out_bf16_nhwc) {
+  if (!c || !frames_bgr || !mean3_host || !std3_host || !out_bf16_nhwc || B < 1 || H < 1 || W < 1 || th < 1 || tw < 1)
+    return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "depth_prep");
+  if (!vd_launch_depth_prep(c->stream, frames_bgr, B, H, W, th, tw, mean3_host, std3_host, out_bf16_nhwc))
+    return set_err(VD3D_E_UNSUPPORTED, "depth_preprocess: %dx%d -> %dx%d exceeds the antialias tap budget", W, H, tw, th);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
   if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

@@ -2,17 +2,18 @@
 // apply_side_mask + apply_sharpening + INTER_AREA fit + SBS / interlaced mux in ONE launch for both eyes
 // (core/render_3d.py:1340-1419).  Replaces k_dof_grade x2 + k_sharp_mux and their two graded planes (-12N B of HBM).
 //
-// Per 64x16 tile of sharpened pixels (384 threads, blockIdx.z = eye):
-//   load    (16+2+8) x (64+8+8) reflect-padded u8 tile -> v/255 (exact 3-op form) -> float planes in LDS, TWO ROWS
-//           INTERLEAVED per element (tile2[c][row/2][x][row&1]) so that a ds_read_b128 yields two aligned (row,row+1) pairs
-//   level l H-pass: one task = (channel, row pair, 4-pixel strip): 6x ds_read_b128, symmetric-pair FMA tap sums on
-//           (row,row+1) float2 vectors => v_pk_add/fma_f32, two row-major ds_write_b128
-//           V-pass: one thread = one strip of the 18x72 graded region, k x ds_read_b128, float4 => v_pk_* again
+// Per 64x16 tile of sharpened pixels (384 threads = 6 waves, blockIdx.z = eye).  The kernel is latency-bound (its time
+// scales 1/occupancy), so the design minimises LDS (30.5 KB -> 5 workgroups per CU) and barriers (3 in total):
+//   load    (16+2+8) x (64+8+8) reflect-padded u8 tile -> v/255 (exact 3-op form) -> planar float tile in LDS
+//   thread  = (graded row 0..17, 4-pixel strip 0..19); one wave owns 3 whole rows (60 lanes), so a strip's horizontal
+//           neighbours are the adjacent LANES: no second LDS buffer, no barrier between the passes
+//   level l V-pass: k x ds_read_b128 down the tile, symmetric-pair FMA tap sums on float4 (v_pk_add/fma_f32);
+//           H-pass: the left / right strips arrive through DPP wave shifts, 12-value register window, 4 outputs
 //   blend the two levels each pixel needs, grade, truncate, side bars -> packed BGR0 dwords in LDS (one b128 per strip)
 //   epilogue: 3x3 sharpen on float4 (4 pixels per lane), integer-ratio box average, 12-byte packed stores;
 //           interior tiles with fit (1,1) / (2,1) take the vector path, everything else the generic per-pixel one.
-// Arithmetic identical to k_dof_grade / k_sharp_mux and the oracle (same association, explicit FMAs only in the
-// Gaussian tap sums, vd_gauss_sym).
+// Arithmetic identical to k_dof_grade / k_sharp_mux and the oracle (vertical pass first, then horizontal; explicit FMAs
+// only in the Gaussian tap sums, vd_gauss_sym).
 // Fast path conditions (else the unfused kernels run): Gaussian taps <= 9 (dof_strength <= 2), fit factors in {1,2,4},
 // format in {Half-SBS, Full-SBS, Passive Interlaced}.
 #include "vd3d_dev.h"
@@ -20,15 +21,14 @@
 
 #define FF_TW 64
 #define FF_TH 16
-#define FF_R 4                      // max Gaussian radius of the fast path
+#define FF_R 4                      // max Gaussian radius of the fast path == strip width
 #define FF_GW (FF_TW + 8)           // graded region width  (4-pixel halo each side: aligned strips; 1 is needed)
 #define FF_GH (FF_TH + 2)           // graded region height (1-pixel halo)
 #define FF_IW (FF_GW + 2 * FF_R)    // input tile width  = 80
 #define FF_IH (FF_GH + 2 * FF_R)    // input tile height = 26
-#define FF_RP (FF_IH / 2)           // row pairs = 13
-#define FF_NS (FF_GW / 4)           // strips per row = 18
+#define FF_IS (FF_IW / 4)           // strips per tile row = 20 (strip 0 and 19 are halo)
 #define FF_GP 76                    // pitch of the graded dword tile (multiple of 4: b128 rows)
-#define FF_NT 384
+#define FF_NT 384                   // 6 waves x 3 rows x 20 strips (4 idle lanes per wave)
 
 struct vd_ff_args {
   int H, W, eh, ew;
@@ -37,47 +37,50 @@ struct vd_ff_args {
   float focal;
 };
 
-typedef float (*ff_tile_t)[FF_RP][FF_IW][2];
-typedef float (*ff_hb_t)[FF_IH][FF_GW];
-#define FF_T2(tile, c, row, x) tile[c][(row) >> 1][x][(row) & 1]
+typedef float (*ff_tile_t)[FF_IH][FF_IW];
 
-// one Gaussian level: K = 9 - 2*OFF taps.  H-pass over (channel,row pair,strip) tasks, then V-pass for the strips that need it.
+// neighbour lanes through DPP (gfx9 wave shifts): value of lane-1 / lane+1 (own value at the wave edge, never used there)
+VD_DEV float ff_from_left(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+VD_DEV float ff_from_right(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+// one Gaussian level: K = 9 - 2*OFF taps, vertical then horizontal.  Executed by every lane of the wave (the DPP exchange
+// needs the neighbours' vertical sums); `mine` = this strip blends with this level.
 template <int OFF>
-VD_DEV void ff_level(ff_tile_t tile, ff_hb_t hb, const float* __restrict__ kern, int tid, bool need,
-                     int sy, int ss, int level, const int lo[4], vd_f4 vlo[3], vd_f4 vhi[3]) {
+VD_DEV void ff_level(ff_tile_t tile, const float* __restrict__ kern, bool active, bool mine, int sy, int ss, int level,
+                     const int lo[4], vd_f4 vlo[3], vd_f4 vhi[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
   float kw[K];
 #pragma unroll
   for (int t = 0; t < K; ++t) kw[t] = kern[t];
-  for (int t = tid; t < 3 * FF_RP * FF_NS; t += FF_NT) {
-    const int c = t / (FF_RP * FF_NS), rem = t - c * FF_RP * FF_NS, rp = rem / FF_NS, s = rem - rp * FF_NS;
-    const vd_f4* wp = reinterpret_cast<const vd_f4*>(&tile[c][rp][4 * s][0]);
-    vd_f2 win[12];   // win[i] = (row 2rp, row 2rp+1) at column 4s+i
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const vd_f4 q = wp[i]; win[2 * i] = q.xy; win[2 * i + 1] = q.zw; }
-    vd_f2 o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = vd_gauss_sym<K, vd_f2>(kw, &win[j + OFF]);
-    vd_f4 r0 = {o[0].x, o[1].x, o[2].x, o[3].x}, r1 = {o[0].y, o[1].y, o[2].y, o[3].y};
-    *reinterpret_cast<vd_f4*>(&hb[c][2 * rp][4 * s]) = r0;
-    *reinterpret_cast<vd_f4*>(&hb[c][2 * rp + 1][4 * s]) = r1;
-  }
-  __syncthreads();
-  if (need) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < 3; ++c) {
+    vd_f4 vs = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
       vd_f4 v[K];
 #pragma unroll
-      for (int tt = 0; tt < K; ++tt) v[tt] = *reinterpret_cast<const vd_f4*>(&hb[c][sy + OFF + tt][4 * ss]);
-      const vd_f4 o = vd_gauss_sym<K, vd_f4>(kw, v);
+      for (int tt = 0; tt < K; ++tt) v[tt] = *reinterpret_cast<const vd_f4*>(&tile[c][sy + OFF + tt][4 * ss]);
+      vs = vd_gauss_sym<K, vd_f4>(kw, v);
+    }
+    float win[12];   // vertical sums at tile columns 4(ss-1) .. 4(ss+1)+3
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      win[4 + q] = vs[q];
+      if (q >= OFF) win[q] = ff_from_left(vs[q]);            // only the columns the K-tap window reaches
+      if (q < 4 - OFF) win[8 + q] = ff_from_right(vs[q]);
+    }
+    if (mine) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (level == lo[q]) vlo[c][q] = o[q];
-        if (level == lo[q] + 1) vhi[c][q] = o[q];
+        const float o = vd_gauss_sym<K, float>(kw, &win[q + OFF]);
+        if (level == lo[q]) vlo[c][q] = o;
+        if (level == lo[q] + 1) vhi[c][q] = o;
       }
     }
   }
-  __syncthreads();
 }
 
 VD_DEV float ff_byte(uint32_t v, int sh) { return (float)((v >> sh) & 0xffu); }   // v_cvt_f32_ubyteN
@@ -109,8 +112,7 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
 __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
                                                         const vd_dev_work* __restrict__ w, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float tile[3][FF_RP][FF_IW][2];
-  __shared__ __attribute__((aligned(16))) float hb[3][FF_IH][FF_GW];
+  __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
   __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
   __shared__ int lvl_mask;                    // levels any pixel of this tile needs
   const int eye = blockIdx.z;
@@ -125,23 +127,18 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
   const bool in_interior = ix0 >= 0 && ix0 + FF_IW <= W && iy0 >= 0 && iy0 + FF_IH <= H && (W & 3) == 0 &&
                            (reinterpret_cast<uintptr_t>(src) & 3) == 0;
   if (in_interior) {
-    // one task = 4 pixels x 2 rows: 2 x 3 dword loads (12 B = 4 BGR pixels), six ds_write_b128
-    for (int t = tid; t < FF_RP * (FF_IW / 4); t += FF_NT) {
-      const int rp = t / (FF_IW / 4), g = t - rp * (FF_IW / 4);
-      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(src + ((size_t)(iy0 + 2 * rp) * W + ix0 + 4 * g) * 3);
-      const uint32_t* p1 = p0 + (size_t)W * 3 / 4;
-      const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+    // one task = 4 pixels of one row: 3 dword loads (12 B = 4 BGR pixels), three ds_write_b128
+    for (int t = tid; t < FF_IH * FF_IS; t += FF_NT) {
+      const int ty = t / FF_IS, g = t - ty * FF_IS;
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(src + ((size_t)(iy0 + ty) * W + ix0 + 4 * g) * 3);
+      const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2];
       // byte k of the 12-byte group: pixel k/3, channel BGR[k%3]
-#define FF_B(d0, d1, d2, k) ff_byte((k) < 4 ? d0 : ((k) < 8 ? d1 : d2), 8 * ((k) & 3))
+#define FF_B(k) ff_byte((k) < 4 ? a0 : ((k) < 8 ? a1 : a2), 8 * ((k) & 3))
 #pragma unroll
       for (int c = 0; c < 3; ++c) {   // plane 0 = R (byte 2), 1 = G (byte 1), 2 = B (byte 0)
         const int bo = 2 - c;
-        const vd_f4 lo4 = {vd_u8_unit(FF_B(a0, a1, a2, 0 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 0 + bo)),
-                           vd_u8_unit(FF_B(a0, a1, a2, 3 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 3 + bo))};
-        const vd_f4 hi4 = {vd_u8_unit(FF_B(a0, a1, a2, 6 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 6 + bo)),
-                           vd_u8_unit(FF_B(a0, a1, a2, 9 + bo)), vd_u8_unit(FF_B(b0, b1, b2, 9 + bo))};
-        *reinterpret_cast<vd_f4*>(&tile[c][rp][4 * g][0]) = lo4;
-        *reinterpret_cast<vd_f4*>(&tile[c][rp][4 * g + 2][0]) = hi4;
+        const vd_f4 v4 = {vd_u8_unit(FF_B(0 + bo)), vd_u8_unit(FF_B(3 + bo)), vd_u8_unit(FF_B(6 + bo)), vd_u8_unit(FF_B(9 + bo))};
+        *reinterpret_cast<vd_f4*>(&tile[c][ty][4 * g]) = v4;
       }
 #undef FF_B
     }
@@ -150,19 +147,22 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       const int ty = t / FF_IW, tx = t - ty * FF_IW;
       const int y = vd_reflect(iy0 + ty, H), x = vd_reflect(ix0 + tx, W);
       const uint8_t* px = src + ((size_t)y * W + x) * 3;
-      FF_T2(tile, 0, ty, tx) = vd_u8_unit((float)px[2]);
-      FF_T2(tile, 1, ty, tx) = vd_u8_unit((float)px[1]);
-      FF_T2(tile, 2, ty, tx) = vd_u8_unit((float)px[0]);
+      tile[0][ty][tx] = vd_u8_unit((float)px[2]);
+      tile[1][ty][tx] = vd_u8_unit((float)px[1]);
+      tile[2][ty][tx] = vd_u8_unit((float)px[0]);
     }
   }
-  // per-strip setup (threads 0..323 own one 4-pixel strip of the graded region)
-  const bool strip = tid < FF_GH * FF_NS;
-  const int sy = tid / FF_NS, ss = tid - sy * FF_NS;   // graded row, strip index
-  const int gy = gy0 + sy, gxs = gx0 + 4 * ss;
+  // thread = (graded row sy, tile strip ss); wave v owns rows 3v..3v+2; strips 1..18 are the graded region
+  const int lane = tid & 63, wv = tid >> 6;
+  const bool active = lane < 3 * FF_IS;
+  const int sy = active ? 3 * wv + lane / FF_IS : 0, ss = active ? lane % FF_IS : 0;
+  const bool strip = active && ss >= 1 && ss <= FF_IS - 2;
+  const int gy = gy0 + sy, gxs = ix0 + 4 * ss;    // image coordinates of the strip's first pixel
   int lo[4] = {0, 0, 0, 0};
   vd_f4 alpha = {0.f, 0.f, 0.f, 0.f};
   int lmin = 9, lmax = -1;
   __syncthreads();   // lvl_mask = 0 visible before the atomicOr below; tile complete
+  int my_mask = 0;
   if (strip && fc.nlev) {
     const float focal = a.use_override ? a.focal : w->focal;
 #pragma unroll
@@ -183,30 +183,26 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       lo[q] = l; alpha[q] = bi - (float)l;
       lmin = min(lmin, l); lmax = max(lmax, l + 1);
     }
-    int m = 0;
-    for (int l = max(lmin, 1); l <= lmax; ++l) m |= 1 << l;
-    if (m) atomicOr(&lvl_mask, m);
+    for (int l = max(lmin, 1); l <= lmax; ++l) my_mask |= 1 << l;
+    if (my_mask) atomicOr(&lvl_mask, my_mask);
   }
   vd_f4 vlo[3], vhi[3];
-  if (strip) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) vlo[c][q] = FF_T2(tile, c, sy + FF_R, 4 * ss + FF_R + q);
-      vhi[c] = vlo[c];
-    }
+  for (int c = 0; c < 3; ++c) {
+    vlo[c] = *reinterpret_cast<const vd_f4*>(&tile[c][sy + FF_R][4 * ss]);
+    vhi[c] = vlo[c];
   }
   __syncthreads();
   const int need_mask = lvl_mask;
   for (int l = 0; l < fc.nlev; ++l) {  // level l+1 of the reference's stack
     if (!(need_mask >> (l + 1) & 1)) continue;  // no pixel of this tile blends with this level (workgroup-uniform)
     const int off = FF_R - fc.ksz[l] / 2;
-    const bool need = strip && l + 1 >= lmin && l + 1 <= lmax;
+    const bool mine = (my_mask >> (l + 1)) & 1;
     switch (off) {  // compile-time tap count => all register indexing is static
-      case 0: ff_level<0>(tile, hb, fc.kern[l], tid, need, sy, ss, l + 1, lo, vlo, vhi); break;
-      case 1: ff_level<1>(tile, hb, fc.kern[l], tid, need, sy, ss, l + 1, lo, vlo, vhi); break;
-      case 2: ff_level<2>(tile, hb, fc.kern[l], tid, need, sy, ss, l + 1, lo, vlo, vhi); break;
-      default: ff_level<3>(tile, hb, fc.kern[l], tid, need, sy, ss, l + 1, lo, vlo, vhi); break;
+      case 0: ff_level<0>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      case 1: ff_level<1>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      case 2: ff_level<2>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      default: ff_level<3>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
     }
   }
   if (strip) {  // blend, grade (:750-767), truncate, side bars (:885-892); float4 = the strip's 4 pixels
@@ -241,7 +237,7 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       const bool masked = bar_w > 0 && ((bar_s == 2 && x < bar_w) || (bar_s == 1 && x >= W - bar_w));
       if (masked) pk[q] = 0u;
     }
-    *reinterpret_cast<uint4*>(&gb[sy][4 * ss]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    *reinterpret_cast<uint4*>(&gb[sy][4 * (ss - 1)]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
   __syncthreads();
   // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux

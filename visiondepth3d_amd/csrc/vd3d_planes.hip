@@ -307,15 +307,15 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
   float* tile = lds;                        // [3][th][tw]
-  float* hb = lds + (size_t)3 * th * tw;    // [3][th][DF_TW]
+  float* vb = lds + (size_t)3 * th * tw;    // [3][DF_TH][tw]   vertical sums (the vertical pass runs first)
   const int x0 = blockIdx.x * DF_TW, y0 = blockIdx.y * DF_TH;
   for (int t = threadIdx.x; t < th * tw; t += 512) {
     const int ty = t / tw, tx = t - ty * tw;
     const int y = vd_reflect(y0 - R + ty, H), x = vd_reflect(x0 - R + tx, W);
     const uint8_t* px = eye_in + ((size_t)y * W + x) * 3;
-    tile[0 * th * tw + t] = (float)px[2] / 255.0f;
-    tile[1 * th * tw + t] = (float)px[1] / 255.0f;
-    tile[2 * th * tw + t] = (float)px[0] / 255.0f;
+    tile[0 * th * tw + t] = vd_u8_unit((float)px[2]);
+    tile[1 * th * tw + t] = vd_u8_unit((float)px[1]);
+    tile[2 * th * tw + t] = vd_u8_unit((float)px[0]);
   }
   __syncthreads();
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -347,18 +347,18 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
   for (int l = 0; l < fc.nlev; ++l) {  // level l+1 of the reference's stack
     const int k = fc.ksz[l], r = k / 2;
     __syncthreads();
-    for (int t = threadIdx.x; t < 3 * th * DF_TW; t += 512) {
-      const int c = t / (th * DF_TW), rem = t - c * th * DF_TW;
-      const int hy = rem / DF_TW, hx = rem - hy * DF_TW;
-      const float* row = tile + (size_t)c * th * tw + hy * tw + hx + R - r;
-      hb[t] = vd_gauss_sym_rt(fc.kern[l], k, row, 1);
+    for (int t = threadIdx.x; t < 3 * DF_TH * tw; t += 512) {   // vertical sums for every tile column
+      const int c = t / (DF_TH * tw), rem = t - c * DF_TH * tw;
+      const int vy = rem / tw, vx = rem - vy * tw;
+      const float* col = tile + (size_t)c * th * tw + (vy + R - r) * tw + vx;
+      vb[t] = vd_gauss_sym_rt(fc.kern[l], k, col, tw);
     }
     __syncthreads();
     if (l + 1 == lo || l + 1 == lo + 1) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float* col = hb + (size_t)c * th * DF_TW + (ty + R - r) * DF_TW + tx;
-        const float s = vd_gauss_sym_rt(fc.kern[l], k, col, DF_TW);
+        const float* row = vb + (size_t)c * DF_TH * tw + ty * tw + tx + R - r;
+        const float s = vd_gauss_sym_rt(fc.kern[l], k, row, 1);
         if (l + 1 == lo) vlo[c] = s; else vhi[c] = s;
       }
     }
@@ -390,7 +390,7 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
                          int bar_width, int bar_side, uint8_t* eye_out) {
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
-  size_t lds = sizeof(float) * 3 * ((size_t)th * tw + (size_t)th * DF_TW);
+  size_t lds = sizeof(float) * 3 * ((size_t)th * tw + (size_t)DF_TH * tw);
   hipLaunchKernelGGL(k_dof_grade, dim3((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH), dim3(512), lds, s, eye_in, dn, eh, ew, H, W,
                      fc, w, focal_override, use_override, bar_width, bar_side, eye_out);
 }

@@ -95,7 +95,10 @@ class DepthPipe:
     device-resident batch path."""
 
     def __init__(self, name: str = "depth-anything-v2-small", device="cuda", dtype=torch.bfloat16, seed: int = 0,
-                 channels_last: bool = True):
+                 channels_last: bool = True, renderer=None):
+        """``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream);
+        when given (and dtype is bf16) the image-processor front end runs as one fused HIP launch
+        (``vd3d_depth_preprocess``) instead of ~8 ATen kernels."""
         from transformers import DepthAnythingForDepthEstimation
         self.name, self.device, self.dtype = name, torch.device(device), dtype
         cfg = build_config(name)
@@ -107,6 +110,7 @@ class DepthPipe:
         self.mean = torch.tensor(IMAGENET_MEAN, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
         self.std = torch.tensor(IMAGENET_STD, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
         self.n_params = sum(p.numel() for p in self.model.parameters())
+        self.renderer = renderer if (renderer is not None and dtype == torch.bfloat16 and self.device.type == "cuda") else None
         self._cache_position_embeddings()
 
     def _cache_position_embeddings(self):
@@ -131,6 +135,19 @@ class DepthPipe:
         depth-estimation pipeline's post-process: bicubic, align_corners=False).  ``raw=True`` returns the model-resolution
         prediction [B,th,tw] instead, for the fused HIP hand-off (Renderer.depth_handoff)."""
         B, H, W, _ = frames_bgr.shape
+        if self.renderer is not None and inference_size is None and frames_bgr.dtype == torch.uint8:
+            th, tw = dpt_resize_target(H, W)
+            x = None
+            try:
+                x = self.renderer.depth_preprocess(frames_bgr, th, tw, IMAGENET_MEAN, IMAGENET_STD)
+            except Exception as e:   # down-scale beyond the kernel's tap budget: the ATen path below is the same math
+                if getattr(e, "code", None) != -4:
+                    raise
+            if x is not None:
+                pred = self.model(pixel_values=x).predicted_depth
+                if raw:
+                    return pred.float()
+                return F.interpolate(pred.float().unsqueeze(1), size=(H, W), mode="bicubic", align_corners=False).squeeze(1)
         x = frames_bgr.to(self.device).flip(-1).permute(0, 3, 1, 2).float()  # RGB, NCHW
         if inference_size is not None:  # hf_batch_safe_pipe: img.resize(inference_size, BICUBIC) first (:1113-1116)
             x = F.interpolate(x, size=(int(inference_size[1]), int(inference_size[0])), mode="bicubic", antialias=True,

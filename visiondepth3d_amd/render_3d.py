@@ -220,6 +220,16 @@ class Renderer:
         _lib.check(self._L.vd3d_subject_depth(self._ctx, _ptr(p), H, W, C.byref(o)))
         return float(o.value)
 
+    def depth_preprocess(self, frames_bgr: torch.Tensor, th: int, tw: int, mean, std) -> torch.Tensor:
+        """DPT image-processor front end fused in one launch: uint8 BGR [B,H,W,3] -> bf16 tensor of logical shape
+        [B,3,th,tw] in channels_last memory (antialiased bicubic resize, 1/255, ImageNet normalise)."""
+        f = frames_bgr.to(self.device, torch.uint8).contiguous()
+        B, H, W, _ = f.shape
+        out = torch.empty((B, th, tw, 3), dtype=torch.bfloat16, device=self.device)
+        m = (C.c_float * 3)(*[float(v) for v in mean]); s = (C.c_float * 3)(*[float(v) for v in std])
+        _lib.check(self._L.vd3d_depth_preprocess(self._ctx, _ptr(f), B, H, W, int(th), int(tw), m, s, _ptr(out)))
+        return out.permute(0, 3, 1, 2)   # NCHW view of NHWC storage == torch.channels_last
+
     def detect_black_bars(self, frame_bgr: torch.Tensor):
         """detect_black_bars(frame_to_tensor(frame)) (core/render_3d.py:293-316) on a uint8 BGR frame -> (top, bottom)."""
         f = frame_bgr.to(self.device, torch.uint8).contiguous()
