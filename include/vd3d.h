@@ -222,6 +222,12 @@ int vd3d_depth_handoff(vd3d_ctx* ctx, const float* pred, int B, int ph, int pw, 
 int vd3d_depth_preprocess(vd3d_ctx* ctx, const uint8_t* frames_bgr, int B, int H, int W, int th, int tw,
                           const float* mean3_host, const float* std3_host, void* out_bf16_nhwc);
 
+/* Transformer-block glue of the depth network (a25): s = x + y, n = LayerNorm(s)*gamma + beta on bfloat16 [rows][cols]
+ * device arrays in one pass (y == NULL: LayerNorm only, out_sum unused).  cols in {384, 768, 1024} (DA-V2 S/B/L), else
+ * VD3D_E_UNSUPPORTED.  Replaces torch's add + layer_norm kernel pair inside DepthPipe's fused backbone. */
+int vd3d_add_layernorm_bf16(vd3d_ctx* ctx, const void* x, const void* y_or_null, const void* gamma, const void* beta,
+                            float eps, int64_t rows, int cols, void* out_sum, void* out_norm);
+
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux
  * (core/render_3d.py:1340-1419) on two u8 eyes. depth_norm is the eye-res normalised depth. */

@@ -55,3 +55,27 @@ def test_depth_pipe_uses_fused_front_end():
     rel = ((a - b).abs().mean() / a.abs().mean()).item()
     assert rel < 2e-2, rel                    # bf16 network: inputs differ in a few last bf16 bits
     r.close()
+
+
+@pytest.mark.parametrize("cols", [384, 768, 1024])
+def test_add_layernorm_matches_torch(cols):
+    from visiondepth3d_amd.render_3d import Renderer
+    r = Renderer(0)
+    g = torch.Generator(device="cuda").manual_seed(cols)
+    x = (torch.randn(2, 1237, cols, device="cuda", generator=g) * 2).to(torch.bfloat16)
+    y = torch.randn(2, 1237, cols, device="cuda", generator=g).to(torch.bfloat16)
+    ln = torch.nn.LayerNorm(cols, eps=1e-6).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(cols, device="cuda", generator=g))
+        ln.bias.copy_(0.1 * torch.randn(cols, device="cuda", generator=g))
+        s_ref = x + y
+        n_ref = torch.nn.functional.layer_norm(s_ref.float(), (cols,), ln.weight.float(), ln.bias.float(), 1e-6)
+        s, n = r.add_layernorm(x, y, ln)
+        assert torch.equal(s, s_ref)                                   # bf16 add is exactly ATen's
+        err = (n.float() - n_ref).abs()
+        assert bool((err <= n_ref.abs() * 2.0 ** -8 + 1e-2).all()), float(err.max())
+        x2, n2 = r.add_layernorm(x, None, ln)
+        assert x2 is x
+        n2_ref = torch.nn.functional.layer_norm(x.float(), (cols,), ln.weight.float(), ln.bias.float(), 1e-6)
+        assert bool(((n2.float() - n2_ref).abs() <= n2_ref.abs() * 2.0 ** -8 + 1e-2).all())
+    r.close()

@@ -630,6 +630,15 @@ VD3D_EXPORT int vd3d_depth_preprocess(vd3d_ctx* c, const uint8_t* frames_bgr, in
   return 0;
 }
 
+VD3D_EXPORT int vd3d_add_layernorm_bf16(vd3d_ctx* c, const void* x, const void* y_or_null, const void* gamma, const void* beta,
+                                        float eps, int64_t rows, int cols, void* out_sum, void* out_norm) {
+  if (!c || !x || !gamma || !beta || !out_norm || rows < 1 || (y_or_null && !out_sum)) return set_err(VD3D_E_INVALID, "bad argument");
+  if (!vd_launch_add_layernorm(c->stream, x, y_or_null, gamma, beta, eps, (long long)rows, cols, out_sum, out_norm))
+    return set_err(VD3D_E_UNSUPPORTED, "add_layernorm: cols %d not in {384,768,1024}", cols);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
   if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

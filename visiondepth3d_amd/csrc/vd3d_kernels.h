@@ -121,6 +121,9 @@ void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t byt
 // ---- vd3d_depthprep.hip
 bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, int W, int th, int tw, const float mean[3],
                           const float stdv[3], void* out_bf16_nhwc);
+// ---- vd3d_netops.hip
+bool vd_launch_add_layernorm(hipStream_t s, const void* x, const void* y, const void* gamma, const void* beta, float eps,
+                             long long rows, int cols, void* out_sum, void* out_norm);
 // ---- vd3d_handoff.hip
 void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint32_t* mm,
                              uint8_t* out);

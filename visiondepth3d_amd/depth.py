@@ -137,7 +137,10 @@ class DepthPipe:
         (N = 3*hidden), LayerScale folded into the output-projection / fc2 weights (lambda * (xW^T + b) == x(lambda*W)^T +
         lambda*b), SDPA called directly.  Per layer: 4 GEMMs + attention + 2 LN + GELU + 2 adds instead of 6 GEMMs + 13
         smaller kernels."""
-        for layer in self.model.backbone.encoder.layer:
+        layers = list(self.model.backbone.encoder.layer)
+        R = self.renderer
+        stash = {"x": None, "h": None}   # LayerNorm1(x) computed by the PREVIOUS layer's fused add+LayerNorm launch
+        for li, layer in enumerate(layers):
             att, out = layer.attention.attention, layer.attention.output.dense
             wqkv = torch.cat([att.query.weight, att.key.weight, att.value.weight], 0).contiguous()
             bqkv = torch.cat([att.query.bias, att.key.bias, att.value.bias], 0).contiguous()
@@ -149,14 +152,31 @@ class DepthPipe:
             b2 = (fc2.bias.float() * l2).to(fc2.bias.dtype).contiguous()
             nh, hd, scaling = att.num_attention_heads, att.attention_head_size, att.scaling
             n1, n2, act = layer.norm1, layer.norm2, layer.mlp.activation
+            nxt = layers[li + 1].norm1 if li + 1 < len(layers) else None
 
-            def fwd(x, wqkv=wqkv, bqkv=bqkv, wo=wo, bo=bo, fc1=fc1, w2=w2, b2=b2, nh=nh, hd=hd, scaling=scaling, n1=n1, n2=n2, act=act):
+            def fwd(x, wqkv=wqkv, bqkv=bqkv, wo=wo, bo=bo, fc1=fc1, w2=w2, b2=b2, nh=nh, hd=hd, scaling=scaling, n1=n1, n2=n2,
+                    act=act, nxt=nxt):
                 B, T, d = x.shape
-                qkv = F.linear(n1(x), wqkv, bqkv).view(B, T, 3, nh, hd)
+                hip = R is not None and x.dtype == torch.bfloat16 and x.is_contiguous() and d in (384, 768, 1024)
+                if hip:   # residual add + LayerNorm pairs as single HIP launches (vd3d_add_layernorm_bf16)
+                    h = stash["h"] if stash["x"] is x else R.add_layernorm(x, None, n1)[1]
+                    stash["x"] = stash["h"] = None
+                else:
+                    h = n1(x)
+                qkv = F.linear(h, wqkv, bqkv).view(B, T, 3, nh, hd)
                 q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
                 o = F.scaled_dot_product_attention(q, k, v, scale=scaling).transpose(1, 2).reshape(B, T, d)
-                x = x + F.linear(o, wo, bo)
-                return x + F.linear(act(fc1(n2(x))), w2, b2)
+                a = F.linear(o, wo, bo)
+                if not hip:
+                    x = x + a
+                    return x + F.linear(act(fc1(n2(x))), w2, b2)
+                x, h = R.add_layernorm(x, a, n2)
+                m = F.linear(act(fc1(h)), w2, b2)
+                if nxt is None:
+                    return x + m
+                x, hn = R.add_layernorm(x, m, nxt)
+                stash["x"], stash["h"] = x, hn
+                return x
 
             layer.forward = fwd
 

@@ -230,6 +230,16 @@ class Renderer:
         _lib.check(self._L.vd3d_depth_preprocess(self._ctx, _ptr(f), B, H, W, int(th), int(tw), m, s, _ptr(out)))
         return out.permute(0, 3, 1, 2)   # NCHW view of NHWC storage == torch.channels_last
 
+    def add_layernorm(self, x: torch.Tensor, y, norm: torch.nn.LayerNorm):
+        """(x + y, LayerNorm(x + y)) for contiguous bf16 [..., cols] tensors in one launch; y=None -> (x, LayerNorm(x))."""
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        out_n = torch.empty_like(x)
+        out_s = torch.empty_like(x) if y is not None else x
+        _lib.check(self._L.vd3d_add_layernorm_bf16(self._ctx, _ptr(x), _ptr(y) if y is not None else None, _ptr(norm.weight), _ptr(norm.bias),
+                                                   float(norm.eps), rows, cols, _ptr(out_s) if y is not None else None, _ptr(out_n)))
+        return out_s, out_n
+
     def detect_black_bars(self, frame_bgr: torch.Tensor):
         """detect_black_bars(frame_to_tensor(frame)) (core/render_3d.py:293-316) on a uint8 BGR frame -> (top, bottom)."""
         f = frame_bgr.to(self.device, torch.uint8).contiguous()
