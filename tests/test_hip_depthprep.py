@@ -54,6 +54,11 @@ def test_depth_pipe_uses_fused_front_end():
     assert r.stage_calls("depth_prep") == 1
     rel = ((a - b).abs().mean() / a.abs().mean()).item()
     assert rel < 2e-2, rel                    # bf16 network: inputs differ in a few last bf16 bits
+    # the stock HF module graph (separate q/k/v, LayerScale modules, unpadded token sequence) gives the same prediction
+    pc = DepthPipe("depth-anything-v2-small", device="cuda", fuse_backbone=False)
+    c = pc.infer_bgr_u8(frames, raw=True)
+    rel = ((a - c).abs().mean() / c.abs().mean()).item()
+    assert rel < 2e-2, rel
     r.close()
 
 

@@ -139,6 +139,24 @@ class DepthPipe:
         smaller kernels."""
         layers = list(self.model.backbone.encoder.layer)
         R = self.renderer
+        # Query-length padding: AOTriton's flash kernel takes a ~1.5x slower path when the QUERY length is not a multiple of
+        # 256 (measured on MI355X: Tq=2443 446 us, Tq=2560 302 us per layer, keys unpadded).  DINOv2 always has an odd token
+        # count (patches + CLS), so the token sequence is padded ONCE after the embeddings with dummy tokens that are never
+        # used as keys/values (k, v are sliced to the real length) and are dropped before the final layer norm: exact.
+        pad_state = {"T": None}
+        bb = self.model.backbone
+        if self.device.type == "cuda":
+            def pad_tokens(_mod, _inp, out):
+                T = out.shape[1]
+                Tp = -(-T // 256) * 256
+                pad_state["T"] = None
+                if out.dtype == torch.bfloat16 and Tp != T and Tp <= T * 1.1:
+                    pad_state["T"] = T
+                    return F.pad(out, (0, 0, 0, Tp - T))
+                return out
+            bb.embeddings.register_forward_hook(pad_tokens)
+            final_ln = bb.layernorm.forward
+            bb.layernorm.forward = lambda x: final_ln(x if pad_state["T"] is None else x[:, :pad_state["T"]])
         stash = {"x": None, "h": None}   # LayerNorm1(x) computed by the PREVIOUS layer's fused add+LayerNorm launch
         for li, layer in enumerate(layers):
             att, out = layer.attention.attention, layer.attention.output.dense
@@ -164,7 +182,8 @@ class DepthPipe:
                 else:
                     h = n1(x)
                 qkv = F.linear(h, wqkv, bqkv).view(B, T, 3, nh, hd)
-                q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+                Tk = pad_state["T"] or T   # real tokens only on the key/value side
+                q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :Tk, 1].transpose(1, 2), qkv[:, :Tk, 2].transpose(1, 2)
                 o = F.scaled_dot_product_attention(q, k, v, scale=scaling).transpose(1, 2).reshape(B, T, d)
                 a = F.linear(o, wo, bo)
                 if not hip:
