@@ -228,6 +228,10 @@ int vd3d_depth_preprocess(vd3d_ctx* ctx, const uint8_t* frames_bgr, int B, int H
 int vd3d_add_layernorm_bf16(vd3d_ctx* ctx, const void* x, const void* y_or_null, const void* gamma, const void* beta,
                             float eps, int64_t rows, int cols, void* out_sum, void* out_norm);
 
+/* F.interpolate(mode="bilinear", align_corners=True) of a bfloat16 NHWC (channels_last) tensor [B][ih][iw][C] ->
+ * [B][oh][ow][C], C a multiple of 8: the up-samplings of the DPT neck / head (a25). */
+int vd3d_upsample_bilinear_nhwc_bf16(vd3d_ctx* ctx, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
+
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux
  * (core/render_3d.py:1340-1419) on two u8 eyes. depth_norm is the eye-res normalised depth. */

@@ -639,6 +639,14 @@ VD3D_EXPORT int vd3d_add_layernorm_bf16(vd3d_ctx* c, const void* x, const void* 
   return 0;
 }
 
+VD3D_EXPORT int vd3d_upsample_bilinear_nhwc_bf16(vd3d_ctx* c, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C) {
+  if (!c || !in || !out || B < 1 || ih < 1 || iw < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  if (!vd_launch_upsample_bilinear_nhwc(c->stream, in, out, B, ih, iw, oh, ow, C))
+    return set_err(VD3D_E_UNSUPPORTED, "upsample_bilinear_nhwc: C %% 8 != 0 or output smaller than 2x2");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
   if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

@@ -124,6 +124,7 @@ bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, in
 // ---- vd3d_netops.hip
 bool vd_launch_add_layernorm(hipStream_t s, const void* x, const void* y, const void* gamma, const void* beta, float eps,
                              long long rows, int cols, void* out_sum, void* out_norm);
+bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
 // ---- vd3d_handoff.hip
 void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint32_t* mm,
                              uint8_t* out);

@@ -114,6 +114,8 @@ class DepthPipe:
         self._cache_position_embeddings()
         if fuse_backbone:
             self._fuse_backbone_layers()
+        if self.renderer is not None:
+            self._patch_dpt_upsampling()
 
     def _cache_position_embeddings(self):
         """DINOv2 re-interpolates its position embedding (bicubic 37x37 -> patch grid) on EVERY forward; for a fixed
@@ -130,6 +132,37 @@ class DepthPipe:
             return cache[key]
 
         emb.interpolate_pos_encoding = cached
+
+    def _patch_dpt_upsampling(self):
+        """Route the align_corners=True bilinear up-samplings of the DPT neck / head (transformers
+        DepthAnythingFeatureFusionLayer / DepthAnythingDepthEstimationHead) through vd3d_upsample_bilinear_nhwc_bf16; the
+        module graphs are otherwise reproduced verbatim."""
+        R = self.renderer
+
+        def up(x, size):
+            if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+                return R.upsample_bilinear(x, size)
+            return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+        for layer in self.model.neck.fusion_stage.layers:
+            def fusion_fwd(hidden_state, residual=None, size=None, layer=layer):
+                if residual is not None:
+                    if hidden_state.shape != residual.shape:
+                        residual = F.interpolate(residual, size=(hidden_state.shape[2], hidden_state.shape[3]), mode="bilinear",
+                                                 align_corners=False)
+                    hidden_state = hidden_state + layer.residual_layer1(residual)
+                hidden_state = layer.residual_layer2(hidden_state)
+                tgt = (2 * hidden_state.shape[2], 2 * hidden_state.shape[3]) if size is None else tuple(size)
+                return layer.projection(up(hidden_state, tgt))
+            layer.forward = fusion_fwd
+        head = self.model.head
+
+        def head_fwd(hidden_states, patch_height, patch_width):
+            h = head.conv1(hidden_states[head.head_in_index])
+            h = up(h, (int(patch_height * head.patch_size), int(patch_width * head.patch_size)))
+            h = head.conv3(head.activation1(head.conv2(h)))
+            return (head.activation2(h) * head.max_depth).squeeze(dim=1)
+        head.forward = head_fwd
 
     @torch.no_grad()
     def _fuse_backbone_layers(self):

@@ -240,6 +240,14 @@ class Renderer:
                                                    float(norm.eps), rows, cols, _ptr(out_s) if y is not None else None, _ptr(out_n)))
         return out_s, out_n
 
+    def upsample_bilinear(self, x: torch.Tensor, size) -> torch.Tensor:
+        """F.interpolate(x, size, mode="bilinear", align_corners=True) for a bf16 channels_last [B,C,h,w] tensor."""
+        B, Cc, ih, iw = x.shape
+        oh, ow = int(size[0]), int(size[1])
+        out = torch.empty((B, Cc, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(self._L.vd3d_upsample_bilinear_nhwc_bf16(self._ctx, _ptr(x), _ptr(out), B, ih, iw, oh, ow, Cc))
+        return out
+
     def detect_black_bars(self, frame_bgr: torch.Tensor):
         """detect_black_bars(frame_to_tensor(frame)) (core/render_3d.py:293-316) on a uint8 BGR frame -> (top, bottom)."""
         f = frame_bgr.to(self.device, torch.uint8).contiguous()
