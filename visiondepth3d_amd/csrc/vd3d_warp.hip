@@ -42,7 +42,39 @@ VD_DEV vd_tap wf_tap(int in, int out, float scale, int o) {  // vd_interp_tap wi
   return t;
 }
 
-// LDS map (floats):  wd[2][wh*ww] (later hs[2][eh*TW]) | e2[2][eh*ew] | tile[3*er*ec]
+// ---- both eyes as ONE packed-float32 vector (x = left eye, y = right eye): every float operation of the two grid_sample
+// chains is issued once as v_pk_mul/add/fma_f32; each element is rounded exactly like the scalar helper it mirrors.
+struct wf_gs2 { int xw[2]; vd_f2 nw, ne, sw, se; bool e_ok[2]; };
+// vd_gs_params for (gx + s, gx - s) sharing the row part (yn, n, s_ = 1 - n computed by the caller)
+VD_DEV wf_gs2 wf_gs_params2(float gx, float s, float n, float sr, int W) {
+  wf_gs2 p;
+  const vd_f2 g = {gx + s, gx - s};
+  vd_f2 ix = (g + 1.f) * ((float)(W - 1) / 2.f);
+  ix.x = fminf((float)(W - 1), fmaxf(ix.x, 0.f)); ix.y = fminf((float)(W - 1), fmaxf(ix.y, 0.f));
+  const vd_f2 xw = {floorf(ix.x), floorf(ix.y)};
+  const vd_f2 w = ix - xw, e = 1.f - w;
+  p.nw = sr * e; p.ne = sr * w; p.sw = n * e; p.se = n * w;
+  p.xw[0] = (int)xw.x; p.xw[1] = (int)xw.y;
+  p.e_ok[0] = (p.xw[0] + 1) < W; p.e_ok[1] = (p.xw[1] + 1) < W;
+  return p;
+}
+// row part of vd_gs_params: clamped iy -> yn, n = iy - yn, s = 1 - n
+VD_DEV void wf_gs_row(float gy, int H, int* yn, float* n, float* sr, bool* s_ok) {
+  float iy = (gy + 1.f) * ((float)(H - 1) / 2.f);
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+  const float f = floorf(iy);
+  *n = iy - f; *sr = 1.f - (iy - f); *yn = (int)f; *s_ok = ((int)f + 1) < H;
+}
+struct wf_tap2 { int i0[2], i1[2]; vd_f2 w0, w1; };
+VD_DEV wf_tap2 wf_tap_pair(int in, int out, float scale, int oa, int ob) {
+  const vd_tap a = wf_tap(in, out, scale, oa), b = wf_tap(in, out, scale, ob);
+  wf_tap2 t;
+  t.i0[0] = a.i0; t.i0[1] = b.i0; t.i1[0] = a.i1; t.i1[1] = b.i1;
+  t.w0 = vd_f2{a.w0, b.w0}; t.w1 = vd_f2{a.w1, b.w1};
+  return t;
+}
+
+// LDS map (floats):  wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2] | tile[3*er*ec]      ([..][2] = the two eyes interleaved)
 #define WF_AI 6  // phase-A positions per thread ((TH+k)(TW+k) <= WF_AI*WF_NT for k <= 9; larger k loops)
 template <bool RESIZE>
 __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
@@ -53,9 +85,9 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   const int x0 = blockIdx.x * WF_TW, y0 = blockIdx.y * WF_TH;
   const int ww = WF_TW + k, wh = WF_TH + k;          // wd region
   const int ew = WF_TW + k - 1, eh = WF_TH + k - 1;  // e2 region
-  float* wd = lds;                                   // [2][wh*ww]   (later hs [2][eh*WF_TW])
-  float* e2 = lds + 2 * wh * ww;                     // [2][eh*ew]
-  float* tile = a.feather ? e2 + 2 * eh * ew : lds;  // [3][er][ec] (the feather buffers are not allocated when feathering is off)
+  vd_f2* wd = reinterpret_cast<vd_f2*>(lds);                       // [wh*ww]   (later hs [eh*WF_TW])
+  vd_f2* e2 = reinterpret_cast<vd_f2*>(lds + 2 * wh * ww);         // [eh*ew]
+  float* tile = a.feather ? lds + 2 * wh * ww + 2 * eh * ew : lds;  // [3][er][ec] (the feather buffers are not allocated when feathering is off)
   const int tid = threadIdx.x;
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
 
@@ -100,25 +132,26 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         if (t < wh * ww) {
           const int ty = wf_div(t, a.m_ww), tx = t - ty * ww;
           const int y = wy0 + ty, x = wx0 + tx;
-          float vl = 0.f, vr = 0.f;
+          vd_f2 v = {0.f, 0.f};
           if (y >= 0 && y < H && x >= 0 && x < W) {
             const float gx = vd_lin11(W, x), gy = vd_lin11(H, y);
-#pragma unroll
-            for (int eye = 0; eye < 2; ++eye) {
-              const vd_gs g = vd_gs_params(eye == 0 ? gx + sv[j] : gx - sv[j], gy, W, H);
-              const float* r0 = D + (size_t)g.yn * W + g.xw;
-              const float vnw = r0[0], vne = g.e_ok ? r0[1] : 0.f;
-              float v;
-              if (g.s_ok && (g.sw != 0.f || g.se != 0.f)) {
-                const float vsw = r0[W], vse = g.e_ok ? r0[W + 1] : 0.f;
-                v = vd_gs_combine(g, vnw, vne, vsw, vse);
-              } else {
-                v = vd_fma(vne, g.ne, vnw * g.nw);   // sw = se = 0 exactly: the south samples add +0
-              }
-              if (eye == 0) vl = v; else vr = v;
+            int yn; float n, sr; bool s_ok;
+            wf_gs_row(gy, H, &yn, &n, &sr, &s_ok);
+            const wf_gs2 g = wf_gs_params2(gx, sv[j], n, sr, W);
+            const float* r0 = D + (size_t)yn * W + g.xw[0];
+            const float* r1 = D + (size_t)yn * W + g.xw[1];
+            const vd_f2 vnw = {r0[0], r1[0]};
+            const vd_f2 vne = {g.e_ok[0] ? r0[1] : 0.f, g.e_ok[1] ? r1[1] : 0.f};
+            // vd_gs_combine; when n == 0 (or no south row) sw = se = 0 exactly and the south samples add +0
+            vd_f2 acc = vd_vfma(vne, g.ne, vnw * g.nw);
+            if (s_ok && n != 0.f) {
+              const vd_f2 vsw = {r0[W], r1[W]};
+              const vd_f2 vse = {g.e_ok[0] ? r0[W + 1] : 0.f, g.e_ok[1] ? r1[W + 1] : 0.f};
+              acc = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, acc));
             }
+            v = acc;
           }
-          wd[t] = vl; wd[wh * ww + t] = vr;
+          wd[t] = v;
         }
       }
     }
@@ -141,32 +174,28 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     for (int t = tid; t < eh * ew; t += WF_NT) {
       const int ty = wf_div(t, a.m_ew), tx = t - ty * ew;
       const int y = y0 - r + ty, x = x0 - r + tx;
-      float el = 0.f, er_ = 0.f;
+      vd_f2 e = {0.f, 0.f};
       if (y >= 0 && y < H && x >= 0 && x < W) {
-#pragma unroll
-        for (int eye = 0; eye < 2; ++eye) {
-          const float* wv = wd + eye * wh * ww + (ty + 1) * ww + (tx + 1);
-          const float c = wv[0];
-          const float gx = x > 0 ? c - wv[-1] : 0.f;
-          const float gy = y > 0 ? c - wv[-ww] : 0.f;
-          const float v = vd_clamp(sqrtf(gx * gx + gy * gy) * a.fs, 0.f, 1.f);
-          if (eye == 0) el = v; else er_ = v;
-        }
+        const vd_f2* wv = wd + (ty + 1) * ww + (tx + 1);
+        const vd_f2 c = wv[0];
+        const vd_f2 z = {0.f, 0.f};
+        const vd_f2 gx = x > 0 ? c - wv[-1] : z;
+        const vd_f2 gy = y > 0 ? c - wv[-ww] : z;
+        const vd_f2 q = gx * gx + gy * gy;
+        const vd_f2 m = vd_f2{sqrtf(q.x), sqrtf(q.y)} * a.fs;
+        e.x = vd_clamp(m.x, 0.f, 1.f); e.y = vd_clamp(m.y, 0.f, 1.f);
       }
-      e2[t] = el; e2[eh * ew + t] = er_;
+      e2[t] = e;
     }
     __syncthreads();
     // phase C: horizontal window sums (ascending x) into the dead wd buffer
-    float* hs = wd;
+    vd_f2* hs = wd;
     for (int t = tid; t < eh * WF_TW; t += WF_NT) {
       const int ty = t >> 6, tx = t & 63;
-#pragma unroll
-      for (int eye = 0; eye < 2; ++eye) {
-        const float* row = e2 + eye * eh * ew + ty * ew + tx;
-        float sacc = 0.f;
-        for (int j = 0; j < k; ++j) sacc += row[j];
-        hs[eye * eh * WF_TW + t] = sacc;
-      }
+      const vd_f2* row = e2 + ty * ew + tx;
+      vd_f2 sacc = {0.f, 0.f};
+      for (int j = 0; j < k; ++j) sacc += row[j];
+      hs[t] = sacc;
     }
   }
   __syncthreads();
@@ -174,7 +203,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   // (sample rows yn / yn+1, their resize taps, the vertical weights) is wave-uniform.  ~70 % of rows have an exactly
   // integral sample row (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 -> skipped
   // (bit-exact: fma(v, 0, acc) == acc for finite v).
-  const float* hs = wd;
+  const vd_f2* hs = wd;
   const float div = (float)(k * k);
   const size_t ni = (size_t)a.ih * a.iw;
   const int lane = tid & 63, wv = tid >> 6;
@@ -182,81 +211,84 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     const int y = y0 + ty;
     if (y >= H) break;
     const float gy = vd_lin11(H, y);
-    const vd_gs grow = vd_gs_params(0.f, gy, W, H);      // row part: yn, s_ok and whether n == 0
-    const bool south = grow.s_ok && (grow.sw != 0.f || grow.se != 0.f);   // n != 0 (e + w == 1, so not both products vanish)
+    int yn; float n, sr; bool s_ok;
+    wf_gs_row(gy, H, &yn, &n, &sr, &s_ok);
+    const bool south = s_ok && n != 0.f;   // n != 0 <=> sw, se not both zero (e + w == 1)
     const vd_tap tyo = wf_tap(a.ih, H, a.scale_h, y);
-    const vd_tap ty0 = wf_tap(a.ih, H, a.scale_h, grow.yn), ty1 = wf_tap(a.ih, H, a.scale_h, min(grow.yn + 1, H - 1));
+    const vd_tap ty0 = wf_tap(a.ih, H, a.scale_h, yn), ty1 = wf_tap(a.ih, H, a.scale_h, min(yn + 1, H - 1));
     const int x = x0 + lane;
     uint32_t pL = 0, pR = 0;
     if (x < W) {
       const size_t o = (size_t)y * W + x;
-      float b[2] = {0.f, 0.f};
+      vd_f2 b = {0.f, 0.f};
       if (a.feather) {
-#pragma unroll
-        for (int eye = 0; eye < 2; ++eye) {
-          const float* col = hs + eye * eh * WF_TW + ty * WF_TW + lane;
-          float sacc = 0.f;
-          for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
-          b[eye] = sacc / div;
-        }
+        const vd_f2* col = hs + ty * WF_TW + lane;
+        vd_f2 sacc = {0.f, 0.f};
+        for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
+        b.x = sacc.x / div; b.y = sacc.y / div;
       }
       const float s = S[o];
       const float gx0 = vd_lin11(W, x);
-      const vd_gs gl = vd_gs_params(gx0 + s, gy, W, H), gr = vd_gs_params(gx0 - s, gy, W, H);
+      const wf_gs2 g = wf_gs_params2(gx0, s, n, sr, W);
+      const vd_f2 omb = 1.0f - b;
       if (RESIZE) {
         const vd_tap txo = wf_tap(a.iw, W, a.scale_w, x);
-        const vd_tap tl0 = wf_tap(a.iw, W, a.scale_w, gl.xw), tl1 = wf_tap(a.iw, W, a.scale_w, min(gl.xw + 1, W - 1));
-        const vd_tap tr0 = wf_tap(a.iw, W, a.scale_w, gr.xw), tr1 = wf_tap(a.iw, W, a.scale_w, min(gr.xw + 1, W - 1));
+        const wf_tap2 ta = wf_tap_pair(a.iw, W, a.scale_w, g.xw[0], g.xw[1]);                                   // column xw of each eye
+        const wf_tap2 tb = wf_tap_pair(a.iw, W, a.scale_w, min(g.xw[0] + 1, W - 1), min(g.xw[1] + 1, W - 1));   // column xw+1
+        const vd_f2 okf = {g.e_ok[0] ? 1.f : 0.f, g.e_ok[1] ? 1.f : 0.f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float* tc = tile + c * er * ec;
-          auto smp = [&](const vd_tap& yy, const vd_tap& xx) {
+          // nested bilinear sample of BOTH eyes: rows yy (wave-uniform), columns xx.{i0,i1}[eye]
+          auto smp2 = [&](const vd_tap& yy, const wf_tap2& xx) {
             const float* q0 = tc + (yy.i0 - er0) * ec - ec0;
             const float* q1 = tc + (yy.i1 - er0) * ec - ec0;
-            return vd_bilerp(q0[xx.i0], q0[xx.i1], q1[xx.i0], q1[xx.i1], xx.w0, xx.w1, yy.w0, yy.w1);
+            const vd_f2 p00 = {q0[xx.i0[0]], q0[xx.i0[1]]}, p01 = {q0[xx.i1[0]], q0[xx.i1[1]]};
+            const vd_f2 p10 = {q1[xx.i0[0]], q1[xx.i0[1]]}, p11 = {q1[xx.i1[0]], q1[xx.i1[1]]};
+            const vd_f2 ra = vd_vfma(p00, xx.w0, xx.w1 * p01);
+            const vd_f2 rb = vd_vfma(p10, xx.w0, xx.w1 * p11);
+            return vd_vfma(ra, (vd_f2)(yy.w0), yy.w1 * rb);
           };
-          const float orig = smp(tyo, txo);
-#pragma unroll
-          for (int eye = 0; eye < 2; ++eye) {
-            const vd_gs& g = eye == 0 ? gl : gr;
-            const vd_tap& xa = eye == 0 ? tl0 : tr0;
-            const vd_tap& xb = eye == 0 ? tl1 : tr1;
-            const float vnw = smp(ty0, xa);
-            const float vne = g.e_ok ? smp(ty0, xb) : 0.f;
-            float v;
-            if (south) {
-              const float vsw = smp(ty1, xa);
-              const float vse = g.e_ok ? smp(ty1, xb) : 0.f;
-              v = vd_gs_combine(g, vnw, vne, vsw, vse);
-            } else {
-              v = vd_fma(vne, g.ne, vnw * g.nw);   // == vd_gs_combine with sw = se = 0 (or no south row)
-            }
-            if (a.feather) v = vd_clamp(v * (1.0f - b[eye]) + orig * b[eye], 0.f, 1.f);
-            const uint32_t u = (uint32_t)(uint8_t)(v * 255.0f);
-            if (eye == 0) pL |= u << (8 * (2 - c)); else pR |= u << (8 * (2 - c));
+          float orig;
+          {
+            const float* q0 = tc + (tyo.i0 - er0) * ec - ec0;
+            const float* q1 = tc + (tyo.i1 - er0) * ec - ec0;
+            orig = vd_bilerp(q0[txo.i0], q0[txo.i1], q1[txo.i0], q1[txo.i1], txo.w0, txo.w1, tyo.w0, tyo.w1);
           }
+          const vd_f2 vnw = smp2(ty0, ta);
+          vd_f2 vne = smp2(ty0, tb);
+          vne.x = g.e_ok[0] ? vne.x : 0.f; vne.y = g.e_ok[1] ? vne.y : 0.f;
+          vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
+          if (south) {
+            const vd_f2 vsw = smp2(ty1, ta);
+            vd_f2 vse = smp2(ty1, tb);
+            vse.x = g.e_ok[0] ? vse.x : 0.f; vse.y = g.e_ok[1] ? vse.y : 0.f;
+            v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
+          }
+          (void)okf;
+          if (a.feather) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
+          const vd_f2 u = v * 255.0f;
+          pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
+          pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
         }
       } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float* pl = rgb + c * ni;
           const float orig = pl[o];
-#pragma unroll
-          for (int eye = 0; eye < 2; ++eye) {
-            const vd_gs& g = eye == 0 ? gl : gr;
-            const float* r0 = pl + (size_t)g.yn * W;
-            const float vnw = r0[g.xw], vne = g.e_ok ? r0[g.xw + 1] : 0.f;
-            float v;
-            if (south) {
-              const float vsw = r0[W + g.xw], vse = g.e_ok ? r0[W + g.xw + 1] : 0.f;
-              v = vd_gs_combine(g, vnw, vne, vsw, vse);
-            } else {
-              v = vd_fma(vne, g.ne, vnw * g.nw);
-            }
-            if (a.feather) v = vd_clamp(v * (1.0f - b[eye]) + orig * b[eye], 0.f, 1.f);
-            const uint32_t u = (uint32_t)(uint8_t)(v * 255.0f);
-            if (eye == 0) pL |= u << (8 * (2 - c)); else pR |= u << (8 * (2 - c));
+          const float* r0 = pl + (size_t)yn * W;
+          const vd_f2 vnw = {r0[g.xw[0]], r0[g.xw[1]]};
+          const vd_f2 vne = {g.e_ok[0] ? r0[g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[g.xw[1] + 1] : 0.f};
+          vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
+          if (south) {
+            const vd_f2 vsw = {r0[W + g.xw[0]], r0[W + g.xw[1]]};
+            const vd_f2 vse = {g.e_ok[0] ? r0[W + g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[W + g.xw[1] + 1] : 0.f};
+            v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
+          if (a.feather) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
+          const vd_f2 u = v * 255.0f;
+          pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
+          pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
         }
       }
     }
