@@ -25,9 +25,17 @@
 struct vd_wf_args {
   int ih, iw, H, W, k, feather, bound;  // bound: rigorous host-side bound on |pixel shift| (+ margin)
   int er_max, ec_max;                   // eye tile capacity (rows, cols) when resizing
+  int ncol;                             // entries of the column-tap table (WF_TW + 2*bound + 6)
   uint32_t m_ww, m_ew, m_ec, m_erec;    // ceil(2^32/d) reciprocals: q = umulhi(t, m) is exact for t, d < 2^16
   float fs, scale_h, scale_w;
+  float step_x, step_y;                 // linspace steps (1-(-1))/(float)(W-1), .../(H-1): vd_lin11_step
 };
+// LDS tables (built once per tile, so the per-pixel phases only do table look-ups):
+//   rowA[wh][4]   per halo row of phase A : yn, n, 1-n, south flag                      (grid_sample row part)
+//   rowD[TH][16]  per tile row of phase D : 3 resize taps (orig / yn / yn+1) as tile row offsets + weights, n, 1-n, south, yn
+//   colT[ncol][2] per warp-res column     : resize tap of that column as tile column offset + weight (i1 = i0+1: the tile
+//                                           keeps a duplicate of the last image column)
+#define WF_RD 16
 VD_DEV int wf_div(int t, uint32_t m) { return (int)__umulhi((uint32_t)t, m); }
 
 VD_DEV vd_tap wf_tap(int in, int out, float scale, int o) {  // vd_interp_tap with the scale hoisted
@@ -74,7 +82,7 @@ VD_DEV wf_tap2 wf_tap_pair(int in, int out, float scale, int oa, int ob) {
   return t;
 }
 
-// LDS map (floats):  wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2] | tile[3*er*ec]      ([..][2] = the two eyes interleaved)
+// LDS map (floats):  wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2] | tile[3*er*ec] | rowD | rowA | colT      ([..][2] = eyes)
 #define WF_AI 6  // phase-A positions per thread ((TH+k)(TW+k) <= WF_AI*WF_NT for k <= 9; larger k loops)
 template <bool RESIZE>
 __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
@@ -88,8 +96,12 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   vd_f2* wd = reinterpret_cast<vd_f2*>(lds);                       // [wh*ww]   (later hs [eh*WF_TW])
   vd_f2* e2 = reinterpret_cast<vd_f2*>(lds + 2 * wh * ww);         // [eh*ew]
   float* tile = a.feather ? lds + 2 * wh * ww + 2 * eh * ew : lds;  // [3][er][ec] (the feather buffers are not allocated when feathering is off)
+  float* rowD = lds + (((a.feather ? 2 * wh * ww + 2 * eh * ew : 0) + 3 * a.er_max * a.ec_max + 3) & ~3);   // [WF_TH][WF_RD], 16 B aligned
+  float* rowA = rowD + WF_TH * WF_RD;                               // [wh][4]
+  float* colT = rowA + wh * 4;                                      // [ncol][2]
   const int tid = threadIdx.x;
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
+  const int cb = max(x0 - a.bound - 2, 0);                          // first warp-res column of colT
 
   // eye-res RGB tile: global -> registers now, registers -> LDS after phase A (latency hidden behind phase A)
   int er0 = 0, ec0 = 0, er = 0, ec = 0;
@@ -100,8 +112,8 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     er0 = wf_tap(a.ih, H, a.scale_h, ya).i0; er = wf_tap(a.ih, H, a.scale_h, yb).i1 - er0 + 1;
     ec0 = wf_tap(a.iw, W, a.scale_w, xa).i0; ec = wf_tap(a.iw, W, a.scale_w, xb).i1 - ec0 + 1;
     er = min(er, a.er_max); ec = a.ec_max;  // fixed row pitch (host constant) so the reciprocals apply
-    ec0 = min(ec0, a.iw - ec); ec0 = max(ec0, 0);
-    const size_t ni = (size_t)a.ih * a.iw;
+    ec0 = min(ec0, a.iw + 1 - ec); ec0 = max(ec0, 0);   // tile column iw - ec0 (if inside) duplicates the last image column
+    const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
 #pragma unroll
     for (int j = 0; j < WF_PF; ++j) {
       const int t = tid + j * WF_NT;
@@ -109,11 +121,36 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       if (t < 3 * er * ec) {
         const int c = t >= 2 * er * ec ? 2 : (t >= er * ec ? 1 : 0);
         const int rem = t - c * er * ec, ty = wf_div(rem, a.m_ec), tx = rem - ty * ec;
-        if (ec0 + tx < a.iw) v = rgb[c * ni + (size_t)(er0 + ty) * a.iw + (ec0 + tx)];
+        v = rgb[(unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + tx, a.iw - 1)];
       }
       pf[j] = v;
     }
   }
+  // ---- tables
+  if (tid < wh) {   // phase-A rows
+    const int y = wy0 + tid;
+    int yn = 0; float n = 0.f, sr = 1.f; bool s_ok = false;
+    if (y >= 0 && y < H) wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
+    float* t = rowA + tid * 4;
+    t[0] = __int_as_float(yn); t[1] = n; t[2] = sr; t[3] = __int_as_float((s_ok && n != 0.f) ? 1 : 0);
+  } else if (tid >= 64 && tid < 64 + WF_TH) {   // phase-D rows
+    const int ty = tid - 64, y = min(y0 + ty, H - 1);
+    int yn; float n, sr; bool s_ok;
+    wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
+    float* t = rowD + ty * WF_RD;
+    const vd_tap to = wf_tap(a.ih, H, a.scale_h, y), t0 = wf_tap(a.ih, H, a.scale_h, yn), t1 = wf_tap(a.ih, H, a.scale_h, min(yn + 1, H - 1));
+    t[0] = __int_as_float((to.i0 - er0) * ec); t[1] = __int_as_float((to.i1 - er0) * ec); t[2] = to.w0; t[3] = to.w1;
+    t[4] = __int_as_float((t0.i0 - er0) * ec); t[5] = __int_as_float((t0.i1 - er0) * ec); t[6] = t0.w0; t[7] = t0.w1;
+    t[8] = __int_as_float((t1.i0 - er0) * ec); t[9] = __int_as_float((t1.i1 - er0) * ec); t[10] = t1.w0; t[11] = t1.w1;
+    t[12] = n; t[13] = sr; t[14] = __int_as_float((s_ok && n != 0.f) ? 1 : 0); t[15] = __int_as_float(yn);
+  }
+  if (RESIZE) {
+    for (int j = tid; j < a.ncol; j += WF_NT) {
+      const vd_tap t = wf_tap(a.iw, W, a.scale_w, min(cb + j, W - 1));
+      colT[2 * j] = __int_as_float(t.i0 - ec0); colT[2 * j + 1] = t.w1;
+    }
+  }
+  __syncthreads();
   if (a.feather) {
     // phase A: warped depth of both eyes on the (TH+k) x (TW+k) halo region (grid_sample of D, :700-701).
     // Two passes with a fixed unroll so all S loads, then all D gathers, are in flight together.
@@ -124,7 +161,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         const int t = base + tid + j * WF_NT;
         const int ty = wf_div(t, a.m_ww), tx = t - ty * ww;
         const int y = wy0 + ty, x = wx0 + tx;
-        sv[j] = (t < wh * ww && y >= 0 && y < H && x >= 0 && x < W) ? S[(size_t)y * W + x] : 0.f;
+        sv[j] = (t < wh * ww && y >= 0 && y < H && x >= 0 && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < WF_AI; ++j) {
@@ -134,17 +171,18 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
           const int y = wy0 + ty, x = wx0 + tx;
           vd_f2 v = {0.f, 0.f};
           if (y >= 0 && y < H && x >= 0 && x < W) {
-            const float gx = vd_lin11(W, x), gy = vd_lin11(H, y);
-            int yn; float n, sr; bool s_ok;
-            wf_gs_row(gy, H, &yn, &n, &sr, &s_ok);
-            const wf_gs2 g = wf_gs_params2(gx, sv[j], n, sr, W);
-            const float* r0 = D + (size_t)yn * W + g.xw[0];
-            const float* r1 = D + (size_t)yn * W + g.xw[1];
+            const float gx = vd_lin11_step(a.step_x, W, x);
+            const vd_f4 rt = *reinterpret_cast<const vd_f4*>(rowA + ty * 4);
+            const int yn = __float_as_int(rt.x);
+            const wf_gs2 g = wf_gs_params2(gx, sv[j], rt.y, rt.z, W);
+            const unsigned rb = (unsigned)yn * (unsigned)W;
+            const float* r0 = D + (rb + (unsigned)g.xw[0]);
+            const float* r1 = D + (rb + (unsigned)g.xw[1]);
             const vd_f2 vnw = {r0[0], r1[0]};
             const vd_f2 vne = {g.e_ok[0] ? r0[1] : 0.f, g.e_ok[1] ? r1[1] : 0.f};
             // vd_gs_combine; when n == 0 (or no south row) sw = se = 0 exactly and the south samples add +0
             vd_f2 acc = vd_vfma(vne, g.ne, vnw * g.nw);
-            if (s_ok && n != 0.f) {
+            if (__float_as_int(rt.w)) {
               const vd_f2 vsw = {r0[W], r1[W]};
               const vd_f2 vse = {g.e_ok[0] ? r0[W + 1] : 0.f, g.e_ok[1] ? r1[W + 1] : 0.f};
               acc = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, acc));
@@ -162,10 +200,10 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       const int t = tid + j * WF_NT;
       if (t < 3 * er * ec) tile[t] = pf[j];
     }
-    const size_t ni = (size_t)a.ih * a.iw;
+    const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
     for (int t = tid + WF_PF * WF_NT; t < 3 * er * ec; t += WF_NT) {  // only for very large shift bounds
       const int c = t / (er * ec), rem = t - c * er * ec, ty = rem / ec, tx = rem - ty * ec;
-      tile[t] = (ec0 + tx < a.iw) ? rgb[c * ni + (size_t)(er0 + ty) * a.iw + (ec0 + tx)] : 0.f;
+      tile[t] = rgb[(unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + tx, a.iw - 1)];
     }
   }
   __syncthreads();
@@ -200,26 +238,25 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   }
   __syncthreads();
   // phase D: one wave = 64 consecutive pixels of ONE row per iteration, so everything that depends on y only
-  // (sample rows yn / yn+1, their resize taps, the vertical weights) is wave-uniform.  ~70 % of rows have an exactly
-  // integral sample row (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 -> skipped
-  // (bit-exact: fma(v, 0, acc) == acc for finite v).
+  // (sample rows yn / yn+1, their resize taps, the vertical weights) is wave-uniform and comes from rowD.  ~70 % of rows
+  // have an exactly integral sample row (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 ->
+  // skipped (bit-exact: fma(v, 0, acc) == acc for finite v).
   const vd_f2* hs = wd;
   const float div = (float)(k * k);
-  const size_t ni = (size_t)a.ih * a.iw;
-  const int lane = tid & 63, wv = tid >> 6;
+  const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int ty = wv; ty < WF_TH; ty += WF_NT / 64) {
     const int y = y0 + ty;
     if (y >= H) break;
-    const float gy = vd_lin11(H, y);
-    int yn; float n, sr; bool s_ok;
-    wf_gs_row(gy, H, &yn, &n, &sr, &s_ok);
-    const bool south = s_ok && n != 0.f;   // n != 0 <=> sw, se not both zero (e + w == 1)
-    const vd_tap tyo = wf_tap(a.ih, H, a.scale_h, y);
-    const vd_tap ty0 = wf_tap(a.ih, H, a.scale_h, yn), ty1 = wf_tap(a.ih, H, a.scale_h, min(yn + 1, H - 1));
+    const vd_f4* rt = reinterpret_cast<const vd_f4*>(rowD + ty * WF_RD);
+    const vd_f4 ro = rt[0], ra = rt[1], rb = rt[2], rs = rt[3];
+    const float n = rs.x, sr = rs.y;
+    const bool south = __float_as_int(rs.z) != 0;
+    const int yn = __float_as_int(rs.w);
     const int x = x0 + lane;
     uint32_t pL = 0, pR = 0;
     if (x < W) {
-      const size_t o = (size_t)y * W + x;
+      const unsigned o = (unsigned)y * (unsigned)W + (unsigned)x;
       vd_f2 b = {0.f, 0.f};
       if (a.feather) {
         const vd_f2* col = hs + ty * WF_TW + lane;
@@ -228,44 +265,48 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         b.x = sacc.x / div; b.y = sacc.y / div;
       }
       const float s = S[o];
-      const float gx0 = vd_lin11(W, x);
+      const float gx0 = vd_lin11_step(a.step_x, W, x);
       const wf_gs2 g = wf_gs_params2(gx0, s, n, sr, W);
       const vd_f2 omb = 1.0f - b;
       if (RESIZE) {
-        const vd_tap txo = wf_tap(a.iw, W, a.scale_w, x);
-        const wf_tap2 ta = wf_tap_pair(a.iw, W, a.scale_w, g.xw[0], g.xw[1]);                                   // column xw of each eye
-        const wf_tap2 tb = wf_tap_pair(a.iw, W, a.scale_w, min(g.xw[0] + 1, W - 1), min(g.xw[1] + 1, W - 1));   // column xw+1
-        const vd_f2 okf = {g.e_ok[0] ? 1.f : 0.f, g.e_ok[1] ? 1.f : 0.f};
+        // column taps from the table: entry j = resize tap of warp-res column cb + j; xw+1 is the next entry
+        const vd_f2* ct = reinterpret_cast<const vd_f2*>(colT);
+        const vd_f2 eo = ct[x - cb];
+        const vd_f2 eaL = ct[g.xw[0] - cb], ebL = ct[g.xw[0] - cb + 1], eaR = ct[g.xw[1] - cb], ebR = ct[g.xw[1] - cb + 1];
+        const int iaL = __float_as_int(eaL.x), ibL = __float_as_int(ebL.x), iaR = __float_as_int(eaR.x), ibR = __float_as_int(ebR.x);
+        const vd_f2 wa1 = {eaL.y, eaR.y}, wb1 = {ebL.y, ebR.y};
+        const vd_f2 wa0 = 1.f - wa1, wb0 = 1.f - wb1;
+        const int io = __float_as_int(eo.x);
+        const float wo1 = eo.y, wo0 = 1.f - eo.y;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float* tc = tile + c * er * ec;
-          // nested bilinear sample of BOTH eyes: rows yy (wave-uniform), columns xx.{i0,i1}[eye]
-          auto smp2 = [&](const vd_tap& yy, const wf_tap2& xx) {
-            const float* q0 = tc + (yy.i0 - er0) * ec - ec0;
-            const float* q1 = tc + (yy.i1 - er0) * ec - ec0;
-            const vd_f2 p00 = {q0[xx.i0[0]], q0[xx.i0[1]]}, p01 = {q0[xx.i1[0]], q0[xx.i1[1]]};
-            const vd_f2 p10 = {q1[xx.i0[0]], q1[xx.i0[1]]}, p11 = {q1[xx.i1[0]], q1[xx.i1[1]]};
-            const vd_f2 ra = vd_vfma(p00, xx.w0, xx.w1 * p01);
-            const vd_f2 rb = vd_vfma(p10, xx.w0, xx.w1 * p11);
-            return vd_vfma(ra, (vd_f2)(yy.w0), yy.w1 * rb);
+          // nested bilinear sample of BOTH eyes: tile rows r0o / r1o (wave-uniform), tile columns i (and i+1) per eye
+          auto smp2 = [&](const vd_f4& rw, int iL, int iR, const vd_f2& w0, const vd_f2& w1) {
+            const float* q0 = tc + __float_as_int(rw.x);
+            const float* q1 = tc + __float_as_int(rw.y);
+            const vd_f2 p00 = {q0[iL], q0[iR]}, p01 = {q0[iL + 1], q0[iR + 1]};
+            const vd_f2 p10 = {q1[iL], q1[iR]}, p11 = {q1[iL + 1], q1[iR + 1]};
+            const vd_f2 ua = vd_vfma(p00, w0, w1 * p01);
+            const vd_f2 ub = vd_vfma(p10, w0, w1 * p11);
+            return vd_vfma(ua, (vd_f2)(rw.z), rw.w * ub);
           };
           float orig;
           {
-            const float* q0 = tc + (tyo.i0 - er0) * ec - ec0;
-            const float* q1 = tc + (tyo.i1 - er0) * ec - ec0;
-            orig = vd_bilerp(q0[txo.i0], q0[txo.i1], q1[txo.i0], q1[txo.i1], txo.w0, txo.w1, tyo.w0, tyo.w1);
+            const float* q0 = tc + __float_as_int(ro.x);
+            const float* q1 = tc + __float_as_int(ro.y);
+            orig = vd_bilerp(q0[io], q0[io + 1], q1[io], q1[io + 1], wo0, wo1, ro.z, ro.w);
           }
-          const vd_f2 vnw = smp2(ty0, ta);
-          vd_f2 vne = smp2(ty0, tb);
+          const vd_f2 vnw = smp2(ra, iaL, iaR, wa0, wa1);
+          vd_f2 vne = smp2(ra, ibL, ibR, wb0, wb1);
           vne.x = g.e_ok[0] ? vne.x : 0.f; vne.y = g.e_ok[1] ? vne.y : 0.f;
           vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
           if (south) {
-            const vd_f2 vsw = smp2(ty1, ta);
-            vd_f2 vse = smp2(ty1, tb);
+            const vd_f2 vsw = smp2(rb, iaL, iaR, wa0, wa1);
+            vd_f2 vse = smp2(rb, ibL, ibR, wb0, wb1);
             vse.x = g.e_ok[0] ? vse.x : 0.f; vse.y = g.e_ok[1] ? vse.y : 0.f;
             v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
-          (void)okf;
           if (a.feather) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
           const vd_f2 u = v * 255.0f;
           pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
@@ -274,9 +315,9 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float* pl = rgb + c * ni;
+          const float* pl = rgb + (unsigned)c * ni;
           const float orig = pl[o];
-          const float* r0 = pl + (size_t)yn * W;
+          const float* r0 = pl + (unsigned)yn * (unsigned)W;
           const vd_f2 vnw = {r0[g.xw[0]], r0[g.xw[1]]};
           const vd_f2 vne = {g.e_ok[0] ? r0[g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[g.xw[1] + 1] : 0.f};
           vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
@@ -296,19 +337,21 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     const uint32_t nL = (uint32_t)__shfl_down((int)pL, 1, 64), nR = (uint32_t)__shfl_down((int)pR, 1, 64);
     const int q = lane & 3;
     const int xq = x0 + (lane & ~3);
-    const bool full = (xq + 3 < W) && ((((size_t)y * W + xq) * 3) % 4 == 0);
+    const unsigned ob = ((unsigned)y * (unsigned)W + (unsigned)xq) * 3u;
+    const bool full = (xq + 3 < W) && (ob % 4u == 0);
     if (full) {
       if (q < 3) {
         uint32_t dL, dR;
         if (q == 0) { dL = pL | (nL << 24); dR = pR | (nR << 24); }
         else if (q == 1) { dL = (pL >> 8) | (nL << 16); dR = (pR >> 8) | (nR << 16); }
         else { dL = (pL >> 16) | (nL << 8); dR = (pR >> 16) | (nR << 8); }
-        reinterpret_cast<uint32_t*>(L + ((size_t)y * W + xq) * 3)[q] = dL;
-        reinterpret_cast<uint32_t*>(R + ((size_t)y * W + xq) * 3)[q] = dR;
+        reinterpret_cast<uint32_t*>(L + ob)[q] = dL;
+        reinterpret_cast<uint32_t*>(R + ob)[q] = dR;
       }
     } else if (x < W) {
-      uint8_t* ol = L + ((size_t)y * W + x) * 3;
-      uint8_t* orr = R + ((size_t)y * W + x) * 3;
+      const unsigned o1 = ((unsigned)y * (unsigned)W + (unsigned)x) * 3u;
+      uint8_t* ol = L + o1;
+      uint8_t* orr = R + o1;
       ol[0] = (uint8_t)pL; ol[1] = (uint8_t)(pL >> 8); ol[2] = (uint8_t)(pL >> 16);
       orr[0] = (uint8_t)pR; orr[1] = (uint8_t)(pR >> 8); orr[2] = (uint8_t)(pR >> 16);
     }
@@ -333,10 +376,16 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   if (resize) {
     a.er_max = (int)ceil((WF_TH + 2) * (double)a.scale_h) + 3;
     a.ec_max = (int)ceil((WF_TW + 2 * a.bound + 3) * (double)a.scale_w) + 3;
+    a.ec_max += 1;                       // room for the duplicate of the last image column (table taps use i1 = i0 + 1)
     a.ec_max |= 1;                       // odd row pitch: the 4-rows-per-wave gathers of phase D land on distinct banks
-    if (a.ec_max > iw) a.ec_max = iw;
+    if (a.ec_max > iw + 1) a.ec_max = iw + 1;
     fl += (size_t)3 * a.er_max * a.ec_max;
   }
+  a.ncol = WF_TW + 2 * a.bound + 6;
+  fl = (fl + 3) & ~(size_t)3;            // tables start 16 B aligned (ds_read_b128)
+  fl += (size_t)WF_TH * WF_RD + (size_t)(WF_TH + k) * 4 + (size_t)2 * a.ncol;
+  if (fl & 3) fl += 4 - (fl & 3);
+  a.step_x = (1.f - (-1.f)) / (float)(W - 1); a.step_y = (1.f - (-1.f)) / (float)(H - 1);
   auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
   a.m_ww = magic(WF_TW + k); a.m_ew = magic(WF_TW + k - 1); a.m_ec = magic(a.ec_max > 0 ? a.ec_max : 1); a.m_erec = 0;
   if ((WF_TH + k) * (WF_TW + k) >= 65536 || 3 * a.er_max * a.ec_max >= 65536) return false;
