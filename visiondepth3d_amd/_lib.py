@@ -9,7 +9,7 @@ from . import _abi
 from ._abi import FrameScalars, RenderParams, ShiftParams, State
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvd3d_hip.so")
+LIB_PATH = os.environ.get("VD3D_LIB_PATH") or os.path.join(_HERE, "libvd3d_hip.so")   # override: A/B builds of the same ABI
 
 # every symbol include/vd3d.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = (

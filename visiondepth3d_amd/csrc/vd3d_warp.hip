@@ -26,6 +26,7 @@ struct vd_wf_args {
   int ih, iw, H, W, k, feather, bound;  // bound: rigorous host-side bound on |pixel shift| (+ margin)
   int er_max, ec_max;                   // eye tile capacity (rows, cols) when resizing
   int ncol;                             // entries of the column-tap table (WF_TW + 2*bound + 6)
+  int tab_off;                          // float offset of the tables in LDS
   uint32_t m_ww, m_ew, m_ec, m_erec;    // ceil(2^32/d) reciprocals: q = umulhi(t, m) is exact for t, d < 2^16
   float fs, scale_h, scale_w;
   float step_x, step_y;                 // linspace steps (1-(-1))/(float)(W-1), .../(H-1): vd_lin11_step
@@ -82,9 +83,22 @@ VD_DEV wf_tap2 wf_tap_pair(int in, int out, float scale, int oa, int ob) {
   return t;
 }
 
+// RGB tile: prefetched registers -> LDS (+ the rare overflow elements straight from global)
+#define WF_STORE_TILE                                                                                                   \
+  {                                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < WF_PF; ++j) {                                                                 \
+      const int t = tid + j * WF_NT;                                                                                    \
+      if (t < 3 * er * ec) tile[t] = pf[j];                                                                             \
+    }                                                                                                                   \
+    const unsigned ni_ = (unsigned)a.ih * (unsigned)a.iw;                                                               \
+    for (int t = tid + WF_PF * WF_NT; t < 3 * er * ec; t += WF_NT) { /* only for very large shift bounds */            \
+      const int c = t / (er * ec), rem = t - c * er * ec, ty = rem / ec, tx = rem - ty * ec;                            \
+      tile[t] = rgb[(unsigned)c * ni_ + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + tx, a.iw - 1)];    \
+    }                                                                                                                   \
+  }
 // LDS map (floats):  wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2] | tile[3*er*ec] | rowD | rowA | colT      ([..][2] = eyes)
 #define WF_AI 6  // phase-A positions per thread ((TH+k)(TW+k) <= WF_AI*WF_NT for k <= 9; larger k loops)
-template <bool RESIZE>
+template <bool RESIZE, bool FEATHER>
 __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
                                                       uint8_t* __restrict__ R) {
@@ -93,10 +107,13 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   const int x0 = blockIdx.x * WF_TW, y0 = blockIdx.y * WF_TH;
   const int ww = WF_TW + k, wh = WF_TH + k;          // wd region
   const int ew = WF_TW + k - 1, eh = WF_TH + k - 1;  // e2 region
+  // LDS aliasing (floats): wd2 [0, 2*wh*ww) is dead after phase B and becomes hs2 [0, 2*eh*TW); e2_2 follows wd2 and is dead
+  // after phase C; the RGB tile is parked in registers until then and lands at [2*eh*TW, ...) over the dead tail of wd2 and
+  // e2_2.  Live maximum = hs2 + tile (+ tables) = 53 KB at 4K / k = 9  =>  3 workgroups per CU instead of 2.
   vd_f2* wd = reinterpret_cast<vd_f2*>(lds);                       // [wh*ww]   (later hs [eh*WF_TW])
   vd_f2* e2 = reinterpret_cast<vd_f2*>(lds + 2 * wh * ww);         // [eh*ew]
-  float* tile = a.feather ? lds + 2 * wh * ww + 2 * eh * ew : lds;  // [3][er][ec] (the feather buffers are not allocated when feathering is off)
-  float* rowD = lds + (((a.feather ? 2 * wh * ww + 2 * eh * ew : 0) + 3 * a.er_max * a.ec_max + 3) & ~3);   // [WF_TH][WF_RD], 16 B aligned
+  float* tile = FEATHER ? lds + 2 * eh * WF_TW : lds;              // [3][er][ec]
+  float* rowD = lds + a.tab_off;                                    // [WF_TH][WF_RD], 16 B aligned (host: after the aliased buffers)
   float* rowA = rowD + WF_TH * WF_RD;                               // [wh][4]
   float* colT = rowA + wh * 4;                                      // [ncol][2]
   const int tid = threadIdx.x;
@@ -113,18 +130,25 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     ec0 = wf_tap(a.iw, W, a.scale_w, xa).i0; ec = wf_tap(a.iw, W, a.scale_w, xb).i1 - ec0 + 1;
     er = min(er, a.er_max); ec = a.ec_max;  // fixed row pitch (host constant) so the reciprocals apply
     ec0 = min(ec0, a.iw + 1 - ec); ec0 = max(ec0, 0);   // tile column iw - ec0 (if inside) duplicates the last image column
+    if (!FEATHER) {
     const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
+    // element t = tid + j*WF_NT of the [3*er][ec] tile, (row, tx) advanced incrementally (no integer division / 32-bit multiply)
+    const int pq = WF_NT / ec, pr = WF_NT - pq * ec;
+    int prow = wf_div(tid, a.m_ec), ptx = tid - prow * ec;
 #pragma unroll
     for (int j = 0; j < WF_PF; ++j) {
-      const int t = tid + j * WF_NT;
       float v = 0.f;
-      if (t < 3 * er * ec) {
-        const int c = t >= 2 * er * ec ? 2 : (t >= er * ec ? 1 : 0);
-        const int rem = t - c * er * ec, ty = wf_div(rem, a.m_ec), tx = rem - ty * ec;
-        v = rgb[(unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + tx, a.iw - 1)];
+      if (prow < 3 * er) {
+        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);
+        const int ty = prow - c * er;
+        const unsigned pb = c == 2 ? 2u * ni : (c == 1 ? ni : 0u);
+        v = rgb[pb + __umul24((unsigned)(er0 + ty), (unsigned)a.iw) + (unsigned)min(ec0 + ptx, a.iw - 1)];
       }
       pf[j] = v;
+      prow += pq; ptx += pr;
+      if (ptx >= ec) { ptx -= ec; ++prow; }
     }
+      }
   }
   // ---- tables
   if (tid < wh) {   // phase-A rows
@@ -151,7 +175,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     }
   }
   __syncthreads();
-  if (a.feather) {
+  if (FEATHER) {
     // phase A: warped depth of both eyes on the (TH+k) x (TW+k) halo region (grid_sample of D, :700-701).
     // Two passes with a fixed unroll so all S loads, then all D gathers, are in flight together.
     for (int base = 0; base < wh * ww; base += WF_AI * WF_NT) {
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         const int t = base + tid + j * WF_NT;
         const int ty = wf_div(t, a.m_ww), tx = t - ty * ww;
         const int y = wy0 + ty, x = wx0 + tx;
-        sv[j] = (t < wh * ww && y >= 0 && y < H && x >= 0 && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
+        sv[j] = (t < wh * ww && y >= 0 && y < H && x >= 0 && x < W) ? S[__umul24((unsigned)y, (unsigned)W) + (unsigned)x] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < WF_AI; ++j) {
@@ -175,7 +199,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
             const vd_f4 rt = *reinterpret_cast<const vd_f4*>(rowA + ty * 4);
             const int yn = __float_as_int(rt.x);
             const wf_gs2 g = wf_gs_params2(gx, sv[j], rt.y, rt.z, W);
-            const unsigned rb = (unsigned)yn * (unsigned)W;
+            const unsigned rb = __umul24((unsigned)yn, (unsigned)W);
             const float* r0 = D + (rb + (unsigned)g.xw[0]);
             const float* r1 = D + (rb + (unsigned)g.xw[1]);
             const vd_f2 vnw = {r0[0], r1[0]};
@@ -194,27 +218,38 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       }
     }
   }
-  if (RESIZE) {
-#pragma unroll
-    for (int j = 0; j < WF_PF; ++j) {
-      const int t = tid + j * WF_NT;
-      if (t < 3 * er * ec) tile[t] = pf[j];
-    }
-    const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
-    for (int t = tid + WF_PF * WF_NT; t < 3 * er * ec; t += WF_NT) {  // only for very large shift bounds
-      const int c = t / (er * ec), rem = t - c * er * ec, ty = rem / ec, tx = rem - ty * ec;
-      tile[t] = rgb[(unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + tx, a.iw - 1)];
-    }
+  if (RESIZE && !FEATHER) {
+    WF_STORE_TILE
   }
   __syncthreads();
-  if (a.feather) {
+  if (FEATHER && RESIZE) {   // tile prefetch: in flight during phases B and C only (keeps the register footprint of phase A small)
+    const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
+    // element t = tid + j*WF_NT of the [3*er][ec] tile, (row, tx) advanced incrementally (no integer division / 32-bit multiply)
+    const int pq = WF_NT / ec, pr = WF_NT - pq * ec;
+    int prow = wf_div(tid, a.m_ec), ptx = tid - prow * ec;
+#pragma unroll
+    for (int j = 0; j < WF_PF; ++j) {
+      float v = 0.f;
+      if (prow < 3 * er) {
+        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);
+        const int ty = prow - c * er;
+        const unsigned pb = c == 2 ? 2u * ni : (c == 1 ? ni : 0u);
+        v = rgb[pb + __umul24((unsigned)(er0 + ty), (unsigned)a.iw) + (unsigned)min(ec0 + ptx, a.iw - 1)];
+      }
+      pf[j] = v;
+      prow += pq; ptx += pr;
+      if (ptx >= ec) { ptx -= ec; ++prow; }
+    }
+    }
+  if (FEATHER) {
     // phase B: e2 = clamp(|grad WD| * fs, 0, 1) (:347-352), zero outside the image (avg_pool2d zero padding)
+    const int bq = WF_NT / ew, br = WF_NT - bq * ew;
+    int ty = wf_div(tid, a.m_ew), tx = tid - ty * ew;
     for (int t = tid; t < eh * ew; t += WF_NT) {
-      const int ty = wf_div(t, a.m_ew), tx = t - ty * ew;
       const int y = y0 - r + ty, x = x0 - r + tx;
       vd_f2 e = {0.f, 0.f};
       if (y >= 0 && y < H && x >= 0 && x < W) {
-        const vd_f2* wv = wd + (ty + 1) * ww + (tx + 1);
+        const vd_f2* wv = wd + __umul24((unsigned)(ty + 1), (unsigned)ww) + (tx + 1);
         const vd_f2 c = wv[0];
         const vd_f2 z = {0.f, 0.f};
         const vd_f2 gx = x > 0 ? c - wv[-1] : z;
@@ -224,6 +259,8 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         e.x = vd_clamp(m.x, 0.f, 1.f); e.y = vd_clamp(m.y, 0.f, 1.f);
       }
       e2[t] = e;
+      ty += bq; tx += br;
+      if (tx >= ew) { tx -= ew; ++ty; }
     }
     __syncthreads();
     // phase C: horizontal window sums (ascending x) into the dead wd buffer
@@ -234,6 +271,10 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       vd_f2 sacc = {0.f, 0.f};
       for (int j = 0; j < k; ++j) sacc += row[j];
       hs[t] = sacc;
+    }
+    if (RESIZE) {
+      __syncthreads();   // every read of e2 is done: the tile may overwrite it
+      WF_STORE_TILE
     }
   }
   __syncthreads();
@@ -256,9 +297,9 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     const int x = x0 + lane;
     uint32_t pL = 0, pR = 0;
     if (x < W) {
-      const unsigned o = (unsigned)y * (unsigned)W + (unsigned)x;
+      const unsigned o = __umul24((unsigned)y, (unsigned)W) + (unsigned)x;
       vd_f2 b = {0.f, 0.f};
-      if (a.feather) {
+      if (FEATHER) {
         const vd_f2* col = hs + ty * WF_TW + lane;
         vd_f2 sacc = {0.f, 0.f};
         for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
@@ -307,7 +348,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
             vse.x = g.e_ok[0] ? vse.x : 0.f; vse.y = g.e_ok[1] ? vse.y : 0.f;
             v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
-          if (a.feather) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
+          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
           const vd_f2 u = v * 255.0f;
           pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
           pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
@@ -317,7 +358,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         for (int c = 0; c < 3; ++c) {
           const float* pl = rgb + (unsigned)c * ni;
           const float orig = pl[o];
-          const float* r0 = pl + (unsigned)yn * (unsigned)W;
+          const float* r0 = pl + __umul24((unsigned)yn, (unsigned)W);
           const vd_f2 vnw = {r0[g.xw[0]], r0[g.xw[1]]};
           const vd_f2 vne = {g.e_ok[0] ? r0[g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[g.xw[1] + 1] : 0.f};
           vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
@@ -326,7 +367,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
             const vd_f2 vse = {g.e_ok[0] ? r0[W + g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[W + g.xw[1] + 1] : 0.f};
             v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
-          if (a.feather) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
+          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
           const vd_f2 u = v * 255.0f;
           pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
           pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
@@ -337,7 +378,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     const uint32_t nL = (uint32_t)__shfl_down((int)pL, 1, 64), nR = (uint32_t)__shfl_down((int)pR, 1, 64);
     const int q = lane & 3;
     const int xq = x0 + (lane & ~3);
-    const unsigned ob = ((unsigned)y * (unsigned)W + (unsigned)xq) * 3u;
+    const unsigned ob = (__umul24((unsigned)y, (unsigned)W) + (unsigned)xq) * 3u;
     const bool full = (xq + 3 < W) && (ob % 4u == 0);
     if (full) {
       if (q < 3) {
@@ -372,34 +413,46 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   const bool resize = !(ih == H && iw == W);
   a.er_max = a.ec_max = 0;
   const int k = a.k;
-  size_t fl = a.feather ? (size_t)2 * (WF_TH + k) * (WF_TW + k) + (size_t)2 * (WF_TH + k - 1) * (WF_TW + k - 1) : 0;
+  size_t sz_tile = 0;
   if (resize) {
     a.er_max = (int)ceil((WF_TH + 2) * (double)a.scale_h) + 3;
     a.ec_max = (int)ceil((WF_TW + 2 * a.bound + 3) * (double)a.scale_w) + 3;
     a.ec_max += 1;                       // room for the duplicate of the last image column (table taps use i1 = i0 + 1)
     a.ec_max |= 1;                       // odd row pitch: the 4-rows-per-wave gathers of phase D land on distinct banks
     if (a.ec_max > iw + 1) a.ec_max = iw + 1;
-    fl += (size_t)3 * a.er_max * a.ec_max;
+    sz_tile = (size_t)3 * a.er_max * a.ec_max;
+  }
+  // aliased layout (see the kernel): max(wd2 + e2_2, hs2 + tile) when feathering, else the tile alone
+  size_t fl = sz_tile;
+  if (a.feather) {
+    const size_t sz_wd = (size_t)2 * (WF_TH + k) * (WF_TW + k), sz_e2 = (size_t)2 * (WF_TH + k - 1) * (WF_TW + k - 1);
+    const size_t sz_hs = (size_t)2 * (WF_TH + k - 1) * WF_TW;
+    fl = sz_wd + sz_e2 > sz_hs + sz_tile ? sz_wd + sz_e2 : sz_hs + sz_tile;
   }
   a.ncol = WF_TW + 2 * a.bound + 6;
   fl = (fl + 3) & ~(size_t)3;            // tables start 16 B aligned (ds_read_b128)
+  a.tab_off = (int)fl;
   fl += (size_t)WF_TH * WF_RD + (size_t)(WF_TH + k) * 4 + (size_t)2 * a.ncol;
   if (fl & 3) fl += 4 - (fl & 3);
   a.step_x = (1.f - (-1.f)) / (float)(W - 1); a.step_y = (1.f - (-1.f)) / (float)(H - 1);
   auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
   a.m_ww = magic(WF_TW + k); a.m_ew = magic(WF_TW + k - 1); a.m_ec = magic(a.ec_max > 0 ? a.ec_max : 1); a.m_erec = 0;
   if ((WF_TH + k) * (WF_TW + k) >= 65536 || 3 * a.er_max * a.ec_max >= 65536) return false;
+  if (H >= (1 << 24) || W >= (1 << 24) || (unsigned long long)H * W * 3ull >= (1ull << 32) || (unsigned long long)ih * iw * 3ull >= (1ull << 32)) return false;  // 24-bit multiplies, 32-bit offsets
   const size_t bytes = fl * sizeof(float);
-  if (bytes > 78 * 1024) return false;  // keep 2 workgroups per CU
+  if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 53.1 KB)
   dim3 g((W + WF_TW - 1) / WF_TW, (H + WF_TH - 1) / WF_TH);
-  if (resize) {
-    static bool attr1 = false;
-    if (!attr1) { (void)hipFuncSetAttribute((const void*)k_warp_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
-    hipLaunchKernelGGL(k_warp_fused<true>, g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
-  } else {
-    static bool attr0 = false;
-    if (!attr0) { (void)hipFuncSetAttribute((const void*)k_warp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr0 = true; }
-    hipLaunchKernelGGL(k_warp_fused<false>, g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_warp_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_warp_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_warp_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_warp_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
   }
+  if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
+  else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
+  else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
+  else hipLaunchKernelGGL((k_warp_fused<false, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
   return true;
 }
