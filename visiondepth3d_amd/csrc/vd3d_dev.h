@@ -16,6 +16,10 @@ VD_DEV float vd_clamp(float x, float lo, float hi) {
   return t > hi ? hi : t;
 }
 VD_DEV float vd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// clamp for FINITE x and lo < hi as one v_med3_f32 (vd_clamp needs 2 compares + 2 selects to keep NaN/-0 semantics).
+// Differs from vd_clamp only in NaN propagation and in the sign of a zero result; used where neither can reach the output
+// (pixel arithmetic that ends in a uint8 truncation), never for histogram keys.
+VD_DEV float vd_clamp_fin(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 // torch.linspace float32, element form: step=(end-start)/(steps-1); i<steps/2 ? fma(step,i,start) : fma(-step,steps-1-i,end)
 VD_DEV float vd_linspace(float start, float end, int steps, int i) {
@@ -142,9 +146,7 @@ VD_DEV int vd_reflect(int i, int n) {
   return i;
 }
 VD_DEV uint8_t vd_sat_rne_u8(float v) {
-  float r = rintf(v);
-  r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
-  return (uint8_t)r;
+  return (uint8_t)__builtin_amdgcn_fmed3f(rintf(v), 0.f, 255.f);   // finite v (sums of uint8 * weights)
 }
 
 // 64-bit wave reductions (wave = 64 lanes on gfx950)

@@ -176,8 +176,8 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
         const float* r1 = dn + (size_t)ay.i1 * a.ew;
         dd = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
       }
-      const float bw = vd_clamp(fabsf(dd - focal) / fc.fw, 0.f, 1.f);
-      const float bi = vd_clamp(bw * (float)fc.nlev, 0.f, fc.imax);
+      const float bw = vd_clamp_fin(fabsf(dd - focal) / fc.fw, 0.f, 1.f);
+      const float bi = vd_clamp_fin(bw * (float)fc.nlev, 0.f, fc.imax);
       int l = (int)floorf(bi);
       l = l > fc.nlev - 1 ? fc.nlev - 1 : (l < 0 ? 0 : l);
       lo[q] = l; alpha[q] = bi - (float)l;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       if (fc.nlev) {
         v = (1.0f - alpha) * vlo[c] + alpha * vhi[c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = vd_clamp(v[q], 0.f, 1.f);
+        for (int q = 0; q < 4; ++q) v[q] = vd_clamp_fin(v[q], 0.f, 1.f);
       }
       rgbv[c] = v;
     }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       v = v + fc.bri;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float vc = vd_clamp(v[q], 0.f, 1.f);
+        const float vc = vd_clamp_fin(v[q], 0.f, 1.f);
         pk[q] |= (uint32_t)(uint8_t)(vc * 255.0f) << (8 * (2 - c));  // byte 0 = B, 1 = G, 2 = R
       }
     }

@@ -46,7 +46,7 @@ VD_DEV vd_tap wf_tap(int in, int out, float scale, int o) {  // vd_interp_tap wi
   if (src < 0.f) src = 0.f;
   int i0 = (int)floorf(src);
   if (i0 > in - 1) i0 = in - 1;
-  float l1 = vd_clamp(src - (float)i0, 0.f, 1.f);
+  float l1 = vd_clamp_fin(src - (float)i0, 0.f, 1.f);
   t.i0 = i0; t.i1 = i0 + (i0 < in - 1 ? 1 : 0); t.w1 = l1; t.w0 = 1.f - l1;
   return t;
 }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         const vd_f2 gy = y > 0 ? c - wv[-ww] : z;
         const vd_f2 q = gx * gx + gy * gy;
         const vd_f2 m = vd_f2{sqrtf(q.x), sqrtf(q.y)} * a.fs;
-        e.x = vd_clamp(m.x, 0.f, 1.f); e.y = vd_clamp(m.y, 0.f, 1.f);
+        e.x = vd_clamp_fin(m.x, 0.f, 1.f); e.y = vd_clamp_fin(m.y, 0.f, 1.f);
       }
       e2[t] = e;
       ty += bq; tx += br;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
             vse.x = g.e_ok[0] ? vse.x : 0.f; vse.y = g.e_ok[1] ? vse.y : 0.f;
             v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
-          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
+          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f); }
           const vd_f2 u = v * 255.0f;
           pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
           pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
             const vd_f2 vse = {g.e_ok[0] ? r0[W + g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[W + g.xw[1] + 1] : 0.f};
             v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
-          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp(v.x, 0.f, 1.f); v.y = vd_clamp(v.y, 0.f, 1.f); }
+          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f); }
           const vd_f2 u = v * 255.0f;
           pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
           pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
