@@ -68,3 +68,21 @@ def test_synth_is_deterministic_and_well_conditioned():
     assert int(f1.astype(np.int64).sum()) == int(synth.synth_frame(5, 108, 192)[0].astype(np.int64).sum())
     g = synth.depth_to_u8_bgr(d1)
     assert g.shape == (108, 192, 3) and np.array_equal(g[..., 0], g[..., 2])
+
+
+def test_u8_unit_is_the_exact_division():
+    """vd_u8_unit (csrc/vd3d_dev.h): q0 = x*rc; q = fma(fma(-q0, 255, x), rc, q0) equals float32(x)/float32(255) for all 256
+    inputs -- the device kernels use it instead of an IEEE division (restated here in float64-emulated float32 arithmetic)."""
+    import math
+    f32 = np.float32
+    rc = f32(1.0) / f32(255.0)
+
+    def fma32(a, b, c):   # exact product and sum in float64 (24-bit x 24-bit fits), one rounding to float32
+        return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+    for v in range(256):
+        x = f32(v)
+        q0 = f32(x * rc)
+        q = fma32(fma32(-q0, f32(255.0), x), rc, q0)
+        assert q == x / f32(255.0), v
+    assert math.isfinite(float(rc))

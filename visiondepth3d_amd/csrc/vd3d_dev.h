@@ -165,13 +165,18 @@ template <typename HistPtr>
 VD_DEV void vd_hist_add_agg(HistPtr hist, unsigned key, bool valid) {
   unsigned long long mask = __ballot(valid);
   const int lane = threadIdx.x & 63;
-  while (mask) {
-    int leader = __ffsll((long long)mask) - 1;
-    unsigned lk = __shfl((int)key, leader, 64);
-    unsigned long long same = __ballot(valid && key == lk) & mask;
+  // at most two leader rounds (a constant or two-valued plane collapses to <= 2 atomics per wave); whatever is left has
+  // many distinct keys, where one plain atomic per lane is cheaper than one ballot/shuffle round per key
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (!mask) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    const unsigned lk = __shfl((int)key, leader, 64);
+    const unsigned long long same = __ballot(valid && key == lk) & mask;
     if (lane == leader) atomicAdd(&hist[lk], (unsigned)__popcll(same));
     mask &= ~same;
   }
+  if ((mask >> lane) & 1ull) atomicAdd(&hist[key], 1u);
 }
 
 // LDS histogram add: a plain returnless ds_add_u32.  Same-address lanes serialise at ~1 lane/clk inside the LDS, so

@@ -45,10 +45,10 @@ VD_DEV float vd_curved_depth(const float* __restrict__ dn, int ih, int iw, int H
 // eye-res pixel, and the TemporalDepthFilter update (:225-229) of that pixel in place.  Returns the new filtered value.
 VD_DEV float vd_depth_at(const void* depth, int fmt, size_t idx) {
   if (fmt == VD3D_DEPTH_F32) return ((const float*)depth)[idx];
-  if (fmt == VD3D_DEPTH_GRAY_U8) return (float)((const uint8_t*)depth)[idx] / 255.0f;
+  if (fmt == VD3D_DEPTH_GRAY_U8) return vd_u8_unit((float)((const uint8_t*)depth)[idx]);   // == v / 255.0f for every uint8 v
   const uint8_t* p = (const uint8_t*)depth + idx * 3;  // cv2.COLOR_BGR2GRAY fixed point
   int g = (p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14;
-  return (float)g / 255.0f;
+  return vd_u8_unit((float)g);
 }
 VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt, const vd3d_render_params& p,
                              int tdf_valid, float* __restrict__ rgb_eye, float* __restrict__ tdf, int ey, int ex) {
@@ -62,8 +62,8 @@ VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __re
 #pragma unroll
     for (int c = 0; c < 3; ++c) {  // output plane c = R,G,B ; source byte 2-c
       const int sc = 2 - c;
-      float p00 = (float)frame[i00 * 3 + sc] / 255.0f, p01 = (float)frame[i01 * 3 + sc] / 255.0f;
-      float p10 = (float)frame[i10 * 3 + sc] / 255.0f, p11 = (float)frame[i11 * 3 + sc] / 255.0f;
+      float p00 = vd_u8_unit((float)frame[i00 * 3 + sc]), p01 = vd_u8_unit((float)frame[i01 * 3 + sc]);
+      float p10 = vd_u8_unit((float)frame[i10 * 3 + sc]), p11 = vd_u8_unit((float)frame[i11 * 3 + sc]);
       rgb_eye[c * ne + o] = vd_bilerp(p00, p01, p10, p11, tx.w0, tx.w1, ty.w0, ty.w1);
     }
   }

@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
 #pragma unroll
     for (int c = 0; c < 3; ++c) o0[c] = px[y & 1][c];
   } else {  // Dubois anaglyph on the BGR-ordered planes as-is (:866-883)
-    const float l0 = (float)px[0][0] / 255.0f, l1 = (float)px[0][1] / 255.0f, l2 = (float)px[0][2] / 255.0f;
-    const float r0 = (float)px[1][0] / 255.0f, r1 = (float)px[1][1] / 255.0f, r2 = (float)px[1][2] / 255.0f;
+    const float l0 = vd_u8_unit((float)px[0][0]), l1 = vd_u8_unit((float)px[0][1]), l2 = vd_u8_unit((float)px[0][2]);
+    const float r0 = vd_u8_unit((float)px[1][0]), r1 = vd_u8_unit((float)px[1][1]), r2 = vd_u8_unit((float)px[1][2]);
     const float red = ((float)0.4561 * l0 + (float)0.5005 * l1) + (float)0.1762 * l2;
     const float green = ((float)0.3764 * r0 + (float)0.7616 * r1) - (float)0.1876 * r2;
     const float blue = ((float)-0.0401 * r0 - (float)0.1126 * r1) + (float)1.2723 * r2;

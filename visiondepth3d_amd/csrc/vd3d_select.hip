@@ -598,6 +598,39 @@ VD_DEV void lds_hist_flush(const uint32_t* h, uint32_t* g) {
 }
 VD_DEV unsigned key_a(float v) { unsigned k = __float_as_uint(v) >> 16; return k < (NBL - 1) ? k : (NBL - 1); }
 
+// Grid-stride walk over a float plane for the pass kernels: 4 consecutive pixels per thread and iteration (one 16-byte load, one
+// integer division) when the row length allows it -- these loops were latency-bound with one 4-byte load in flight per
+// thread (16 dependent round trips per thread at 4K).  body(valid, y, x, v) is called uniformly by every lane (it may ballot).
+// VEC4 = false for the pass-B kernels: their hits are one value band of a smooth plane, i.e. spatially clustered, and the
+// 16-byte walk would put a band on 4x fewer workgroups (measured 2x slower).
+template <bool VEC4, class Body>
+VD_DEV void vd_plane_walk(const float* __restrict__ p, long long n, int W, int wg, int nwg, Body body) {
+  if (VEC4 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    const long long n4 = n >> 2;
+    for (long long b4 = (long long)wg * 1024; b4 < n4; b4 += (long long)nwg * 1024) {
+      const long long i4 = b4 + threadIdx.x;
+      const bool ok = i4 < n4;
+      vd_f4 v = {0.f, 0.f, 0.f, 0.f};
+      int y = 0, x = 0;
+      if (ok) {
+        v = reinterpret_cast<const vd_f4*>(p)[i4];
+        const unsigned i = (unsigned)i4 * 4u;
+        y = (int)(i / (unsigned)W); x = (int)(i - (unsigned)y * (unsigned)W);
+      }
+      body(ok, y, x, v.x); body(ok, y, x + 1, v.y); body(ok, y, x + 2, v.z); body(ok, y, x + 3, v.w);
+    }
+  } else {
+    for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
+      const long long i = base + threadIdx.x;
+      const bool ok = i < n;
+      float v = 0.f; int y = 0, x = 0;
+      if (ok) { v = p[i]; y = (int)((unsigned)i / (unsigned)W); x = (int)((unsigned)i - (unsigned)y * (unsigned)W); }
+      body(ok, y, x, v);
+    }
+  }
+}
+
+
 // K0 (only when auto_crop_black_bars): detect_black_bars (:293-316) + crop_black_bars_torch (:318-326) + the aspect crop of
 // :1236-1248, decided on device.  One wave per source row: integer sum of the cv2 RGB2GRAY of the frame after the
 // reference's float32 round trip ((v/255)*255 truncated); row is "content" iff sum > 10*w (== np.mean(row) > 10).
@@ -679,14 +712,13 @@ __global__ __launch_bounds__(1024) void k_chain_b0(const float* __restrict__ tdf
   const uint32_t nt = c->ntargets;
   uint32_t tp[VD_MAX_T];
   for (int t = 0; t < VD_MAX_T; ++t) tp[t] = c->tprefix[t];
-  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
-    const long long i = base + threadIdx.x;
-    const unsigned bits = i < n ? __float_as_uint(vd_clamp(tdf[i], 0.f, 1.f)) : 0u;
+  vd_plane_walk<false>(tdf, n, (n & 3) == 0 ? 4 : 1, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, float d) {
+    const unsigned bits = ok ? __float_as_uint(vd_clamp(d, 0.f, 1.f)) : 0u;
     bool hit = false; unsigned key = 0;
-    for (uint32_t t = 0; t < nt; ++t) if (i < n && (bits >> 16) == tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
+    for (uint32_t t = 0; t < nt; ++t) if (ok && (bits >> 16) == tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
     vd_hist_add_agg(histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, key, hit);
     vd_hist_add_agg(vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, key >> 8, hit);
-  }
+  });
   if (last_workgroup(&w->ticket[1], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B0; run_scalar_stage(w, histA, histB, a, sm); }
 }
 
@@ -763,6 +795,27 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(const float* __restrict__
   } else {
     const long long n = (long long)f.H * f.W;
     const int nwg = (int)gridDim.x - n_eye_wg, wg = (int)blockIdx.x - n_eye_wg;
+    if ((f.W & 3) == 0 && (reinterpret_cast<uintptr_t>(dc) & 15) == 0) {
+      const long long n4 = n >> 2;
+      for (long long b4 = (long long)wg * 1024; b4 < n4; b4 += (long long)nwg * 1024) {
+        const long long i4 = b4 + threadIdx.x;
+        const bool ok = i4 < n4;
+        vd_f4 v = {0.f, 0.f, 0.f, 0.f};
+        int y = 0, x = 0;
+        if (ok) {
+          const unsigned i = (unsigned)i4 * 4u;
+          y = (int)(i / (unsigned)f.W); x = (int)(i - (unsigned)y * (unsigned)f.W);
+          v.x = f.at(y, x); v.y = f.at(y, x + 1); v.z = f.at(y, x + 2); v.w = f.at(y, x + 3);
+          reinterpret_cast<vd_f4*>(dc)[i4] = v;   // curved depth plane: pass B and the shape kernel stream it
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned key = key_a(v[q]);
+          vd_lds_hist_add(h0, key, ok);
+          vd_lds_hist_add(h1, key, ok && vd_in_subject_crop(y, x + q, f.H, f.W, v[q]));
+        }
+      }
+    } else {
     for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
       const long long i = base + threadIdx.x;
       float v = 0.f; bool in_crop = false;
@@ -775,6 +828,7 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(const float* __restrict__
       const unsigned key = key_a(v);
       vd_lds_hist_add(h0, key, i < n);
       vd_lds_hist_add(h1, key, in_crop);
+    }
     }
     __syncthreads();
     lds_hist_flush(h0, histA + (size_t)VD_J_WORK_Q * VD_NB_A);
@@ -805,23 +859,14 @@ __global__ __launch_bounds__(1024) void k_chain_b1(const float* __restrict__ dn_
   const vd_targets t_eye = load_targets(&w->job[VD_J_EYE_SUBJ]), t_q = load_targets(&w->job[VD_J_WORK_Q]),
                    t_s0 = load_targets(&w->job[VD_J_WORK_S0]);
   if ((int)blockIdx.x < n_eye_wg) {
-    const long long n = (long long)eh * ew;
-    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)n_eye_wg * 1024) {
-      const long long i = base + threadIdx.x;
-      float v = 0.f; bool in_crop = false;
-      if (i < n) { v = dn_cur[i]; const int y = (int)((unsigned)i / (unsigned)ew), x = (int)((unsigned)i - (unsigned)y * (unsigned)ew); in_crop = vd_in_subject_crop(y, x, eh, ew, v); }
-      hist_b_add(histB, VD_J_EYE_SUBJ, t_eye, v, in_crop);
-    }
+    vd_plane_walk<false>(dn_cur, (long long)eh * ew, ew, (int)blockIdx.x, n_eye_wg, [&](bool ok, int y, int x, float v) {
+      hist_b_add(histB, VD_J_EYE_SUBJ, t_eye, v, ok && vd_in_subject_crop(y, x, eh, ew, v));
+    });
   } else {
-    const long long n = (long long)f.H * f.W;
-    const int nwg = (int)gridDim.x - n_eye_wg, wg = (int)blockIdx.x - n_eye_wg;
-    for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
-      const long long i = base + threadIdx.x;
-      float v = 0.f; bool in_crop = false;
-      if (i < n) { const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W); v = dc[i]; in_crop = vd_in_subject_crop(y, x, f.H, f.W, v); }
-      hist_b_add(histB, VD_J_WORK_Q, t_q, v, i < n);
-      hist_b_add(histB, VD_J_WORK_S0, t_s0, v, in_crop);
-    }
+    vd_plane_walk<false>(dc, (long long)f.H * f.W, f.W, (int)blockIdx.x - n_eye_wg, (int)gridDim.x - n_eye_wg, [&](bool ok, int y, int x, float v) {
+      hist_b_add(histB, VD_J_WORK_Q, t_q, v, ok);
+      hist_b_add(histB, VD_J_WORK_S0, t_s0, v, ok && vd_in_subject_crop(y, x, f.H, f.W, v));
+    });
   }
   if (last_workgroup(&w->ticket[3], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B1; run_scalar_stage(w, histA, histB, a, sm); }
 }
@@ -837,21 +882,42 @@ __global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* _
   const long long n = (long long)f.H * f.W;
   const int stretch = w->shp_stretch;
   const float lo = w->shp_lo, den = w->shp_den, subj_s = w->shp_subj_s;
-  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
-    const long long i = base + threadIdx.x;
-    float v = 0.f; bool in_crop = false;
-    if (i < n) {
-      const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W);
-      const float d = dc[i];
-      const float ds = stretch ? vd_clamp((d - lo) / den, 0.f, 1.f) : d;
-      const float centered = (ds - subj_s) + mid;
-      const float t = centered - mid;
-      const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
-      v = vd_clamp(sgn * vd_pow_cr(fabsf(t), gamma) + mid, 0.f, 1.f);
-      D[i] = v;
-      in_crop = vd_in_subject_crop(y, x, f.H, f.W, v);
+  auto shape1 = [&](float d) {   // shape_depth_for_pop :519-558 for one pixel
+    const float ds = stretch ? vd_clamp((d - lo) / den, 0.f, 1.f) : d;
+    const float centered = (ds - subj_s) + mid;
+    const float t = centered - mid;
+    const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+    return vd_clamp(sgn * vd_pow_cr(fabsf(t), gamma) + mid, 0.f, 1.f);
+  };
+  if ((f.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(dc) | reinterpret_cast<uintptr_t>(D)) & 15) == 0) {
+    const long long n4 = n >> 2;   // 4 pixels per thread: one 16-byte load / store, one integer division, 4 independent pow chains
+    for (long long b4 = (long long)blockIdx.x * 1024; b4 < n4; b4 += (long long)gridDim.x * 1024) {
+      const long long i4 = b4 + threadIdx.x;
+      const bool ok = i4 < n4;
+      vd_f4 v = {0.f, 0.f, 0.f, 0.f};
+      int y = 0, x = 0;
+      if (ok) {
+        const vd_f4 d = reinterpret_cast<const vd_f4*>(dc)[i4];
+        v.x = shape1(d.x); v.y = shape1(d.y); v.z = shape1(d.z); v.w = shape1(d.w);
+        reinterpret_cast<vd_f4*>(D)[i4] = v;
+        const unsigned i = (unsigned)i4 * 4u;
+        y = (int)(i / (unsigned)f.W); x = (int)(i - (unsigned)y * (unsigned)f.W);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vd_lds_hist_add(h1, key_a(v[q]), ok && vd_in_subject_crop(y, x + q, f.H, f.W, v[q]));
     }
-    vd_lds_hist_add(h1, key_a(v), in_crop);
+  } else {
+    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+      const long long i = base + threadIdx.x;
+      float v = 0.f; bool in_crop = false;
+      if (i < n) {
+        const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W);
+        v = shape1(dc[i]);
+        D[i] = v;
+        in_crop = vd_in_subject_crop(y, x, f.H, f.W, v);
+      }
+      vd_lds_hist_add(h1, key_a(v), in_crop);
+    }
   }
   __syncthreads();
   lds_hist_flush(h1, histA + (size_t)VD_J_WORK_S1 * VD_NB_A);
@@ -864,12 +930,9 @@ __global__ __launch_bounds__(1024) void k_chain_b2(const float* __restrict__ D, 
   __shared__ uint32_t sm[128];
   const long long n = (long long)H * W;
   const vd_targets t_s1 = load_targets(&w->job[VD_J_WORK_S1]);
-  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
-    const long long i = base + threadIdx.x;
-    float v = 0.f; bool in_crop = false;
-    if (i < n) { v = D[i]; const int y = (int)((unsigned)i / (unsigned)W), x = (int)((unsigned)i - (unsigned)y * (unsigned)W); in_crop = vd_in_subject_crop(y, x, H, W, v); }
-    hist_b_add(histB, VD_J_WORK_S1, t_s1, v, in_crop);
-  }
+  vd_plane_walk<false>(D, n, W, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int y, int x, float v) {
+    hist_b_add(histB, VD_J_WORK_S1, t_s1, v, ok && vd_in_subject_crop(y, x, H, W, v));
+  });
   if (last_workgroup(&w->ticket[5], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B2; run_scalar_stage(w, histA, histB, a, sm); }
 }
 
