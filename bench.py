@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
     ap.add_argument("--sharded", action="store_true", help="use the three-phase sharding protocol even at N=1 (it is the N>1 path)")
+    ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
+                    "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     args = ap.parse_args()
@@ -109,6 +111,11 @@ def main():
     frames = torch.stack([torch.from_numpy(f) for f in frames_np]).cuda()          # [C,h,w,3] u8
     depths = torch.stack([torch.from_numpy(d) for d in depths_np]).cuda()          # [C,h,w] f32
     outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
+    ring = h_clip = None
+    if args.host_io:   # the clip lives in pinned host memory, results return to pinned host memory
+        from visiondepth3d_amd.frame_io import PinnedRing
+        h_clip = frames.cpu().pin_memory()
+        ring = PinnedRing(B, (sh, sw, 3), (p.out_h, p.out_w, 3), torch.device("cuda", local_rank), depth=3)
 
     shr = None
     if world > 1 or args.sharded:
@@ -131,6 +138,11 @@ def main():
         idx = [(i * B + j) % args.clip for j in range(B)]
         fb = frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
         k = i % NBUF
+        outs_k = outs
+        if ring is not None:
+            kr = i % ring.n
+            ring.upload(kr, h_clip[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else h_clip[idx])
+            fb, outs_k = ring.d_in[kr], ring.d_out[kr]
         if overlap:
             torch.cuda.current_stream().wait_event(done[k])  # hand-off buffer k is free again (no-op until first recorded)
         if pipe is not None:
@@ -146,9 +158,16 @@ def main():
             ev = torch.cuda.Event()
             ev.record()
             dibr_stream.wait_event(ev)
+        if ring is not None:
+            if overlap:
+                dibr_stream.wait_event(ring.ev_in[kr])
+                with torch.cuda.stream(dibr_stream):
+                    ring.reserve_output(kr)
+            else:
+                ring.reserve_output(kr)
         if shr is None:
             for j in range(B):
-                r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs[j])
+                r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs_k[j])
         else:  # three-phase sharding: pass 1 over all world*B frames, s1 exchange (collective 2: B floats per rank), replay, pixels
             shr.pass1(fb, gathered[k] if world > 1 else dloc)
             if overlap:
@@ -156,9 +175,15 @@ def main():
                     s1_all = shr.gather(shr.s1_local)
             else:
                 s1_all = shr.gather(shr.s1_local)
-            shr.finish(s1_all, outs)
+            shr.finish(s1_all, outs_k)
         if overlap:
             done[k].record(dibr_stream)
+        if ring is not None:
+            if overlap:
+                with torch.cuda.stream(dibr_stream):
+                    ring.download(kr)
+            else:
+                ring.download(kr)
 
     def fence():
         torch.cuda.synchronize()
@@ -223,7 +248,8 @@ def main():
             "value": round(value, 3), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 DIBR kernels (u8 in/out)" + (" + bf16 depth net" if pipe is not None else ""),
-            "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)",
+            "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)" if ring is None else
+                    "synthetic; frames start in pinned host memory and muxed frames are copied back to pinned host memory (PCIe-inclusive run)",
             "config": {"workload": args.workload, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
                        "frames_per_step": B, "depth_model": model_name,
                        "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes, eye-res chain on every rank, all-gather of s1, "

@@ -134,3 +134,21 @@ def test_upscaling_inter_area_is_refused(R):
                                 sharpness_factor=0.2, dof_strength=0.0)     # fixed 1920x1080 eyes from a 128x72 warp
     with pytest.raises(Vd3dError):
         R.render_frame(T(np.zeros((72, 128, 3), np.uint8)), T(np.zeros((72, 128), np.float32)), p)
+
+
+def test_pinned_ring_clip_equals_sequential(R, oracle):
+    """frame_io.render_clip_pipelined (pinned staging, copy streams) returns the same bytes as frame-by-frame rendering."""
+    from visiondepth3d_amd.frame_io import render_clip_pipelined
+    sh, sw, n = 108, 192, 9
+    frames, depths = synth.synth_clip(n, sh, sw)
+    dep = [synth.depth_to_u8_bgr(d) for d in depths]
+    p = render_kwargs_to_params(sw, sh, output_format="Half-SBS", output_height=sh, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                sharpness_factor=0.2, dof_strength=2.0, feather_strength=10.0, blur_ksize=9,
+                                use_subject_tracking=True, use_floating_window=True)
+    R.reset_state(); R.new_clip()
+    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in list(zip(frames, dep))[1:]]
+    R.reset_state()
+    got = list(render_clip_pipelined(R, frames, dep, p, depth=3))
+    assert len(got) == len(seq) == n - 1
+    for a, b in zip(got, seq):
+        assert np.array_equal(a, b)
