@@ -17,6 +17,7 @@ bracketed by barrier + synchronize and the MAX over ranks is reported.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -72,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
     ap.add_argument("--sharded", action="store_true", help="use the three-phase sharding protocol even at N=1 (it is the N>1 path)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="N=1 only: run this rank's share of a G-rank sharded step (foreign frames "
+                    "included, collectives replaced by local replication) to estimate the per-rank step time at G GPUs")
     ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
                     "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -118,9 +121,12 @@ def main():
         ring = PinnedRing(B, (sh, sw, 3), (p.out_h, p.out_w, 3), torch.device("cuda", local_rank), depth=3)
 
     shr = None
-    if world > 1 or args.sharded:
-        from visiondepth3d_amd.sharded import StepShardedRenderer
-        shr = StepShardedRenderer(r, p, rank, world, B)
+    emu = args.emulate_world if (world == 1 and args.emulate_world > 1) else 0
+    if world > 1 or args.sharded or emu:
+        from visiondepth3d_amd.sharded import MeasureReplaySharder
+        shr = MeasureReplaySharder(r, p, rank, emu or world, B)
+        if emu:   # every "other rank" contributes a copy of this rank's planes: same kernel work as a real G-rank step, no fabric
+            shr.gather = lambda t: t.repeat((emu,) + (1,) * (t.dim() - 1))
 
     pipe = None
     if model_name:
@@ -131,7 +137,7 @@ def main():
     gathered = [torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if world > 1 else None
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     done = [torch.cuda.Event() for _ in range(NBUF)]
-    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded) else None
+    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded or emu) else None
 
     def step(i):
         # this rank's B frames of the step; global frame order inside a step: (j, g) for j in range(B) for g in range(world)
@@ -168,14 +174,16 @@ def main():
         if shr is None:
             for j in range(B):
                 r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs_k[j])
-        else:  # three-phase sharding: pass 1 over all world*B frames, s1 exchange (collective 2: B floats per rank), replay, pixels
-            shr.pass1(fb, gathered[k] if world > 1 else dloc)
-            if overlap:
-                with torch.cuda.stream(dibr_stream):
-                    s1_all = shr.gather(shr.s1_local)
-            else:
-                s1_all = shr.gather(shr.s1_local)
-            shr.finish(s1_all, outs_k)
+        else:  # measure / replay sharding: P1 over all world*B frames (foreign: plane EMA only), exchange of 2 floats per frame, EMA
+               # replay, P3 on own frames, exchange of 4 x int64 per frame, tracker replay, pixel pass (sharded.MeasureReplaySharder)
+            shr.p1(fb, gathered[k] if world > 1 else (shr.gather(dloc) if emu else dloc))
+            ctx_s = torch.cuda.stream(dibr_stream) if overlap else contextlib.nullcontext()
+            with ctx_s:   # the small collectives are enqueued relative to the DIBR stream, not the depth net's
+                shr.r.shard2_r1(shr._frame_order(shr.gather(shr.q_local)))
+            shr.p3()
+            with ctx_s:
+                m_all = shr.gather(shr.m_local)
+            shr.finish(m_all, outs_k)
         if overlap:
             done[k].record(dibr_stream)
         if ring is not None:
@@ -251,9 +259,10 @@ def main():
             "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)" if ring is None else
                     "synthetic; frames start in pinned host memory and muxed frames are copied back to pinned host memory (PCIe-inclusive run)",
             "config": {"workload": args.workload, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
-                       "frames_per_step": B, "depth_model": model_name,
-                       "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes, eye-res chain on every rank, all-gather of s1, "
-                                   "tracker replay, pixel pass on the owner (bit-identical to 1 GPU)",
+                       "frames_per_step": B, "depth_model": model_name, "emulated_world": emu or None,
+                       "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes; foreign frames cost one plane-EMA launch; "
+                                   "owners measure, 2 floats + 4 int64 per frame are all-gathered, scalar trackers replayed on every rank "
+                                   "(bit-identical to 1 GPU)",
                        "params": "render_cli.py defaults + dof_strength 2.0"},
         }
         if stage_ms:

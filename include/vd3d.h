@@ -211,6 +211,17 @@ int vd3d_shard_pass1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void
 int vd3d_shard_pass2(vd3d_ctx* ctx, const float* s1_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);
 int vd3d_shard_pixels(vd3d_ctx* ctx, int slot, const vd3d_render_params* p, uint8_t* out_bgr);
 
+/* Measure / replay variant (the one bench.py uses for N > 1): the only replicated work per foreign frame is the
+ * TemporalDepthFilter plane EMA.  Per step: vd3d_shard2_p1 for every frame in order (own frames also measure q.02/q.98);
+ * all-gather of 2 floats per frame; vd3d_shard2_r1 (DepthPercentileEMA replay); vd3d_shard2_p3 per own frame (all other
+ * measurements, 4 x int64 per frame); all-gather; vd3d_shard2_r2 (remaining trackers replayed in frame order, own slots
+ * patched); vd3d_shard_pixels per own frame.  Bit-identical to the sequential render. */
+int vd3d_shard2_p1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void* depth, int depth_fmt,
+                   const vd3d_render_params* p, int step_idx, int slot, float* q_out_dev);
+int vd3d_shard2_r1(vd3d_ctx* ctx, const float* q_all_dev, int n);
+int vd3d_shard2_p3(vd3d_ctx* ctx, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev);
+int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);
+
 /* ---- depth hand-off (a24): transformers' bicubic post-process to (H,W) + convert_depth_to_grayscale
  * (core/render_depth.py:585-611,1914-1916) for a batch of B predictions [B][ph][pw] float32 -> uint8 [B][H][W].
  * Replaces the reference's 8-bit depth video on disk while keeping its quantisation. */

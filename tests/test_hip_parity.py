@@ -318,6 +318,77 @@ def test_three_phase_sharding_equals_sequential(R, oracle):
         rr.close()
 
 
+@pytest.mark.parametrize("G,B", [(2, 3), (3, 2), (4, 1)])
+def test_measure_replay_sharding_equals_sequential(R, oracle, G, B):
+    """MeasureReplaySharder (vd3d_shard2_*): G contexts play the ranks, the three all-gathers are done by hand.  Muxed frames, the
+    per-frame scalars of every own frame and the final tracker state must equal the sequential render bit for bit.  Three steps
+    (state carried across steps, first step starts a clip), plus the world = 1 degenerate case."""
+    from visiondepth3d_amd.render_3d import Renderer
+    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    sh, sw = 108, 192
+    kw = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    steps = 3
+    n = steps * B * G
+    frames, depths = synth.synth_clip(n, sh, sw)
+    gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
+    gray[2 * B * G - 1][:] = 77          # a frame whose depth collapses (hi - lo < 1e-5): DepthPercentileEMA guard path
+    R.reset_state(); R.new_clip()
+    seq, seq_sc = [], []
+    for f, d in zip(frames, gray):
+        seq.append(R.render_frame(T(f), T(d), p).cpu().numpy())
+        seq_sc.append(R.last_scalars().as_dict())
+    st_seq = R.export_state().as_dict()
+    ranks = [Renderer(0) for _ in range(G)]
+    shd = []
+    for g_, rr in enumerate(ranks):
+        rr.reset_state(); rr.new_clip()
+        shd.append(MeasureReplaySharder(rr, p, g_, G, B))
+    for step in range(steps):
+        base = step * B * G
+        loc_f = [[T(frames[base + j * G + g_]) for j in range(B)] for g_ in range(G)]
+        depth_all = torch.cat([torch.stack([T(gray[base + j * G + g_]) for j in range(B)]) for g_ in range(G)])   # rank-major
+        for g_ in range(G):
+            shd[g_].p1(loc_f[g_], depth_all)
+        q_all = torch.cat([shd[g_].q_local for g_ in range(G)])
+        for g_ in range(G):
+            shd[g_].world = G   # _frame_order uses world/B
+            shd[g_].r.shard2_r1(shd[g_]._frame_order(q_all.clone()))
+            shd[g_].p3()
+        m_all = torch.cat([shd[g_].m_local for g_ in range(G)])
+        for g_ in range(G):
+            outs = shd[g_].finish(m_all.clone())
+            for j in range(B):
+                t = base + j * G + g_
+                assert np.array_equal(outs[j].cpu().numpy(), seq[t]), (step, g_, j, u8_diff_stats(outs[j].cpu().numpy(), seq[t]))
+    states = [rr.export_state().as_dict() for rr in ranks]
+    assert all(st == st_seq for st in states), [{k: (st[k], st_seq[k]) for k in st if st[k] != st_seq[k]} for st in states]
+    for rr in ranks:
+        rr.close()
+
+
+def test_measure_replay_world1_and_continuation(R, oracle):
+    """world = 1 degenerates to the sequential render; a sequential frame rendered AFTER sharded steps continues exactly."""
+    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    sh, sw = 108, 192
+    kw = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    frames, depths = synth.synth_clip(8, sh, sw)
+    gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
+    R.reset_state(); R.new_clip()
+    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
+    st_seq = R.export_state().as_dict()
+    R.reset_state(); R.new_clip()
+    one = MeasureReplaySharder(R, p, 0, 1, 4)
+    outs = one.render_step([T(f) for f in frames[:4]], torch.stack([T(d) for d in gray[:4]]))
+    outs = [o.cpu().numpy() for o in outs]
+    outs += [o.cpu().numpy() for o in one.render_step([T(f) for f in frames[4:]], torch.stack([T(d) for d in gray[4:]]))]
+    assert all(np.array_equal(a, b) for a, b in zip(outs, seq))
+    assert R.export_state().as_dict() == st_seq
+
+
 # ------------------------------------------------------------------------------------------ full-size
 @pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840)])
 def test_full_size_properties(R, oracle, hw):

@@ -55,6 +55,8 @@ struct vd3d_ctx {
   // frame sharding (three-phase protocol): per-slot planes of the frames this rank owns inside the current step
   int n_slots = 0, slot_eh = 0, slot_ew = 0, slot_H = 0, slot_W = 0;
   std::vector<float*> slot_rgb, slot_dn, slot_D;
+  std::vector<float*> slot_tdf, slot_tdfp;   // measure/replay protocol: filtered plane of the own frame and of the frame before it
+  float* etab = nullptr;                     // [VD_MAX_STEP + 1][VD_ETAB] replayed normalisation table of the current step
   vd_dev_work* slot_work = nullptr;
   int* own_slot_dev = nullptr; int* own_slot_pin = nullptr;   // depth hand-off min/max keys [B][3]
   // profiling
@@ -168,7 +170,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -489,14 +491,18 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
   for (auto q : c->slot_rgb) hipFree(q);
   for (auto q : c->slot_dn) hipFree(q);
   for (auto q : c->slot_D) hipFree(q);
-  c->slot_rgb.clear(); c->slot_dn.clear(); c->slot_D.clear();
+  for (auto q : c->slot_tdf) hipFree(q);
+  for (auto q : c->slot_tdfp) hipFree(q);
+  c->slot_rgb.clear(); c->slot_dn.clear(); c->slot_D.clear(); c->slot_tdf.clear(); c->slot_tdfp.clear();
   const size_t ne = (size_t)p->eye_h * p->eye_w, n = (size_t)p->warp_h * p->warp_w;
   for (int i = 0; i < n_slots; ++i) {
-    float *a = nullptr, *b = nullptr, *d = nullptr;
+    float *a = nullptr, *b = nullptr, *d = nullptr, *t0 = nullptr, *t1 = nullptr;
     HIPCHK(hipMalloc((void**)&a, 3 * ne * sizeof(float))); HIPCHK(hipMalloc((void**)&b, ne * sizeof(float)));
     HIPCHK(hipMalloc((void**)&d, n * sizeof(float)));
-    c->slot_rgb.push_back(a); c->slot_dn.push_back(b); c->slot_D.push_back(d);
+    HIPCHK(hipMalloc((void**)&t0, ne * sizeof(float))); HIPCHK(hipMalloc((void**)&t1, ne * sizeof(float)));
+    c->slot_rgb.push_back(a); c->slot_dn.push_back(b); c->slot_D.push_back(d); c->slot_tdf.push_back(t0); c->slot_tdfp.push_back(t1);
   }
+  if (!c->etab) HIPCHK(hipMalloc((void**)&c->etab, (size_t)(VD_MAX_STEP + 1) * VD_ETAB * sizeof(float)));
   HIPCHK(re_alloc(&c->slot_work, (size_t)n_slots));
   c->n_slots = n_slots; c->slot_eh = p->eye_h; c->slot_ew = p->eye_w; c->slot_H = p->warp_h; c->slot_W = p->warp_w;
   return 0;
@@ -555,6 +561,92 @@ VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_param
   }
   HIPCHK(hipGetLastError());
   return run_finish(c, c->L, c->R, c->slot_dn[slot], p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr, wk);
+}
+
+
+// ---- frame sharding, measure / replay protocol (visiondepth3d_amd/sharded.py: MeasureReplaySharder) ----------
+// Replicated work per foreign frame = ONE small kernel (the TemporalDepthFilter plane EMA); everything else is measured by the
+// owner, exchanged as a few numbers per frame and replayed as scalar recurrences on every rank.
+static void shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args* a, vd3d_shift_params* sp) {
+  *sp = p->shift;
+  sp->parallax_balance = 0.8; sp->depth_pop_gamma = 0.85; sp->depth_pop_mid = 0.50; sp->depth_stretch_lo = 0.05;
+  sp->depth_stretch_hi = 0.95; sp->fg_pop_multiplier = 1.20; sp->bg_push_multiplier = 1.10; sp->subject_lock_strength = 1.00;
+  memset(a, 0, sizeof *a);
+  a->have_eye = 1; a->W = p->warp_w; a->H = p->warp_h; a->n_eye = (long long)p->eye_h * p->eye_w;
+  a->n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
+  a->ipd_factor = p->ipd_factor; a->shift = *sp; a->etab = c->etab;
+}
+// P1, for EVERY frame of the step in order.  slot < 0: foreign frame -> plane EMA only.  slot >= 0: own frame -> ingest (RGB kept
+// in the slot), plane EMA, exact q.02 / q.98 of the filtered plane written to q_out_dev[0..1]; the filtered planes of this frame
+// and of the frame before it are kept in the slot.
+VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params* p,
+                               int step_idx, int slot, float* q_out_dev) {
+  if (!c || !depth || !p || step_idx < 0 || step_idx >= VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+  if (slot >= c->n_slots) return set_err(VD3D_E_INVALID, "slot %d out of range (vd3d_shard_begin)", slot);
+  if (slot >= 0 && (!frame_bgr || !q_out_dev)) return set_err(VD3D_E_INVALID, "own frame needs the frame and a destination for its quantiles");
+  if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
+  if (p->auto_crop_black_bars) return set_err(VD3D_E_UNSUPPORTED, "auto_crop_black_bars is not available in frame-sharded steps");
+  if (!c->use_fused) return set_err(VD3D_E_UNSUPPORTED, "frame sharding needs the fused chain (unset VD3D_UNFUSED)");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  vd_stage_args a; vd3d_shift_params sp;
+  shard2_args(c, p, &a, &sp);
+  a.shard_idx = step_idx;
+  const size_t ne = (size_t)p->eye_h * p->eye_w;
+  StageTimer t(c, slot >= 0 ? "p1_own" : "p1_foreign");
+  if (slot < 0) {
+    a.shard = 4;
+    const long long nel = (long long)ne;
+    (void)nel;
+    vd_launch_chain_eye_lite(s, depth, depth_fmt, *p, c->work, c->tdf, a);
+  } else {
+    a.shard = 3; a.q_out = q_out_dev;
+    HIPCHK(hipMemcpyAsync(c->slot_tdfp[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
+    vd_launch_chain_eye(s, frame_bgr, depth, depth_fmt, *p, c->work, c->slot_rgb[slot], c->tdf, c->histA, c->histB, a);
+    HIPCHK(hipMemcpyAsync(c->slot_tdf[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// R1: replay DepthPercentileEMA over the n frames of the step from the exchanged quantiles q_all_dev[n][2] (frame order)
+VD3D_EXPORT int vd3d_shard2_r1(vd3d_ctx* c, const float* q_all_dev, int n) {
+  if (!c || !q_all_dev || n < 1 || n > VD_MAX_STEP || !c->etab) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  vd_launch_shard2_r1(c->stream, c->work, q_all_dev, n, c->etab);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// P3, own frames only: normalise, eye-res statistics, warp-res select chain, shaped depth plane, s1 -> measurements
+// m_out_dev[0..3] = {sum1, sum2, sum_mad, (s_norm | s1 << 32)}; planes and shape constants stay in the slot.
+VD3D_EXPORT int vd3d_shard2_p3(vd3d_ctx* c, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev) {
+  if (!c || !p || !m_out_dev || slot < 0 || slot >= c->n_slots || step_idx < 0 || step_idx >= VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  vd_stage_args a; vd3d_shift_params sp;
+  shard2_args(c, p, &a, &sp);
+  int rc;
+  if ((rc = check_shift_params(&sp, p->warp_h, p->warp_w))) return rc;
+  a.shard = 3; a.shard_idx = step_idx; a.m_out = m_out_dev;
+  StageTimer t(c, "p3_own");
+  HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));   // the select jobs of this frame start from empty histograms
+  vd_launch_chain_work(s, 1, c->slot_tdf[slot], c->slot_dn[slot], c->slot_tdfp[slot], p->eye_h, p->eye_w, p->warp_h, p->warp_w, c->work,
+                       (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, c->dc, c->slot_D[slot], c->histA, c->histB, a);
+  HIPCHK(hipMemcpyAsync(&c->slot_work[slot], c->work, sizeof(vd_dev_work), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// R2: replay every remaining tracker over the n frames of the step from the exchanged measurements m_all_dev[n][4] (frame order);
+// own_slot_host[t] = slot of frame t on this rank or -1.  Afterwards vd3d_shard_pixels(slot) renders the own frames.
+VD3D_EXPORT int vd3d_shard2_r2(vd3d_ctx* c, const long long* m_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p) {
+  if (!c || !m_all_dev || !own_slot_host || !p || n < 1 || n > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  vd_stage_args a; vd3d_shift_params sp;
+  shard2_args(c, p, &a, &sp);
+  StageTimer t(c, "replay");
+  vd_launch_shard2_r2(c->stream, c->work, m_all_dev, c->etab, own_slot_host, n, c->slot_work, a);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 // ---- diagnostics / tests --------------------------------------------------------------------------

@@ -9,6 +9,7 @@ enum { VD_ST_A0 = 0, VD_ST_B0, VD_ST_A1, VD_ST_B1, VD_ST_A2, VD_ST_B2,
 #define PL_KMAX_HOST 33   // largest blur_ksize the pool kernel's LDS tile is sized for
 #define DF_RMAX_HOST 15   // largest Gaussian radius of the DOF kernel
 
+#define VD_ETAB 8
 struct vd_stage_args {
   int stage;
   int have_eye;        // 1: full render_frame chain (eye-res stages exist); 0: bare pixel_shift_cuda
@@ -16,9 +17,14 @@ struct vd_stage_args {
   long long n_eye;     // eye_h*eye_w
   long long n_crop;    // centre-crop population of compute_dynamic_parallax_scale
   double ipd_factor;
-  int shard;           // frame sharding: 0 = normal frame, 1 = own frame (s1 measured, tracker deferred), 2 = foreign frame
+  int shard;           // frame sharding: 0 = normal frame, 1 = own frame (s1 measured, tracker deferred), 2 = foreign frame;
+                       // measure/replay protocol: 3 = own frame (measurements only, no tracker touched), 4 = foreign frame (tdf EMA only)
   int shard_idx;       // frame index inside the sharded step
   float* s1_out;       // shard == 1: where the measured s1 goes (device)
+  float* q_out;        // shard == 3: {q_lo, q_hi} of this frame (device, 2 floats)
+  long long* m_out;    // shard == 3: {sum1, sum2, sum_mad, (s_norm | s1 << 32)} of this frame (device, 4 x int64)
+  const float* etab;   // shard == 3: per-frame normalisation table of the step, VD_ETAB floats per entry:
+                       // entry t = {ema_lo, ema_den, collapse, have_prev, ema_hi} in force BEFORE frame t
   int dbg;             // development probes: bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket + fences
   vd3d_shift_params shift;
 };
@@ -77,9 +83,14 @@ VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __re
 #endif
 
 // ---- vd3d_select.hip (fused chain)
+void vd_launch_shard2_r1(hipStream_t s, vd_dev_work* w, const float* q_all, int n, float* etab);
+void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, const float* etab, const int* own_slot_host, int n,
+                         vd_dev_work* slot_work, const vd_stage_args& a);
 void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w);
 void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w,
                          float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a);
+void vd_launch_chain_eye_lite(hipStream_t s, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
+                              const vd_stage_args& a);   // a.shard == 4: the plane EMA of a foreign frame, nothing else
 void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
                           vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
                           const vd_stage_args& a);   // a.shard == 2 (foreign frame): eye-res part only, no warp-res select

@@ -405,6 +405,11 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
         float hi = quantile_lerp(c->val[2], c->val[3], c->w[1]);
         vd3d_state* st = &w->st;
         w->fs.q_lo = lo; w->fs.q_hi = hi;
+        if (a.shard == 3) {   // measure/replay sharding: the quantiles are exchanged, the EMA runs in k_shard2_r1 on every rank
+          a.q_out[0] = lo; a.q_out[1] = hi;
+          st->tdf_valid = 1;
+          w->sum1 = 0; w->sum2 = 0; w->sum_mad = 0;
+        } else
         if ((hi - lo) < 1e-5f) {
           w->collapse = 1;
         } else {
@@ -416,11 +421,13 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
             st->ema_hi = al * st->ema_hi + be * hi;
           }
         }
-        w->ema_lo = st->ema_lo;
-        w->ema_den = (st->ema_hi - st->ema_lo) + (float)1e-6;
-        w->fs.ema_lo = st->ema_lo; w->fs.ema_hi = st->ema_hi; w->fs.collapse = w->collapse;
-        st->tdf_valid = 1;
-        w->sum1 = 0; w->sum2 = 0; w->sum_mad = 0;
+        if (a.shard != 3) {
+          w->ema_lo = st->ema_lo;
+          w->ema_den = (st->ema_hi - st->ema_lo) + (float)1e-6;
+          w->fs.ema_lo = st->ema_lo; w->fs.ema_hi = st->ema_hi; w->fs.collapse = w->collapse;
+          st->tdf_valid = 1;
+          w->sum1 = 0; w->sum2 = 0; w->sum_mad = 0;
+        }
       }
     } break;
     case VD_ST_A1:
@@ -449,6 +456,12 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
         const float subj = vd_clamp(s0, 0.f, 1.f);
         w->shp_stretch = stretch; w->shp_lo = lo; w->shp_den = den;
         w->shp_subj_s = stretch ? vd_clamp((subj - lo) / den, 0.f, 1.f) : subj;
+        if (a.have_eye && a.shard == 3) {   // measurements only: the recurrences run in k_shard2_r2
+          w->fs.s_norm = subject_from_job(&lcs[VD_J_EYE_SUBJ]);
+          a.m_out[0] = w->sum1; a.m_out[1] = w->sum2; a.m_out[2] = w->sum_mad;
+          reinterpret_cast<float*>(&a.m_out[3])[0] = w->fs.s_norm;
+          w->sum1 = 0; w->sum2 = 0; w->sum_mad = 0;
+        } else
         if (a.have_eye) {
           vd3d_state* st = &w->st;
           w->fs.s_norm = subject_from_job(&lcs[VD_J_EYE_SUBJ]);
@@ -521,9 +534,10 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           const float s1 = subject_from_job(&lcs[VD_J_WORK_S1]);
           w->fs.s1 = s1;
           if (a.shard == 1) { if (a.s1_out) *a.s1_out = s1; }  // sharded: the FloatingWindowTracker is replayed after the exchange
+          else if (a.shard == 3) reinterpret_cast<float*>(&a.m_out[3])[1] = s1;
           else shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);
         }
-        if (a.have_eye) {  // floating-window bars :1390-1403
+        if (a.have_eye && a.shard != 3) {  // floating-window bars :1390-1403
           vd3d_state* st = &w->st;
           const float s = w->fs.s_norm;
           const float rz = ((((-s) * (float)w->fg_d) + ((-s) * (float)w->mg_d)) + (s * (float)w->bg_d)) /
@@ -690,6 +704,7 @@ __global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict
   const long long n = (long long)p.eye_h * p.eye_w;
   const int tdf_valid = w->st.tdf_valid;
   if (p.auto_crop_black_bars) { p.crop_x = w->acrop[0]; p.crop_y = w->acrop[1]; p.crop_w = w->acrop[2]; p.crop_h = w->acrop[3]; }
+  const bool lite = a.shard == 4;   // foreign frame of the measure/replay protocol: the plane EMA only (no histogram, no scan)
   for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
     const long long i = base + threadIdx.x;
     float v = 0.f;
@@ -697,11 +712,14 @@ __global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict
       const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
       v = vd_ingest_pixel(frame, depth, fmt, p, tdf_valid, rgb_eye, tdf, ey, ex);
     }
-    vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
+    if (!lite) vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
   }
   __syncthreads();
-  lds_hist_flush(h0, histA + (size_t)VD_J_EYE_Q * VD_NB_A);
-  if (last_workgroup(&w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A0; run_scalar_stage(w, histA, histB, a, sm); }
+  if (!lite) lds_hist_flush(h0, histA + (size_t)VD_J_EYE_Q * VD_NB_A);
+  if (last_workgroup(&w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) {
+    if (lite) { if (threadIdx.x == 0) w->st.tdf_valid = 1; }
+    else { a.stage = VD_ST_A0; run_scalar_stage(w, histA, histB, a, sm); }
+  }
 }
 
 // K2: pass B of J0; last workgroup: scan B0 + DepthPercentileEMA
@@ -757,13 +775,22 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(const float* __restrict__
   __shared__ uint32_t h1[NBL];
   __shared__ uint32_t sm[128];
   __shared__ long long part[3][16];
-  if (f.norm) { f.lo = w->ema_lo; f.den = w->ema_den; f.collapse = w->collapse; }  // device scalars from stage B0
+  // normalisation scalars: stage B0's (device) or, in the measure/replay sharding, this frame's row of the replayed table;
+  // there dn_prev is the PREVIOUS FILTERED plane and is normalised on the fly with the previous frame's row
+  const bool m3 = a.shard == 3;
+  const float* e_cur = m3 ? a.etab + VD_ETAB * (a.shard_idx + 1) : nullptr;
+  const float* e_prv = m3 ? a.etab + VD_ETAB * a.shard_idx : nullptr;
+  const float n_lo = m3 ? e_cur[0] : w->ema_lo, n_den = m3 ? e_cur[1] : w->ema_den;
+  const int n_col = m3 ? (int)e_cur[2] : w->collapse;
+  if (f.norm) { f.lo = n_lo; f.den = n_den; f.collapse = n_col; }
   for (int b = threadIdx.x; b < NBL; b += 1024) { h0[b] = 0; h1[b] = 0; }
   __syncthreads();
   if ((int)blockIdx.x < n_eye_wg) {
     const long long n = (long long)eh * ew;
-    const float lo = w->ema_lo, den = w->ema_den;
-    const int collapse = w->collapse, have_prev = w->st.prev_depth_valid;
+    const float lo = n_lo, den = n_den;
+    const int collapse = n_col, have_prev = m3 ? (int)e_prv[3] : w->st.prev_depth_valid;
+    const float p_lo = m3 ? e_prv[0] : 0.f, p_den = m3 ? e_prv[1] : 1.f;
+    const int p_col = m3 ? (int)e_prv[2] : 0;
     long long s1 = 0, s2 = 0, sd = 0;
     for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)n_eye_wg * 1024) {
       const long long i = base + threadIdx.x;
@@ -777,7 +804,11 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(const float* __restrict__
           const double dv = (double)v;
           s1 += vd_fx40(dv); s2 += vd_fx40(dv * dv);
         }
-        if (have_prev) sd += vd_fx40((double)fabsf(v - dn_prev[i]));
+        if (have_prev) {
+          float vp = dn_prev[i];
+          if (m3) { const float dp = vd_clamp(vp, 0.f, 1.f); vp = p_col ? dp : vd_clamp((dp - p_lo) / p_den, 0.f, 1.f); }
+          sd += vd_fx40((double)fabsf(v - vp));
+        }
         in_crop = vd_in_subject_crop(y, x, eh, ew, v);
       }
       vd_lds_hist_add(h1, key_a(v), in_crop);
@@ -949,6 +980,13 @@ void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth,
   hipLaunchKernelGGL(k_chain_b0, dim3(chain_grid(ne, 4096, 256)), dim3(1024), 0, s, tdf, ne, w, histA, histB, a);
 }
 
+void vd_launch_chain_eye_lite(hipStream_t s, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
+                              const vd_stage_args& a) {
+  const long long ne = (long long)p.eye_h * p.eye_w;
+  hipLaunchKernelGGL(k_chain_ingest, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, (const uint8_t*)nullptr, depth, fmt, p, w,
+                     (float*)nullptr, tdf, (uint32_t*)nullptr, (const uint32_t*)nullptr, a);
+}
+
 // src = the filtered plane (render path: have_eye) or the caller's depth plane (bare pixel_shift_cuda)
 void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
                           vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
@@ -978,9 +1016,128 @@ void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* 
   hipLaunchKernelGGL(k_chain_b2, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, D, H, W, w, histA, histB, a);
 }
 
+struct vd_own_slots { short v[VD_MAX_STEP]; };  // passed by value in the kernel arguments (1 KB): no staging copy, no sync
+// ================================================================================================
+// Measure / replay frame sharding: owners measure, every rank replays the scalar recurrences.
+// k_shard2_r1: DepthPercentileEMA (:249-261) over the exchanged (q_lo, q_hi) of ALL frames of the step, in frame order.
+//   etab[t] = {ema_lo, ema_den, collapse, have_prev} in force BEFORE frame t (etab[0] = carry-in), etab[t+1] after it.
+// ================================================================================================
+__global__ void k_shard2_r1(vd_dev_work* w, const float* __restrict__ q_all, int n, float* __restrict__ etab) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  vd3d_state* st = &w->st;
+  etab[0] = w->ema_lo; etab[1] = w->ema_den; etab[2] = (float)w->collapse; etab[3] = (float)st->prev_depth_valid; etab[4] = st->ema_hi;
+  for (int t = 0; t < n; ++t) {
+    const float lo = q_all[2 * t], hi = q_all[2 * t + 1];
+    int collapse;
+    if ((hi - lo) < 1e-5f) collapse = 1;
+    else {
+      collapse = 0;
+      if (!st->ema_valid) { st->ema_lo = lo; st->ema_hi = hi; st->ema_valid = 1; }
+      else {
+        const float al = (float)0.92, be = (float)(1 - 0.92);
+        st->ema_lo = al * st->ema_lo + be * lo;
+        st->ema_hi = al * st->ema_hi + be * hi;
+      }
+    }
+    float* e = etab + VD_ETAB * (t + 1);
+    e[0] = st->ema_lo; e[1] = (st->ema_hi - st->ema_lo) + (float)1e-6; e[2] = (float)collapse; e[3] = 1.f; e[4] = st->ema_hi;
+  }
+}
+void vd_launch_shard2_r1(hipStream_t s, vd_dev_work* w, const float* q_all, int n, float* etab) {
+  hipLaunchKernelGGL(k_shard2_r1, dim3(1), dim3(64), 0, s, w, q_all, n, etab);
+}
+
+// k_shard2_r2: every remaining recurrence of the loop body, in frame order, from the exchanged measurements
+//   m_all[t] = {sum1, sum2, sum_mad, (s_norm | s1 << 32)}: dynamic parallax scale + ShiftSmoother (:412-427,470-477,1276,1308),
+//   motion metric + FocalDepthTracker (:895-929), pixel_shift_cuda scalars incl. FloatingWindowTracker (:633-671),
+//   ConvergenceEMA + FloatingBarEaser (:1390-1403).  Own frames get their constants patched into their slot.
+__global__ void k_shard2_r2(vd_dev_work* w, const long long* __restrict__ m_all, const float* __restrict__ etab, vd_own_slots own, int n,
+                            vd_dev_work* slot_work, vd_stage_args a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  vd3d_state* st = &w->st;
+  for (int t = 0; t < n; ++t) {
+    const long long sum1 = m_all[4 * t], sum2 = m_all[4 * t + 1], sum_mad = m_all[4 * t + 2];
+    const float s_norm = reinterpret_cast<const float*>(&m_all[4 * t + 3])[0], s1 = reinterpret_cast<const float*>(&m_all[4 * t + 3])[1];
+    const int have_prev = (int)etab[VD_ETAB * t + 3];
+    // ---- stage B1
+    w->fs.s_norm = s_norm;
+    const double nn = (double)a.n_crop;
+    const double s1d = (double)sum1 / VD_FX, s2d = (double)sum2 / VD_FX;
+    const float mean = (float)(s1d / nn);
+    const float var = (float)((s2d - s1d * s1d / nn) / (a.n_crop > 1 ? nn - 1.0 : 1.0));
+    const float nv = vd_clamp(var / (mean + 1e-5f), 0.f, 1.f);
+    const float scale = (float)0.90 + nv * (float)(1.15 - 0.90);
+    w->fs.mean_c = mean; w->fs.var_c = var; w->fs.dyn_scale = (double)scale;
+    double fg = a.shift.fg_shift, mg = a.shift.mg_shift, bg = a.shift.bg_shift;
+    const double al = 0.15;
+    if (!st->smooth_valid) { st->sm_fg = fg; st->sm_mg = mg; st->sm_bg = bg; st->smooth_valid = 1; }
+    else {
+      st->sm_fg = al * fg + (1 - al) * st->sm_fg;
+      st->sm_mg = al * mg + (1 - al) * st->sm_mg;
+      st->sm_bg = al * bg + (1 - al) * st->sm_bg;
+    }
+    fg = st->sm_fg; mg = st->sm_mg; bg = st->sm_bg;
+    fg *= (double)scale; mg *= (double)scale; bg *= (double)scale;
+    if (a.ipd_factor != 0.0) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
+    w->fg_d = fg; w->mg_d = mg; w->bg_d = bg;
+    w->fs.mad = 0.f;
+    double motion = 0.0;
+    if (have_prev) {
+      const float mad = (float)(((double)sum_mad / VD_FX) / (double)a.n_eye);
+      w->fs.mad = mad;
+      const double m = (double)mad * 4.0;
+      motion = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
+    }
+    w->fs.focal = focal_update(st, motion, (double)s_norm);
+    w->focal = (float)w->fs.focal;
+    // ---- stage B2
+    w->fs.s1 = s1;
+    shift_scalars(w, a.shift, a.W, s1, fg, mg, bg);
+    {
+      const float s = s_norm;
+      const float rz = ((((-s) * (float)w->fg_d) + ((-s) * (float)w->mg_d)) + (s * (float)w->bg_d)) / (float)((double)a.W / 2 + 1e-6);
+      if (!st->conv_valid) { st->conv_val = (double)rz; st->conv_valid = 1; }
+      else st->conv_val = 0.97 * st->conv_val + (1 - 0.97) * (double)rz;
+      const double sz = st->conv_val;
+      w->fs.stable_zero = sz;
+      int bw = 0, side = 0;
+      if (a.shift.enable_floating_window && a.shift.use_subject_tracking) {
+        const int raw_bar = (int)(fabs(sz) * a.W * 0.75);
+        st->bar_prev_width = (int)(0.85 * st->bar_prev_width + (1 - 0.85) * raw_bar);
+        bw = st->bar_prev_width < 80 ? st->bar_prev_width : 80;
+        bw = bw > 0 ? bw : 0;
+        if (sz > 0.005) side = 1; else if (sz < -0.005) side = 2;
+      }
+      w->bar_width = bw; w->bar_side = side;
+      w->fs.bar_width = bw; w->fs.bar_side = side;
+    }
+    const int sl = own.v[t];
+    if (sl >= 0) {
+      vd_dev_work* d = &slot_work[sl];
+      d->fg = w->fg; d->mg = w->mg; d->bg = w->bg;
+      d->zpo_f = w->zpo_f; d->have_zpo = w->have_zpo; d->msn = w->msn; d->conv = w->conv; d->have_conv = w->have_conv;
+      d->focal = w->focal; d->bar_width = w->bar_width; d->bar_side = w->bar_side;
+      const float* e = etab + VD_ETAB * (t + 1);
+      vd3d_frame_scalars* fs = &d->fs;   // diagnostics of the slot = what vd3d_last_scalars reports for a sequential frame
+      fs->ema_lo = e[0]; fs->ema_hi = e[4]; fs->collapse = (int)e[2];
+      fs->mean_c = mean; fs->var_c = var; fs->dyn_scale = (double)scale; fs->s_norm = s_norm; fs->mad = w->fs.mad;
+      fs->s1 = s1; fs->zpo_raw = w->fs.zpo_raw; fs->zpo = w->fs.zpo; fs->focal = w->fs.focal; fs->stable_zero = w->fs.stable_zero;
+      fs->bar_width = w->bar_width; fs->bar_side = w->bar_side;
+    }
+  }
+  const float* e = etab + VD_ETAB * n;   // what a sequential run leaves behind for the next frame
+  w->ema_lo = e[0]; w->ema_den = e[1]; w->collapse = (int)e[2];
+  st->prev_depth_valid = 1;
+}
+void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, const float* etab, const int* own_slot_host, int n,
+                         vd_dev_work* slot_work, const vd_stage_args& a) {
+  vd_own_slots own;
+  for (int t = 0; t < VD_MAX_STEP; ++t) own.v[t] = (short)(t < n ? own_slot_host[t] : -1);
+  hipLaunchKernelGGL(k_shard2_r2, dim3(1), dim3(64), 0, s, w, m_all, etab, own, n, slot_work, a);
+}
+
 // Tracker replay of a sharded step: the FloatingWindowTracker (and everything shift_scalars derives from s1) is advanced over
 // ALL frames of the step in order from the exchanged s1 values; own frames get their final constants patched into their slot.
-struct vd_own_slots { short v[VD_MAX_STEP]; };  // passed by value in the kernel arguments (1 KB): no staging copy, no sync
 __global__ void k_shard_replay(vd_dev_work* w, const float* __restrict__ s1_all, vd_own_slots own, int n,
                                vd_dev_work* slot_work, vd_stage_args a) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -180,6 +180,26 @@ class Renderer:
         s1 = s1_all.to(self.device, torch.float32).contiguous()
         _lib.check(self._L.vd3d_shard_pass2(self._ctx, _ptr(s1), arr, n, C.byref(params)))
 
+    # measure / replay protocol (include/vd3d.h vd3d_shard2_*)
+    def shard2_p1(self, frame, depth, params: RenderParams, step_idx: int, slot: int = -1, q_out: torch.Tensor | None = None):
+        d = depth.to(self.device).contiguous()
+        f = frame.to(self.device).contiguous() if frame is not None else None
+        _lib.check(self._L.vd3d_shard2_p1(self._ctx, _ptr(f) if f is not None else None, _ptr(d), self._depth_fmt(d), C.byref(params),
+                                          int(step_idx), int(slot), _ptr(q_out) if q_out is not None else None))
+
+    def shard2_r1(self, q_all: torch.Tensor):
+        q = q_all.to(self.device, torch.float32).contiguous()
+        _lib.check(self._L.vd3d_shard2_r1(self._ctx, _ptr(q), q.numel() // 2))
+
+    def shard2_p3(self, slot: int, step_idx: int, params: RenderParams, m_out: torch.Tensor):
+        _lib.check(self._L.vd3d_shard2_p3(self._ctx, int(slot), int(step_idx), C.byref(params), _ptr(m_out)))
+
+    def shard2_r2(self, m_all: torch.Tensor, own_slots, params: RenderParams):
+        n = len(own_slots)
+        arr = (C.c_int * n)(*[int(v) for v in own_slots])
+        m = m_all.to(self.device, torch.int64).contiguous()
+        _lib.check(self._L.vd3d_shard2_r2(self._ctx, _ptr(m), arr, n, C.byref(params)))
+
     def shard_pixels(self, slot: int, params: RenderParams, out: torch.Tensor | None = None):
         if out is None:
             out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)

@@ -161,3 +161,73 @@ class StepShardedRenderer:
         depth_all = self.gather(depth_local)
         self.pass1(frames_local, depth_all)
         return self.finish(self.gather(self.s1_local), outs)
+
+
+class MeasureReplaySharder:
+    """Measure / replay frame sharding (include/vd3d.h ``vd3d_shard2_*``): the N > 1 path of bench.py.
+
+    Same step layout as StepShardedRenderer (global order t = j * world + g), but the only REPLICATED work per foreign
+    frame is the TemporalDepthFilter plane EMA (one small launch).  Per step and rank:
+
+      0. (caller) depth inference for the B local frames, all-gather of the uint8 depth planes       [collective 1]
+      1. P1 over all world*B frames in order: foreign -> plane EMA; own -> ingest + plane EMA + exact q.02/q.98
+      2. all-gather of (q_lo, q_hi) per frame (8 B x frames)                                          [collective 2]
+         R1: DepthPercentileEMA replayed on every rank
+      3. P3 per own frame: normalise, eye-res statistics, warp-res select chain, shaped depth, s1
+      4. all-gather of 4 x int64 per frame                                                            [collective 3]
+         R2: dynamic parallax scale, ShiftSmoother, FocalDepthTracker, FloatingWindowTracker, ConvergenceEMA,
+         FloatingBarEaser replayed in frame order on every rank; own slots patched
+      5. pixel pass (shift plane, fused warp, fused finish) per own frame
+
+    Output equals the sequential 1-GPU render bit for bit (tests/test_hip_parity.py, ranks emulated with one context each).
+    """
+
+    def __init__(self, renderer, params, rank: int, world: int, frames_per_rank: int, group=None):
+        self.r, self.p, self.rank, self.world, self.B, self.group = renderer, params, rank, world, frames_per_rank, group
+        if world * frames_per_rank > 512:
+            raise ValueError("a sharded step holds at most 512 frames")
+        renderer.shard_begin(params, frames_per_rank)
+        self.q_local = torch.zeros((frames_per_rank, 2), dtype=torch.float32, device=renderer.device)
+        self.m_local = torch.zeros((frames_per_rank, 4), dtype=torch.int64, device=renderer.device)
+        self.own_slots = [(t // world if t % world == rank else -1) for t in range(world * frames_per_rank)]
+
+    def gather(self, local: torch.Tensor) -> torch.Tensor:
+        """all-gather along dim 0: [B, ...] per rank -> [world*B, ...] laid out rank-major."""
+        if self.world == 1:
+            return local
+        shp = tuple(local.shape)
+        out = torch.empty((self.world * shp[0],) + shp[1:], dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        return out
+
+    def _frame_order(self, gathered: torch.Tensor) -> torch.Tensor:
+        """rank-major [world*B, k] -> frame order t = j * world + g."""
+        if self.world == 1:
+            return gathered
+        G, B = self.world, self.B
+        return gathered.view(G, B, -1).transpose(0, 1).reshape(G * B, -1).contiguous()
+
+    def p1(self, frames_local, depth_all: torch.Tensor):
+        G, B = self.world, self.B
+        for j in range(B):
+            for g in range(G):
+                t = j * G + g
+                d = depth_all[g * B + j]
+                if g == self.rank:
+                    self.r.shard2_p1(frames_local[j], d, self.p, t, slot=j, q_out=self.q_local[j])
+                else:
+                    self.r.shard2_p1(None, d, self.p, t, slot=-1)
+
+    def p3(self):
+        for j in range(self.B):
+            self.r.shard2_p3(j, j * self.world + self.rank, self.p, self.m_local[j])
+
+    def finish(self, m_gathered: torch.Tensor, outs=None):
+        self.r.shard2_r2(self._frame_order(m_gathered), self.own_slots, self.p)
+        return [self.r.shard_pixels(j, self.p, out=None if outs is None else outs[j]) for j in range(self.B)]
+
+    def render_step(self, frames_local, depth_local: torch.Tensor, outs=None):
+        self.p1(frames_local, self.gather(depth_local))
+        self.r.shard2_r1(self._frame_order(self.gather(self.q_local)))
+        self.p3()
+        return self.finish(self.gather(self.m_local), outs)
