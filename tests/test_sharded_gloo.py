@@ -168,3 +168,81 @@ def test_three_phase_protocol_world2(tmp_path):
         assert rec["s1"].tolist() == [1000.0 + t for t in range(world * B)]
         assert rec["own"] == [(t // world if t % world == rank else -1) for t in range(world * B)]
         assert rec["outs"] == list(range(B))
+
+
+# ---------------------------------------------------------------------------------------------------
+# measure / replay protocol (MeasureReplaySharder, the N > 1 path of bench.py): orchestration + the three all-gathers on gloo
+# ---------------------------------------------------------------------------------------------------
+class _FakeRenderer2:
+    """shard2_* surface of Renderer on CPU tensors; records the order of calls and what the replays were given."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.log, self.r1, self.r2 = [], None, None
+
+    def shard_begin(self, params, n_slots):
+        self.n_slots = n_slots
+
+    def shard2_p1(self, frame, depth, params, step_idx, slot=-1, q_out=None):
+        key = int(depth[0, 0])
+        self.log.append(("p1", step_idx, slot, key, frame is not None))
+        if slot >= 0:
+            assert int(frame[0, 0, 0]) == key
+            q_out[0] = 10.0 + key; q_out[1] = 20.0 + key
+
+    def shard2_r1(self, q_all):
+        self.log.append(("r1",))
+        self.r1 = q_all.clone()
+
+    def shard2_p3(self, slot, step_idx, params, m_out):
+        self.log.append(("p3", step_idx, slot))
+        m_out[:] = torch.tensor([step_idx, 100 + step_idx, 200 + step_idx, 300 + step_idx], dtype=torch.int64)
+
+    def shard2_r2(self, m_all, own_slots, params):
+        self.log.append(("r2",))
+        self.r2 = (m_all.clone(), list(own_slots))
+
+    def shard_pixels(self, slot, params, out=None):
+        self.log.append(("px", slot))
+        return torch.tensor([slot])
+
+
+def _proto2_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from visiondepth3d_amd.sharded import MeasureReplaySharder
+        B = 3
+        fr = _FakeRenderer2()
+        sr = MeasureReplaySharder(fr, None, rank, world, B)
+        depth_local = torch.stack([torch.full((4, 5), j * world + rank, dtype=torch.uint8) for j in range(B)])
+        frames_local = [torch.full((4, 5, 3), j * world + rank, dtype=torch.uint8) for j in range(B)]
+        outs = sr.render_step(frames_local, depth_local)
+        torch.save({"log": fr.log, "r1": fr.r1, "r2": fr.r2, "outs": [int(o) for o in outs]}, os.path.join(outdir, f"q{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_measure_replay_protocol_world2(tmp_path):
+    world, B = 2, 3
+    mp.spawn(_proto2_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    n = world * B
+    for rank in range(world):
+        rec = torch.load(tmp_path / f"q{rank}.pt")
+        log = rec["log"]
+        p1 = [e for e in log if e[0] == "p1"]
+        # P1 visits every frame of the step once, in frame order, with frame t's depth plane; owns its round-robin share
+        assert [e[1] for e in p1] == list(range(n)) and [e[3] for e in p1] == list(range(n))
+        for t, (_, idx, slot, key, has_frame) in enumerate(p1):
+            assert (slot >= 0) == (t % world == rank) == has_frame and (slot < 0 or slot == t // world)
+        # phase order: all P1, then R1, then the own P3s, then R2, then the pixel passes
+        kinds = [e[0] for e in log]
+        assert kinds == ["p1"] * n + ["r1"] + ["p3"] * B + ["r2"] + ["px"] * B
+        assert [e[1] for e in log if e[0] == "p3"] == [j * world + rank for j in range(B)]
+        # both replays see every frame's record in FRAME order (the all-gather is rank-major: needs the transpose)
+        assert rec["r1"].tolist() == [[10.0 + t, 20.0 + t] for t in range(n)]
+        m_all, own = rec["r2"]
+        assert m_all.tolist() == [[t, 100 + t, 200 + t, 300 + t] for t in range(n)]
+        assert own == [(t // world if t % world == rank else -1) for t in range(n)]
+        assert rec["outs"] == list(range(B))
