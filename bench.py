@@ -158,12 +158,14 @@ def main():
             dloc = None
         if shr is not None and dloc is None:
             dloc = depths_u8[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else depths_u8[idx]
-        if world > 1:
-            dist.all_gather_into_tensor(gathered[k], dloc.contiguous())   # data-path collective 1: uint8 depth planes [world*B,h,w]
         if overlap:  # hand the batch to the DIBR stream; this (torch) stream goes on to the next batch's depth inference
             ev = torch.cuda.Event()
             ev.record()
             dibr_stream.wait_event(ev)
+        if world > 1:   # data-path collective 1: uint8 depth planes [world*B,h,w]; ordered on the DIBR stream so that the ring
+                        # transfer overlaps the next batch's depth inference instead of stalling the depth-net stream
+            with (torch.cuda.stream(dibr_stream) if overlap else contextlib.nullcontext()):
+                dist.all_gather_into_tensor(gathered[k], dloc.contiguous())
         if ring is not None:
             if overlap:
                 dibr_stream.wait_event(ring.ev_in[kr])
