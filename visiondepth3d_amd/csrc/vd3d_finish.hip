@@ -59,11 +59,18 @@ VD_DEV void ff_level(ff_tile_t tile, const float* __restrict__ kern, bool active
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     vd_f4 vs = {0.f, 0.f, 0.f, 0.f};
-    if (active) {
-      vd_f4 v[K];
+    if (active) {   // vd_gauss_sym with the loads consumed pair by pair (sched_barrier: keep at most one pair of rows in flight,
+                    // the kernel is register-limited and other waves hide the LDS latency)
+      constexpr int r = K / 2;
+      auto ld = [&](int tt) { return *reinterpret_cast<const vd_f4*>(&tile[c][sy + OFF + tt][4 * ss]); };
+      vd_f4 acc = kw[0] * (ld(0) + ld(K - 1));
 #pragma unroll
-      for (int tt = 0; tt < K; ++tt) v[tt] = *reinterpret_cast<const vd_f4*>(&tile[c][sy + OFF + tt][4 * ss]);
-      vs = vd_gauss_sym<K, vd_f4>(kw, v);
+      for (int tt = 1; tt < r; ++tt) {
+        __builtin_amdgcn_sched_barrier(0);
+        acc = vd_vfma((vd_f4)(kw[tt]), ld(tt) + ld(K - 1 - tt), acc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      vs = vd_vfma((vd_f4)(kw[r]), ld(r), acc);
     }
     float win[12];   // vertical sums at tile columns 4(ss-1) .. 4(ss+1)+3
 #pragma unroll
