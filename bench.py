@@ -274,8 +274,8 @@ def main():
             traffic, traffic_src = None, None
             try:  # HBM bytes per launch from the committed PMC passes (only when they were taken on this workload)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-                if pm.get("workload") == args.workload:
-                    traffic, traffic_src = pm["corrected_bytes_per_launch"], pm["source"]
+                if args.workload in pm:
+                    traffic, traffic_src = pm[args.workload]["corrected_bytes_per_launch"], pm[args.workload]["source"]
             except Exception:
                 pass
             res["roofline"] = {"bound": "hbm", "kernel": "k_warp_fused (W1: feather mask + pool + warp + blend, one launch)",
