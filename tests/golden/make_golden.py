@@ -343,6 +343,9 @@ def gen_widen():
     for nm, (dw, dh) in {"area_4_3": (96, 54), "area_3_2": (85, 48), "area_2p5": (51, 28), "area_mixed": (64, 54),
                          "area_1p07": (120, 67)}.items():
         out[nm] = cv2.resize(bgr, (dw, dh), interpolation=cv2.INTER_AREA)
+    for nm, (dw, dh) in {"area_up_1p5": (192, 108), "area_up_quirk": (191, 108), "area_up_mixed": (256, 60), "area_up_y": (100, 90)}.items():
+        out[nm] = cv2.resize(bgr, (dw, dh), interpolation=cv2.INTER_AREA)     # OpenCV: linear machinery, area-mode coefficients
+    out["pad_up_720_like"] = r.pad_to_aspect_ratio(bgr, 192, 108)   # the 1280x720 -> 1920x1080 Full-SBS case in miniature
     out["pad_frac_wide"] = r.pad_to_aspect_ratio(bgr, 96, 60)     # 4/3 down + vertical bars
     out["pad_frac_tall"] = r.pad_to_aspect_ratio(bgr, 100, 48)    # 3/2 down + horizontal bars
     out["fmt__VR_identity"] = r.format_3d_output(np.zeros((1600, 1440, 3), np.uint8) + 7, np.zeros((1600, 1440, 3), np.uint8) + 9, "VR")[::200, ::240]

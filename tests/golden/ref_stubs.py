@@ -124,7 +124,9 @@ def _resize_area(src, dw, dh):
         scale = np.float32(1.0 / (isx * isy))
         return _rne_u8(a.astype(np.float32) * scale)
     if sx < 1 or sy < 1:
-        raise NotImplementedError("INTER_AREA upscale (falls back to linear in OpenCV)")
+        # any up-scaling dimension: hal::resize skips the area paths and runs the INTER_LINEAR machinery with the
+        # "area_mode" coefficients (sx = floor(dx*scale), fx = (dx+1) - (sx+1)*inv_scale, fx -= floor(fx))
+        return _resize_linear_u8(src, dw, dh, area_mode=True)
     xt, yt = _area_tab(sw, dw, sx), _area_tab(sh, dh, sy)
     s = src.astype(np.float32)
     # horizontal pass into per-source-row buffers, then vertical accumulation (float32)
@@ -137,21 +139,28 @@ def _resize_area(src, dw, dh):
     return _rne_u8(out)
 
 
-def _resize_linear_u8(src, dw, dh):
-    """OpenCV INTER_LINEAR for 8-bit: 11-bit fixed-point coefficients, two-stage rounding."""
+def _resize_linear_u8(src, dw, dh, area_mode=False):
+    """OpenCV INTER_LINEAR for 8-bit: 11-bit fixed-point coefficients, two-stage rounding.  area_mode = the coefficient rule
+    hal::resize uses when INTER_AREA is asked to up-scale."""
     sh, sw = src.shape[:2]
     if (sw, sh) == (dw, dh):
         return src.copy()
     SC = 2048
 
     def tab(ssz, dsz):
-        sc = ssz / dsz
+        inv = dsz / ssz
+        sc = 1.0 / inv if area_mode else ssz / dsz
         idx = np.zeros(dsz, np.int64)
         a = np.zeros((dsz, 2), np.int64)
         for d in range(dsz):
-            f = np.float32((d + 0.5) * sc - 0.5)
-            i = int(math.floor(f))
-            f = np.float32(f - i)
+            if area_mode:
+                i = int(math.floor(d * sc))
+                f = np.float32((d + 1) - (i + 1) * inv)
+                f = np.float32(0) if f <= 0 else np.float32(f - np.float32(math.floor(f)))
+            else:
+                f = np.float32((d + 0.5) * sc - 0.5)
+                i = int(math.floor(f))
+                f = np.float32(f - i)
             if i < 0:
                 i, f = 0, np.float32(0)
             if i >= ssz - 1:

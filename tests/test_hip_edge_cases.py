@@ -132,10 +132,10 @@ def test_finish_frame_padded_canvas_and_unsupported_ratio(R, oracle):
     p.fit_w, p.fit_h, p.out_w, p.out_h = 100, 72, 200, 72      # fractional INTER_AREA (1.28): generic area-table path
     got = R.finish_frame(T(L_), T(R_), T(dn), p, 0.5, 0, 0).cpu().numpy()
     assert np.array_equal(got, oracle.finish_frame(L_, R_, dn, p, 0.5, 0, 0))
-    p.fit_w, p.fit_h, p.out_w, p.out_h = 200, 72, 400, 72      # INTER_AREA up-scale (OpenCV's linear area mode): not built -> loud
-    with pytest.raises(Vd3dError) as e:
-        R.finish_frame(T(L_), T(R_), T(dn), p, 0.5, 0, 0)
-    assert e.value.code == -4
+    for fw, fh in ((200, 72), (192, 108), (130, 100)):            # INTER_AREA asked to up-scale: OpenCV's linear area mode
+        p.fit_w, p.fit_h, p.out_w, p.out_h = fw, fh, 2 * fw, fh
+        got = R.finish_frame(T(L_), T(R_), T(dn), p, 0.5, 0, 0).cpu().numpy()
+        assert np.array_equal(got, oracle.finish_frame(L_, R_, dn, p, 0.5, 0, 0)), (fw, fh)
 
 
 @pytest.mark.parametrize("dof", [0.0, 0.7, 1.0, 2.0, 3.3, 5.0])
@@ -165,7 +165,8 @@ def test_unsupported_features_fail_loudly():
         render_kwargs_to_params(96, 54, output_height=54, skip_blank_frames=True, output_format="Half-SBS", **{k: v for k, v in BASE.items()})
     from visiondepth3d_amd.render_3d import Renderer
     r = Renderer(0)
-    p = render_kwargs_to_params(96, 54, **dict(BASE, output_format="VR", output_height=54))   # 96x54 warp -> 1440x810: up-scale
+    p = render_kwargs_to_params(96, 54, **dict(BASE, output_format="VR", output_height=54))
+    p.fit_w, p.fit_h, p.out_w = 720, 800, 1440          # a VR canvas other than 1440x1600 would need format_3d_output's INTER_LINEAR resize
     with pytest.raises(Vd3dError) as e:
         r.render_frame(torch.zeros(54, 96, 3, dtype=torch.uint8).cuda(), torch.zeros(54, 96).cuda(), p)
     assert e.value.code == -4

@@ -129,11 +129,17 @@ def test_vr_loop_bit_exact_and_golden(R, oracle):
         assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2, (a, b, mx, frac, frac_gt1)
 
 
-def test_upscaling_inter_area_is_refused(R):
-    p = render_kwargs_to_params(128, 72, output_format="Full-SBS", output_height=72, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
-                                sharpness_factor=0.2, dof_strength=0.0)     # fixed 1920x1080 eyes from a 128x72 warp
-    with pytest.raises(Vd3dError):
-        R.render_frame(T(np.zeros((72, 128, 3), np.uint8)), T(np.zeros((72, 128), np.float32)), p)
+def test_full_sbs_720_like_upscale_loop(R, oracle):
+    """Non-preserve Full-SBS from a source smaller than 1080p: fixed 1920x1080 eyes, pad_to_aspect_ratio up-scales with
+    INTER_AREA (OpenCV: linear machinery with area-mode coefficients)."""
+    sh, sw = 72, 128
+    frames, depths = synth.synth_clip(3, sh, sw)
+    p = render_kwargs_to_params(sw, sh, output_format="Full-SBS", output_height=sh, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                sharpness_factor=0.2, dof_strength=2.0)
+    assert (p.fit_w, p.fit_h, p.out_w, p.out_h) == (1920, 1080, 3840, 1080)
+    got, exp = _loop(R, oracle, frames, [synth.depth_to_u8_bgr(d) for d in depths], p)
+    assert np.array_equal(got, exp), u8_diff_stats(got, exp)
+    assert got[:, :, 1900:1920].any() and got[:, 0].any() and got[:, 1079].any()     # the picture fills the 1920x1080 eye canvas
 
 
 def test_pinned_ring_clip_equals_sequential(R, oracle):

@@ -345,10 +345,9 @@ static int check_fit(const vd3d_render_params* p) {
     if (ca > ta) { in_w = p->fit_w; in_h = (int)(p->fit_w / ca); }
     else { in_h = p->fit_h; in_w = (int)(ca * p->fit_h); }
   }
-  if (in_w < 1 || in_h < 1 || in_w > p->warp_w || in_h > p->warp_h)
-    return set_err(VD3D_E_UNSUPPORTED, "fit %dx%d -> %dx%d up-scales: OpenCV's INTER_AREA switches to its linear area mode there (not built)",
-                   p->warp_w, p->warp_h, in_w, in_h);
-  if ((p->warp_w % in_w || p->warp_h % in_h) && ((double)p->warp_w / in_w > VD_AREA_MAXT_HOST - 2 || (double)p->warp_h / in_h > VD_AREA_MAXT_HOST - 2))
+  if (in_w < 1 || in_h < 1) return set_err(VD3D_E_INVALID, "empty fit %dx%d", in_w, in_h);
+  const bool upscale = in_w > p->warp_w || in_h > p->warp_h;   // OpenCV: linear machinery with area-mode coefficients (k_sharp_mux)
+  if (!upscale && (p->warp_w % in_w || p->warp_h % in_h) && ((double)p->warp_w / in_w > VD_AREA_MAXT_HOST - 2 || (double)p->warp_h / in_h > VD_AREA_MAXT_HOST - 2))
     return set_err(VD3D_E_UNSUPPORTED, "fractional INTER_AREA ratio above %d not built", VD_AREA_MAXT_HOST - 2);
   const int mux_w = (p->format == VD3D_FMT_HALF_SBS || p->format == VD3D_FMT_FULL_SBS || p->format == VD3D_FMT_VR) ? 2 * p->fit_w : p->fit_w;
   if (p->out_w != mux_w || p->out_h != p->fit_h) return set_err(VD3D_E_INVALID, "out size %dx%d does not match mux %dx%d", p->out_w, p->out_h, mux_w, p->fit_h);

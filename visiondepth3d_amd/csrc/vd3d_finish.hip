@@ -362,7 +362,7 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
     else { a.in_h = p.fit_h; a.in_w = (int)(ca * p.fit_h); }
     a.xo = (p.fit_w - a.in_w) / 2; a.yo = (p.fit_h - a.in_h) / 2;
   }
-  if (a.in_w < 1 || a.in_h < 1 || p.warp_w % a.in_w || p.warp_h % a.in_h) return false;   // fractional INTER_AREA: unfused path
+  if (a.in_w < 1 || a.in_h < 1 || a.in_w > p.warp_w || a.in_h > p.warp_h || p.warp_w % a.in_w || p.warp_h % a.in_h) return false;   // fractional / up-scaling INTER_AREA: unfused path
   a.fx = p.warp_w / a.in_w; a.fy = p.warp_h / a.in_h;
   if (!((a.fx == 1 || a.fx == 2 || a.fx == 4) && (a.fy == 1 || a.fy == 2 || a.fy == 4))) return false;
   if ((FF_TW / a.fx) % 4) return false;

@@ -415,9 +415,21 @@ struct vd_mux_geom {
   int xo, yo;          // its offset
   int fx, fy;          // integer down-scale factors
   int out_w, out_h, format;
-  int frac;            // non-integer (or mixed) INTER_AREA ratio: generic area table path
+  int frac;            // 1: non-integer (or mixed) INTER_AREA down-scale, generic area table path; 2: some dimension up-scales
   double sx, sy;       // OpenCV's scale = 1./((double)dsize/ssize)
 };
+// hal::resize linear coefficients in "area mode" (INTER_AREA with an up-scaling dimension), one destination index
+VD_DEV void vd_area_lin_coef(int ssize, int dsize, int d, int* idx, int* a0, int* a1) {
+  const double inv = (double)dsize / ssize, scale = 1.0 / inv;
+  int sx = (int)floor(d * scale);
+  float fx = (float)((d + 1) - (sx + 1) * inv);
+  fx = fx <= 0 ? 0.f : fx - floorf(fx);
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+  *idx = sx;
+  *a0 = (int)rintf((1.f - fx) * 2048.f);
+  *a1 = (int)rintf(fx * 2048.f);
+}
 // computeResizeAreaTab (OpenCV resize.cpp) for ONE destination index: consecutive source indices s0..s0+n-1 with weights a[].
 #define VD_AREA_MAXT 12
 VD_DEV int vd_area_taps(int ssize, double scale, int d, int* s0, float* a) {
@@ -450,7 +462,16 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       uint8_t v = 0;
-      if (inside && m.frac) {  // ResizeArea_<uchar,float>: per source row sum_k S*alpha (float32), then sum_j row*beta
+      if (inside && m.frac == 2) {  // INTER_AREA asked to up-scale: hal::resize's linear path with area-mode coefficients (11-bit fixed point)
+        int xi, xa0, xa1, yi, yb0, yb1;
+        vd_area_lin_coef(m.W, m.in_w, ix, &xi, &xa0, &xa1);
+        vd_area_lin_coef(m.H, m.in_h, iy, &yi, &yb0, &yb1);
+        const int x1 = xi + 1 < m.W ? xi + 1 : m.W - 1, y1 = yi + 1 < m.H ? yi + 1 : m.H - 1;
+        const int r0 = (int)sharp_at(g, m.H, m.W, yi, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, yi, x1, c, kn, kc) * xa1;
+        const int r1 = (int)sharp_at(g, m.H, m.W, y1, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, y1, x1, c, kn, kc) * xa1;
+        const int q = (((yb0 * (r0 >> 4)) >> 16) + ((yb1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+      } else if (inside && m.frac) {  // ResizeArea_<uchar,float>: per source row sum_k S*alpha (float32), then sum_j row*beta
         float ax[VD_AREA_MAXT], ay[VD_AREA_MAXT];
         int x0s, y0s;
         const int nx = vd_area_taps(m.W, m.sx, ix, &x0s, ax), ny = vd_area_taps(m.H, m.sy, iy, &y0s, ay);
@@ -511,6 +532,7 @@ void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
   m.fx = m.in_w > 0 ? p.warp_w / m.in_w : 1; m.fy = m.in_h > 0 ? p.warp_h / m.in_h : 1;
   m.sx = 1.0 / ((double)m.in_w / p.warp_w); m.sy = 1.0 / ((double)m.in_h / p.warp_h);
   m.frac = (p.warp_w % m.in_w || p.warp_h % m.in_h) ? 1 : 0;
+  if (m.in_w > p.warp_w || m.in_h > p.warp_h) m.frac = 2;
   hipLaunchKernelGGL(k_sharp_mux, dim3((p.fit_w + 63) / 64, (p.fit_h + 3) / 4), dim3(256), 0, s, gL, gR, m, fc.sharp_kn, fc.sharp_kc, out);
 }
 
