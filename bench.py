@@ -179,13 +179,14 @@ def main():
         else:  # measure / replay sharding: P1 over all world*B frames (foreign: plane EMA only), exchange of 2 floats per frame, EMA
                # replay, P3 on own frames, exchange of 4 x int64 per frame, tracker replay, pixel pass (sharded.MeasureReplaySharder)
             shr.p1(fb, gathered[k] if world > 1 else (shr.gather(dloc) if emu else dloc))
-            ctx_s = torch.cuda.stream(dibr_stream) if overlap else contextlib.nullcontext()
-            with ctx_s:   # the small collectives are enqueued relative to the DIBR stream, not the depth net's
+            on_dibr = (lambda: torch.cuda.stream(dibr_stream)) if overlap else contextlib.nullcontext
+            with on_dibr():   # the small collectives (and the torch ops that reorder their results) are enqueued on the DIBR stream,
+                              # where the records are produced and consumed -- not on the depth net's stream
                 shr.r.shard2_r1(shr._frame_order(shr.gather(shr.q_local)))
             shr.p3()
-            with ctx_s:
-                m_all = shr.gather(shr.m_local)
-            shr.finish(m_all, outs_k)
+            with on_dibr():
+                m_ord = shr._frame_order(shr.gather(shr.m_local))
+            shr.finish(m_ord, outs_k, ordered=True)
         if overlap:
             done[k].record(dibr_stream)
         if ring is not None:

@@ -222,8 +222,10 @@ class MeasureReplaySharder:
         for j in range(self.B):
             self.r.shard2_p3(j, j * self.world + self.rank, self.p, self.m_local[j])
 
-    def finish(self, m_gathered: torch.Tensor, outs=None):
-        self.r.shard2_r2(self._frame_order(m_gathered), self.own_slots, self.p)
+    def finish(self, m_gathered: torch.Tensor, outs=None, ordered: bool = False):
+        """``ordered``: m_gathered is already in frame order (callers that run the renderer on a private stream do the reordering
+        inside that stream's context, see bench.py)."""
+        self.r.shard2_r2(m_gathered if ordered else self._frame_order(m_gathered), self.own_slots, self.p)
         return [self.r.shard_pixels(j, self.p, out=None if outs is None else outs[j]) for j in range(self.B)]
 
     def render_step(self, frames_local, depth_local: torch.Tensor, outs=None):
