@@ -216,6 +216,10 @@ int vd3d_shard_pixels(vd3d_ctx* ctx, int slot, const vd3d_render_params* p, uint
  * all-gather of 2 floats per frame; vd3d_shard2_r1 (DepthPercentileEMA replay); vd3d_shard2_p3 per own frame (all other
  * measurements, 4 x int64 per frame); all-gather; vd3d_shard2_r2 (remaining trackers replayed in frame order, own slots
  * patched); vd3d_shard_pixels per own frame.  Bit-identical to the sequential render. */
+/* with auto_crop_black_bars: vd3d_shard2_p0 per own frame (crop rectangle {x,y,w,h} -> device int[4]), all-gather of the
+ * rectangles, vd3d_shard2_set_crops(frame order) -- before vd3d_shard2_p1 of the step */
+int vd3d_shard2_p0(vd3d_ctx* ctx, const uint8_t* frame_bgr, const vd3d_render_params* p, int* crop_out_dev);
+int vd3d_shard2_set_crops(vd3d_ctx* ctx, const int* crops_all_dev, int n);
 int vd3d_shard2_p1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void* depth, int depth_fmt,
                    const vd3d_render_params* p, int step_idx, int slot, float* q_out_dev);
 int vd3d_shard2_r1(vd3d_ctx* ctx, const float* q_all_dev, int n);

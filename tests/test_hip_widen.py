@@ -158,3 +158,52 @@ def test_pinned_ring_clip_equals_sequential(R, oracle):
     assert len(got) == len(seq) == n - 1
     for a, b in zip(got, seq):
         assert np.array_equal(a, b)
+
+
+def test_autocrop_in_sharded_steps_equals_sequential(R):
+    """auto_crop_black_bars inside measure/replay sharded steps: owners detect the bars (P0), the crop rectangles are exchanged,
+    every rank's plane EMA uses frame t's rectangle.  Two emulated ranks (one context each) vs the sequential render."""
+    from visiondepth3d_amd.render_3d import Renderer
+    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    sh, sw, G, B, steps = 120, 192, 2, 2, 2
+    n = steps * G * B
+    frames, depth_bgr = synth.letterbox_clip(n, sh, sw, 10, 14)
+    gray = [d[..., 0].copy() for d in depth_bgr]
+    p = render_kwargs_to_params(sw, sh, output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0,
+                                sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0, blur_ksize=9,
+                                use_subject_tracking=True, use_floating_window=True, auto_crop_black_bars=True)
+    R.reset_state(); R.new_clip()
+    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
+    st_seq = R.export_state().as_dict()
+    ranks = [Renderer(0) for _ in range(G)]
+    shd = []
+    for g_, rr in enumerate(ranks):
+        rr.reset_state(); rr.new_clip()
+        shd.append(MeasureReplaySharder(rr, p, g_, G, B))
+    assert all(s_.auto_crop for s_ in shd)
+    for step in range(steps):
+        base = step * B * G
+        loc_f = [[T(frames[base + j * G + g_]) for j in range(B)] for g_ in range(G)]
+        depth_all = torch.cat([torch.stack([T(gray[base + j * G + g_]) for j in range(B)]) for g_ in range(G)])
+        for g_ in range(G):
+            for j in range(B):
+                shd[g_].r.shard2_p0(loc_f[g_][j], p, shd[g_].c_local[j])
+        c_all = torch.cat([shd[g_].c_local for g_ in range(G)])
+        for g_ in range(G):
+            shd[g_].r.shard2_set_crops(shd[g_]._frame_order(c_all.clone()))
+            shd[g_].p1(loc_f[g_], depth_all)
+        q_all = torch.cat([shd[g_].q_local for g_ in range(G)])
+        for g_ in range(G):
+            shd[g_].r.shard2_r1(shd[g_]._frame_order(q_all.clone()))
+            shd[g_].p3()
+        m_all = torch.cat([shd[g_].m_local for g_ in range(G)])
+        for g_ in range(G):
+            outs = shd[g_].finish(m_all.clone())
+            for j in range(B):
+                t = base + j * G + g_
+                assert np.array_equal(outs[j].cpu().numpy(), seq[t]), (step, g_, j)
+    assert all(rr.export_state().as_dict() == st_seq for rr in ranks)
+    crops = c_all.view(G, B, 4).transpose(0, 1).reshape(-1, 4).cpu().numpy()
+    assert (crops[:, 1] >= 10).all() and (crops[:, 3] <= 96).all()      # the letterbox rows are gone from every frame's rectangle
+    for rr in ranks:
+        rr.close()

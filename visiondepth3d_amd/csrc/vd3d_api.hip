@@ -57,6 +57,8 @@ struct vd3d_ctx {
   std::vector<float*> slot_rgb, slot_dn, slot_D;
   std::vector<float*> slot_tdf, slot_tdfp;   // measure/replay protocol: filtered plane of the own frame and of the frame before it
   float* etab = nullptr;                     // [VD_MAX_STEP + 1][VD_ETAB] replayed normalisation table of the current step
+  int* crop_tab = nullptr;                   // [VD_MAX_STEP][4] exchanged auto-crop rectangles of the current step
+  bool crop_tab_set = false;
   vd_dev_work* slot_work = nullptr;
   int* own_slot_dev = nullptr; int* own_slot_pin = nullptr;   // depth hand-off min/max keys [B][3]
   // profiling
@@ -170,7 +172,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -502,6 +504,7 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
     c->slot_rgb.push_back(a); c->slot_dn.push_back(b); c->slot_D.push_back(d); c->slot_tdf.push_back(t0); c->slot_tdfp.push_back(t1);
   }
   if (!c->etab) HIPCHK(hipMalloc((void**)&c->etab, (size_t)(VD_MAX_STEP + 1) * VD_ETAB * sizeof(float)));
+  if (!c->crop_tab) HIPCHK(hipMalloc((void**)&c->crop_tab, (size_t)VD_MAX_STEP * 4 * sizeof(int)));
   HIPCHK(re_alloc(&c->slot_work, (size_t)n_slots));
   c->n_slots = n_slots; c->slot_eh = p->eye_h; c->slot_ew = p->eye_w; c->slot_H = p->warp_h; c->slot_W = p->warp_w;
   return 0;
@@ -584,13 +587,15 @@ VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void
   if (slot >= c->n_slots) return set_err(VD3D_E_INVALID, "slot %d out of range (vd3d_shard_begin)", slot);
   if (slot >= 0 && (!frame_bgr || !q_out_dev)) return set_err(VD3D_E_INVALID, "own frame needs the frame and a destination for its quantiles");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
-  if (p->auto_crop_black_bars) return set_err(VD3D_E_UNSUPPORTED, "auto_crop_black_bars is not available in frame-sharded steps");
+  if (p->auto_crop_black_bars && !c->crop_tab_set)
+    return set_err(VD3D_E_INVALID, "auto_crop_black_bars in a sharded step: call vd3d_shard2_p0 on the own frames and vd3d_shard2_set_crops first");
   if (!c->use_fused) return set_err(VD3D_E_UNSUPPORTED, "frame sharding needs the fused chain (unset VD3D_UNFUSED)");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   vd_stage_args a; vd3d_shift_params sp;
   shard2_args(c, p, &a, &sp);
   a.shard_idx = step_idx;
+  a.crop_tab = p->auto_crop_black_bars ? c->crop_tab : nullptr;
   const size_t ne = (size_t)p->eye_h * p->eye_w;
   StageTimer t(c, slot >= 0 ? "p1_own" : "p1_foreign");
   if (slot < 0) {
@@ -606,6 +611,25 @@ VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void
     HIPCHK(hipMemcpyAsync(c->slot_tdf[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+// P0 (only with auto_crop_black_bars), own frames: detect_black_bars + the per-frame aspect crop -> crop_out_dev[0..3] = {x, y, w, h}.
+// The rectangles of ALL frames of the step are then all-gathered by the caller and installed with vd3d_shard2_set_crops.
+VD3D_EXPORT int vd3d_shard2_p0(vd3d_ctx* c, const uint8_t* frame_bgr, const vd3d_render_params* p, int* crop_out_dev) {
+  if (!c || !frame_bgr || !p || !crop_out_dev) return set_err(VD3D_E_INVALID, "NULL argument");
+  if (!(p->target_ratio > 0.0) || p->src_w < 1 || p->src_h < 1) return set_err(VD3D_E_INVALID, "auto_crop_black_bars needs target_ratio > 0");
+  HIPCHK(hipSetDevice(c->device));
+  if (p->src_h > c->rowflag_cap) { HIPCHK(re_alloc(&c->rowflag, (size_t)p->src_h)); c->rowflag_cap = p->src_h; }
+  vd_launch_autocrop(c->stream, frame_bgr, p->src_h, p->src_w, p->target_ratio, c->rowflag, c->work, crop_out_dev);
+  c->crop_scalars_dirty = true;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+VD3D_EXPORT int vd3d_shard2_set_crops(vd3d_ctx* c, const int* crops_all_dev, int n) {
+  if (!c || !crops_all_dev || n < 1 || n > VD_MAX_STEP || !c->crop_tab) return set_err(VD3D_E_INVALID, "bad argument (vd3d_shard_begin first)");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->crop_tab, crops_all_dev, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  c->crop_tab_set = true;
   return 0;
 }
 // R1: replay DepthPercentileEMA over the n frames of the step from the exchanged quantiles q_all_dev[n][2] (frame order)

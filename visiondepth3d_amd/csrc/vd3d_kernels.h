@@ -23,6 +23,7 @@ struct vd_stage_args {
   float* s1_out;       // shard == 1: where the measured s1 goes (device)
   float* q_out;        // shard == 3: {q_lo, q_hi} of this frame (device, 2 floats)
   long long* m_out;    // shard == 3: {sum1, sum2, sum_mad, (s_norm | s1 << 32)} of this frame (device, 4 x int64)
+  const int* crop_tab; // shard 3/4 with auto_crop_black_bars: per-frame crop rectangles {x, y, w, h} of the step (device), else NULL
   const float* etab;   // shard == 3: per-frame normalisation table of the step, VD_ETAB floats per entry:
                        // entry t = {ema_lo, ema_den, collapse, have_prev, ema_hi} in force BEFORE frame t
   int dbg;             // development probes: bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket + fences
@@ -86,7 +87,8 @@ VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __re
 void vd_launch_shard2_r1(hipStream_t s, vd_dev_work* w, const float* q_all, int n, float* etab);
 void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, const float* etab, const int* own_slot_host, int n,
                          vd_dev_work* slot_work, const vd_stage_args& a);
-void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w);
+void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w,
+                        int* crop_out = nullptr);   // crop_out: optional device int[4] copy of the rectangle (sharded steps)
 void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w,
                          float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a);
 void vd_launch_chain_eye_lite(hipStream_t s, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,

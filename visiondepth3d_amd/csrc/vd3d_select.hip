@@ -650,7 +650,7 @@ VD_DEV void vd_plane_walk(const float* __restrict__ p, long long n, int W, int w
 // reference's float32 round trip ((v/255)*255 truncated); row is "content" iff sum > 10*w (== np.mean(row) > 10).
 // Last workgroup: first / last content row -> top / bottom -> crop rectangle in vd_dev_work::acrop.
 __global__ __launch_bounds__(256) void k_autocrop(const uint8_t* __restrict__ frame, int h, int wd, double target_ratio,
-                                                  uint32_t* __restrict__ rowflag, vd_dev_work* w) {
+                                                  uint32_t* __restrict__ rowflag, vd_dev_work* w, int* __restrict__ crop_out) {
   __shared__ uint32_t sflag;
   __shared__ int s_first, s_last;
   const int lane = threadIdx.x & 63;
@@ -686,10 +686,12 @@ __global__ __launch_bounds__(256) void k_autocrop(const uint8_t* __restrict__ fr
     }
     w->acrop[0] = cx; w->acrop[1] = cy; w->acrop[2] = cw; w->acrop[3] = ch;
     w->fs.crop_top = top; w->fs.crop_bottom = bottom;
+    if (crop_out) { crop_out[0] = cx; crop_out[1] = cy; crop_out[2] = cw; crop_out[3] = ch; }
   }
 }
-void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w) {
-  hipLaunchKernelGGL(k_autocrop, dim3((h + 3) / 4), dim3(256), 0, s, frame, h, wd, target_ratio, rowflag, w);
+void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w,
+                        int* crop_out) {
+  hipLaunchKernelGGL(k_autocrop, dim3((h + 3) / 4), dim3(256), 0, s, frame, h, wd, target_ratio, rowflag, w, crop_out);
 }
 
 // K1: ingest (+ TemporalDepthFilter) + pass A of J0; last workgroup: scan A0
@@ -703,7 +705,10 @@ __global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict
   __syncthreads();
   const long long n = (long long)p.eye_h * p.eye_w;
   const int tdf_valid = w->st.tdf_valid;
-  if (p.auto_crop_black_bars) { p.crop_x = w->acrop[0]; p.crop_y = w->acrop[1]; p.crop_w = w->acrop[2]; p.crop_h = w->acrop[3]; }
+  if (p.auto_crop_black_bars) {   // per-frame rectangle: k_autocrop's (sequential) or the exchanged table of a sharded step
+    const int* cr = a.crop_tab ? a.crop_tab + 4 * a.shard_idx : w->acrop;
+    p.crop_x = cr[0]; p.crop_y = cr[1]; p.crop_w = cr[2]; p.crop_h = cr[3];
+  }
   const bool lite = a.shard == 4;   // foreign frame of the measure/replay protocol: the plane EMA only (no histogram, no scan)
   for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
     const long long i = base + threadIdx.x;

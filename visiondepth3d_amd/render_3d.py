@@ -181,6 +181,14 @@ class Renderer:
         _lib.check(self._L.vd3d_shard_pass2(self._ctx, _ptr(s1), arr, n, C.byref(params)))
 
     # measure / replay protocol (include/vd3d.h vd3d_shard2_*)
+    def shard2_p0(self, frame, params: RenderParams, crop_out: torch.Tensor):
+        f = frame.to(self.device).contiguous()
+        _lib.check(self._L.vd3d_shard2_p0(self._ctx, _ptr(f), C.byref(params), _ptr(crop_out)))
+
+    def shard2_set_crops(self, crops_all: torch.Tensor):
+        cr = crops_all.to(self.device, torch.int32).contiguous()
+        _lib.check(self._L.vd3d_shard2_set_crops(self._ctx, _ptr(cr), cr.numel() // 4))
+
     def shard2_p1(self, frame, depth, params: RenderParams, step_idx: int, slot: int = -1, q_out: torch.Tensor | None = None):
         d = depth.to(self.device).contiguous()
         f = frame.to(self.device).contiguous() if frame is not None else None

@@ -189,6 +189,8 @@ class MeasureReplaySharder:
         renderer.shard_begin(params, frames_per_rank)
         self.q_local = torch.zeros((frames_per_rank, 2), dtype=torch.float32, device=renderer.device)
         self.m_local = torch.zeros((frames_per_rank, 4), dtype=torch.int64, device=renderer.device)
+        self.c_local = torch.zeros((frames_per_rank, 4), dtype=torch.int32, device=renderer.device)
+        self.auto_crop = bool(getattr(params, "auto_crop_black_bars", 0)) if params is not None else False
         self.own_slots = [(t // world if t % world == rank else -1) for t in range(world * frames_per_rank)]
 
     def gather(self, local: torch.Tensor) -> torch.Tensor:
@@ -206,6 +208,12 @@ class MeasureReplaySharder:
             return gathered
         G, B = self.world, self.B
         return gathered.view(G, B, -1).transpose(0, 1).reshape(G * B, -1).contiguous()
+
+    def p0(self, frames_local):
+        """auto_crop_black_bars: black-bar detection on the own frames, all-gather of the crop rectangles (16 B x frames)."""
+        for j in range(self.B):
+            self.r.shard2_p0(frames_local[j], self.p, self.c_local[j])
+        self.r.shard2_set_crops(self._frame_order(self.gather(self.c_local)))
 
     def p1(self, frames_local, depth_all: torch.Tensor):
         G, B = self.world, self.B
@@ -229,6 +237,8 @@ class MeasureReplaySharder:
         return [self.r.shard_pixels(j, self.p, out=None if outs is None else outs[j]) for j in range(self.B)]
 
     def render_step(self, frames_local, depth_local: torch.Tensor, outs=None):
+        if self.auto_crop:
+            self.p0(frames_local)
         self.p1(frames_local, self.gather(depth_local))
         self.r.shard2_r1(self._frame_order(self.gather(self.q_local)))
         self.p3()
