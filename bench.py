@@ -299,6 +299,12 @@ def main():
                 res["roofline_e1"] = {"bound": "hbm", "kernel": "k_finish_fused (E1)", "achieved": round(e1, 2), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round(e1 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": e1_bytes,
                                       "avg_launch_ms": fin_ms}
+            fr_ms = stage_ms.get("frame", -1)
+            if fr_ms > 0:  # whole DIBR chain = RGB 3N + depth 4N twice + two u8 eyes 6N = 17 N per stereo pair
+                ch = 17 * N / (fr_ms * 1e-3) / 1e9
+                res["roofline_chain"] = {"bound": "hbm", "kernel": "whole DIBR frame (9 launches: K1-K6, k_shift, W1, E1)", "achieved": round(ch, 2),
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ch / HBM_PEAK_GBS, 5),
+                                         "algorithmic_bytes_per_frame": 17 * N, "avg_frame_ms": fr_ms}
             res["stage_ms"] = stage_ms
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sh, sw)
