@@ -247,6 +247,18 @@ int vd3d_add_layernorm_bf16(vd3d_ctx* ctx, const void* x, const void* y_or_null,
  * [B][oh][ow][C], C a multiple of 8: the up-samplings of the DPT neck / head (a25). */
 int vd3d_upsample_bilinear_nhwc_bf16(vd3d_ctx* ctx, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
 
+/* ---- preview visualisers: generate_preview_image, core/preview_utils.py:23-84, the exactly defined types.
+ * left / right: uint8 BGR [h][w][3] eyes (outputs of vd3d_pixel_shift).  out: [h][w][3], except HSBS: [h][2*(w/2)][3].
+ * The colour-mapped heat-maps and the arrow overlay (OpenCV colour-map tables / line rasteriser) return VD3D_E_UNSUPPORTED. */
+typedef enum vd3d_preview {
+  VD3D_PREVIEW_INTERLACED = 0,   /* even rows left, odd rows right */
+  VD3D_PREVIEW_HSBS = 1,         /* cv2.resize(eye, (w/2, h)) (INTER_LINEAR, 11-bit fixed point) + hstack */
+  VD3D_PREVIEW_LR_DIFF = 2,      /* cv2.absdiff */
+  VD3D_PREVIEW_FEATHER_BLEND = 3,/* the left eye */
+  VD3D_PREVIEW_RED_BLUE = 4      /* (right.B, right.G, left.R) */
+} vd3d_preview;
+int vd3d_preview_image(vd3d_ctx* ctx, int type, const uint8_t* left_bgr, const uint8_t* right_bgr, int h, int w, uint8_t* out_bgr);
+
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux
  * (core/render_3d.py:1340-1419) on two u8 eyes. depth_norm is the eye-res normalised depth. */

@@ -208,6 +208,23 @@ def resize_area(img, dw, dh):
     return out
 
 
+PREVIEW_TYPES = {"Passive Interlaced": 0, "HSBS": 1, "Left-Right Diff": 2, "Feather Blend": 3, "Red-Blue Anaglyph": 4}
+
+
+def preview_image(preview_type, left, right):
+    """generate_preview_image(preview_type, left, right, shift_map, w, h) for the exactly defined types."""
+    if preview_type not in PREVIEW_TYPES:
+        raise NotImplementedError(f"oracle: preview type {preview_type!r}")
+    L, pl = _u(left)
+    R, pr = _u(right)
+    h, w = L.shape[:2]
+    t = PREVIEW_TYPES[preview_type]
+    out = np.empty((h, 2 * (w // 2) if t == 1 else w, 3), np.uint8)
+    if lib().vo_preview_image(t, pl, pr, h, w, out.ctypes.data_as(_u8p)):
+        raise NotImplementedError(f"oracle: preview type {preview_type!r}")
+    return out
+
+
 def detect_black_bars(frame_bgr):
     """detect_black_bars(frame_to_tensor(frame_bgr)) -> (top, bottom)."""
     img, pi = _u(frame_bgr)

@@ -371,8 +371,28 @@ def gen_widen():
     save("widen.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 6. preview visualisers: core/preview_utils.py:generate_preview_image, the exactly defined types
+# ------------------------------------------------------------------------------------------
+PREVIEW_TYPES = ["Passive Interlaced", "HSBS", "Left-Right Diff", "Feather Blend", "Red-Blue Anaglyph"]
+
+
+def gen_previews():
+    pu = rl.load_preview_utils()
+    out = {}
+    for tag, (h, w) in {"even": (54, 96), "odd": (37, 75)}.items():
+        left = synth.synth_frame(1, h, w)[0]
+        right = synth.synth_frame(2, h, w)[0]
+        shift = torch.zeros(1, h, w)
+        for pt in PREVIEW_TYPES:
+            out[f"{tag}__{pt}"] = pu.generate_preview_image(pt, left, right, shift, w, h)
+    save("previews.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews"]
+    if "previews" in which:
+        gen_previews()
     if "widen" in which:
         gen_widen()
     if "kat" in which:

@@ -52,6 +52,20 @@ def load():
     return _cached
 
 
+def load_preview_utils():
+    """The reference's ``core/preview_utils.py`` (needs ``core.render_3d`` loaded first)."""
+    load()
+    name = "preview_utils"
+    if f"core.{name}" in sys.modules:
+        return sys.modules[f"core.{name}"]
+    spec = importlib.util.spec_from_file_location(f"core.{name}", os.path.join(REF_ROOT, "core", f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[f"core.{name}"] = mod
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(mod)
+    return mod
+
+
 def reset_state(r3d=None):
     """Reset the module-level tracker singletons."""
     r3d = r3d or load()

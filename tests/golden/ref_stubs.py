@@ -200,6 +200,10 @@ def split(img):
     return [np.ascontiguousarray(img[..., i]) for i in range(img.shape[2])]
 
 
+def absdiff(a, b):
+    return np.abs(np.asarray(a).astype(np.int16) - np.asarray(b).astype(np.int16)).astype(np.uint8)
+
+
 def merge(chs):
     return np.stack(chs, axis=2)
 
@@ -318,7 +322,7 @@ def install():
         "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR",
         "INTER_NEAREST", "INTER_LINEAR", "INTER_CUBIC", "INTER_AREA",
         "CAP_PROP_POS_FRAMES", "CAP_PROP_FRAME_WIDTH", "CAP_PROP_FRAME_HEIGHT", "CAP_PROP_FPS",
-        "CAP_PROP_FRAME_COUNT", "cvtColor", "filter2D", "resize", "split", "merge", "bitwise_and",
+        "CAP_PROP_FRAME_COUNT", "cvtColor", "filter2D", "resize", "split", "merge", "absdiff", "bitwise_and",
         "VideoWriter_fourcc", "VideoCapture", "VideoWriter")}
     _mod("cv2", _vd3d_stub=True, **cv2_attrs)
 

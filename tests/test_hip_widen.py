@@ -207,3 +207,18 @@ def test_autocrop_in_sharded_steps_equals_sequential(R):
     assert (crops[:, 1] >= 10).all() and (crops[:, 3] <= 96).all()      # the letterbox rows are gone from every frame's rectangle
     for rr in ranks:
         rr.close()
+
+
+def test_preview_visualisers_vs_oracle_and_golden(R, oracle):
+    from visiondepth3d_amd.preview_utils import PREVIEW_TYPES, generate_preview_image, preview_image
+    g = load_golden("previews.npz")
+    for tag, (h, w) in {"even": (54, 96), "odd": (37, 75), "hd": (1080, 1920)}.items():
+        left, right = synth.synth_frame(1, h, w)[0], synth.synth_frame(2, h, w)[0]
+        for pt in PREVIEW_TYPES:
+            got = preview_image(R, pt, T(left), T(right)).cpu().numpy()
+            assert np.array_equal(got, oracle.preview_image(pt, left, right)), (tag, pt)
+            if tag != "hd":
+                assert np.array_equal(got, g[f"{tag}__{pt}"]), (tag, pt)
+    with pytest.raises(NotImplementedError):
+        generate_preview_image("Shift Heatmap", left, right, None, w, h)
+    assert generate_preview_image("no such preview", left, right, None, w, h) is None      # the reference returns None as well

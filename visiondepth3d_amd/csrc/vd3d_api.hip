@@ -762,6 +762,15 @@ VD3D_EXPORT int vd3d_upsample_bilinear_nhwc_bf16(vd3d_ctx* c, const void* in, vo
   return 0;
 }
 
+VD3D_EXPORT int vd3d_preview_image(vd3d_ctx* c, int type, const uint8_t* left_bgr, const uint8_t* right_bgr, int h, int w, uint8_t* out_bgr) {
+  if (!c || !left_bgr || !right_bgr || !out_bgr || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!vd_launch_preview(c->stream, type, left_bgr, right_bgr, h, w, out_bgr))
+    return set_err(VD3D_E_UNSUPPORTED, "preview type %d (colour-mapped heat-maps / arrow overlay need OpenCV's tables and rasteriser)", type);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
   if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

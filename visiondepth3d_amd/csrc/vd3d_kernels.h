@@ -131,6 +131,7 @@ void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
                          const vd_finish_consts& fc, uint8_t* out);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
 
+bool vd_launch_preview(hipStream_t s, int type, const uint8_t* L, const uint8_t* R, int h, int w, uint8_t* out);
 // ---- vd3d_depthprep.hip
 bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, int W, int th, int tw, const float mean[3],
                           const float stdv[3], void* out_bf16_nhwc);

@@ -547,3 +547,56 @@ void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t byt
   hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
   if (bytes % 16) hipMemcpyAsync((char*)dst + n16 * 16, (const char*)src + n16 * 16, bytes % 16, hipMemcpyDeviceToDevice, s);
 }
+
+// ------------------------------------------------------------------------------------------------
+// preview visualisers (core/preview_utils.py:23-84): one thread per output pixel
+// ------------------------------------------------------------------------------------------------
+// hal::resize INTER_LINEAR coefficients for 8-bit (11-bit fixed point), one destination index
+VD_DEV void vd_lin_coef(int ssize, int dsize, int d, int* idx, int* a0, int* a1) {
+  const double scale = 1.0 / ((double)dsize / ssize);
+  float fx = (float)((d + 0.5) * scale - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+  *idx = sx;
+  *a0 = (int)rintf((1.f - fx) * 2048.f);
+  *a1 = (int)rintf(fx * 2048.f);
+}
+__global__ __launch_bounds__(256) void k_preview(int type, const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int h, int w,
+                                                 uint8_t* __restrict__ out) {
+  const int ow = type == VD3D_PREVIEW_HSBS ? 2 * (w / 2) : w;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ow || y >= h) return;
+  uint8_t* o = out + ((size_t)y * ow + x) * 3;
+  const size_t i = ((size_t)y * w + x) * 3;
+  switch (type) {
+    case VD3D_PREVIEW_INTERLACED: { const uint8_t* s = (y & 1) ? R : L; o[0] = s[i]; o[1] = s[i + 1]; o[2] = s[i + 2]; } break;
+    case VD3D_PREVIEW_LR_DIFF:
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { const int d = (int)L[i + c] - (int)R[i + c]; o[c] = (uint8_t)(d < 0 ? -d : d); }
+      break;
+    case VD3D_PREVIEW_FEATHER_BLEND: o[0] = L[i]; o[1] = L[i + 1]; o[2] = L[i + 2]; break;
+    case VD3D_PREVIEW_RED_BLUE: o[0] = R[i]; o[1] = R[i + 1]; o[2] = L[i + 2]; break;
+    case VD3D_PREVIEW_HSBS: {
+      const int hw = w / 2;
+      const uint8_t* s = x < hw ? L : R;
+      int xi, a0, a1;
+      vd_lin_coef(w, hw, x < hw ? x : x - hw, &xi, &a0, &a1);
+      const int x1 = xi + 1 < w ? xi + 1 : w - 1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {   // height unchanged: beta = (2048, 0)
+        const int r0 = (int)s[((size_t)y * w + xi) * 3 + c] * a0 + (int)s[((size_t)y * w + x1) * 3 + c] * a1;
+        const int q = (((2048 * (r0 >> 4)) >> 16) + 2) >> 2;
+        o[c] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+      }
+    } break;
+  }
+}
+bool vd_launch_preview(hipStream_t s, int type, const uint8_t* L, const uint8_t* R, int h, int w, uint8_t* out) {
+  if (type < VD3D_PREVIEW_INTERLACED || type > VD3D_PREVIEW_RED_BLUE) return false;
+  const int ow = type == VD3D_PREVIEW_HSBS ? 2 * (w / 2) : w;
+  if (ow < 1) return false;
+  hipLaunchKernelGGL(k_preview, dim3((ow + 63) / 64, (h + 3) / 4), dim3(256), 0, s, type, L, R, h, w, out);
+  return true;
+}
