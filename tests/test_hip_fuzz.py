@@ -1,0 +1,112 @@
+"""Seeded randomised parity sweep (-m gpu): HIP (C ABI) vs the CPU oracle over the parameter space of the loop body and of
+pixel_shift_cuda -- sizes, formats, fit ratios, feather kernels, DOF radii, colour grade, tracking switches, crops, depth formats.
+Every case is bit-exact (muxed frames, per-frame scalars, tracker state).  Deterministic: case i uses numpy Generator(seed i)."""
+import numpy as np
+import pytest
+
+from conftest import u8_diff_stats
+from visiondepth3d_amd import synth
+from visiondepth3d_amd._abi import ShiftParams, State
+from visiondepth3d_amd._lib import Vd3dError
+from visiondepth3d_amd.params import render_kwargs_to_params
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+FORMATS = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph", "VR"]
+
+
+@pytest.fixture(scope="module")
+def R():
+    from visiondepth3d_amd.render_3d import Renderer
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _random_render_kw(rng):
+    fmt = FORMATS[int(rng.integers(0, len(FORMATS)))]
+    # source sizes: mostly 16:9-ish, sometimes 4:3 / scope so the aspect crop triggers
+    h = int(rng.integers(36, 110))
+    aspect = [16 / 9, 16 / 9, 4 / 3, 2.39, 1.0][int(rng.integers(0, 5))]
+    w = max(32, int(round(h * aspect)))
+    preserve = bool(rng.integers(0, 2)) and fmt != "VR"
+    kw = dict(output_format=fmt, output_height=int(rng.integers(40, 120)) if fmt != "VR" else int(rng.integers(820, 1100)),
+              fg_shift=float(rng.uniform(0, 25)), mg_shift=float(rng.uniform(-8, 4)), bg_shift=float(rng.uniform(-20, 0)),
+              sharpness_factor=float(rng.uniform(0.0, 0.6)), dof_strength=float([0.0, 1.0, 2.0, 2.0, 3.0][int(rng.integers(0, 5))]),
+              feather_strength=float(rng.uniform(0, 20)), blur_ksize=int(rng.integers(1, 12)),
+              use_subject_tracking=bool(rng.integers(0, 2)), use_floating_window=bool(rng.integers(0, 2)),
+              max_pixel_shift_percent=float(rng.uniform(0.005, 0.05)), zero_parallax_strength=float(rng.uniform(0, 0.02)),
+              enable_edge_masking=bool(rng.integers(0, 4) > 0), enable_feathering=bool(rng.integers(0, 4) > 0),
+              convergence_strength=float([0.0, 0.0, 2.0, -1.5][int(rng.integers(0, 4))]),
+              enable_dynamic_convergence=bool(rng.integers(0, 2)), ipd_factor=float([1.0, 1.0, 0.0, 1.3][int(rng.integers(0, 4))]),
+              color_saturation=float(rng.uniform(0.8, 1.4)), color_contrast=float(rng.uniform(0.9, 1.2)),
+              color_brightness=float(rng.uniform(-0.05, 0.05)), auto_crop_black_bars=bool(rng.integers(0, 4) == 0))
+    if preserve:
+        kw.update(preserve_original_aspect=True, original_video_width=w, original_video_height=h)
+    return h, w, kw
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_render_loop_fuzz(R, oracle, seed):
+    rng = np.random.default_rng(seed)
+    sh, sw, kw = _random_render_kw(rng)
+    try:
+        p = render_kwargs_to_params(sw, sh, **kw)
+    except NotImplementedError:
+        pytest.skip("feature outside the built scope")
+    depth_as = ["bgr_u8", "gray_u8", "f32"][int(rng.integers(0, 3))]
+    n = 3
+    if kw["auto_crop_black_bars"] and sh >= 60:
+        frames, dbgr = synth.letterbox_clip(n, sh, sw, int(rng.integers(2, 9)), int(rng.integers(2, 9)))
+        depths = [d[..., 0].astype(np.float32) / 255.0 for d in dbgr]
+    else:
+        frames, depths = synth.synth_clip(n, sh, sw, start=seed)
+        dbgr = [synth.depth_to_u8_bgr(d) for d in depths]
+    ds = {"bgr_u8": dbgr, "gray_u8": [d[..., 0].copy() for d in dbgr], "f32": [np.ascontiguousarray(d, np.float32) for d in depths]}[depth_as]
+    fmt_id = {"bgr_u8": 1, "gray_u8": 2, "f32": 0}[depth_as]
+    R.reset_state(); R.new_clip()
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    for t in range(n):
+        try:
+            got = R.render_frame(T(frames[t]), T(ds[t]), p).cpu().numpy()
+        except Vd3dError as e:
+            assert e.code == -4, (seed, kw, str(e))      # loud refusal of something outside the built scope is fine; anything else is not
+            pytest.skip(f"refused: {e}")
+        exp = ro.render(frames[t], ds[t], fmt_id)
+        a, b = R.last_scalars().as_dict(), ro.last.as_dict()
+        assert a == b, (seed, t, {k: (a[k], b[k]) for k in a if a[k] != b[k]}, kw)
+        assert np.array_equal(got, exp), (seed, t, u8_diff_stats(got, exp), kw)
+    assert R.export_state().as_dict() == ro.state.as_dict(), (seed, kw)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_pixel_shift_fuzz(R, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    ih, iw = int(rng.integers(16, 90)), int(rng.integers(24, 150))
+    if rng.integers(0, 3) == 0:
+        H, W = ih, iw
+    else:
+        H, W = int(rng.integers(16, 140)), int(rng.integers(24, 230))
+    kw = dict(blur_ksize=int(rng.integers(1, 14)), feather_strength=float(rng.uniform(0, 25)),
+              use_subject_tracking=bool(rng.integers(0, 2)), enable_floating_window=bool(rng.integers(0, 2)),
+              max_pixel_shift_percent=float(rng.uniform(0.004, 0.08)), zero_parallax_strength=float(rng.uniform(0, 0.03)),
+              enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+              convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+              depth_pop_gamma=float(rng.uniform(0.6, 1.3)), depth_pop_mid=float(rng.uniform(0.35, 0.65)),
+              parallax_balance=float(rng.uniform(0.5, 1.0)))
+    bgr, d = synth.synth_frame(seed, ih, iw)
+    ft = oracle.frame_to_tensor(bgr)
+    p = ShiftParams.defaults(float(rng.uniform(0, 30)), float(rng.uniform(-10, 5)), float(rng.uniform(-25, 0)), **kw)
+    st = State()
+    o = oracle.pixel_shift(ft, d[None], W, H, p, st, want_shift=True)
+    R.reset_state()
+    L, Rr, S = R.pixel_shift(T(ft), T(d[None]), W, H, p, want_shift=True)
+    assert np.array_equal(S.cpu().numpy(), o["shift"]), (seed, ih, iw, H, W, kw)
+    assert np.array_equal(L.cpu().numpy(), o["left"]), (seed, ih, iw, H, W, kw, u8_diff_stats(L.cpu().numpy(), o["left"]))
+    assert np.array_equal(Rr.cpu().numpy(), o["right"]), (seed, ih, iw, H, W, kw)
+    assert R.export_state().fw_prev_offset == st.fw_prev_offset
