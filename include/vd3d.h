@@ -222,6 +222,9 @@ int vd3d_shard2_p0(vd3d_ctx* ctx, const uint8_t* frame_bgr, const vd3d_render_pa
 int vd3d_shard2_set_crops(vd3d_ctx* ctx, const int* crops_all_dev, int n);
 int vd3d_shard2_p1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void* depth, int depth_fmt,
                    const vd3d_render_params* p, int step_idx, int slot, float* q_out_dev);
+/* a run of `count` consecutive FOREIGN frames in one launch (== count calls of vd3d_shard2_p1 with slot = -1) */
+int vd3d_shard2_p1_foreign(vd3d_ctx* ctx, const void* const* depth_ptrs_host, int count, int depth_fmt,
+                           const vd3d_render_params* p, int step_idx_first);
 int vd3d_shard2_r1(vd3d_ctx* ctx, const float* q_all_dev, int n);
 int vd3d_shard2_p3(vd3d_ctx* ctx, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev);
 int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);

@@ -632,6 +632,33 @@ VD3D_EXPORT int vd3d_shard2_set_crops(vd3d_ctx* c, const int* crops_all_dev, int
   c->crop_tab_set = true;
   return 0;
 }
+// P1 for a RUN of consecutive foreign frames (step indices step_idx_first .. +count-1): one launch instead of `count`
+// (depth_ptrs_host: `count` device pointers to the depth planes, same depth_fmt).  Equivalent to `count` vd3d_shard2_p1(slot = -1) calls.
+VD3D_EXPORT int vd3d_shard2_p1_foreign(vd3d_ctx* c, const void* const* depth_ptrs_host, int count, int depth_fmt,
+                                       const vd3d_render_params* p, int step_idx_first) {
+  if (!c || !depth_ptrs_host || !p || count < 1 || step_idx_first < 0 || step_idx_first + count > VD_MAX_STEP)
+    return set_err(VD3D_E_INVALID, "bad argument");
+  if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
+  if (p->auto_crop_black_bars && !c->crop_tab_set)
+    return set_err(VD3D_E_INVALID, "auto_crop_black_bars in a sharded step: call vd3d_shard2_p0 / vd3d_shard2_set_crops first");
+  if (!c->tdf || c->eye_h != p->eye_h || c->eye_w != p->eye_w) return set_err(VD3D_E_INVALID, "vd3d_shard_begin first");
+  HIPCHK(hipSetDevice(c->device));
+  vd_stage_args a; vd3d_shift_params sp;
+  shard2_args(c, p, &a, &sp);
+  a.shard = 4;
+  a.crop_tab = p->auto_crop_black_bars ? c->crop_tab : nullptr;
+  StageTimer t(c, "p1_foreign");
+  for (int done = 0; done < count; done += VD_MULTI_MAX) {
+    const int m = count - done < VD_MULTI_MAX ? count - done : VD_MULTI_MAX;
+    vd_depth_list dl;
+    for (int k = 0; k < VD_MULTI_MAX; ++k) dl.d[k] = k < m ? depth_ptrs_host[done + k] : nullptr;
+    if (!dl.d[0]) return set_err(VD3D_E_INVALID, "NULL depth plane");
+    a.shard_idx = step_idx_first + done;
+    vd_launch_tdf_multi(c->stream, dl, m, depth_fmt, *p, c->work, c->tdf, a);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 // R1: replay DepthPercentileEMA over the n frames of the step from the exchanged quantiles q_all_dev[n][2] (frame order)
 VD3D_EXPORT int vd3d_shard2_r1(vd3d_ctx* c, const float* q_all_dev, int n) {
   if (!c || !q_all_dev || n < 1 || n > VD_MAX_STEP || !c->etab) return set_err(VD3D_E_INVALID, "bad argument");

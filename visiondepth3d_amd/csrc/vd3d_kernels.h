@@ -93,6 +93,10 @@ void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth,
                          float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a);
 void vd_launch_chain_eye_lite(hipStream_t s, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
                               const vd_stage_args& a);   // a.shard == 4: the plane EMA of a foreign frame, nothing else
+#define VD_MULTI_MAX 15
+struct vd_depth_list { const void* d[VD_MULTI_MAX]; };
+void vd_launch_tdf_multi(hipStream_t s, const vd_depth_list& dl, int count, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
+                         const vd_stage_args& a);   // plane EMA over `count` consecutive foreign frames in one launch
 void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
                           vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
                           const vd_stage_args& a);   // a.shard == 2 (foreign frame): eye-res part only, no warp-res select

@@ -992,6 +992,43 @@ void vd_launch_chain_eye_lite(hipStream_t s, const void* depth, int fmt, const v
                      (float*)nullptr, tdf, (uint32_t*)nullptr, (const uint32_t*)nullptr, a);
 }
 
+// TemporalDepthFilter (:220-229) over `count` CONSECUTIVE foreign frames of a sharded step in one launch: each eye-res pixel's EMA
+// chain is independent of every other pixel, so the frames are walked per pixel in registers (same float32 expression per frame as
+// vd_ingest_pixel: nv = 0.5f*prev + (float)(1-0.5)*cur), one read of each depth plane, one read + one write of the filtered plane.
+__global__ __launch_bounds__(1024) void k_tdf_multi(vd_depth_list dl, int count, int fmt, vd3d_render_params p, vd_dev_work* w,
+                                                    float* __restrict__ tdf, vd_stage_args a) {
+  __shared__ uint32_t sflag;
+  const long long n = (long long)p.eye_h * p.eye_w;
+  const int tdf_valid = w->st.tdf_valid;
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+    const long long i = base + threadIdx.x;
+    if (i >= n) continue;
+    const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
+    float prev = tdf_valid ? tdf[i] : 0.f;
+    int valid = tdf_valid;
+    for (int k = 0; k < count; ++k) {
+      int cx = p.crop_x, cy = p.crop_y, cw = p.crop_w, ch = p.crop_h;
+      if (p.auto_crop_black_bars) { const int* cr = a.crop_tab + 4 * (a.shard_idx + k); cx = cr[0]; cy = cr[1]; cw = cr[2]; ch = cr[3]; }
+      const vd_tap ty = vd_interp_tap(ch, p.eye_h, ey), tx = vd_interp_tap(cw, p.eye_w, ex);
+      const size_t i00 = (size_t)(ty.i0 + cy) * p.src_w + (tx.i0 + cx), i01 = (size_t)(ty.i0 + cy) * p.src_w + (tx.i1 + cx);
+      const size_t i10 = (size_t)(ty.i1 + cy) * p.src_w + (tx.i0 + cx), i11 = (size_t)(ty.i1 + cy) * p.src_w + (tx.i1 + cx);
+      const void* dk = dl.d[k];
+      const float cur = vd_bilerp(vd_depth_at(dk, fmt, i00), vd_depth_at(dk, fmt, i01), vd_depth_at(dk, fmt, i10), vd_depth_at(dk, fmt, i11),
+                                  tx.w0, tx.w1, ty.w0, ty.w1);
+      const float pv = valid ? prev : cur;
+      prev = 0.5f * pv + (float)(1 - 0.5) * cur;
+      valid = 1;
+    }
+    tdf[i] = prev;
+  }
+  if (last_workgroup(&w->ticket[0], &sflag, a.dbg) && threadIdx.x == 0) w->st.tdf_valid = 1;
+}
+void vd_launch_tdf_multi(hipStream_t s, const vd_depth_list& dl, int count, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
+                         const vd_stage_args& a) {
+  const long long ne = (long long)p.eye_h * p.eye_w;
+  hipLaunchKernelGGL(k_tdf_multi, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, dl, count, fmt, p, w, tdf, a);
+}
+
 // src = the filtered plane (render path: have_eye) or the caller's depth plane (bare pixel_shift_cuda)
 void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
                           vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,

@@ -195,6 +195,12 @@ class Renderer:
         _lib.check(self._L.vd3d_shard2_p1(self._ctx, _ptr(f) if f is not None else None, _ptr(d), self._depth_fmt(d), C.byref(params),
                                           int(step_idx), int(slot), _ptr(q_out) if q_out is not None else None))
 
+    def shard2_p1_foreign(self, depths, params: RenderParams, step_idx_first: int):
+        """A run of consecutive foreign frames (list of device depth planes of one format) in one launch."""
+        ds = [d.to(self.device).contiguous() for d in depths]
+        arr = (C.c_void_p * len(ds))(*[d.data_ptr() for d in ds])
+        _lib.check(self._L.vd3d_shard2_p1_foreign(self._ctx, arr, len(ds), self._depth_fmt(ds[0]), C.byref(params), int(step_idx_first)))
+
     def shard2_r1(self, q_all: torch.Tensor):
         q = q_all.to(self.device, torch.float32).contiguous()
         _lib.check(self._L.vd3d_shard2_r1(self._ctx, _ptr(q), q.numel() // 2))

@@ -216,15 +216,34 @@ class MeasureReplaySharder:
         self.r.shard2_set_crops(self._frame_order(self.gather(self.c_local)))
 
     def p1(self, frames_local, depth_all: torch.Tensor):
+        """Every frame of the step in order; runs of consecutive foreign frames go down as ONE launch each (per-pixel EMA chains
+        are independent), so a rank issues about 2 * B launches for the foreign frames of a step instead of (world-1) * B."""
         G, B = self.world, self.B
+        run, run_first = [], 0
+        multi = hasattr(self.r, "shard2_p1_foreign")
+
+        def flush():
+            nonlocal run
+            if run:
+                if multi:
+                    self.r.shard2_p1_foreign(run, self.p, run_first)
+                else:
+                    for k, d in enumerate(run):
+                        self.r.shard2_p1(None, d, self.p, run_first + k, slot=-1)
+                run = []
+
         for j in range(B):
             for g in range(G):
                 t = j * G + g
                 d = depth_all[g * B + j]
                 if g == self.rank:
+                    flush()
                     self.r.shard2_p1(frames_local[j], d, self.p, t, slot=j, q_out=self.q_local[j])
                 else:
-                    self.r.shard2_p1(None, d, self.p, t, slot=-1)
+                    if not run:
+                        run_first = t
+                    run.append(d)
+        flush()
 
     def p3(self):
         for j in range(self.B):
