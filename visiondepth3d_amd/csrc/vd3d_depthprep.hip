@@ -18,7 +18,7 @@
 struct vd_prep_args {
   int B, H, W, th, tw;
   float scale_h, scale_w;
-  float mean[3], rstd_dummy[3], stdv[3];
+  float mean[3], stdv[3];
   int in_rows_max, in_cols_max;   // capacity of the input tile (host-computed bound)
 };
 
@@ -121,7 +121,7 @@ bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, in
   a.scale_h = (float)H / (float)th; a.scale_w = (float)W / (float)tw;
   const float sup_w = a.scale_w >= 1.f ? 2.f * a.scale_w : 2.f, sup_h = a.scale_h >= 1.f ? 2.f * a.scale_h : 2.f;
   if ((int)(2.f * sup_w) + 2 > DP_KMAX || (int)(2.f * sup_h) + 2 > DP_KMAX) return false;
-  for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.stdv[c] = stdv[c]; a.rstd_dummy[c] = 0.f; }
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.stdv[c] = stdv[c]; }
   a.in_cols_max = (int)(a.scale_w * DP_TX + 2.f * sup_w) + 4;
   a.in_rows_max = (int)(a.scale_h * DP_TY + 2.f * sup_h) + 4;
   size_t lds = sizeof(float) * (DP_TX + DP_TY) * DP_KMAX + sizeof(int) * 2 * (DP_TX + DP_TY) +

@@ -4,10 +4,11 @@
 // (core/render_3d.py:684-712): warped-depth gradient mask -> k x k separable window average -> RGB warp of both
 // eyes -> feather blend -> tensor_to_frame truncation, with NO intermediate planes in HBM.
 //
-// Per 64x32 output tile (512 threads, 2 workgroups per CU):
-//   phase A warped depth of both eyes on the (TH+k) x (TW+k) halo: S loads then D gathers (L2), fixed unroll for ILP
-//   (the eye-res RGB tile is requested from HBM before phase A into registers and lands in LDS afterwards)
+// Per 64x32 output tile (512 threads, 3 workgroups per CU at 4K / k = 9: the LDS buffers alias, see the kernel):
+//   tables  row taps (wave-uniform) and column taps of the resize, grid_sample row parts -> LDS, once per tile
+//   phase A warped depth of BOTH eyes (one packed-f32 vector) on the (TH+k) x (TW+k) halo: S loads, then D gathers (L2)
 //   phase B e2 = clamp(|grad WD| * fs, 0, 1)            phase C horizontal k-sums (ascending x)
+//           (the eye-res RGB tile is prefetched into registers during B / C and lands over the dead wd / e2 buffers)
 //   phase D vertical k-sums -> b, RGB samples = nested bilinear (resize of :595 inside the grid_sample of :697)
 //           read from the LDS eye tile, one row per wave (row-uniform taps; exact skip of the south samples when the
 //           sample row is integral), blend, truncate, shuffle-packed 12-byte stores per 4 lanes.
@@ -74,15 +75,6 @@ VD_DEV void wf_gs_row(float gy, int H, int* yn, float* n, float* sr, bool* s_ok)
   const float f = floorf(iy);
   *n = iy - f; *sr = 1.f - (iy - f); *yn = (int)f; *s_ok = ((int)f + 1) < H;
 }
-struct wf_tap2 { int i0[2], i1[2]; vd_f2 w0, w1; };
-VD_DEV wf_tap2 wf_tap_pair(int in, int out, float scale, int oa, int ob) {
-  const vd_tap a = wf_tap(in, out, scale, oa), b = wf_tap(in, out, scale, ob);
-  wf_tap2 t;
-  t.i0[0] = a.i0; t.i0[1] = b.i0; t.i1[0] = a.i1; t.i1[1] = b.i1;
-  t.w0 = vd_f2{a.w0, b.w0}; t.w1 = vd_f2{a.w1, b.w1};
-  return t;
-}
-
 // RGB tile: prefetched registers -> LDS (+ the rare overflow elements straight from global)
 #define WF_STORE_TILE                                                                                                   \
   {                                                                                                                     \
