@@ -3,15 +3,18 @@
 // Replaces the reference's torch.quantile / torch.median / torch.histc call sites
 // (core/render_3d.py:154-170,249-250,536-537; 51 % of the reference's CPU time is aten::sort there).
 // No sort: values live in [0,1], so the float bit pattern is a monotone uint32 key.
-//   pass A  : 16-bit-prefix histogram (16257 live bins) privatised in LDS (65 KB / job), wave-aggregated
-//             ds_add, one global atomic per non-empty bin per workgroup;
+//   pass A  : 16-bit-prefix histogram (16257 live bins) privatised in LDS (65 KB / job), plain returnless ds_add
+//             (measured faster than ballot / shuffle aggregation), one global atomic per non-empty bin per workgroup;
 //   scan A  : one workgroup prefix-scans the bins, derives the requested ranks on device
 //             (torch.quantile's float32 rank arithmetic, the lower-median index, the 64-bin histc arg-max
 //             which is an exact aggregation of the prefix bins) and records <= 4 target prefixes;
 //   pass B  : elements whose prefix is a target add to a 65536-bin histogram of their low 16 bits
-//             (global atomics, wave-aggregated -- a constant plane costs N/64 atomics, not N);
+//             (global atomics: <= 2 wave-leader aggregation rounds -- a constant plane costs N/64 atomics -- then one plain
+//             atomic per remaining lane: the hits are one value band of the plane, usually with distinct low bits);
 //   scan B  : locates each rank inside its target bin -> the exact float, then the scalar stage runs.
-// Everything stays on the device: no host synchronisation anywhere in the frame.
+// Everything stays on the device: no host synchronisation anywhere in the frame.  The file also holds the fused select chain
+// (K0-K6: passes riding on the producer kernels, scans + scalar stages run by the last workgroup) and the replay kernels of
+// the two frame-sharding protocols.
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 
