@@ -92,3 +92,47 @@ def test_render_loop_random_configurations(ref, oracle, seed):
     assert got.shape == written.shape, (got.shape, written.shape, kw)
     mx, frac, frac_gt1 = u8_diff_stats(got, written)
     assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2, (seed, mx, frac, frac_gt1, kw)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_helpers_random_inputs(ref, oracle, seed):
+    """Leaf functions of the path on random planes / parameters against the live reference: order statistics, subject depth,
+    dynamic parallax scale and motion metric exact; shaping, DOF and grade within 1 ULP / 1 LSB (SLEEF pow / exp in torch)."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    h, w = int(rng.integers(20, 70)), int(rng.integers(30, 110))
+    d = synth.synth_frame(seed, h, w)[1]
+    if seed % 3 == 0:     # a quantised plane (an 8-bit depth video): many ties in the order statistics
+        d = (np.floor(d * 255) / 255).astype(np.float32)
+    dt = torch.from_numpy(d.copy())[None]
+    # order statistics / subject depth: exact
+    for q in (0.02, 0.05, 0.5, 0.95, 0.98):
+        assert np.float32(oracle.quantile(d, q)) == np.float32(torch.quantile(dt.flatten(), q).item()), (seed, q)
+    assert np.float32(oracle.subject_depth(d)) == np.float32(ref.estimate_subject_depth(dt).item()), seed
+    # reductions: exact (the oracle's fixed-point sums are exact, torch's float32 tree sum is within the same float)
+    got = oracle.dynamic_parallax_scale(d, 0.90, 1.15)
+    exp = ref.compute_dynamic_parallax_scale(dt, 0.90, 1.15)
+    assert abs(got - exp) < 2e-6, (seed, got, exp)
+    d2 = synth.synth_frame(seed + 50, h, w)[1]
+    mm = oracle.motion_metric(d, d2)
+    assert abs(mm - ref.compute_motion_metric(dt, torch.from_numpy(d2.copy())[None])) < 2e-6, seed
+    # curvature + shaping: pow through SLEEF in torch vs correctly rounded here -> <= 1 ULP of values in [0,1]
+    c = oracle.curvature_clamp(d, 0.08)
+    c_ref = torch.clamp(ref.enhance_curvature(dt, strength=0.08), 0, 1)[0].numpy()
+    assert np.max(np.abs(c - c_ref)) <= 6e-8, seed
+    gamma, mid = float(rng.uniform(0.6, 1.3)), float(rng.uniform(0.4, 0.6))
+    s0 = ref.estimate_subject_depth(torch.from_numpy(c_ref.copy())[None])
+    sh_ref = ref.shape_depth_for_pop(torch.from_numpy(c_ref.copy())[None], s0, stretch_lo=0.05, stretch_hi=0.95, depth_mid=mid, gamma=gamma)[0].numpy()
+    sh = oracle.shape_depth_for_pop(c_ref, float(s0), 0.05, 0.95, mid, gamma)[0]
+    assert np.max(np.abs(sh - sh_ref)) <= 1.2e-7, (seed, float(np.max(np.abs(sh - sh_ref))))
+    # DOF + grade on a small eye: <= 1 LSB after truncation
+    bgr = synth.synth_frame(seed + 7, h, w)[0]
+    t = ref.frame_to_tensor(bgr)
+    focal, ms = float(rng.uniform(0.2, 0.8)), float([1.0, 2.0, 2.0, 3.0][int(rng.integers(0, 4))])
+    dof_ref = ref.apply_dof_cuda(t, dt, focal, max_sigma=ms, focus_width=0.35)
+    sat, con, bri = float(rng.uniform(0.8, 1.4)), float(rng.uniform(0.9, 1.2)), float(rng.uniform(-0.05, 0.05))
+    out_ref = ref.tensor_to_frame(ref.apply_color_grade(dof_ref, sat, con, bri))
+    tt = oracle.frame_to_tensor(bgr)
+    out = oracle.tensor_to_frame(oracle.color_grade(oracle.apply_dof(tt, d, focal, ms), sat, con, bri))
+    mx, frac, _ = u8_diff_stats(out, out_ref)
+    assert mx <= 1 and frac < 2e-2, (seed, mx, frac)     # separable FMA association vs torch's dense conv: 1-LSB truncation cliffs
