@@ -106,6 +106,17 @@ VD_DEV vd_tap vd_interp_tap_s(int in, int out, float scale, int o) {  // vd_inte
   return t;
 }
 
+// vd_interp_tap(in, 2*in, o) in closed form: scale = 0.5 exactly, src = 0.5*(o + 0.5) - 0.5 = 0.5*o - 0.25 (exact in float32), clamped
+// at 0 for o = 0; even o = 2m: i0 = m-1, l1 = 0.75; odd o = 2m+1: i0 = m, l1 = 0.25.  Same values as the general routine.
+VD_DEV vd_tap vd_tap21(int in, int o) {
+  vd_tap t;
+  if (o == 0) { t.i0 = 0; t.w1 = 0.f; }
+  else { t.i0 = (o - 1) >> 1; t.w1 = (o & 1) ? 0.25f : 0.75f; }
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  t.w0 = 1.f - t.w1;
+  return t;
+}
+
 // ATen Interpolate<>::eval association: fma(t0,w0,t1*w1), rows then columns
 VD_DEV float vd_bilerp(float p00, float p01, float p10, float p11, float wx0, float wx1, float wy0, float wy1) {
   float a = vd_fma(p00, wx0, wx1 * p01);

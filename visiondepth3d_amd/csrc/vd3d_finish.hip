@@ -90,16 +90,6 @@ VD_DEV void ff_level(ff_tile_t tile, const float* __restrict__ kern, bool active
   }
 }
 
-// vd_interp_tap(in, 2*in, o) in closed form: scale = 0.5 exactly, src = 0.5*(o + 0.5) - 0.5 = 0.5*o - 0.25 (exact in float32), clamped
-// at 0 for o = 0; even o = 2m: i0 = m-1, l1 = 0.75; odd o = 2m+1: i0 = m, l1 = 0.25.  Same values as the general routine.
-VD_DEV vd_tap ff_tap21(int in, int o) {
-  vd_tap t;
-  if (o == 0) { t.i0 = 0; t.w1 = 0.f; }
-  else { t.i0 = (o - 1) >> 1; t.w1 = (o & 1) ? 0.25f : 0.75f; }
-  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
-  t.w0 = 1.f - t.w1;
-  return t;
-}
 VD_DEV float ff_byte(uint32_t v, int sh) { return (float)((v >> sh) & 0xffu); }   // v_cvt_f32_ubyteN
 
 // 3x3 sharpen (:717-732) of 4 consecutive pixels of one row of the graded dword tile (interior: no reflection needed)
@@ -188,7 +178,7 @@ __global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restric
       float dd;
       if (a.eh == H && a.ew == W) dd = dn[(size_t)y * W + x];
       else if (2 * a.eh == H && 2 * a.ew == W) {   // exact 2:1 (Half-SBS): src = 0.5*o - 0.25 is exact, the tap is a parity rule
-        const vd_tap ay = ff_tap21(a.eh, y), ax = ff_tap21(a.ew, x);
+        const vd_tap ay = vd_tap21(a.eh, y), ax = vd_tap21(a.ew, x);
         const float* r0 = dn + (size_t)ay.i0 * a.ew;
         const float* r1 = dn + (size_t)ay.i1 * a.ew;
         dd = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);

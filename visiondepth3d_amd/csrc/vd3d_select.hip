@@ -763,7 +763,9 @@ struct FWorkSrc {
     float d;
     if (ih == H && iw == W) d = tap((size_t)y * W + x);
     else {
-      const vd_tap ty = vd_interp_tap_s(ih, H, scale_h, y), tx = vd_interp_tap_s(iw, W, scale_w, x);
+      const bool two = 2 * ih == H && 2 * iw == W;   // exact 2:1 (Half-SBS): closed-form taps, same values
+      const vd_tap ty = two ? vd_tap21(ih, y) : vd_interp_tap_s(ih, H, scale_h, y);
+      const vd_tap tx = two ? vd_tap21(iw, x) : vd_interp_tap_s(iw, W, scale_w, x);
       d = vd_bilerp(tap((size_t)ty.i0 * iw + tx.i0), tap((size_t)ty.i0 * iw + tx.i1), tap((size_t)ty.i1 * iw + tx.i0),
                     tap((size_t)ty.i1 * iw + tx.i1), tx.w0, tx.w1, ty.w0, ty.w1);
     }
