@@ -128,8 +128,10 @@ bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, in
                sizeof(float) * (size_t)a.in_rows_max * DP_TX * 3 + (size_t)a.in_rows_max * a.in_cols_max * 3;
   lds = (lds + 15) & ~(size_t)15;
   if (lds > 150 * 1024) return false;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_depth_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[64] = {false};   // per device: the attribute belongs to the device's copy of the code object
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)k_depth_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; }
   dim3 g((tw + DP_TX - 1) / DP_TX, (th + DP_TY - 1) / DP_TY, B);
   hipLaunchKernelGGL(k_depth_prep, g, dim3(256), lds, s, frames, a, reinterpret_cast<uint16_t*>(out_bf16_nhwc));
   return true;

@@ -434,13 +434,15 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   const size_t bytes = fl * sizeof(float);
   if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 53.1 KB)
   dim3 g((W + WF_TW - 1) / WF_TW, (H + WF_TH - 1) / WF_TH);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {false};   // per device: the attribute belongs to the device's copy of the code object
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr[dev]) {
     (void)hipFuncSetAttribute((const void*)k_warp_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_warp_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_warp_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_warp_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
+    attr[dev] = true;
   }
   if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
   else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
