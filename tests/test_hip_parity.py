@@ -368,6 +368,49 @@ def test_measure_replay_sharding_equals_sequential(R, oracle, G, B):
         rr.close()
 
 
+def test_measure_replay_partial_last_step(R, oracle):
+    """A clip whose length is not a multiple of world * B: the last step is partial (n_valid), frames past the end are skipped."""
+    from visiondepth3d_amd.render_3d import Renderer
+    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    sh, sw, G, B = 108, 192, 3, 2
+    kw = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    n = G * B + 4                    # one full step + a partial one with 4 of 6 frames
+    frames, depths = synth.synth_clip(n, sh, sw)
+    gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
+    R.reset_state(); R.new_clip()
+    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
+    st_seq = R.export_state().as_dict()
+    ranks = [Renderer(0) for _ in range(G)]
+    shd = []
+    for g_, rr in enumerate(ranks):
+        rr.reset_state(); rr.new_clip()
+        shd.append(MeasureReplaySharder(rr, p, g_, G, B))
+    zero_f, zero_d = T(np.zeros_like(frames[0])), T(np.zeros_like(gray[0]))
+    for base, nv in ((0, G * B), (G * B, 4)):
+        def fr(t):
+            return (T(frames[base + t]), T(gray[base + t])) if t < nv else (zero_f, zero_d)
+        loc_f = [[fr(j * G + g_)[0] for j in range(B)] for g_ in range(G)]
+        depth_all = torch.cat([torch.stack([fr(j * G + g_)[1] for j in range(B)]) for g_ in range(G)])
+        for g_ in range(G):
+            shd[g_].p1(loc_f[g_], depth_all, nv)
+        q_all = torch.cat([shd[g_].q_local for g_ in range(G)])
+        for g_ in range(G):
+            shd[g_].r.shard2_r1(shd[g_]._frame_order(q_all.clone())[:nv])
+            shd[g_].p3(nv)
+        m_all = torch.cat([shd[g_].m_local for g_ in range(G)])
+        for g_ in range(G):
+            outs = shd[g_].finish(m_all.clone(), n_valid=nv)
+            own = [j * G + g_ for j in range(B) if j * G + g_ < nv]
+            assert len(outs) == len(own)
+            for o, t in zip(outs, own):
+                assert np.array_equal(o.cpu().numpy(), seq[base + t]), (base, g_, t)
+    assert all(rr.export_state().as_dict() == st_seq for rr in ranks)
+    for rr in ranks:
+        rr.close()
+
+
 def test_measure_replay_world1_and_continuation(R, oracle):
     """world = 1 degenerates to the sequential render; a sequential frame rendered AFTER sharded steps continues exactly."""
     from visiondepth3d_amd.sharded import MeasureReplaySharder

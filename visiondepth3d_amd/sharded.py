@@ -209,16 +209,28 @@ class MeasureReplaySharder:
         G, B = self.world, self.B
         return gathered.view(G, B, -1).transpose(0, 1).reshape(G * B, -1).contiguous()
 
-    def p0(self, frames_local):
-        """auto_crop_black_bars: black-bar detection on the own frames, all-gather of the crop rectangles (16 B x frames)."""
-        for j in range(self.B):
-            self.r.shard2_p0(frames_local[j], self.p, self.c_local[j])
-        self.r.shard2_set_crops(self._frame_order(self.gather(self.c_local)))
+    # ``n_valid`` (all methods): number of real frames in this step (default: world * B).  The LAST step of a clip may be partial:
+    # frames t >= n_valid do not exist, their owners skip them, the collectives still move full-size buffers, and the replays stop
+    # at n_valid.  Valid frames are always a prefix of the step's frame order.
+    def _nv(self, n_valid):
+        n = self.world * self.B if n_valid is None else int(n_valid)
+        if not (1 <= n <= self.world * self.B):
+            raise ValueError("n_valid out of range")
+        return n
 
-    def p1(self, frames_local, depth_all: torch.Tensor):
+    def p0(self, frames_local, n_valid=None):
+        """auto_crop_black_bars: black-bar detection on the own frames, all-gather of the crop rectangles (16 B x frames)."""
+        n = self._nv(n_valid)
+        for j in range(self.B):
+            if j * self.world + self.rank < n:
+                self.r.shard2_p0(frames_local[j], self.p, self.c_local[j])
+        self.r.shard2_set_crops(self._frame_order(self.gather(self.c_local))[:n])
+
+    def p1(self, frames_local, depth_all: torch.Tensor, n_valid=None):
         """Every frame of the step in order; runs of consecutive foreign frames go down as ONE launch each (per-pixel EMA chains
         are independent), so a rank issues about 2 * B launches for the foreign frames of a step instead of (world-1) * B."""
         G, B = self.world, self.B
+        n = self._nv(n_valid)
         run, run_first = [], 0
         multi = hasattr(self.r, "shard2_p1_foreign")
 
@@ -235,6 +247,8 @@ class MeasureReplaySharder:
         for j in range(B):
             for g in range(G):
                 t = j * G + g
+                if t >= n:
+                    continue
                 d = depth_all[g * B + j]
                 if g == self.rank:
                     flush()
@@ -245,20 +259,24 @@ class MeasureReplaySharder:
                     run.append(d)
         flush()
 
-    def p3(self):
+    def p3(self, n_valid=None):
+        n = self._nv(n_valid)
         for j in range(self.B):
-            self.r.shard2_p3(j, j * self.world + self.rank, self.p, self.m_local[j])
+            if j * self.world + self.rank < n:
+                self.r.shard2_p3(j, j * self.world + self.rank, self.p, self.m_local[j])
 
-    def finish(self, m_gathered: torch.Tensor, outs=None, ordered: bool = False):
+    def finish(self, m_gathered: torch.Tensor, outs=None, ordered: bool = False, n_valid=None):
         """``ordered``: m_gathered is already in frame order (callers that run the renderer on a private stream do the reordering
-        inside that stream's context, see bench.py)."""
-        self.r.shard2_r2(m_gathered if ordered else self._frame_order(m_gathered), self.own_slots, self.p)
-        return [self.r.shard_pixels(j, self.p, out=None if outs is None else outs[j]) for j in range(self.B)]
+        inside that stream's context, see bench.py).  Returns the muxed frames of the valid own frames."""
+        n = self._nv(n_valid)
+        m = m_gathered if ordered else self._frame_order(m_gathered)
+        self.r.shard2_r2(m[:n], self.own_slots[:n], self.p)
+        return [self.r.shard_pixels(j, self.p, out=None if outs is None else outs[j]) for j in range(self.B) if j * self.world + self.rank < n]
 
-    def render_step(self, frames_local, depth_local: torch.Tensor, outs=None):
+    def render_step(self, frames_local, depth_local: torch.Tensor, outs=None, n_valid=None):
         if self.auto_crop:
-            self.p0(frames_local)
-        self.p1(frames_local, self.gather(depth_local))
-        self.r.shard2_r1(self._frame_order(self.gather(self.q_local)))
-        self.p3()
-        return self.finish(self.gather(self.m_local), outs)
+            self.p0(frames_local, n_valid)
+        self.p1(frames_local, self.gather(depth_local), n_valid)
+        self.r.shard2_r1(self._frame_order(self.gather(self.q_local))[:self._nv(n_valid)])
+        self.p3(n_valid)
+        return self.finish(self.gather(self.m_local), outs, n_valid=n_valid)
