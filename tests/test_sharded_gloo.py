@@ -219,7 +219,14 @@ def _proto2_worker(rank, world, port, outdir):
         depth_local = torch.stack([torch.full((4, 5), j * world + rank, dtype=torch.uint8) for j in range(B)])
         frames_local = [torch.full((4, 5, 3), j * world + rank, dtype=torch.uint8) for j in range(B)]
         outs = sr.render_step(frames_local, depth_local)
-        torch.save({"log": fr.log, "r1": fr.r1, "r2": fr.r2, "outs": [int(o) for o in outs]}, os.path.join(outdir, f"q{rank}.pt"))
+        rec = {"log": list(fr.log), "r1": fr.r1, "r2": fr.r2, "outs": [int(o) for o in outs]}
+        # a whole clip whose length (8) is not a multiple of world * B (6): one full step + a partial one
+        fr.log.clear()
+        got = list(sr.render_clip(8, lambda t: torch.full((4, 5, 3), t % 6, dtype=torch.uint8), lambda t: torch.full((4, 5), t % 6, dtype=torch.uint8)))
+        rec["clip_owned"] = [t for t, _ in got]
+        rec["clip_log_kinds"] = [e[0] for e in fr.log]
+        rec["clip_r2_len"] = int(fr.r2[0].shape[0])
+        torch.save(rec, os.path.join(outdir, f"q{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -246,3 +253,7 @@ def test_measure_replay_protocol_world2(tmp_path):
         assert m_all.tolist() == [[t, 100 + t, 200 + t, 300 + t] for t in range(n)]
         assert own == [(t // world if t % world == rank else -1) for t in range(n)]
         assert rec["outs"] == list(range(B))
+        # render_clip: 8 frames = step of 6 + partial step of 2 (frames 6, 7 -> one own frame per rank); replays stop at n_valid
+        assert rec["clip_owned"] == [t for t in range(8) if t % world == rank]
+        assert rec["clip_log_kinds"] == ["p1"] * 6 + ["r1"] + ["p3"] * 3 + ["r2"] + ["px"] * 3 + ["p1"] * 2 + ["r1"] + ["p3"] + ["r2"] + ["px"]
+        assert rec["clip_r2_len"] == 2

@@ -280,3 +280,28 @@ class MeasureReplaySharder:
         self.r.shard2_r1(self._frame_order(self.gather(self.q_local))[:self._nv(n_valid)])
         self.p3(n_valid)
         return self.finish(self.gather(self.m_local), outs, n_valid=n_valid)
+
+    def render_clip(self, n_frames: int, get_frame, get_depth):
+        """Render frames 0..n_frames-1 of one clip (callables return device tensors: uint8 BGR frame / depth plane of frame t).
+        Yields (t, muxed_frame) for the frames this rank owns, in increasing t; the last step may be partial.  Every rank must
+        call this with the same n_frames (the collectives are matched)."""
+        G, B = self.world, self.B
+        per_step = G * B
+        proto_f, proto_d = None, None
+        for base in range(0, n_frames, per_step):
+            nv = min(per_step, n_frames - base)
+            fl, dl = [], []
+            for j in range(B):
+                t = base + j * G + self.rank
+                if t < n_frames:
+                    f, d = get_frame(t), get_depth(t)
+                    proto_f, proto_d = f, d
+                else:   # past the end of the clip: a dummy contribution keeps the collectives full-size
+                    if proto_f is None:
+                        proto_f, proto_d = get_frame(n_frames - 1), get_depth(n_frames - 1)
+                    f, d = torch.zeros_like(proto_f), torch.zeros_like(proto_d)
+                fl.append(f); dl.append(d)
+            outs = self.render_step(fl, torch.stack(dl), n_valid=nv)
+            own = [base + j * G + self.rank for j in range(B) if j * G + self.rank < nv]
+            for t, o in zip(own, outs):
+                yield t, o
