@@ -118,6 +118,10 @@ def main():
                     "included, collectives replaced by local replication) to estimate the per-rank step time at G GPUs")
     ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
                     "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
+    ap.add_argument("--gated", action="store_true", help="alternative schedule: only the latency-bound measurement chain of batch i overlaps "
+                    "the depth net of batch i+1; the pixel kernels (k_shift, W1, E1) of batch i-1 run between two depth-net batches with "
+                    "the GPU to themselves (W1 at its isolated speed, but 4.5 %% lower end-to-end throughput than the default, where the "
+                    "whole DIBR chain shares the GPU with the depth net)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     args = ap.parse_args()
@@ -163,11 +167,15 @@ def main():
 
     shr = None
     emu = args.emulate_world if (world == 1 and args.emulate_world > 1) else 0
-    if world > 1 or args.sharded or emu:
+    gated = overlap and args.gated
+    shr2 = None
+    if world > 1 or args.sharded or emu or gated:
         from visiondepth3d_amd.sharded import MeasureReplaySharder
         shr = MeasureReplaySharder(r, p, rank, emu or world, B)
+        shr2 = [shr, MeasureReplaySharder(r, p, rank, emu or world, B, slot_base=B)] if gated else None
         if emu:   # every "other rank" contributes a copy of this rank's planes: same kernel work as a real G-rank step, no fabric
-            shr.gather = lambda t: t.repeat((emu,) + (1,) * (t.dim() - 1))
+            for s_ in (shr2 or [shr]):
+                s_.gather = lambda t: t.repeat((emu,) + (1,) * (t.dim() - 1))
 
     pipe = None
     if model_name:
@@ -179,6 +187,73 @@ def main():
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     done = [torch.cuda.Event() for _ in range(NBUF)]
     depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded or emu) else None
+    ev_pix = [None]          # gated schedule: completion of the most recently enqueued pixel pass
+    pending = [None]         # gated schedule: (sharder, ring slot or None) whose pixel pass has not been enqueued yet
+
+    def pixel_pass():
+        """gated schedule: pixel kernels of the pending step on the DIBR stream (the caller has ordered them after the depth net)."""
+        if pending[0] is None:
+            return
+        sh_, kr_ = pending[0]
+        with torch.cuda.stream(dibr_stream):
+            o_ = outs
+            if ring is not None:
+                ring.reserve_output(kr_)
+                o_ = ring.d_out[kr_]
+            sh_.pixels(o_)
+            if ring is not None:
+                ring.download(kr_)
+            e_ = torch.cuda.Event()
+            e_.record(dibr_stream)
+        ev_pix[0] = e_
+        pending[0] = None
+
+    def step_gated(i):
+        """D(i) on the depth-net stream | pixels(i-1) alone | chain(i) on the DIBR stream, overlapping D(i+1)."""
+        idx = [(i * B + j) % args.clip for j in range(B)]
+        contiguous = idx == list(range(idx[0], idx[0] + B))
+        fb = frames[idx[0]:idx[0] + B] if contiguous else frames[idx]
+        k = i % NBUF
+        sh_ = shr2[i % 2]
+        kr = None
+        if ring is not None:
+            kr = i % ring.n
+            ring.upload(kr, h_clip[idx[0]:idx[0] + B] if contiguous else h_clip[idx])
+            fb = ring.d_in[kr]
+        cur = torch.cuda.current_stream()
+        if ev_pix[0] is not None:
+            cur.wait_event(ev_pix[0])          # the depth net of this batch starts after the previous pixel pass: no sharing
+        cur.wait_event(done[k])                # hand-off buffer k: its measurement chain (two steps ago) is finished
+        pred = pipe.infer_bgr_u8(fb, raw=True)
+        dloc = rh.depth_handoff(pred, sh, sw, out=dbuf[k])
+        ev = torch.cuda.Event()
+        ev.record()
+        dibr_stream.wait_event(ev)             # DIBR stream: everything below runs after this batch's depth net
+        if ring is not None:
+            dibr_stream.wait_event(ring.ev_in[kr])
+        pixel_pass()                           # pixels(i-1): between D(i) and D(i+1), with the GPU to themselves
+        with torch.cuda.stream(dibr_stream):
+            dall = dloc
+            if world > 1:
+                dist.all_gather_into_tensor(gathered[k], dloc.contiguous())
+                dall = gathered[k]
+            elif emu:
+                dall = sh_.gather(dloc)
+        sh_.p1(fb, dall)
+        with torch.cuda.stream(dibr_stream):
+            sh_.r.shard2_r1(sh_._frame_order(sh_.gather(sh_.q_local)))
+        sh_.p3()
+        with torch.cuda.stream(dibr_stream):
+            sh_.replay(sh_._frame_order(sh_.gather(sh_.m_local)))
+        done[k].record(dibr_stream)
+        pending[0] = (sh_, kr)
+
+    def drain():
+        """gated schedule: the pixel pass of the last enqueued step (so that a timed region holds exactly its own steps)."""
+        if gated and pending[0] is not None:
+            if ev_pix[0] is not None:
+                pass
+            pixel_pass()
 
     def step(i):
         # this rank's B frames of the step; global frame order inside a step: (j, g) for j in range(B) for g in range(world)
@@ -243,14 +318,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run_step = step_gated if gated else step
     for i in range(args.warmup):
-        step(i)
+        run_step(i)
+    drain()
     fence()
     if not args.no_profile:
         r.set_profiling(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        run_step(args.warmup + i)
+    drain()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -267,7 +345,7 @@ def main():
     # W1 / E1 without the depth net sharing the CUs: a short DIBR-only pass AFTER the timed region (same frames, same kernels), so that
     # the contention of the overlapped end-to-end step can be told apart from the kernel itself (reported as roofline.isolated_*)
     iso_ms = {}
-    if rank == 0 and pipe is not None and not args.no_profile and shr is None:
+    if rank == 0 and pipe is not None and not args.no_profile and (shr is None or gated) and world == 1 and not emu:
         r.set_profiling(True)   # clears the accumulators of the timed region (already read above)
         for j in range(min(B, 8, len(depths))):
             r.render_frame(frames[j], depths[j], p, out=outs[j])

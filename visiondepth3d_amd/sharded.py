@@ -182,16 +182,19 @@ class MeasureReplaySharder:
     Output equals the sequential 1-GPU render bit for bit (tests/test_hip_parity.py, ranks emulated with one context each).
     """
 
-    def __init__(self, renderer, params, rank: int, world: int, frames_per_rank: int, group=None):
+    def __init__(self, renderer, params, rank: int, world: int, frames_per_rank: int, group=None, slot_base: int = 0):
+        """``slot_base``: first slot of the renderer this sharder uses (two sharders with slot_base 0 and B on one renderer keep
+        two steps in flight: the pixel pass of step i-1 can run after the measurements of step i were enqueued, bench.py)."""
         self.r, self.p, self.rank, self.world, self.B, self.group = renderer, params, rank, world, frames_per_rank, group
+        self.slot_base = int(slot_base)
         if world * frames_per_rank > 512:
             raise ValueError("a sharded step holds at most 512 frames")
-        renderer.shard_begin(params, frames_per_rank)
+        renderer.shard_begin(params, self.slot_base + frames_per_rank)
         self.q_local = torch.zeros((frames_per_rank, 2), dtype=torch.float32, device=renderer.device)
         self.m_local = torch.zeros((frames_per_rank, 4), dtype=torch.int64, device=renderer.device)
         self.c_local = torch.zeros((frames_per_rank, 4), dtype=torch.int32, device=renderer.device)
         self.auto_crop = bool(getattr(params, "auto_crop_black_bars", 0)) if params is not None else False
-        self.own_slots = [(t // world if t % world == rank else -1) for t in range(world * frames_per_rank)]
+        self.own_slots = [(self.slot_base + t // world if t % world == rank else -1) for t in range(world * frames_per_rank)]
 
     def gather(self, local: torch.Tensor) -> torch.Tensor:
         """all-gather along dim 0: [B, ...] per rank -> [world*B, ...] laid out rank-major."""
@@ -252,7 +255,7 @@ class MeasureReplaySharder:
                 d = depth_all[g * B + j]
                 if g == self.rank:
                     flush()
-                    self.r.shard2_p1(frames_local[j], d, self.p, t, slot=j, q_out=self.q_local[j])
+                    self.r.shard2_p1(frames_local[j], d, self.p, t, slot=self.slot_base + j, q_out=self.q_local[j])
                 else:
                     if not run:
                         run_first = t
@@ -263,7 +266,7 @@ class MeasureReplaySharder:
         n = self._nv(n_valid)
         for j in range(self.B):
             if j * self.world + self.rank < n:
-                self.r.shard2_p3(j, j * self.world + self.rank, self.p, self.m_local[j])
+                self.r.shard2_p3(self.slot_base + j, j * self.world + self.rank, self.p, self.m_local[j])
 
     def finish(self, m_gathered: torch.Tensor, outs=None, ordered: bool = False, n_valid=None):
         """``ordered``: m_gathered is already in frame order (callers that run the renderer on a private stream do the reordering
@@ -271,7 +274,17 @@ class MeasureReplaySharder:
         n = self._nv(n_valid)
         m = m_gathered if ordered else self._frame_order(m_gathered)
         self.r.shard2_r2(m[:n], self.own_slots[:n], self.p)
-        return [self.r.shard_pixels(j, self.p, out=None if outs is None else outs[j]) for j in range(self.B) if j * self.world + self.rank < n]
+        return self.pixels(outs, n_valid)
+
+    def replay(self, m_ordered: torch.Tensor, n_valid=None):
+        """R2 only (frame-ordered records): the pixel pass can then be issued later with ``pixels``."""
+        n = self._nv(n_valid)
+        self.r.shard2_r2(m_ordered[:n], self.own_slots[:n], self.p)
+
+    def pixels(self, outs=None, n_valid=None):
+        n = self._nv(n_valid)
+        return [self.r.shard_pixels(self.slot_base + j, self.p, out=None if outs is None else outs[j]) for j in range(self.B)
+                if j * self.world + self.rank < n]
 
     def render_step(self, frames_local, depth_local: torch.Tensor, outs=None, n_valid=None):
         if self.auto_crop:
