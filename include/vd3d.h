@@ -193,6 +193,13 @@ int vd3d_pixel_shift(vd3d_ctx* ctx, const float* rgb_chw, const float* depth, in
 int vd3d_render_frame(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
                       const vd3d_render_params* p, uint8_t* out_bgr);
 
+/* The same loop iteration for a frame listed by skip_blank_frames (core/render_3d.py:1046-1060, branch :1278-1281): both eyes are
+ * the raw source frame (source size), pixel_shift_cuda / ipd scaling / focal tracker / DOF / colour grade are skipped, the depth
+ * filters, ShiftSmoother, dynamic scale and floating-window bars advance; sharpen, fit and mux run on the source-sized frame.
+ * Which frames are blank is the caller's knowledge (the reference asks ffmpeg's blackdetect, core/ffmpeg_blackdetect.py:23-81). */
+int vd3d_render_frame_blank(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
+                            const vd3d_render_params* p, uint8_t* out_bgr);
+
 /* Advance all temporal state (TemporalDepthFilter / percentile EMA / trackers) over one frame exactly as
  * vd3d_render_frame does, without rendering pixels; needs only the depth.  Frame sharding across GPUs:
  * every rank advances over all frames, and renders only its own. */

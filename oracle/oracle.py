@@ -319,7 +319,8 @@ class RenderOracle:
         s.prev_depth_valid = 0
         s.focal_valid = 0
 
-    def render(self, frame_bgr, depth, depth_fmt, want_eyes=False):
+    def render(self, frame_bgr, depth, depth_fmt, want_eyes=False, blank=False):
+        """blank=True: the frame is in the skip_blank_frames set (core/render_3d.py:1278-1281)."""
         p = self.p
         fb, pf = _u(frame_bgr)
         if depth_fmt == 0:
@@ -327,6 +328,14 @@ class RenderOracle:
         else:
             dd = np.ascontiguousarray(depth, dtype=np.uint8)
         out = np.empty((p.out_h, p.out_w, 3), np.uint8)
+        if blank:
+            rc = lib().vo_render_frame_blank(pf, dd.ctypes.data_as(C.c_void_p), int(depth_fmt), C.byref(p),
+                                             C.byref(self.state), self.tdf_prev.ctypes.data_as(_f32p),
+                                             self.norm_prev.ctypes.data_as(_f32p), out.ctypes.data_as(_u8p),
+                                             C.byref(self.last))
+            if rc:
+                raise NotImplementedError("oracle: unsupported fit/format")
+            return (out, None, None) if want_eyes else out
         L = np.empty((p.warp_h, p.warp_w, 3), np.uint8) if want_eyes else None
         R = np.empty((p.warp_h, p.warp_w, 3), np.uint8) if want_eyes else None
         rc = lib().vo_render_frame(pf, dd.ctypes.data_as(C.c_void_p), int(depth_fmt), C.byref(p),

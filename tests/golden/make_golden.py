@@ -389,8 +389,60 @@ def gen_previews():
     save("previews.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 7. skip_blank_frames: the real loop with the blackdetect side channel replaced by a fixed list (ffmpeg is absent here;
+#    the list is what detect_black_white_frames would return -- absolute frame indices, compared against loop index + start)
+# ------------------------------------------------------------------------------------------
+_CLI = dict(fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0,
+            blur_ksize=9, use_subject_tracking=True, use_floating_window=True, skip_blank_frames=True)
+BLANK_CASES = {
+    # name: (src_h, src_w, n_frames, blank list, kwargs)
+    "blank_half_sbs": (108, 192, 8, [1, 3, 4], dict(_CLI, output_format="Half-SBS", output_height=108, ipd_factor=1.1,
+                                                    color_saturation=1.2, color_contrast=1.05, color_brightness=0.02)),
+    # source 160x90 rendered at 192x108: the blank frame stays 160x90 and pad_to_aspect_ratio up-scales it by 1.2
+    "blank_interlaced_up": (90, 160, 6, [0, 2], dict(_CLI, output_format="Passive Interlaced", output_height=108)),
+    # 4:3 source: the blank frame is the UNCROPPED 160x120 frame -> INTER_AREA 4/3 down + pillar bars
+    "blank_anaglyph_43": (120, 160, 6, [2, 3, 5], dict(_CLI, output_format="Red-Cyan Anaglyph", output_height=90, ipd_factor=0.9)),
+}
+
+
+def run_blank_loop(name):
+    sh, sw, n, blank, kw = BLANK_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ref_stubs._Clip.clips["in.mp4"] = frames
+    ref_stubs._Clip.clips["depth.mp4"] = [synth.depth_to_u8_bgr(d) for d in depths]
+    rl.reset_state()
+    args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0,
+                output_width=sw, selected_aspect_ratio=_Aspect("Default (16:9)"), aspect_ratios=r.aspect_ratios,
+                suspend_flag=threading.Event(), cancel_flag=threading.Event())
+    args.update(kw)
+    saved = r.detect_black_white_frames
+    r.detect_black_white_frames = lambda *a, **k: list(blank)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()) as so:
+            r.render_sbs_3d(**args)
+    finally:
+        r.detect_black_white_frames = saved
+    if "crashed" in so.getvalue():
+        raise RuntimeError(so.getvalue())
+    assert so.getvalue().count("Skipping blank frame") == len([b for b in blank if b < n - 1]), so.getvalue()
+    return ref_stubs._Clip.written["out.avi"]
+
+
+def gen_blank():
+    out = {}
+    for name in BLANK_CASES:
+        written = run_blank_loop(name)
+        out[f"{name}__frames"] = np.stack(written)
+        print(f"  blank loop {name}: {len(written)} frames of {written[0].shape}")
+    out["cases_json"] = np.frombuffer(json.dumps({k: list(v) for k, v in BLANK_CASES.items()}).encode(), dtype=np.uint8)
+    save("blank.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank"]
+    if "blank" in which:
+        gen_blank()
     if "previews" in which:
         gen_previews()
     if "widen" in which:

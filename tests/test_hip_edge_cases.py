@@ -161,8 +161,6 @@ def test_degenerate_depth_planes(R, oracle):
 
 
 def test_unsupported_features_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        render_kwargs_to_params(96, 54, output_height=54, skip_blank_frames=True, output_format="Half-SBS", **{k: v for k, v in BASE.items()})
     from visiondepth3d_amd.render_3d import Renderer
     r = Renderer(0)
     p = render_kwargs_to_params(96, 54, **dict(BASE, output_format="VR", output_height=54))

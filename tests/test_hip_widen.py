@@ -222,3 +222,51 @@ def test_preview_visualisers_vs_oracle_and_golden(R, oracle):
     with pytest.raises(NotImplementedError):
         generate_preview_image("Shift Heatmap", left, right, None, w, h)
     assert generate_preview_image("no such preview", left, right, None, w, h) is None      # the reference returns None as well
+
+
+# ---- skip_blank_frames (core/render_3d.py:1046-1060,1278-1281; tests/golden/blank.npz) ---------------------------------
+def test_blank_frame_loops(R, oracle):
+    """vd3d_render_frame_blank inside real loops: HIP vs oracle bit-exact (pixels and every reported scalar, blank or not),
+    blank frames bit-exact vs the reference golden, the others within the B2 bar."""
+    g = load_golden("blank.npz")
+    for name, (sh, sw, n, blank, kw) in golden_json(g, "cases_json").items():
+        frames, depths = synth.synth_clip(n, sh, sw)
+        p = render_kwargs_to_params(sw, sh, **kw)
+        R.reset_state(); R.new_clip()
+        ro = oracle.RenderOracle(p); ro.new_clip()
+        for idx, (f, d) in enumerate(list(zip(frames, depths))[1:]):
+            d8 = synth.depth_to_u8_bgr(d)
+            b = idx in blank
+            got = R.render_frame(T(f), T(d8), p, blank=b).cpu().numpy()
+            exp = ro.render(f, d8, 1, blank=b)
+            assert np.array_equal(got, exp), (name, idx, b, u8_diff_stats(got, exp))
+            sa, sb = R.last_scalars().as_dict(), ro.last.as_dict()
+            assert sa == sb, (name, idx, {k: (sa[k], sb[k]) for k in sa if sa[k] != sb[k]})
+            ref = g[f"{name}__frames"][idx]
+            if b:
+                assert np.array_equal(got, ref), (name, idx)
+            else:
+                mx, frac, frac_gt1 = u8_diff_stats(got, ref)
+                assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2, (name, idx, mx, frac, frac_gt1)
+        assert R.export_state().as_dict() == ro.state.as_dict(), name
+
+
+def test_render_clip_blank_list(R, oracle):
+    """render_clip(skip_blank_frames=True, blank_frames=[...]) == the per-frame calls; without the flag the list is ignored."""
+    from visiondepth3d_amd.render_3d import render_clip
+    g = load_golden("blank.npz")
+    sh, sw, n, blank, kw = golden_json(g, "cases_json")["blank_half_sbs"]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    d8 = [synth.depth_to_u8_bgr(d) for d in depths]
+    R.reset_state()
+    outs = np.stack(list(render_clip(frames, d8, renderer=R, blank_frames=blank, **kw)))
+    mxs = [u8_diff_stats(outs[i], g["blank_half_sbs__frames"][i])[0] for i in range(len(outs))]
+    assert all(m == 0 for i, m in enumerate(mxs) if i in blank) and max(mxs) <= 8
+    # start_frame_idx shifts which loop iterations hit the list (:1063,1278)
+    R.reset_state()
+    outs2 = np.stack(list(render_clip(frames, d8, renderer=R, blank_frames=[b + 100 for b in blank], start_frame_idx=100, **kw)))
+    assert np.array_equal(outs, outs2)
+    kw2 = dict(kw); kw2["skip_blank_frames"] = False
+    R.reset_state()
+    outs3 = np.stack(list(render_clip(frames, d8, renderer=R, blank_frames=blank, **kw2)))
+    assert not np.array_equal(outs3[blank[0]], outs[blank[0]])

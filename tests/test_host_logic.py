@@ -41,9 +41,9 @@ def test_render_kwargs_mirror_reference_forwarding():
     with pytest.raises(TypeError):
         render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0, output_format="Half-SBS",
                                 dof_strength=0, codec="XVID")  # render_cli.py's stale kwarg is a TypeError in the reference too
-    with pytest.raises(NotImplementedError):
-        render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0,
-                                output_format="Half-SBS", dof_strength=0, skip_blank_frames=True)
+    # skip_blank_frames is loop-level: the per-clip block is the same with and without it
+    pk = dict(output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0, output_format="Half-SBS", dof_strength=0)
+    assert bytes(render_kwargs_to_params(192, 108, skip_blank_frames=True, **pk)) == bytes(render_kwargs_to_params(192, 108, **pk))
     pa = render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0,
                                  output_format="Half-SBS", dof_strength=0, auto_crop_black_bars=True, target_ratio=2.39)
     assert pa.auto_crop_black_bars == 1 and pa.target_ratio == 2.39 and p.auto_crop_black_bars == 0
@@ -86,3 +86,22 @@ def test_u8_unit_is_the_exact_division():
         q = fma32(fma32(-q0, f32(255.0), x), rc, q0)
         assert q == x / f32(255.0), v
     assert math.isfinite(float(rc))
+
+
+def test_blackdetect_log_parsing(tmp_path):
+    """The skip_blank_frames side channel (core/ffmpeg_blackdetect.py:23-81): start times -> int(t * fps), cache file, and the
+    reference's behaviours kept as they are (only black_start frames, 'd.d' pattern, [] when ffmpeg is missing)."""
+    from visiondepth3d_amd import blackdetect as bd
+    log = ("[blackdetect @ 0x1] black_start:0.5 black_end:1.25 black_duration:0.75\n"
+           "[blackdetect @ 0x1] black_start:12.041667 black_end:12.5 black_duration:0.458333\n"
+           "[blackdetect @ 0x1] black_start:3 black_end:4 black_duration:1\n")          # integral seconds: not matched (:65)
+    assert bd.parse_blackdetect_log(log, 24.0) == [12, 289]
+    assert bd.parse_blackdetect_log(log, 23.976) == [11, 288]
+    assert bd.blackdetect_filter("black", 0.1, 0.10) == "blackdetect=d=0.1:pix_th=0.1"
+    assert "{duration_threshold}" in bd.blackdetect_filter("white", 0.1, 0.1)    # the reference's raw string (:51)
+    with pytest.raises(ValueError):
+        bd.blackdetect_filter("grey", 0.1, 0.1)
+    vid = str(tmp_path / "clip.mp4")
+    (tmp_path / "clip.mp4.blankcache.json").write_text("[7, 3, 9]")
+    assert bd.detect_black_white_frames(vid) == [7, 3, 9]                           # cache is returned as stored (:38-41)
+    assert bd.detect_black_white_frames(str(tmp_path / "none.mp4"), cache=False) == []   # no ffmpeg here -> [] like :79-81

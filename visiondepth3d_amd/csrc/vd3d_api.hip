@@ -51,6 +51,7 @@ struct vd3d_ctx {
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
   uint32_t* mm = nullptr; int mm_cap = 0;
   uint32_t* rowflag = nullptr; int rowflag_cap = 0;   // k_autocrop: one flag per source row
+  uint8_t* blank_eye = nullptr; size_t blank_cap = 0; // skip_blank_frames: the side-masked source frame (source size)
   bool crop_scalars_dirty = false;                    // fs.crop_top/bottom hold a previous auto-crop result
   // frame sharding (three-phase protocol): per-slot planes of the frames this rank owns inside the current step
   int n_slots = 0, slot_eh = 0, slot_ew = 0, slot_H = 0, slot_W = 0;
@@ -172,7 +173,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -388,7 +389,7 @@ VD3D_EXPORT int vd3d_finish_frame(vd3d_ctx* c, const uint8_t* left_bgr, const ui
 // ---- B2 ---------------------------------------------------------------------------------------
 static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
                              const vd3d_render_params* p, uint8_t* out_bgr, bool state_only, int shard = 0, int step_idx = 0,
-                             int slot = -1, float* s1_out = nullptr) {
+                             int slot = -1, float* s1_out = nullptr, bool blank = false) {
   if (!c || !depth || !p || (!state_only && (!frame_bgr || !out_bgr))) return set_err(VD3D_E_INVALID, "NULL argument");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
   if (!p->auto_crop_black_bars &&
@@ -402,6 +403,13 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   if (p->eye_w < 2 || p->eye_h < 2) return set_err(VD3D_E_INVALID, "eye size too small");
   int rc = check_fit(p);
   if (rc) return rc;
+  // blank frame: the source-sized frame itself goes through sharpen / fit / mux (:1279-1281, :1406-1419)
+  vd3d_render_params pb = *p;
+  if (blank) {
+    pb.warp_w = p->src_w; pb.warp_h = p->src_h;
+    if (p->src_w < 1 || p->src_h < 1) return set_err(VD3D_E_INVALID, "bad source size");
+    if ((rc = check_fit(&pb))) return rc;
+  }
   // render_sbs_3d forwards literals for the pop/lock controls and never forwards parallax_balance (:1284-1331)
   vd3d_shift_params sp = p->shift;
   sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
@@ -419,7 +427,7 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   memset(&a, 0, sizeof a);
   a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.n_eye = ne;
   { const char* e = getenv("VD3D_DBG"); a.dbg = e ? atoi(e) : 0; }
-  a.shard = shard; a.shard_idx = step_idx; a.s1_out = s1_out;
+  a.shard = shard; a.shard_idx = step_idx; a.s1_out = s1_out; a.blank = blank ? 1 : 0;
   float* const save_D = c->D; float* const save_rgb = c->rgb_eye;
   if (shard == 1) { c->D = c->slot_D[slot]; c->rgb_eye = c->slot_rgb[slot]; }
   a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
@@ -451,14 +459,23 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
     vd_launch_eye_stats(s, c->tdf, dn_cur, dn_prev, p->eye_h, p->eye_w, c->work);
   }
   }
-  rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, state_only);
+  // a blank frame still runs the whole select chain (its eye-res half carries the filters and the bars; the work-res half only
+  // computes unused pop-shaping constants -- blank frames are rare and this keeps one code path), but no shift map and no warp
+  rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, state_only || blank);
   c->D = save_D; c->rgb_eye = save_rgb;
   if (rc) return rc;
   if (shard == 1) {  // keep what the deferred pixel pass needs: this frame's normalised depth and all per-frame constants
     HIPCHK(hipMemcpyAsync(c->slot_dn[slot], dn_cur, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(&c->slot_work[slot], c->work, sizeof(vd_dev_work), hipMemcpyDeviceToDevice, s));
   }
-  if (!state_only) {
+  if (!state_only && blank) {
+    StageTimer t(c, "finish");
+    const size_t nb = (size_t)p->src_h * p->src_w * 3;
+    if (nb > c->blank_cap) { HIPCHK(re_alloc(&c->blank_eye, nb)); c->blank_cap = nb; }
+    vd_launch_blank_eye(s, frame_bgr, p->src_h, p->src_w, c->work, c->blank_eye);
+    vd_launch_sharp_mux(s, c->blank_eye, c->blank_eye, pb, fc, out_bgr);
+    HIPCHK(hipGetLastError());
+  } else if (!state_only) {
     rc = run_finish(c, c->L, c->R, dn_cur, p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr);
     if (rc) return rc;
   }
@@ -469,6 +486,14 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
 VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
                                   const vd3d_render_params* p, uint8_t* out_bgr) {
   return render_frame_impl(c, frame_bgr, depth, depth_fmt, p, out_bgr, false);
+}
+
+// The frame is in the skip_blank_frames set (core/render_3d.py:1046-1060, 1278-1281): both eyes are the raw source frame; the
+// depth filters, ShiftSmoother, dynamic parallax scale and the floating-window bars advance, pixel_shift_cuda (FloatingWindowTracker),
+// the ipd scaling, the focal tracker, DOF and the colour grade do not run.  Sharpen / fit / mux work on the source-sized frame.
+VD3D_EXPORT int vd3d_render_frame_blank(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
+                                        const vd3d_render_params* p, uint8_t* out_bgr) {
+  return render_frame_impl(c, frame_bgr, depth, depth_fmt, p, out_bgr, false, 0, 0, -1, nullptr, true);
 }
 
 // Advance every temporal tracker (planes + scalars) exactly as vd3d_render_frame would for this frame, WITHOUT producing

@@ -27,6 +27,7 @@ struct vd_stage_args {
   const float* etab;   // shard == 3: per-frame normalisation table of the step, VD_ETAB floats per entry:
                        // entry t = {ema_lo, ema_den, collapse, have_prev, ema_hi} in force BEFORE frame t
   int dbg;             // development probes: bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket + fences
+  int blank;           // skip_blank_frames hit (core/render_3d.py:1278-1281): no ipd scaling, no FloatingWindowTracker / focal update
   vd3d_shift_params shift;
 };
 
@@ -134,6 +135,7 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
                          const vd_finish_consts& fc, uint8_t* out);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
+void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const vd_dev_work* wk, uint8_t* dst);
 
 bool vd_launch_preview(hipStream_t s, int type, const uint8_t* L, const uint8_t* R, int h, int w, uint8_t* out);
 // ---- vd3d_depthprep.hip

@@ -536,6 +536,21 @@ void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
   hipLaunchKernelGGL(k_sharp_mux, dim3((p.fit_w + 63) / 64, (p.fit_h + 3) / 4), dim3(256), 0, s, gL, gR, m, fc.sharp_kn, fc.sharp_kc, out);
 }
 
+// blank frame (skip_blank_frames, core/render_3d.py:1278-1281 + :1398-1403): both eyes are the raw source frame with the floating-window
+// side mask applied; the bar comes from the device-resident frame constants (no host round trip)
+__global__ __launch_bounds__(256) void k_blank_eye(const uint8_t* __restrict__ src, int h, int w, const vd_dev_work* __restrict__ wk,
+                                                   uint8_t* __restrict__ dst) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const int bw = min(wk->bar_width, w), bs = wk->bar_side;
+  const bool masked = bw > 0 && ((bs == 2 && x < bw) || (bs == 1 && x >= w - bw));
+  const size_t i = ((size_t)y * w + x) * 3;
+  dst[i] = masked ? 0 : src[i]; dst[i + 1] = masked ? 0 : src[i + 1]; dst[i + 2] = masked ? 0 : src[i + 2];
+}
+void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const vd_dev_work* wk, uint8_t* dst) {
+  hipLaunchKernelGGL(k_blank_eye, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, src, h, w, wk, dst);
+}
+
 // ------------------------------------------------------------------------------------------------
 // streaming copy: the measured-peak yardstick for roofline.frac (16 B / lane, grid-stride)
 // ------------------------------------------------------------------------------------------------

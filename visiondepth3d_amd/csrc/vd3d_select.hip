@@ -487,7 +487,7 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           }
           fg = st->sm_fg; mg = st->sm_mg; bg = st->sm_bg;
           fg *= (double)scale; mg *= (double)scale; bg *= (double)scale;
-          if (a.ipd_factor != 0.0) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
+          if (a.ipd_factor != 0.0 && !a.blank) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
           w->fg_d = fg; w->mg_d = mg; w->bg_d = bg;
           if (a.shard && a.shard_idx >= 0 && a.shard_idx < VD_MAX_STEP) {
             w->step_fg[a.shard_idx] = fg; w->step_mg[a.shard_idx] = mg; w->step_bg[a.shard_idx] = bg;
@@ -495,13 +495,14 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           // compute_motion_metric :924-929
           w->fs.mad = 0.f;
           double motion = 0.0;
-          if (st->prev_depth_valid) {
+          if (st->prev_depth_valid && !a.blank) {
             const float mad = (float)(((double)w->sum_mad / VD_FX) / (double)a.n_eye);
             w->fs.mad = mad;
             double m = (double)mad * 4.0;
             motion = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
           }
-          w->fs.focal = focal_update(st, motion, (double)w->fs.s_norm);
+          if (!a.blank) w->fs.focal = focal_update(st, motion, (double)w->fs.s_norm);   // :1334-1337 sit in the non-blank branch
+          else w->fs.focal = st->focal;
           w->focal = (float)w->fs.focal;
           st->prev_depth_valid = 1;
         } else {
@@ -538,7 +539,7 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           w->fs.s1 = s1;
           if (a.shard == 1) { if (a.s1_out) *a.s1_out = s1; }  // sharded: the FloatingWindowTracker is replayed after the exchange
           else if (a.shard == 3) reinterpret_cast<float*>(&a.m_out[3])[1] = s1;
-          else shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);
+          else if (!a.blank) shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);   // blank: pixel_shift_cuda never runs
         }
         if (a.have_eye && a.shard != 3) {  // floating-window bars :1390-1403
           vd3d_state* st = &w->st;
@@ -559,6 +560,9 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           }
           w->bar_width = bw; w->bar_side = side;
           w->fs.bar_width = bw; w->fs.bar_side = side;
+        }
+        if (a.blank) {   // pixel_shift_cuda did not run for this frame: its reported scalars are those of "no call"
+          w->fs.s0 = 0.f; w->fs.q05 = 0.f; w->fs.q95 = 0.f; w->fs.s1 = 0.f; w->fs.zpo_raw = 0.f; w->fs.zpo = 0.0;
         }
       }
     } break;

@@ -43,8 +43,8 @@ def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, 
         raise TypeError(f"render_sbs_3d() got unexpected keyword argument(s) {sorted(unknown)}")
     o = dict(RENDER_DEFAULTS)
     o.update(kw)
-    if o["skip_blank_frames"]:
-        raise NotImplementedError("skip_blank_frames needs the ffmpeg blackdetect side-channel (out of scope)")
+    # skip_blank_frames is loop-level (which frames are blank comes from ffmpeg's blackdetect, :1046-1060): render_clip /
+    # Renderer.render_frame(blank=True) carry it, the per-clip parameter block does not change
     geom = plan_geometry(src_w, src_h, output_height, output_format, target_ratio, o["preserve_original_aspect"],
                          o["original_video_width"], o["original_video_height"])
     shift = ShiftParams.defaults(

@@ -118,9 +118,10 @@ class Renderer:
 
     # ---- B2 ----
     def render_frame(self, frame_bgr: torch.Tensor, depth: torch.Tensor, params: RenderParams,
-                     out: torch.Tensor | None = None) -> torch.Tensor:
+                     out: torch.Tensor | None = None, blank: bool = False) -> torch.Tensor:
         """One iteration of the render loop on device tensors.  frame_bgr: uint8 [h,w,3]; depth: float32 [h,w]
-        (precomputed), uint8 [h,w,3] (depth-video frame) or uint8 [h,w]."""
+        (precomputed), uint8 [h,w,3] (depth-video frame) or uint8 [h,w].  ``blank``: the frame is in the
+        skip_blank_frames set (core/render_3d.py:1278-1281): the source frame itself becomes both eyes."""
         if frame_bgr.dtype != torch.uint8 or frame_bgr.dim() != 3 or frame_bgr.shape[2] != 3:
             raise AssertionError("frame must be uint8 [h,w,3] BGR")
         if tuple(frame_bgr.shape[:2]) != (params.src_h, params.src_w):
@@ -139,7 +140,8 @@ class Renderer:
         d = depth.to(self.device).contiguous()
         if out is None:
             out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
-        _lib.check(self._L.vd3d_render_frame(self._ctx, _ptr(f), _ptr(d), fmt, C.byref(params), _ptr(out)))
+        fn = self._L.vd3d_render_frame_blank if blank else self._L.vd3d_render_frame
+        _lib.check(fn(self._ctx, _ptr(f), _ptr(d), fmt, C.byref(params), _ptr(out)))
         return out
 
     def advance_state(self, depth: torch.Tensor, params: RenderParams) -> None:
@@ -340,11 +342,17 @@ def pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg_shift, mg_shi
     return res[0].cpu().numpy(), res[1].cpu().numpy()
 
 
-def render_clip(frames, depths, *, renderer: Renderer | None = None, target_ratio=16 / 9, keep_on_device=False, **kw):
+def render_clip(frames, depths, *, renderer: Renderer | None = None, target_ratio=16 / 9, keep_on_device=False,
+                blank_frames=None, start_frame_idx=0, **kw):
     """The render_sbs_3d frame loop over in-memory frames (uint8 BGR arrays/tensors) and depths
     (float32 [h,w] or uint8 depth-video frames).  Yields muxed frames.  Mirrors the reference's read
-    order: the first frame of the clip is consumed before the loop and never rendered (:1026,1184,1222)."""
+    order: the first frame of the clip is consumed before the loop and never rendered (:1026,1184,1222).
+
+    ``skip_blank_frames=True`` uses ``blank_frames`` (absolute frame indices, what
+    ``detect_black_white_frames`` returns; tested as ``start_frame_idx + loop index`` like :1063,1278); without a
+    list it renders every frame, which is what the reference does when its detection fails (:1058-1060)."""
     r = renderer or default_renderer()
+    blank = set(blank_frames or ()) if kw.get("skip_blank_frames") else set()
     it = iter(zip(frames, depths))
     first = next(it, None)
     if first is None:
@@ -353,10 +361,11 @@ def render_clip(frames, depths, *, renderer: Renderer | None = None, target_rati
     sh, sw = int(f0.shape[0]), int(f0.shape[1])
     params = render_kwargs_to_params(sw, sh, target_ratio=target_ratio, **kw)
     r.new_clip()
-    for f, d in it:
+    for idx, (f, d) in enumerate(it):
         ft = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
         dt = d if torch.is_tensor(d) else torch.from_numpy(np.ascontiguousarray(d))
-        out = r.render_frame(ft.to(r.device, non_blocking=True), dt.to(r.device, non_blocking=True), params)
+        out = r.render_frame(ft.to(r.device, non_blocking=True), dt.to(r.device, non_blocking=True), params,
+                             blank=(start_frame_idx + idx) in blank)
         yield out if keep_on_device else out.cpu().numpy()
 
 
@@ -396,7 +405,15 @@ def render_sbs_3d(input_path, depth_path, output_path, selected_codec, fps, outp
 
     target_ratio = aspect_ratios.get(selected_aspect_ratio.get(), 16 / 9)
     writer = None
-    for i, out in enumerate(render_clip(gen(cap), gen(dcap), target_ratio=target_ratio, output_height=output_height,
+    blank_frames = None
+    if kw.get("skip_blank_frames"):   # :1046-1060
+        from .blackdetect import detect_black_white_frames
+        try:
+            blank_frames = detect_black_white_frames(input_path, mode="black", duration_threshold=0.1, pixel_threshold=0.10, cache=True)
+        except Exception as e:
+            print(f"Blank frame detection failed: {e}")
+    for i, out in enumerate(render_clip(gen(cap), gen(dcap), target_ratio=target_ratio, blank_frames=blank_frames,
+                                        start_frame_idx=start_idx, output_height=output_height,
                                         fg_shift=fg_shift, mg_shift=mg_shift, bg_shift=bg_shift,
                                         sharpness_factor=sharpness_factor, output_format=output_format,
                                         dof_strength=dof_strength, **kw)):
