@@ -122,6 +122,11 @@ def main():
                     "the depth net of batch i+1; the pixel kernels (k_shift, W1, E1) of batch i-1 run between two depth-net batches with "
                     "the GPU to themselves (W1 at its isolated speed, but 4.5 %% lower end-to-end throughput than the default, where the "
                     "whole DIBR chain shares the GPU with the depth net)")
+    ap.add_argument("--pixel-overlap", dest="pixel_overlap", action="store_true", default=None,
+                    help="two slot sets + vd3d_set_pixel_overlap: the pixel kernels of step i run on a second stream of the renderer while "
+                    "the (latency-bound) measurement chain of step i+1 runs on the first (the default; measured +27 %% / +14 %% on the 1080p / 4K "
+                    "DIBR-only workloads, +1 %% end to end with the depth net)")
+    ap.add_argument("--no-pixel-overlap", dest="pixel_overlap", action="store_false")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     args = ap.parse_args()
@@ -169,10 +174,14 @@ def main():
     emu = args.emulate_world if (world == 1 and args.emulate_world > 1) else 0
     gated = overlap and args.gated
     shr2 = None
-    if world > 1 or args.sharded or emu or gated:
+    pix_ov = True if args.pixel_overlap is None else bool(args.pixel_overlap)
+    pix_ov = pix_ov and not gated
+    if world > 1 or args.sharded or emu or gated or pix_ov:
         from visiondepth3d_amd.sharded import MeasureReplaySharder
         shr = MeasureReplaySharder(r, p, rank, emu or world, B)
-        shr2 = [shr, MeasureReplaySharder(r, p, rank, emu or world, B, slot_base=B)] if gated else None
+        shr2 = [shr, MeasureReplaySharder(r, p, rank, emu or world, B, slot_base=B)] if (gated or pix_ov) else None
+        if pix_ov:
+            r.set_pixel_overlap(True)
         if emu:   # every "other rank" contributes a copy of this rank's planes: same kernel work as a real G-rank step, no fabric
             for s_ in (shr2 or [shr]):
                 s_.gather = lambda t: t.repeat((emu,) + (1,) * (t.dim() - 1))
@@ -182,11 +191,12 @@ def main():
         from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
         pipe = DepthPipe(model_name, device="cuda", dtype=torch.bfloat16, renderer=rh)   # fused image-processor front end
 
+    shr_one = shr
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
     gathered = [torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if world > 1 else None
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     done = [torch.cuda.Event() for _ in range(NBUF)]
-    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded or emu) else None
+    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded or emu or pix_ov) else None
     ev_pix = [None]          # gated schedule: completion of the most recently enqueued pixel pass
     pending = [None]         # gated schedule: (sharder, ring slot or None) whose pixel pass has not been enqueued yet
 
@@ -257,6 +267,7 @@ def main():
 
     def step(i):
         # this rank's B frames of the step; global frame order inside a step: (j, g) for j in range(B) for g in range(world)
+        shr = shr2[i % 2] if pix_ov else shr_one    # pixel overlap: alternate slot sets so the next chain never waits for these pixels
         idx = [(i * B + j) % args.clip for j in range(B)]
         fb = frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
         k = i % NBUF
@@ -273,7 +284,8 @@ def main():
         else:
             dloc = None
         if shr is not None and dloc is None:
-            dloc = depths_u8[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else depths_u8[idx]
+            dsrc = depths if (pix_ov and world == 1 and not emu and not args.sharded) else depths_u8   # 1 GPU: the precomputed f32 planes
+            dloc = dsrc[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else dsrc[idx]
         if overlap:  # hand the batch to the DIBR stream; this (torch) stream goes on to the next batch's depth inference
             ev = torch.cuda.Event()
             ev.record()
@@ -306,6 +318,8 @@ def main():
         if overlap:
             done[k].record(dibr_stream)
         if ring is not None:
+            if pix_ov:
+                r.join_pixels()   # the download is ordered on the renderer's first stream: wait for this step's pixel pass
             if overlap:
                 with torch.cuda.stream(dibr_stream):
                     ring.download(kr)
@@ -345,7 +359,7 @@ def main():
     # W1 / E1 without the depth net sharing the CUs: a short DIBR-only pass AFTER the timed region (same frames, same kernels), so that
     # the contention of the overlapped end-to-end step can be told apart from the kernel itself (reported as roofline.isolated_*)
     iso_ms = {}
-    if rank == 0 and pipe is not None and not args.no_profile and (shr is None or gated) and world == 1 and not emu:
+    if rank == 0 and pipe is not None and not args.no_profile and (shr is None or gated or pix_ov) and world == 1 and not emu:
         r.set_profiling(True)   # clears the accumulators of the timed region (already read above)
         for j in range(min(B, 8, len(depths))):
             r.render_frame(frames[j], depths[j], p, out=outs[j])
@@ -382,6 +396,7 @@ def main():
                     "synthetic; frames start in pinned host memory and muxed frames are copied back to pinned host memory (PCIe-inclusive run)",
             "config": {"workload": args.workload, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
                        "frames_per_step": B, "depth_model": model_name, "emulated_world": emu or None,
+                       "pixel_overlap": bool(pix_ov),
                        "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes; foreign frames cost one plane-EMA launch; "
                                    "owners measure, 2 floats + 4 int64 per frame are all-gathered, scalar trackers replayed on every rank "
                                    "(bit-identical to 1 GPU)",

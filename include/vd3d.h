@@ -217,6 +217,14 @@ int vd3d_shard_pass1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void
                      const vd3d_render_params* p, int step_idx, int slot, float* s1_out_dev);
 int vd3d_shard_pass2(vd3d_ctx* ctx, const float* s1_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);
 int vd3d_shard_pixels(vd3d_ctx* ctx, int slot, const vd3d_render_params* p, uint8_t* out_bgr);
+/* Overlapped pixel passes (no reference counterpart: the reference renders strictly frame by frame, core/render_3d.py:1194-1463).
+ * enable != 0: vd3d_shard_pixels is enqueued on a second stream of the context, ordered after all work enqueued so far; the
+ * measurement chain of the next step (vd3d_shard2_p1 .. r2; latency-bound scans) then overlaps the pixel kernels of this one.  A call
+ * that overwrites a slot first waits for the pixel pass still reading it, so callers alternate between two slot sets to get the overlap.
+ * Outputs are complete after vd3d_sync, or -- for consumers ordered on the context's stream -- after vd3d_join_pixels. */
+int vd3d_set_pixel_overlap(vd3d_ctx* ctx, int enable);
+int vd3d_join_pixels(vd3d_ctx* ctx);
+int vd3d_wait_pixels(vd3d_ctx* ctx, int slot);   /* host waits for the outstanding overlapped pixel pass of `slot` (no-op if none) */
 
 /* Measure / replay variant (the one bench.py uses for N > 1): the only replicated work per foreign frame is the
  * TemporalDepthFilter plane EMA.  Per step: vd3d_shard2_p1 for every frame in order (own frames also measure q.02/q.98);

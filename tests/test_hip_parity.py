@@ -432,6 +432,62 @@ def test_measure_replay_world1_and_continuation(R, oracle):
     assert R.export_state().as_dict() == st_seq
 
 
+@pytest.mark.parametrize("two_sets", [True, False])
+def test_overlapped_pixel_passes_equal_sequential(R, oracle, two_sets):
+    """vd3d_set_pixel_overlap: pixel passes on the context's second stream while the next step's measurement chain runs on the
+    first.  Two alternating slot sets (real overlap) and ONE reused slot set (every chain call first waits for the pixel pass that
+    still reads its slot) both reproduce the sequential render bit for bit; an unsharded frame afterwards continues exactly."""
+    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    sh, sw, B, steps = 270, 480, 3, 4
+    kw = dict(output_format="Half-SBS", output_height=sh, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    n = B * steps + 1
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ft, dt = [T(f) for f in frames], [T(d) for d in depths]
+    R.reset_state(); R.new_clip()
+    seq = [R.render_frame(f, d, p).cpu().numpy() for f, d in zip(ft, dt)]
+    st_seq = R.export_state().as_dict()
+    R.reset_state(); R.new_clip()
+    sets = [MeasureReplaySharder(R, p, 0, 1, B), MeasureReplaySharder(R, p, 0, 1, B, slot_base=B)] if two_sets else [MeasureReplaySharder(R, p, 0, 1, B)] * 2
+    R.set_pixel_overlap(True)
+    try:
+        outs = []
+        for i in range(steps):
+            outs += sets[i % 2].render_step(ft[i * B:(i + 1) * B], torch.stack(dt[i * B:(i + 1) * B]))
+        last = R.render_frame(ft[-1], dt[-1], p)     # joins the outstanding pixel passes before it touches L / R / S
+        R.sync()
+        got = [o.cpu().numpy() for o in outs] + [last.cpu().numpy()]
+    finally:
+        R.set_pixel_overlap(False)
+    assert len(got) == len(seq) and all(np.array_equal(a, b) for a, b in zip(got, seq))
+    assert R.export_state().as_dict() == st_seq
+
+
+def test_render_clip_overlapped_pixels(R, oracle):
+    """MeasureReplaySharder.render_clip(overlap_pixels=True): frames are yielded one step late, after a host wait on their
+    pixel pass; whole clip incl. a partial last step == the sequential render, and the context is left in sequential mode."""
+    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    sh, sw, B, n = 270, 480, 3, 11
+    kw = dict(output_format="Half-SBS", output_height=sh, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ft, dt = [T(f) for f in frames], [T(d) for d in depths]
+    R.reset_state(); R.new_clip()
+    seq = [R.render_frame(f, d, p).cpu().numpy() for f, d in zip(ft, dt)]
+    st_seq = R.export_state().as_dict()
+    R.reset_state(); R.new_clip()
+    shr = MeasureReplaySharder(R, p, 0, 1, B)
+    got = [(t, o.cpu().numpy()) for t, o in shr.render_clip(n, lambda t: ft[t], lambda t: dt[t], overlap_pixels=True)]
+    assert [t for t, _ in got] == list(range(n))
+    assert all(np.array_equal(o, seq[t]) for t, o in got)
+    assert R.export_state().as_dict() == st_seq
+    R.reset_state(); R.new_clip()
+    again = [o.cpu().numpy() for _, o in shr.render_clip(n, lambda t: ft[t], lambda t: dt[t])]   # sequential mode still works after
+    assert all(np.array_equal(a, b) for a, b in zip(again, seq))
+
+
 # ------------------------------------------------------------------------------------------ full-size
 @pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840)])
 def test_full_size_properties(R, oracle, hw):

@@ -206,6 +206,12 @@ class _FakeRenderer2:
         self.log.append(("px", slot))
         return torch.tensor([slot])
 
+    def set_pixel_overlap(self, on):
+        self.log.append(("ov", bool(on)))
+
+    def wait_pixels(self, slot):
+        self.log.append(("wait", slot))
+
 
 def _proto2_worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -226,6 +232,12 @@ def _proto2_worker(rank, world, port, outdir):
         rec["clip_owned"] = [t for t, _ in got]
         rec["clip_log_kinds"] = [e[0] for e in fr.log]
         rec["clip_r2_len"] = int(fr.r2[0].shape[0])
+        # the same clip (14 frames: two full steps + a partial one) with overlapped pixel passes
+        fr.log.clear()
+        got = list(sr.render_clip(14, lambda t: torch.full((4, 5, 3), t % 6, dtype=torch.uint8), lambda t: torch.full((4, 5), t % 6, dtype=torch.uint8),
+                                  overlap_pixels=True))
+        rec["ov_owned"] = [t for t, _ in got]
+        rec["ov_log"] = [e for e in fr.log if e[0] in ("ov", "px", "wait", "r2")]
         torch.save(rec, os.path.join(outdir, f"q{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -257,3 +269,10 @@ def test_measure_replay_protocol_world2(tmp_path):
         assert rec["clip_owned"] == [t for t in range(8) if t % world == rank]
         assert rec["clip_log_kinds"] == ["p1"] * 6 + ["r1"] + ["p3"] * 3 + ["r2"] + ["px"] * 3 + ["p1"] * 2 + ["r1"] + ["p3"] + ["r2"] + ["px"]
         assert rec["clip_r2_len"] == 2
+        # overlapped: frames still come out in order; steps alternate between slot sets {0,1,2} and {3,4,5}; a step's frames are
+        # waited for (and yielded) only after the NEXT step's chain and pixel passes were enqueued; overlap is switched off at the end
+        assert rec["ov_owned"] == [t for t in range(14) if t % world == rank]
+        px = lambda sl: [("px", s_) for s_ in sl]
+        wt = lambda sl: [("wait", s_) for s_ in sl]
+        assert rec["ov_log"] == ([("ov", True), ("r2",)] + px([0, 1, 2]) + [("r2",)] + px([3, 4, 5]) + wt([0, 1, 2]) +
+                                 [("r2",)] + px([0]) + wt([3, 4, 5]) + wt([0]) + [("ov", False)])

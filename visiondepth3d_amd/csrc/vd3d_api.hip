@@ -61,6 +61,11 @@ struct vd3d_ctx {
   int* crop_tab = nullptr;                   // [VD_MAX_STEP][4] exchanged auto-crop rectangles of the current step
   bool crop_tab_set = false;
   vd_dev_work* slot_work = nullptr;
+  // overlapped pixel passes (vd3d_set_pixel_overlap): vd3d_shard_pixels runs on pix_stream behind the measurement chain of the
+  // NEXT step, which stays on `stream`; slot_done[slot] guards the slot's planes against being overwritten too early
+  hipStream_t pix_stream = nullptr; bool pix_overlap = false; bool pix_pending = false;
+  hipEvent_t ev_chain = nullptr, ev_pix_last = nullptr;
+  std::vector<hipEvent_t> slot_done; std::vector<char> slot_busy;
   int* own_slot_dev = nullptr; int* own_slot_pin = nullptr;   // depth hand-off min/max keys [B][3]
   // profiling
   bool profiling = false;
@@ -96,6 +101,24 @@ static void prof_collect(vd3d_ctx* c) {
     c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
   }
   c->recs.clear();
+}
+
+// main stream waits until the overlapped pixel pass that still reads `slot` has finished (no-op without overlap)
+static int wait_slot(vd3d_ctx* c, int slot) {
+  if (c->pix_overlap && slot >= 0 && slot < (int)c->slot_busy.size() && c->slot_busy[slot]) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->slot_done[slot], 0));
+    c->slot_busy[slot] = 0;
+  }
+  return 0;
+}
+// main stream waits for every outstanding overlapped pixel pass (they share L / R / S and write the caller's outputs)
+static int join_pixels(vd3d_ctx* c) {
+  if (c->pix_pending) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pix_last, 0));
+    c->pix_pending = false;
+    std::fill(c->slot_busy.begin(), c->slot_busy.end(), 0);
+  }
+  return 0;
 }
 
 template <class T> static hipError_t re_alloc(T** p, size_t n) {
@@ -175,11 +198,16 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   for (auto e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (c->pix_stream) { hipStreamSynchronize(c->pix_stream); hipStreamDestroy(c->pix_stream); }
+  for (auto e : c->slot_done) hipEventDestroy(e);
+  if (c->ev_chain) hipEventDestroy(c->ev_chain);
+  if (c->ev_pix_last) hipEventDestroy(c->ev_pix_last);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
 VD3D_EXPORT int vd3d_sync(vd3d_ctx* c) {
+  if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   prof_collect(c);
   return 0;
@@ -280,6 +308,7 @@ VD3D_EXPORT int vd3d_pixel_shift(vd3d_ctx* c, const float* rgb_chw, const float*
   int rc = check_shift_params(p, H, W);
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
+  if ((rc = join_pixels(c))) return rc;
   if ((rc = ensure_work(c, H, W))) return rc;
   StageTimer tf(c, "pixel_shift");
   HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, c->stream));
@@ -382,6 +411,7 @@ VD3D_EXPORT int vd3d_finish_frame(vd3d_ctx* c, const uint8_t* left_bgr, const ui
   vd_finish_consts fc;
   if ((rc = make_finish_consts(p, &fc))) return rc;
   HIPCHK(hipSetDevice(c->device));
+  if ((rc = join_pixels(c))) return rc;
   if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
   return run_finish(c, left_bgr, right_bgr, depth_norm, eye_h, eye_w, p, fc, (float)focal_depth, 1, bar_width, bar_side, out_bgr);
 }
@@ -418,6 +448,8 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   vd_finish_consts fc;
   if ((rc = make_finish_consts(p, &fc))) return rc;
   HIPCHK(hipSetDevice(c->device));
+  if (!state_only && (rc = join_pixels(c))) return rc;   // the unsharded pixel pass shares L / R / S with overlapped ones
+  if (shard == 1 && (rc = wait_slot(c, slot))) return rc;
   if ((rc = ensure_eye(c, p->eye_h, p->eye_w))) return rc;
   if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
   hipStream_t s = c->stream;
@@ -513,6 +545,8 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
   if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
   const bool same = c->n_slots >= n_slots && c->slot_eh == p->eye_h && c->slot_ew == p->eye_w && c->slot_H == p->warp_h && c->slot_W == p->warp_w;
   if (same) return 0;
+  if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
+  c->pix_pending = false; std::fill(c->slot_busy.begin(), c->slot_busy.end(), 0);
   HIPCHK(hipStreamSynchronize(c->stream));
   for (auto q : c->slot_rgb) hipFree(q);
   for (auto q : c->slot_dn) hipFree(q);
@@ -555,6 +589,7 @@ VD3D_EXPORT int vd3d_shard_pass2(vd3d_ctx* c, const float* s1_all_dev, const int
   vd_stage_args a;
   memset(&a, 0, sizeof a);
   a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.shift = sp;
+  for (int t = 0; t < n; ++t) { int rc = wait_slot(c, own_slot_host[t]); if (rc) return rc; }
   StageTimer t(c, "replay");
   vd_launch_shard_replay(c->stream, c->work, s1_all_dev, own_slot_host, n, c->slot_work, a);
   HIPCHK(hipGetLastError());
@@ -571,6 +606,23 @@ VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_param
   vd_finish_consts fc;
   if ((rc = make_finish_consts(p, &fc))) return rc;
   HIPCHK(hipSetDevice(c->device));
+  // overlapped mode: this pass runs on pix_stream behind everything enqueued on the main stream so far (the slot's measurements and
+  // the replay that patched its constants); the main stream is free to start the next step's measurement chain meanwhile
+  struct StreamSwap {
+    vd3d_ctx* c; hipStream_t saved;
+    explicit StreamSwap(vd3d_ctx* ctx) : c(ctx), saved(ctx->stream) {}
+    ~StreamSwap() { c->stream = saved; }
+  } swap(c);
+  if (c->pix_overlap) {
+    while ((int)c->slot_done.size() <= slot) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->slot_done.push_back(e); c->slot_busy.push_back(0);
+    }
+    HIPCHK(hipEventRecord(c->ev_chain, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->pix_stream, c->ev_chain, 0));
+    c->stream = c->pix_stream;
+  }
   hipStream_t s = c->stream;
   const int H = p->warp_h, W = p->warp_w;
   const vd_dev_work* wk = &c->slot_work[slot];
@@ -587,7 +639,44 @@ VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_param
     }
   }
   HIPCHK(hipGetLastError());
-  return run_finish(c, c->L, c->R, c->slot_dn[slot], p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr, wk);
+  rc = run_finish(c, c->L, c->R, c->slot_dn[slot], p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr, wk);
+  if (rc) return rc;
+  if (c->pix_overlap) {
+    HIPCHK(hipEventRecord(c->slot_done[slot], c->pix_stream));
+    HIPCHK(hipEventRecord(c->ev_pix_last, c->pix_stream));
+    c->slot_busy[slot] = 1; c->pix_pending = true;
+  }
+  return 0;
+}
+
+// Overlapped pixel passes: with enable != 0, vd3d_shard_pixels is enqueued on a second stream of the context, ordered after all work
+// enqueued so far, and returns; the measurement chain of the NEXT step (vd3d_shard2_p1 ... r2, latency-bound) then runs concurrently with
+// the pixel kernels of this one.  Slots are guarded: a call that overwrites a slot first waits for the pixel pass that still reads it, so
+// a caller that alternates between two slot sets gets the overlap and a caller that does not gets the sequential order.  Outputs are
+// complete after vd3d_sync, or, for consumers ordered on the context's stream, after vd3d_join_pixels.
+VD3D_EXPORT int vd3d_set_pixel_overlap(vd3d_ctx* c, int enable) {
+  if (!c) return set_err(VD3D_E_INVALID, "NULL context");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = join_pixels(c);
+  if (rc) return rc;
+  if (enable && !c->pix_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->pix_stream, hipStreamNonBlocking));   // stream priorities: measured, no effect either way
+    HIPCHK(hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_pix_last, hipEventDisableTiming));
+  }
+  c->pix_overlap = enable != 0;
+  return 0;
+}
+VD3D_EXPORT int vd3d_join_pixels(vd3d_ctx* c) {
+  if (!c) return set_err(VD3D_E_INVALID, "NULL context");
+  HIPCHK(hipSetDevice(c->device));
+  return join_pixels(c);
+}
+// host-side wait for the overlapped pixel pass of one slot (its output frame is then complete); no-op if none is outstanding
+VD3D_EXPORT int vd3d_wait_pixels(vd3d_ctx* c, int slot) {
+  if (!c || slot < 0) return set_err(VD3D_E_INVALID, "bad argument");
+  if (slot < (int)c->slot_busy.size() && c->slot_busy[slot]) HIPCHK(hipEventSynchronize(c->slot_done[slot]));
+  return 0;
 }
 
 
@@ -616,6 +705,7 @@ VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void
     return set_err(VD3D_E_INVALID, "auto_crop_black_bars in a sharded step: call vd3d_shard2_p0 on the own frames and vd3d_shard2_set_crops first");
   if (!c->use_fused) return set_err(VD3D_E_UNSUPPORTED, "frame sharding needs the fused chain (unset VD3D_UNFUSED)");
   HIPCHK(hipSetDevice(c->device));
+  { int rcw = wait_slot(c, slot); if (rcw) return rcw; }
   hipStream_t s = c->stream;
   vd_stage_args a; vd3d_shift_params sp;
   shard2_args(c, p, &a, &sp);
@@ -703,6 +793,7 @@ VD3D_EXPORT int vd3d_shard2_p3(vd3d_ctx* c, int slot, int step_idx, const vd3d_r
   int rc;
   if ((rc = check_shift_params(&sp, p->warp_h, p->warp_w))) return rc;
   a.shard = 3; a.shard_idx = step_idx; a.m_out = m_out_dev;
+  if ((rc = wait_slot(c, slot))) return rc;
   StageTimer t(c, "p3_own");
   HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));   // the select jobs of this frame start from empty histograms
   vd_launch_chain_work(s, 1, c->slot_tdf[slot], c->slot_dn[slot], c->slot_tdfp[slot], p->eye_h, p->eye_w, p->warp_h, p->warp_w, c->work,
@@ -718,6 +809,7 @@ VD3D_EXPORT int vd3d_shard2_r2(vd3d_ctx* c, const long long* m_all_dev, const in
   HIPCHK(hipSetDevice(c->device));
   vd_stage_args a; vd3d_shift_params sp;
   shard2_args(c, p, &a, &sp);
+  for (int t = 0; t < n; ++t) { int rc = wait_slot(c, own_slot_host[t]); if (rc) return rc; }
   StageTimer t(c, "replay");
   vd_launch_shard2_r2(c->stream, c->work, m_all_dev, c->etab, own_slot_host, n, c->slot_work, a);
   HIPCHK(hipGetLastError());

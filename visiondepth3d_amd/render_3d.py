@@ -216,6 +216,19 @@ class Renderer:
         m = m_all.to(self.device, torch.int64).contiguous()
         _lib.check(self._L.vd3d_shard2_r2(self._ctx, _ptr(m), arr, n, C.byref(params)))
 
+    def set_pixel_overlap(self, on: bool):
+        """Run ``shard_pixels`` on a second stream of the context, behind the measurement chain of the next step
+        (``vd3d_set_pixel_overlap``).  Outputs are complete after ``sync()`` / ``join_pixels()``."""
+        _lib.check(self._L.vd3d_set_pixel_overlap(self._ctx, 1 if on else 0))
+
+    def join_pixels(self):
+        """Order the context's stream after every outstanding overlapped pixel pass."""
+        _lib.check(self._L.vd3d_join_pixels(self._ctx))
+
+    def wait_pixels(self, slot: int):
+        """Block the host until the overlapped pixel pass of ``slot`` (if any) has written its frame."""
+        _lib.check(self._L.vd3d_wait_pixels(self._ctx, int(slot)))
+
     def shard_pixels(self, slot: int, params: RenderParams, out: torch.Tensor | None = None):
         if out is None:
             out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)

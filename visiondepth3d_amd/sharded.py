@@ -294,27 +294,57 @@ class MeasureReplaySharder:
         self.p3(n_valid)
         return self.finish(self.gather(self.m_local), outs, n_valid=n_valid)
 
-    def render_clip(self, n_frames: int, get_frame, get_depth):
+    def render_clip(self, n_frames: int, get_frame, get_depth, overlap_pixels: bool = False):
         """Render frames 0..n_frames-1 of one clip (callables return device tensors: uint8 BGR frame / depth plane of frame t).
         Yields (t, muxed_frame) for the frames this rank owns, in increasing t; the last step may be partial.  Every rank must
-        call this with the same n_frames (the collectives are matched)."""
+        call this with the same n_frames (the collectives are matched).
+
+        ``overlap_pixels``: steps alternate between two slot sets and the pixel kernels of step i run on the renderer's second
+        stream (``vd3d_set_pixel_overlap``) while the measurement chain of step i+1 runs on the first; the frames of step i are
+        yielded once step i+1 has been enqueued and their pixel passes have completed (host wait per frame).  Same bytes."""
         G, B = self.world, self.B
         per_step = G * B
         proto_f, proto_d = None, None
-        for base in range(0, n_frames, per_step):
-            nv = min(per_step, n_frames - base)
-            fl, dl = [], []
-            for j in range(B):
-                t = base + j * G + self.rank
-                if t < n_frames:
-                    f, d = get_frame(t), get_depth(t)
-                    proto_f, proto_d = f, d
-                else:   # past the end of the clip: a dummy contribution keeps the collectives full-size
-                    if proto_f is None:
-                        proto_f, proto_d = get_frame(n_frames - 1), get_depth(n_frames - 1)
-                    f, d = torch.zeros_like(proto_f), torch.zeros_like(proto_d)
-                fl.append(f); dl.append(d)
-            outs = self.render_step(fl, torch.stack(dl), n_valid=nv)
-            own = [base + j * G + self.rank for j in range(B) if j * G + self.rank < nv]
-            for t, o in zip(own, outs):
+        sets = [self]
+        if overlap_pixels:
+            if getattr(self, "_twin", None) is None:
+                self._twin = MeasureReplaySharder(self.r, self.p, self.rank, G, B, self.group, slot_base=self.slot_base + B)
+            sets = [self, self._twin]
+            self.r.set_pixel_overlap(True)
+
+        def drain(step):
+            own, outs, sh = step
+            for j, (t, o) in enumerate(zip(own, outs)):
+                self.r.wait_pixels(sh.slot_base + j)
                 yield t, o
+
+        pending = None
+        try:
+            for k, base in enumerate(range(0, n_frames, per_step)):
+                nv = min(per_step, n_frames - base)
+                fl, dl = [], []
+                for j in range(B):
+                    t = base + j * G + self.rank
+                    if t < n_frames:
+                        f, d = get_frame(t), get_depth(t)
+                        proto_f, proto_d = f, d
+                    else:   # past the end of the clip: a dummy contribution keeps the collectives full-size
+                        if proto_f is None:
+                            proto_f, proto_d = get_frame(n_frames - 1), get_depth(n_frames - 1)
+                        f, d = torch.zeros_like(proto_f), torch.zeros_like(proto_d)
+                    fl.append(f); dl.append(d)
+                sh = sets[k % len(sets)]
+                outs = sh.render_step(fl, torch.stack(dl), n_valid=nv)
+                own = [base + j * G + self.rank for j in range(B) if j * G + self.rank < nv]
+                if overlap_pixels:
+                    if pending is not None:
+                        yield from drain(pending)
+                    pending = (own, outs, sh)
+                else:
+                    for t, o in zip(own, outs):
+                        yield t, o
+            if pending is not None:
+                yield from drain(pending)
+        finally:
+            if overlap_pixels:
+                self.r.set_pixel_overlap(False)   # joins whatever is still in flight
