@@ -174,7 +174,8 @@ def main():
     emu = args.emulate_world if (world == 1 and args.emulate_world > 1) else 0
     gated = overlap and args.gated
     shr2 = None
-    pix_ov = True if args.pixel_overlap is None else bool(args.pixel_overlap)
+    pix_ov = (not args.host_io) if args.pixel_overlap is None else bool(args.pixel_overlap)   # host-io: the D2H copy is ordered on the
+                                                                                                # first stream and would join every step
     pix_ov = pix_ov and not gated
     if world > 1 or args.sharded or emu or gated or pix_ov:
         from visiondepth3d_amd.sharded import MeasureReplaySharder
