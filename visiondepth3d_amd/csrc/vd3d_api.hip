@@ -675,7 +675,9 @@ VD3D_EXPORT int vd3d_join_pixels(vd3d_ctx* c) {
 // host-side wait for the overlapped pixel pass of one slot (its output frame is then complete); no-op if none is outstanding
 VD3D_EXPORT int vd3d_wait_pixels(vd3d_ctx* c, int slot) {
   if (!c || slot < 0) return set_err(VD3D_E_INVALID, "bad argument");
-  if (slot < (int)c->slot_busy.size() && c->slot_busy[slot]) HIPCHK(hipEventSynchronize(c->slot_done[slot]));
+  // not gated on slot_busy: a later chain call may already have ordered the first stream behind this pass (clearing the flag)
+  // while the host has not waited yet; synchronising a completed or never-recorded event returns at once
+  if (slot < (int)c->slot_done.size()) HIPCHK(hipEventSynchronize(c->slot_done[slot]));
   return 0;
 }
 
