@@ -66,7 +66,6 @@ struct vd3d_ctx {
   hipStream_t pix_stream = nullptr; bool pix_overlap = false; bool pix_pending = false;
   hipEvent_t ev_chain = nullptr, ev_pix_last = nullptr;
   std::vector<hipEvent_t> slot_done; std::vector<char> slot_busy;
-  int* own_slot_dev = nullptr; int* own_slot_pin = nullptr;   // depth hand-off min/max keys [B][3]
   // profiling
   bool profiling = false;
   bool use_fused = true;   // VD3D_UNFUSED=1 selects the one-stage-per-kernel v0 path (A/B and debugging)
@@ -80,13 +79,13 @@ struct StageTimer {
   StageTimer(vd3d_ctx* ctx, const char* name) : c(ctx), on(ctx->profiling) {
     if (!on) return;
     r.name = name;
-    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else hipEventCreate(&e); return e; };
+    auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     r.a = get(); r.b = get();
-    hipEventRecord(r.a, c->stream);
+    (void)hipEventRecord(r.a, c->stream);
   }
   ~StageTimer() {
     if (!on) return;
-    hipEventRecord(r.b, c->stream);
+    (void)hipEventRecord(r.b, c->stream);
     c->recs.push_back(r);
   }
 };
@@ -192,17 +191,20 @@ VD3D_EXPORT int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out) {
 }
 VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   if (!c) return 0;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
-  for (auto e : c->ev_pool) hipEventDestroy(e);
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
-  for (void* p : ptrs) if (p) hipFree(p);
-  if (c->pix_stream) { hipStreamSynchronize(c->pix_stream); hipStreamDestroy(c->pix_stream); }
-  for (auto e : c->slot_done) hipEventDestroy(e);
-  if (c->ev_chain) hipEventDestroy(c->ev_chain);
-  if (c->ev_pix_last) hipEventDestroy(c->ev_pix_last);
-  if (c->own_stream) hipStreamDestroy(c->stream);
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
+    for (float* q : *v) (void)hipFree(q);
+  if (c->slot_work) (void)hipFree(c->slot_work);
+  if (c->pix_stream) { (void)hipStreamSynchronize(c->pix_stream); (void)hipStreamDestroy(c->pix_stream); }
+  for (auto e : c->slot_done) (void)hipEventDestroy(e);
+  if (c->ev_chain) (void)hipEventDestroy(c->ev_chain);
+  if (c->ev_pix_last) (void)hipEventDestroy(c->ev_pix_last);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
@@ -548,11 +550,11 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
   if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
   c->pix_pending = false; std::fill(c->slot_busy.begin(), c->slot_busy.end(), 0);
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (auto q : c->slot_rgb) hipFree(q);
-  for (auto q : c->slot_dn) hipFree(q);
-  for (auto q : c->slot_D) hipFree(q);
-  for (auto q : c->slot_tdf) hipFree(q);
-  for (auto q : c->slot_tdfp) hipFree(q);
+  for (auto q : c->slot_rgb) (void)hipFree(q);
+  for (auto q : c->slot_dn) (void)hipFree(q);
+  for (auto q : c->slot_D) (void)hipFree(q);
+  for (auto q : c->slot_tdf) (void)hipFree(q);
+  for (auto q : c->slot_tdfp) (void)hipFree(q);
   c->slot_rgb.clear(); c->slot_dn.clear(); c->slot_D.clear(); c->slot_tdf.clear(); c->slot_tdfp.clear();
   const size_t ne = (size_t)p->eye_h * p->eye_w, n = (size_t)p->warp_h * p->warp_w;
   for (int i = 0; i < n_slots; ++i) {

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const uint4* __restrict__ s
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes) {
   size_t n16 = bytes / 16;
   hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
-  if (bytes % 16) hipMemcpyAsync((char*)dst + n16 * 16, (const char*)src + n16 * 16, bytes % 16, hipMemcpyDeviceToDevice, s);
+  if (bytes % 16) (void)hipMemcpyAsync((char*)dst + n16 * 16, (const char*)src + n16 * 16, bytes % 16, hipMemcpyDeviceToDevice, s);
 }
 
 // ------------------------------------------------------------------------------------------------
