@@ -1,11 +1,11 @@
-python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "overlapped or measure_replay" 2>&1 | tail -4
+#!/bin/bash
+# A/B of the overlapped pixel passes (vd3d_set_pixel_overlap) on one GPU box: same box, back to back.
+#   gpurun --timeout 500 -- 'bash tools/ab_pixel_overlap.sh'
 run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
-import sys,json,os
+import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); rf=d.get('roofline',{})
 print('$*', d['value'], d['ms_per_step'], rf.get('frac'), rf.get('isolated_frac'), d['config'].get('pixel_overlap'))"; }
-run
-run --emulate-world 8
-run --emulate-world 8 --no-pixel-overlap
-run --host-io
-run --workload 4k-dav2b-dibr --steps 8 --warmup 3
-run --workload 4k-dav2b-dibr --steps 8 --warmup 3 --no-pixel-overlap
+for w in 4k-dibr 1080p-dibr 1080p-dav2s-dibr; do
+  run --workload $w --no-pixel-overlap
+  run --workload $w
+done
