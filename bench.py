@@ -361,7 +361,7 @@ def main():
     # W1 / E1 without the depth net sharing the CUs: a short DIBR-only pass AFTER the timed region (same frames, same kernels), so that
     # the contention of the overlapped end-to-end step can be told apart from the kernel itself (reported as roofline.isolated_*)
     iso_ms = {}
-    if rank == 0 and pipe is not None and not args.no_profile and (shr is None or gated or pix_ov) and world == 1 and not emu:
+    if rank == 0 and (pipe is not None or pix_ov) and not args.no_profile and (shr is None or gated or pix_ov) and world == 1 and not emu:
         r.set_profiling(True)   # clears the accumulators of the timed region (already read above)
         for j in range(min(B, 8, len(depths))):
             r.render_frame(frames[j], depths[j], p, out=outs[j])
