@@ -28,6 +28,20 @@ def u8_diff_stats(a, b):
     return int(d.max()), float(np.count_nonzero(d)) / d.size, float(np.count_nonzero(d > 1)) / d.size
 
 
+def b2_max_bound(kw):
+    """Largest end-to-end difference (in LSB) a <= 1-LSB difference at the warp output (the B1 bar: SLEEF 1-ULP pow / exp in torch vs
+    correctly rounded here) can grow to in the muxed frame: the colour grade scales a channel by up to max(1,sat)*max(1,con) before the
+    uint8 truncation, the sharpen kernel has L1 norm (9+f)/(1+f) (core/render_3d.py:719-728), the Dubois anaglyph rows up to 1.43
+    (:866-883).  CLI defaults (sat = con = 1, f = 0.15): 8."""
+    import math
+    g = max(1.0, float(kw.get("color_saturation", 1.0))) * max(1.0, float(kw.get("color_contrast", 1.0)))
+    f = float(kw.get("sharpness_factor", 0.0))
+    b = math.ceil(math.ceil(g - 1e-9) * (9.0 + f) / (1.0 + f) - 1e-9)
+    if kw.get("output_format") == "Red-Cyan Anaglyph":
+        b = math.ceil(b * 1.43)
+    return b
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import u8_diff_stats
+from conftest import b2_max_bound, u8_diff_stats
 from visiondepth3d_amd import synth
 from visiondepth3d_amd._abi import ShiftParams, State
 
@@ -26,7 +26,7 @@ def ref():
     return ref_loader.load()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + [101, 112, 239, 248, 261, 310])   # + the worst of a 300-seed offline sweep
 def test_pixel_shift_random_parameters(ref, oracle, seed):
     import torch
     rng = np.random.default_rng(5000 + seed)
@@ -52,14 +52,17 @@ def test_pixel_shift_random_parameters(ref, oracle, seed):
     o = oracle.pixel_shift(ft, d[None], W, H, ShiftParams.defaults(fg, mg, bg, **kw), st, want_shift=True)
     assert st.fw_prev_offset == ref.floating_window_tracker.prev_offset, (seed, kw)
     # shift map: the reference's pow / exp / sigmoid are SLEEF 1-ULP kernels, the oracle's are correctly rounded; one ULP of a
-    # layer weight is amplified by (1.2 fg + |mg| + 1.1 |bg|) * balance / (W/2).  5e-7 in normalised units is < 1e-4 pixel here.
-    assert np.max(np.abs(o["shift"] - rs.numpy())) < 5e-7, (seed, kw)
+    # layer weight (6e-8) is amplified by amp = (1.2 fg + |mg| + 1.1 |bg|) / (W/2) -- above 1 only for the tiny widths of this sweep.
+    # 6e-7 * max(1, amp) in normalised units is < 1e-4 pixel.  (Offline sweep of 300 more seeds: worst 8.5e-7 at amp 2.6, eyes equal.)
+    amp = (1.2 * fg + abs(mg) + 1.1 * abs(bg)) / (W / 2)
+    assert np.max(np.abs(o["shift"] - rs.numpy())) < 6e-7 * max(1.0, amp), (seed, amp, kw)
     for got, exp, eye in ((o["left"], rl, "L"), (o["right"], rr, "R")):
         mx, frac, _ = u8_diff_stats(got, np.asarray(exp))
-        assert mx <= 1 and frac < 3e-3, (seed, eye, mx, frac, kw)      # <= 1 LSB (pow / exp 1-ULP differences on truncation cliffs)
+        # <= 1 LSB everywhere (the B1 bar); how MANY samples sit on a truncation cliff depends on the content: 300-seed sweep max 0.5 %
+        assert mx <= 1 and frac < 8e-3, (seed, eye, mx, frac, kw)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", list(range(8)) + [114, 136, 151, 153])   # + the worst of a 60-seed offline sweep
 def test_render_loop_random_configurations(ref, oracle, seed):
     """The real ``render_sbs_3d`` loop of the live reference (fake VideoCapture / VideoWriter of ref_stubs) vs the oracle on
     random configurations; bars of the committed B2 goldens (tests/test_oracle_vs_golden.py)."""
@@ -91,7 +94,8 @@ def test_render_loop_random_configurations(ref, oracle, seed):
     got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
     assert got.shape == written.shape, (got.shape, written.shape, kw)
     mx, frac, frac_gt1 = u8_diff_stats(got, written)
-    assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2, (seed, mx, frac, frac_gt1, kw)
+    # >= 99.5 % of the samples within 1 LSB; the maximum is bounded by what grade / sharpen / anaglyph can make of 1 LSB (conftest)
+    assert mx <= b2_max_bound(kw) and frac_gt1 < 5e-3 and frac < 1.5e-2, (seed, mx, b2_max_bound(kw), frac, frac_gt1, kw)
 
 
 @pytest.mark.parametrize("seed", range(10))
