@@ -95,7 +95,62 @@ def test_render_loop_random_configurations(ref, oracle, seed):
     assert got.shape == written.shape, (got.shape, written.shape, kw)
     mx, frac, frac_gt1 = u8_diff_stats(got, written)
     # >= 99.5 % of the samples within 1 LSB; the maximum is bounded by what grade / sharpen / anaglyph can make of 1 LSB (conftest)
-    assert mx <= b2_max_bound(kw) and frac_gt1 < 5e-3 and frac < 1.5e-2, (seed, mx, b2_max_bound(kw), frac, frac_gt1, kw)
+    fb, fb1 = _cliff_bars(kw)
+    assert mx <= b2_max_bound(kw) and frac_gt1 < fb1 and frac < fb, (seed, mx, b2_max_bound(kw), frac, frac_gt1, kw)
+
+
+def _cliff_bars(kw):
+    """(fraction of differing samples, fraction differing by > 1 LSB) allowed end to end.  apply_dof_cuda blends level 0 (the pixel
+    itself, exactly c/255) with level 1 = gaussian_blur(sigma = max_sigma/4).  Wherever the 4-neighbour Laplacian of the uint8 eye
+    is exactly 0 (about 3 % of the samples of the noisy synthetic frames), level 1 equals c/255 up to float32 summation noise --
+    for sigma <= 0.25 the corner taps (weight 1e-7) are below that noise as well -- so `(x*255).astype(uint8)` lands on c or c-1
+    by accident of the conv's summation order: the reference is not reproducible there (its dense conv vs any other association;
+    the float outputs agree to 6e-7, test_helpers_random_inputs).  For max_sigma >= 2 the corner taps (weight 1e-2) break the tie
+    for all but ~0.2 % of the samples.  Measured over a 40-configuration offline sweep: <= 2.6 % / 1.1 % at max_sigma = 1."""
+    if 0.0 < float(kw.get("dof_strength", 0.0)) < 1.5:
+        return 4e-2, 2e-2
+    return 1.5e-2, 5e-3
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 14, 36])   # 14, 36: the worst of a 40-seed offline sweep (small-sigma DOF cliffs)
+def test_blank_frame_loops_random_configurations(ref, oracle, seed):
+    """skip_blank_frames in the real loop of the live reference (blackdetect list injected) on random configurations, incl. output
+    heights that differ from the source (the blank frame keeps the SOURCE size): blank frames bit-exact, the others within the bars."""
+    import make_golden as mg
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    rng = np.random.default_rng(11000 + seed)
+    fmt = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph"][int(rng.integers(0, 4))]
+    sh = int(rng.integers(40, 100)) // 2 * 2
+    sw = int(round(sh * [16 / 9, 16 / 9, 4 / 3, 2.0][int(rng.integers(0, 4))])) // 2 * 2
+    oh = [sh, sh, int(rng.integers(40, 110)) // 2 * 2][int(rng.integers(0, 3))]
+    kw = dict(output_format=fmt, output_height=oh, fg_shift=float(rng.uniform(2, 20)), mg_shift=float(rng.uniform(-6, 2)),
+              bg_shift=float(rng.uniform(-15, 0)), sharpness_factor=float(rng.uniform(0.0, 0.4)),
+              dof_strength=float([0.0, 1.0, 2.0][int(rng.integers(0, 3))]), feather_strength=float(rng.uniform(0, 15)),
+              blur_ksize=int(rng.integers(0, 5)) * 2 + 1, use_subject_tracking=bool(rng.integers(0, 2)),
+              use_floating_window=bool(rng.integers(0, 2)), ipd_factor=float([1.0, 0.0, 1.2][int(rng.integers(0, 3))]),
+              skip_blank_frames=True)
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    n = 7
+    blank = sorted(set(int(v) for v in rng.integers(0, n - 1, size=int(rng.integers(1, 4)))))
+    name = f"_live_blank_{seed}"
+    mg.BLANK_CASES[name] = (sh, sw, n, blank, kw)
+    try:
+        written = np.stack(mg.run_blank_loop(name))
+    finally:
+        del mg.BLANK_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ro = oracle.RenderOracle(render_kwargs_to_params(sw, sh, **kw))
+    ro.new_clip()
+    got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1, blank=(i in blank)) for i, (f, d) in enumerate(list(zip(frames, depths))[1:])])
+    assert got.shape == written.shape, (got.shape, written.shape, kw)
+    fb, fb1 = _cliff_bars(kw)
+    for i in range(len(got)):
+        mx, frac, frac_gt1 = u8_diff_stats(got[i], written[i])
+        if i in blank:
+            assert mx == 0, (seed, i, mx, frac, kw)
+        else:
+            assert mx <= b2_max_bound(kw) and frac_gt1 < fb1 and frac < fb, (seed, i, mx, frac, frac_gt1, kw)
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -134,6 +189,8 @@ def test_helpers_random_inputs(ref, oracle, seed):
     t = ref.frame_to_tensor(bgr)
     focal, ms = float(rng.uniform(0.2, 0.8)), float([1.0, 2.0, 2.0, 3.0][int(rng.integers(0, 4))])
     dof_ref = ref.apply_dof_cuda(t, dt, focal, max_sigma=ms, focus_width=0.35)
+    # float domain: separable symmetric-pair FMA sums (oracle, HIP) vs the dense k x k conv of torchvision: summation noise only
+    assert np.max(np.abs(oracle.apply_dof(oracle.frame_to_tensor(bgr), d, focal, ms) - dof_ref.numpy())) < 8e-7, (seed, ms)
     sat, con, bri = float(rng.uniform(0.8, 1.4)), float(rng.uniform(0.9, 1.2)), float(rng.uniform(-0.05, 0.05))
     out_ref = ref.tensor_to_frame(ref.apply_color_grade(dof_ref, sat, con, bri))
     tt = oracle.frame_to_tensor(bgr)
