@@ -30,13 +30,14 @@ def u8_diff_stats(a, b):
 
 def b2_max_bound(kw):
     """Largest end-to-end difference (in LSB) a <= 1-LSB difference at the warp output (the B1 bar: SLEEF 1-ULP pow / exp in torch vs
-    correctly rounded here) can grow to in the muxed frame: the colour grade scales a channel by up to max(1,sat)*max(1,con) before the
-    uint8 truncation, the sharpen kernel has L1 norm (9+f)/(1+f) (core/render_3d.py:719-728), the Dubois anaglyph rows up to 1.43
-    (:866-883).  CLI defaults (sat = con = 1, f = 0.15): 8."""
+    correctly rounded here) can grow to in the muxed frame.  The colour grade scales a channel by up to max(1,sat)*max(1,con) and
+    then truncates to uint8 AGAIN -- even the identity grade maps some values v to v-1 (luma mix + two affine steps in float32;
+    observed: eyes 63 / 64 -> graded 62 / 64), so one LSB in can be ceil(gain) + 1 out; the sharpen kernel has L1 norm (9+f)/(1+f)
+    (core/render_3d.py:719-728), the Dubois anaglyph rows up to 1.43 (:866-883).  The committed fixtures stay within 8."""
     import math
     g = max(1.0, float(kw.get("color_saturation", 1.0))) * max(1.0, float(kw.get("color_contrast", 1.0)))
     f = float(kw.get("sharpness_factor", 0.0))
-    b = math.ceil(math.ceil(g - 1e-9) * (9.0 + f) / (1.0 + f) - 1e-9)
+    b = math.ceil((math.ceil(g - 1e-9) + 1) * (9.0 + f) / (1.0 + f) - 1e-9)
     if kw.get("output_format") == "Red-Cyan Anaglyph":
         b = math.ceil(b * 1.43)
     return b

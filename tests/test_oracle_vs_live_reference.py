@@ -112,6 +112,54 @@ def _cliff_bars(kw):
     return 1.5e-2, 5e-3
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_letterbox_aspect_loops_random_configurations(ref, oracle, seed):
+    """Random letterbox bars x auto_crop_black_bars on / off x the reference's seven aspect-ratio labels x formats x output heights
+    through the real loop (40-seed offline sweep: one configuration exceeded the old fixed maximum of 8 -- 1 LSB at the warp output
+    turned into 2 by the identity grade's own truncation, then x 8 by the sharpen; b2_max_bound now states that bound)."""
+    import contextlib
+    import io
+    import threading
+    import make_golden as mg
+    import ref_stubs
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    rng = np.random.default_rng(13000 + [29, 0, 1, 2, 3, 4][seed])
+    labels = list(ref.aspect_ratios)
+    fmt = ["Half-SBS", "Passive Interlaced", "Red-Cyan Anaglyph", "Full-SBS"][int(rng.integers(0, 4))]
+    sh = int(rng.integers(60, 130)) // 2 * 2
+    sw = int(round(sh * [16 / 9, 2.0, 4 / 3, 2.39][int(rng.integers(0, 4))])) // 2 * 2
+    oh = [sh, int(rng.integers(40, 110)) // 2 * 2][int(rng.integers(0, 2))]
+    label = labels[int(rng.integers(0, len(labels)))]
+    top, bottom = int(rng.integers(0, sh // 5)), int(rng.integers(0, sh // 5))
+    auto = bool(rng.integers(0, 2))
+    kw = dict(output_format=fmt, output_height=oh, fg_shift=float(rng.uniform(2, 20)), mg_shift=float(rng.uniform(-6, 2)),
+              bg_shift=float(rng.uniform(-15, 0)), sharpness_factor=float(rng.uniform(0.0, 0.4)),
+              dof_strength=float([0.0, 2.0][int(rng.integers(0, 2))]), feather_strength=float(rng.uniform(0, 15)),
+              blur_ksize=int(rng.integers(0, 5)) * 2 + 1, use_subject_tracking=bool(rng.integers(0, 2)),
+              use_floating_window=bool(rng.integers(0, 2)), auto_crop_black_bars=auto)
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    n = 4
+    frames, depth_bgr = synth.letterbox_clip(n, sh, sw, top, bottom)
+    ref_stubs._Clip.clips["in.mp4"] = frames
+    ref_stubs._Clip.clips["depth.mp4"] = depth_bgr
+    ref_loader.reset_state(ref)
+    args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0,
+                output_width=sw, selected_aspect_ratio=mg._Aspect(label), aspect_ratios=ref.aspect_ratios,
+                suspend_flag=threading.Event(), cancel_flag=threading.Event())
+    args.update(kw)
+    with contextlib.redirect_stdout(io.StringIO()) as so:
+        ref.render_sbs_3d(**args)
+    assert "crashed" not in so.getvalue(), so.getvalue()[-300:]
+    written = np.stack(ref_stubs._Clip.written["out.avi"])
+    ro = oracle.RenderOracle(render_kwargs_to_params(sw, sh, target_ratio=ref.aspect_ratios[label], **kw))
+    ro.new_clip()
+    got = np.stack([ro.render(f, d, 1) for f, d in list(zip(frames, depth_bgr))[1:]])
+    assert got.shape == written.shape, (got.shape, written.shape, kw, label)
+    mx, frac, frac_gt1 = u8_diff_stats(got, written)
+    assert mx <= b2_max_bound(kw) and frac_gt1 < 5e-3 and frac < 1.5e-2, (seed, mx, b2_max_bound(kw), frac, frac_gt1, kw, label)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 14, 36])   # 14, 36: the worst of a 40-seed offline sweep (small-sigma DOF cliffs)
 def test_blank_frame_loops_random_configurations(ref, oracle, seed):
     """skip_blank_frames in the real loop of the live reference (blackdetect list injected) on random configurations, incl. output
