@@ -170,6 +170,7 @@ int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out);
 int vd3d_ctx_destroy(vd3d_ctx* ctx);
 int vd3d_sync(vd3d_ctx* ctx);                            /* hipStreamSynchronize */
 void* vd3d_ctx_stream(vd3d_ctx* ctx);
+void* vd3d_ctx_pixel_stream(vd3d_ctx* ctx);              /* second stream of vd3d_set_pixel_overlap (NULL before it was enabled) */
 
 /* ---- tracker state (replaces the module singletons; lets ranks exchange it) -- */
 int vd3d_state_reset(vd3d_ctx* ctx);                     /* fresh process + fresh render */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VD3D_LIB_PATH") or os.path.join(_HERE, "libvd3d_hip.s
 # every symbol include/vd3d.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = (
     "vd3d_abi_version", "vd3d_last_error", "vd3d_shift_params_default", "vd3d_render_params_default",
-    "vd3d_ctx_create", "vd3d_ctx_destroy", "vd3d_sync", "vd3d_ctx_stream",
+    "vd3d_ctx_create", "vd3d_ctx_destroy", "vd3d_sync", "vd3d_ctx_stream", "vd3d_ctx_pixel_stream",
     "vd3d_state_reset", "vd3d_state_new_clip", "vd3d_state_export", "vd3d_state_import", "vd3d_state_planes",
     "vd3d_last_scalars", "vd3d_pixel_shift", "vd3d_render_frame", "vd3d_render_frame_blank", "vd3d_advance_state", "vd3d_depth_handoff",
     "vd3d_shard_begin", "vd3d_shard_pass1", "vd3d_shard_pass2", "vd3d_shard_pixels", "vd3d_set_pixel_overlap", "vd3d_join_pixels", "vd3d_wait_pixels", "vd3d_finish_frame", "vd3d_quantiles",
@@ -48,6 +48,8 @@ def lib():
     L.vd3d_sync.argtypes = [vp]
     L.vd3d_ctx_stream.argtypes = [vp]
     L.vd3d_ctx_stream.restype = vp
+    L.vd3d_ctx_pixel_stream.argtypes = [vp]
+    L.vd3d_ctx_pixel_stream.restype = vp
     for n in ("vd3d_state_reset", "vd3d_state_new_clip"):
         getattr(L, n).argtypes = [vp]
     L.vd3d_state_export.argtypes = [vp, C.POINTER(State)]

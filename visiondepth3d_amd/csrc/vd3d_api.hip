@@ -215,6 +215,7 @@ VD3D_EXPORT int vd3d_sync(vd3d_ctx* c) {
   return 0;
 }
 VD3D_EXPORT void* vd3d_ctx_stream(vd3d_ctx* c) { return (void*)c->stream; }
+VD3D_EXPORT void* vd3d_ctx_pixel_stream(vd3d_ctx* c) { return c ? (void*)c->pix_stream : nullptr; }
 
 // ---- state ------------------------------------------------------------------------------------
 VD3D_EXPORT int vd3d_state_export(vd3d_ctx* c, vd3d_state* out) {

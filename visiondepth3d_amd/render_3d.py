@@ -52,6 +52,13 @@ class Renderer:
             return torch.cuda.default_stream(self.device)
         return torch.cuda.ExternalStream(int(ptr), device=self.device)
 
+    @property
+    def pixel_stream(self):
+        """The second stream (overlapped pixel passes) as a torch stream object, or None before ``set_pixel_overlap(True)``.
+        Consumers of the muxed frames (e.g. a D2H copy) order themselves behind it."""
+        ptr = self._L.vd3d_ctx_pixel_stream(self._ctx)
+        return torch.cuda.ExternalStream(int(ptr), device=self.device) if ptr else None
+
     def close(self):
         if self._ctx:
             self._L.vd3d_ctx_destroy(self._ctx)
