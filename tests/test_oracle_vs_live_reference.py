@@ -267,3 +267,64 @@ def test_pixel_shift_full_size_1080p(ref, oracle):
     for got, exp in ((o["left"], rl), (o["right"], rr)):
         mx, frac, _ = u8_diff_stats(got, np.asarray(exp))
         assert mx <= 1 and frac < 2e-4, (mx, frac)
+
+
+def _reference_function(path, name, namespace):
+    """One function of a reference module that cannot be imported here as a whole (core/render_depth.py pulls in diffusers,
+    onnxruntime, tkinter ...): its ``def`` is located with ``ast`` in the file where it lies and compiled on its own (nothing of the
+    reference is copied into the repo; the GPU box never runs this)."""
+    import ast
+    src = open(path).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = dict(namespace)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def test_depth_handoff_normalisation_vs_reference(oracle):
+    """a24, the per-frame min-max -> uint8 truncation of ``convert_depth_to_grayscale`` (core/render_depth.py:585-611) with the
+    resize being the identity (transformers >= 4.4x hands ``predicted_depth`` back at the frame size): the
+    oracle's hand-off equals the reference function bit for bit, incl. the degenerate-range and NaN frames it maps to zeros."""
+    import torch
+    from PIL import Image
+    path = os.path.join(ref_loader.REF_ROOT if hasattr(ref_loader, "REF_ROOT") else "/root/reference", "core", "render_depth.py")
+    conv = _reference_function(path, "convert_depth_to_grayscale", {"np": np, "torch": torch, "Image": Image, "print": lambda *a, **k: None})
+    rng = np.random.default_rng(77)
+    for i in range(12):
+        h, w = int(rng.integers(8, 70)), int(rng.integers(8, 90))
+        pred = synth.synth_frame(i, h, w)[1].astype(np.float32) * np.float32(rng.uniform(0.01, 40.0)) + np.float32(rng.uniform(-5, 5))
+        if i == 3:
+            pred[:] = 2.5                      # range < 1e-6 -> zeros
+        if i == 4:
+            pred[h // 2, w // 2] = np.nan      # NaN -> zeros
+        if i == 5:
+            pred = (pred - pred.min()) * np.float32(1e-7) + 1.0   # range just below / above the 1e-6 gate
+        exp = conv(torch.from_numpy(pred.copy()))
+        got = oracle.depth_handoff(pred, h, w)
+        assert np.array_equal(got, exp), (i, np.abs(got.astype(int) - exp.astype(int)).max())
+        assert np.array_equal(oracle.depth_handoff(pred, h, w, invert=True), 255 - exp), i     # :1914-1915
+
+
+def test_depth_handoff_with_bicubic_postprocess_vs_torch_and_reference(oracle):
+    """The full a24 hand-off: transformers' post_process_depth_estimation (``F.interpolate(..., mode="bicubic",
+    align_corners=False)`` to the frame size -- torch is the implementation, present here) followed by the reference's
+    ``convert_depth_to_grayscale``.  The oracle restates the bicubic taps in ATen's association: <= 1 LSB after the truncation, and
+    only on truncation cliffs (the float planes agree to a few ULP)."""
+    import torch
+    import torch.nn.functional as F
+    from PIL import Image
+    path = os.path.join(ref_loader.REF_ROOT, "core", "render_depth.py")
+    conv = _reference_function(path, "convert_depth_to_grayscale", {"np": np, "torch": torch, "Image": Image, "print": lambda *a, **k: None})
+    rng = np.random.default_rng(78)
+    worst = 0.0
+    for i in range(8):
+        ph, pw = int(rng.integers(12, 40)), int(rng.integers(16, 60))
+        H, W = int(ph * rng.uniform(1.0, 3.0)), int(pw * rng.uniform(1.0, 3.0))
+        pred = synth.synth_frame(i, ph, pw)[1].astype(np.float32) * np.float32(rng.uniform(0.5, 20.0))
+        up = F.interpolate(torch.from_numpy(pred.copy())[None, None], size=(H, W), mode="bicubic", align_corners=False)[0, 0]
+        exp = conv(up)
+        got = oracle.depth_handoff(pred, H, W)
+        d = np.abs(got.astype(int) - exp.astype(int))
+        worst = max(worst, float((d > 0).mean()))
+        assert d.max() <= 1 and (d > 0).mean() < 5e-3, (i, d.max(), (d > 0).mean())
+    print("hand-off vs torch bicubic + reference normalisation: worst differing fraction", worst)
