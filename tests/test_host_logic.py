@@ -105,3 +105,35 @@ def test_blackdetect_log_parsing(tmp_path):
     (tmp_path / "clip.mp4.blankcache.json").write_text("[7, 3, 9]")
     assert bd.detect_black_white_frames(vid) == [7, 3, 9]                           # cache is returned as stored (:38-41)
     assert bd.detect_black_white_frames(str(tmp_path / "none.mp4"), cache=False) == []   # no ffmpeg here -> [] like :79-81
+
+
+def test_dpt_front_end_matches_the_real_image_processor():
+    """B3 / a25 front end against transformers' own DPTImageProcessor (the Depth-Anything-V2 preprocessor_config values): the
+    target size rule on 70 frame sizes exactly, and the float statement the fused kernel is tested against (antialiased bicubic in
+    float32, tests/test_hip_depthprep.py) within ~1 LSB of the 8-bit image the PIL path rounds to (tolerance 1.5 / 255 / std)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    transformers = pytest.importorskip("transformers")
+    from PIL import Image
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import IMAGENET_MEAN, IMAGENET_STD, dpt_resize_target
+    proc = transformers.DPTImageProcessor(do_resize=True, size={"height": 518, "width": 518}, keep_aspect_ratio=True, ensure_multiple_of=14,
+                                          resample=3, do_rescale=True, rescale_factor=1 / 255, do_normalize=True,
+                                          image_mean=IMAGENET_MEAN, image_std=IMAGENET_STD, do_pad=False)
+    rng = np.random.default_rng(3)
+    sizes = [(1080, 1920), (2160, 3840), (720, 1280), (480, 640), (270, 480), (101, 333), (518, 924), (1000, 1000), (1440, 2560),
+             (1600, 1440)] + [(int(rng.integers(40, 2200)), int(rng.integers(40, 4000))) for _ in range(60)]
+    for h, w in sizes:
+        out = proc(images=Image.fromarray(np.zeros((h, w, 3), np.uint8)), return_tensors="pt")["pixel_values"]
+        assert tuple(out.shape[-2:]) == dpt_resize_target(h, w), (h, w)
+    assert dpt_resize_target(1080, 1920) == (518, 924)
+    h, w = 270, 480
+    bgr = synth.synth_frame(2, h, w)[0]
+    pv = proc(images=Image.fromarray(bgr[..., ::-1].copy()), return_tensors="pt")["pixel_values"][0]
+    th, tw = dpt_resize_target(h, w)
+    x = torch.from_numpy(bgr[..., ::-1].copy()).permute(2, 0, 1)[None].float()
+    x = F.interpolate(x, size=(th, tw), mode="bicubic", antialias=True, align_corners=False)
+    mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    ref = (((x / 255.0) - mean) / std)[0]
+    assert float((pv - ref).abs().max()) < 1.5 / 255 / min(IMAGENET_STD)
