@@ -137,3 +137,42 @@ def test_dpt_front_end_matches_the_real_image_processor():
     mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
     ref = (((x / 255.0) - mean) / std)[0]
     assert float((pv - ref).abs().max()) < 1.5 / 255 / min(IMAGENET_STD)
+
+
+def test_depth_pipe_protocol_against_the_transformers_pipeline():
+    """B3 (core/render_depth.py:1106-1119): ``pipe(list[PIL], inference_size) -> [{"predicted_depth": Tensor[h, w]}]`` against
+    transformers' own ``pipeline("depth-estimation")`` around the stock ``DepthAnythingForDepthEstimation`` with the same synthetic
+    weights, on CPU in float32.  (a) Same pixel_values through the rewritten module graph (fused QKV, folded LayerScale, cached
+    position embedding) and the stock one: 1e-6.  (b) Whole protocol: the prediction comes back at the image size like the
+    pipeline's; values within a few percent -- entirely the 8-bit rounding of the resized image in the PIL / torchvision front
+    ends (the float statement differs from ITS OWN uint8 rounding by the same 1 %: random weights amplify +-0.5 LSB that much)."""
+    import numpy as np
+    import torch
+    transformers = pytest.importorskip("transformers")
+    from PIL import Image
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import IMAGENET_MEAN, IMAGENET_STD, DepthPipe, build_config, synthetic_weights_
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    pipe = DepthPipe("depth-anything-v2-small", device="cpu", dtype=torch.float32)
+    model = transformers.DepthAnythingForDepthEstimation(build_config("depth-anything-v2-small")).eval()
+    synthetic_weights_(model, 0)
+    proc = transformers.DPTImageProcessor(do_resize=True, size={"height": 518, "width": 518}, keep_aspect_ratio=True, ensure_multiple_of=14,
+                                          resample=3, do_rescale=True, rescale_factor=1 / 255, do_normalize=True,
+                                          image_mean=IMAGENET_MEAN, image_std=IMAGENET_STD, do_pad=False)
+    img = Image.fromarray(synth.synth_frame(1, 126, 224)[0][..., ::-1].copy())
+    pv = proc(images=img, return_tensors="pt")["pixel_values"]
+    with torch.no_grad():
+        a = pipe.model(pixel_values=pv).predicted_depth
+        b = model(pixel_values=pv).predicted_depth
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-4
+    hf = transformers.pipeline("depth-estimation", model=model, image_processor=proc, device="cpu")
+    exp = hf([img])[0]["predicted_depth"].squeeze()
+    got = pipe([img])[0]["predicted_depth"]
+    assert tuple(got.shape) == tuple(exp.shape) == (126, 224)
+    assert float((got - exp).abs().mean() / exp.abs().mean()) < 3e-2
+    # hf_batch_safe_pipe with an inference size: the images are pre-resized, the prediction comes back at THAT size (:1113-1116)
+    small = img.resize((112, 70), Image.BICUBIC)
+    exp2 = hf([small])[0]["predicted_depth"].squeeze()
+    got2 = pipe([img], inference_size=(112, 70))[0]["predicted_depth"]
+    assert tuple(got2.shape) == tuple(exp2.shape) == (70, 112)
+    assert float((got2 - exp2).abs().mean() / exp2.abs().mean()) < 5e-2

@@ -233,11 +233,17 @@ class DepthPipe:
             layer.forward = fwd
 
     @torch.no_grad()
-    def infer_bgr_u8(self, frames_bgr: torch.Tensor, inference_size=None, raw: bool = False) -> torch.Tensor:
+    def infer_bgr_u8(self, frames_bgr: torch.Tensor, inference_size=None, raw: bool = False, at_inference_size: bool = False) -> torch.Tensor:
         """uint8 [B,H,W,3] BGR frames in HBM -> float32 [B,H,W] predicted depth at the frame size (the
         depth-estimation pipeline's post-process: bicubic, align_corners=False).  ``raw=True`` returns the model-resolution
-        prediction [B,th,tw] instead, for the fused HIP hand-off (Renderer.depth_handoff)."""
+        prediction [B,th,tw] instead, for the fused HIP hand-off (Renderer.depth_handoff).  ``at_inference_size``: with an
+        ``inference_size`` (W', H') the prediction is returned at (H', W') -- what the transformers pipeline hands back for the
+        pre-resized images of hf_batch_safe_pipe (core/render_depth.py:1113-1116)."""
         B, H, W, _ = frames_bgr.shape
+        if at_inference_size and inference_size is not None:
+            oH, oW = int(inference_size[1]), int(inference_size[0])
+        else:
+            oH, oW = H, W
         if self.renderer is not None and inference_size is None and frames_bgr.dtype == torch.uint8:
             th, tw = dpt_resize_target(H, W)
             x = None
@@ -264,18 +270,20 @@ class DepthPipe:
         pred = self.model(pixel_values=x).predicted_depth  # [B, th, tw]
         if raw:
             return pred.float()
-        pred = F.interpolate(pred.float().unsqueeze(1), size=(H, W), mode="bicubic", align_corners=False).squeeze(1)
+        pred = F.interpolate(pred.float().unsqueeze(1), size=(oH, oW), mode="bicubic", align_corners=False).squeeze(1)
         return pred
 
     def __call__(self, images, inference_size=None):
-        """Reference protocol: list of PIL images (or HxWx3 uint8 RGB arrays) -> list of dicts."""
+        """Reference protocol: list of PIL images (or HxWx3 uint8 RGB arrays) -> list of dicts; ``predicted_depth`` has the size
+        of the image the pipeline saw (the frame, or ``inference_size`` when given -- the caller then resizes the uint8 map back
+        with cv2.INTER_CUBIC, core/render_depth.py:1914-1917)."""
         single = not isinstance(images, (list, tuple))
         imgs = [images] if single else list(images)
         outs = []
         for im in imgs:
             a = np.asarray(im.convert("RGB") if hasattr(im, "convert") else im)
             bgr = torch.from_numpy(np.ascontiguousarray(a[..., ::-1]))[None]
-            outs.append({"predicted_depth": self.infer_bgr_u8(bgr, inference_size)[0]})
+            outs.append({"predicted_depth": self.infer_bgr_u8(bgr, inference_size, at_inference_size=True)[0]})
         return outs
 
     def flops_per_frame(self, h: int, w: int) -> float:
