@@ -26,7 +26,7 @@ def ref():
     return ref_loader.load()
 
 
-@pytest.mark.parametrize("seed", list(range(24)) + [101, 112, 239, 248, 261, 310])   # + the worst of a 300-seed offline sweep
+@pytest.mark.parametrize("seed", list(range(24)) + [101, 112, 159, 239, 248, 261, 310, 426])   # + the worst of a 340-seed offline sweep
 def test_pixel_shift_random_parameters(ref, oracle, seed):
     import torch
     rng = np.random.default_rng(5000 + seed)
@@ -53,9 +53,10 @@ def test_pixel_shift_random_parameters(ref, oracle, seed):
     assert st.fw_prev_offset == ref.floating_window_tracker.prev_offset, (seed, kw)
     # shift map: the reference's pow / exp / sigmoid are SLEEF 1-ULP kernels, the oracle's are correctly rounded; one ULP of a
     # layer weight (6e-8) is amplified by amp = (1.2 fg + |mg| + 1.1 |bg|) / (W/2) -- above 1 only for the tiny widths of this sweep.
-    # 6e-7 * max(1, amp) in normalised units is < 1e-4 pixel.  (Offline sweep of 300 more seeds: worst 8.5e-7 at amp 2.6, eyes equal.)
+    # 4e-7 * max(1, amp) in normalised units is < 1e-4 pixel.  (Offline sweep of 300 more seeds: worst 3.3e-7 * max(1, amp), eyes
+    # equal.  Before the bilinear source index was fused like ATen's -- vo interp_taps -- hard depth edges gave up to 1.6e-6.)
     amp = (1.2 * fg + abs(mg) + 1.1 * abs(bg)) / (W / 2)
-    assert np.max(np.abs(o["shift"] - rs.numpy())) < 6e-7 * max(1.0, amp), (seed, amp, kw)
+    assert np.max(np.abs(o["shift"] - rs.numpy())) < 4e-7 * max(1.0, amp), (seed, amp, kw)
     for got, exp, eye in ((o["left"], rl, "L"), (o["right"], rr, "R")):
         mx, frac, _ = u8_diff_stats(got, np.asarray(exp))
         # <= 1 LSB everywhere (the B1 bar); how MANY samples sit on a truncation cliff depends on the content: 300-seed sweep max 0.5 %

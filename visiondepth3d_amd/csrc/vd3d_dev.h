@@ -83,7 +83,7 @@ VD_DEV vd_tap vd_interp_tap(int in, int out, int o) {
   vd_tap t;
   if (in == out) { t.i0 = o; t.i1 = o; t.w0 = 1.f; t.w1 = 0.f; return t; }
   const float scale = (float)in / (float)out;
-  float src = scale * ((float)o + 0.5f) - 0.5f;
+  float src = vd_fma(scale, (float)o + 0.5f, -0.5f);   // area_pixel_compute_source_index: ONE fused multiply-add in ATen's builds
   if (src < 0.f) src = 0.f;
   int i0 = (int)floorf(src);
   if (i0 > in - 1) i0 = in - 1;
@@ -97,7 +97,7 @@ VD_DEV vd_tap vd_interp_tap(int in, int out, int o) {
 VD_DEV vd_tap vd_interp_tap_s(int in, int out, float scale, int o) {  // vd_interp_tap with scale = (float)in/(float)out hoisted
   vd_tap t;
   if (in == out) { t.i0 = o; t.i1 = o; t.w0 = 1.f; t.w1 = 0.f; return t; }
-  float src = scale * ((float)o + 0.5f) - 0.5f;
+  float src = vd_fma(scale, (float)o + 0.5f, -0.5f);   // area_pixel_compute_source_index: ONE fused multiply-add in ATen's builds
   if (src < 0.f) src = 0.f;
   int i0 = (int)floorf(src);
   if (i0 > in - 1) i0 = in - 1;

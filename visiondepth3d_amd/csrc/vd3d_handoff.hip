@@ -20,7 +20,7 @@ VD_DEV void cubic_coeffs(float t, float c[4]) {
   c[0] = cubic2(t + 1.f, A); c[1] = cubic1(t, A); c[2] = cubic1(1.f - t, A); c[3] = cubic2((1.f - t) + 1.f, A);
 }
 VD_DEV float bicubic_at(const float* __restrict__ p, const vd_handoff_args& a, const float cy[4], int iy, int x) {
-  const float rx = a.sw * ((float)x + 0.5f) - 0.5f;
+  const float rx = vd_fma(a.sw, (float)x + 0.5f, -0.5f);   // fused source index, like the bilinear taps (vd3d_dev.h)
   const float fx = floorf(rx);
   const int ix = (int)fx;
   float cx[4];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_handoff(const float* __restrict__ pred,
 #pragma unroll
       for (int q = 0; q < 4; ++q) if (xq + q < a.W) v[q] = p[(size_t)y * a.W + xq + q];
     } else {
-      const float ry = a.sh * ((float)y + 0.5f) - 0.5f;
+      const float ry = vd_fma(a.sh, (float)y + 0.5f, -0.5f);
       const float fy = floorf(ry);
       float cy[4];
       cubic_coeffs(ry - fy, cy);

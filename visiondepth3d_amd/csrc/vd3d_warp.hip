@@ -43,7 +43,7 @@ VD_DEV int wf_div(int t, uint32_t m) { return (int)__umulhi((uint32_t)t, m); }
 VD_DEV vd_tap wf_tap(int in, int out, float scale, int o) {  // vd_interp_tap with the scale hoisted
   vd_tap t;
   if (in == out) { t.i0 = o; t.i1 = o; t.w0 = 1.f; t.w1 = 0.f; return t; }
-  float src = scale * ((float)o + 0.5f) - 0.5f;
+  float src = vd_fma(scale, (float)o + 0.5f, -0.5f);   // area_pixel_compute_source_index: ONE fused multiply-add in ATen's builds
   if (src < 0.f) src = 0.f;
   int i0 = (int)floorf(src);
   if (i0 > in - 1) i0 = in - 1;
