@@ -329,3 +329,21 @@ def test_depth_handoff_with_bicubic_postprocess_vs_torch_and_reference(oracle):
         worst = max(worst, float((d > 0).mean()))
         assert d.max() <= 1 and (d > 0).mean() < 5e-3, (i, d.max(), (d > 0).mean())
     print("hand-off vs torch bicubic + reference normalisation: worst differing fraction", worst)
+
+
+@pytest.mark.parametrize("k", [2, 4, 8, 12])
+def test_even_blur_ksize_window(ref, oracle, k):
+    """avg_pool2d(kernel k, stride 1, padding k//2) of an EVEN k returns an (H+1) x (W+1) plane that feather_shift_edges crops to
+    [:H, :W] (core/render_3d.py:355-369): the window of pixel x is x-k/2 .. x+k/2-1, zero padded, still divided by k*k."""
+    import torch
+    bgr, d = synth.synth_frame(k, 40, 64)
+    ft = oracle.frame_to_tensor(bgr)
+    for H, W in ((40, 64), (80, 128)):
+        ref_loader.reset_state(ref)
+        with torch.no_grad():
+            rl, rr = ref.pixel_shift_cuda(torch.from_numpy(ft), torch.from_numpy(d[None].copy()), W, H, 10.0, -2.5, -5.0,
+                                          return_shift_map=False, blur_ksize=k, feather_strength=10.0)
+        o = oracle.pixel_shift(ft, d[None], W, H, ShiftParams.defaults(10.0, -2.5, -5.0, blur_ksize=k, feather_strength=10.0), State())
+        for got, exp in ((o["left"], rl), (o["right"], rr)):
+            mx, frac, _ = u8_diff_stats(got, np.asarray(exp))
+            assert mx <= 1 and frac < 8e-3, (k, H, W, mx, frac)
