@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- stereo-pairs/s of the depth -> DIBR hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B] [--depth-dtype f32|bf16]
 
 A "step" is one pass of the hot path over one batch of B synthetic frames already resident in HBM:
-depth inference (workloads with a depth net) -> 8-bit depth hand-off -> the per-frame DIBR chain
-(ingest, exact order statistics, shaping, warp + feather, DOF, grade, sharpen, Half-SBS mux) -> muxed
-frames in HBM.  Default workload = BASELINE.json configs[1] (1080p, Depth-Anything-V2-Small + DIBR).
-For N > 1 the driver launches one rank per GPU with torch.distributed.run and the frames of ONE clip are sharded
-round-robin (frame t -> rank t % N, visiondepth3d_amd/sharded.py StepShardedRenderer): each rank runs depth inference
-and the pixel kernels for its own frames; the data-path collectives are an RCCL all-gather of the uint8 depth planes
-and an all-gather of one float (s1) per frame; every rank runs the cheap eye-res chain for all frames and replays the
-tracker, so the output is bit-identical to the 1-GPU render.  Weak scaling: B frames per rank per step.  The timed region is
-bracketed by barrier + synchronize and the MAX over ranks is reported.
+depth inference (workloads with a depth net, float32 like the reference's Hugging Face path) -> 8-bit depth hand-off ->
+the per-frame DIBR chain (ingest, exact order statistics, shaping, warp + feather, DOF, grade, sharpen, Half-SBS mux) ->
+muxed frames in HBM.
+
+Default run (no --workload), N = 1: the HEADLINE is BASELINE.json configs[3]'s per-GPU slice `4k-dav2b-dibr` (3840x2160,
+Depth-Anything-V2-Base + full DIBR: the configuration every `north_star` target is quoted on), timed over exactly --steps
+steps after --warmup steps; the same invocation then measures, as labelled sub-records of the one JSON line,
+  * `4k-dibr`          configs[2], the HBM-roofline run (>= 200 timed frames, DIBR only, W1 / E1 alone on the GPU),
+  * `1080p-dav2s-dibr` configs[1] (1080p, DA-V2-Small + DIBR),
+  * `1080p-dibr`       the DIBR-only GPU rate that does the SAME work as `cpu_baseline_1080p` (the C oracle has no depth net),
+  * the bf16 variant of the headline (reduced precision, labelled; never `value`).
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the frames of ONE clip are sharded in contiguous
+chunks (visiondepth3d_amd/sharded.py) and only the headline workload runs.  Weak scaling: B frames per rank per step.  The
+timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
 """
 from __future__ import annotations
 
 import argparse
 import contextlib
 import json
+import math
 import os
 import sys
 import time
@@ -35,12 +41,15 @@ WORKLOADS = {
     "4k-dibr": (2160, 3840, None, "BASELINE configs[2]: 4K, precomputed f32 depth, DIBR warp+DOF only (HBM roofline run)"),
     "4k-dav2b-dibr": (2160, 3840, "depth-anything-v2-base", "BASELINE configs[3] per-GPU slice: 4K, DA-V2-Base + DIBR"),
 }
+HEADLINE = "4k-dav2b-dibr"
 RENDER_KW = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
                  feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)  # render_cli.py:24-33
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense f32-input MFMA (= vector rate) / dense bf16
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9           # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz (one wave64 VALU issue = 4 clk)
 
 
-def cpu_baseline(sh, sw, seconds_budget=20.0):
+def cpu_baseline(sh, sw, seconds_budget=20.0, max_frames=30):
     """The CPU oracle (kind "port", 1 core) on a bounded sample of the same frames; DIBR chain only."""
     from oracle import oracle as O
     from visiondepth3d_amd import synth
@@ -49,7 +58,7 @@ def cpu_baseline(sh, sw, seconds_budget=20.0):
     ro = O.RenderOracle(p)
     ro.new_clip()
     n, t_used = 0, 0.0
-    while n < 2 or (t_used < seconds_budget and n < 30):
+    while n < 2 or (t_used < seconds_budget and n < max_frames):
         f, d = synth.synth_frame(n, sh, sw)
         t0 = time.perf_counter()
         ro.render(f, d, 0)
@@ -103,57 +112,62 @@ def cpu_baseline_allcores(sh, sw, frames_per_core, max_cores=64, timeout_s=90.0)
                       f"only); slowest process {tmax:.1f} s, {wall:.1f} s wall incl. start-up"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="1080p-dav2s-dibr", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=16, help="frames per step")
-    ap.add_argument("--clip", type=int, default=16, help="distinct synthetic frames resident in HBM (cycled)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
-    ap.add_argument("--sharded", action="store_true", help="use the three-phase sharding protocol even at N=1 (it is the N>1 path)")
-    ap.add_argument("--emulate-world", type=int, default=0, help="N=1 only: run this rank's share of a G-rank sharded step (foreign frames "
-                    "included, collectives replaced by local replication) to estimate the per-rank step time at G GPUs")
-    ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
-                    "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
-    ap.add_argument("--gated", action="store_true", help="alternative schedule: only the latency-bound measurement chain of batch i overlaps "
-                    "the depth net of batch i+1; the pixel kernels (k_shift, W1, E1) of batch i-1 run between two depth-net batches with "
-                    "the GPU to themselves (W1 at its isolated speed, but 4.5 %% lower end-to-end throughput than the default, where the "
-                    "whole DIBR chain shares the GPU with the depth net)")
-    ap.add_argument("--pixel-overlap", dest="pixel_overlap", action="store_true", default=None,
-                    help="two slot sets + vd3d_set_pixel_overlap: the pixel kernels of step i run on a second stream of the renderer while "
-                    "the (latency-bound) measurement chain of step i+1 runs on the first (the default; measured +27 %% / +14 %% on the 1080p / 4K "
-                    "DIBR-only workloads, +1 %% end to end with the depth net)")
-    ap.add_argument("--no-pixel-overlap", dest="pixel_overlap", action="store_false")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
-    args = ap.parse_args()
-
+def cpu_depth_net(model_name, sh, sw):
+    """The depth net of the headline on the HOST cores (torch CPU float32, all threads -- what the reference's own CPU path runs,
+    core/render_depth.py:758-759 with device 'cpu'): one frame after one warm-up frame."""
     import torch
-    import torch.distributed as dist
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import DepthPipe
+    pipe = DepthPipe(model_name, device="cpu", dtype=torch.float32)
+    f = torch.from_numpy(synth.synth_frame(0, sh, sw)[0])[None]
+    pipe.infer_bgr_u8(f, raw=True)
+    t0 = time.perf_counter()
+    pipe.infer_bgr_u8(f, raw=True)
+    dt = time.perf_counter() - t0
+    return {"seconds_per_frame": round(dt, 3), "cores": torch.get_num_threads(), "kind": "torch-cpu float32 (same module graph)",
+            "sample": f"1 frame {sw}x{sh} -> {model_name} on the host cores"}
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and world > 1:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
 
+class Env:
+    """torch / distributed context shared by the workloads of one invocation"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != max(args.gpus, 1) and self.world > 1:
+            raise SystemExit(f"WORLD_SIZE={self.world} but --gpus {args.gpus}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_dtype: str = "f32", profile: bool = True,
+                 isolated_pass: bool = True):
+    """Time `steps` steps of one workload after `warmup` untimed steps.  Returns a dict with the timing, the HIP-event stage
+    averages taken inside the timed region, and the parameters needed to price them."""
+    torch, dist = env.torch, env.dist
+    rank, world, local_rank = env.rank, env.world, env.local_rank
     from visiondepth3d_amd import synth
     from visiondepth3d_amd.params import render_kwargs_to_params
     from visiondepth3d_amd.render_3d import Renderer
 
-    sh, sw, model_name, desc = WORKLOADS[args.workload]
+    sh, sw, model_name, desc = WORKLOADS[workload]
     p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
-    overlap = (not args.no_overlap) and WORKLOADS[args.workload][2] is not None
-    r = Renderer(local_rank, private_stream=overlap)   # DIBR chain: ~25 small dependent launches per frame
+    overlap = (not args.no_overlap) and model_name is not None
+    r = Renderer(local_rank, private_stream=overlap)   # DIBR chain on its own stream when a depth net shares the GPU
     rh = Renderer(local_rank) if overlap else r        # depth hand-off stays on the depth net's (torch) stream
     dibr_stream = r.stream if overlap else None
     r.new_clip()
@@ -170,146 +184,73 @@ def main():
         h_clip = frames.cpu().pin_memory()
         ring = PinnedRing(B, (sh, sw, 3), (p.out_h, p.out_w, 3), torch.device("cuda", local_rank), depth=3)
 
-    shr = None
-    emu = args.emulate_world if (world == 1 and args.emulate_world > 1) else 0
-    gated = overlap and args.gated
-    shr2 = None
-    # host-io: measured 516 pairs/s with the overlapped passes vs 694 without (same box) -- the sharded step starts its chain only when
-    # the whole batch has crossed PCIe and the copy engines then compete with two compute streams; not understood further this round
+    # host-io: measured slower with the overlapped passes (the copy engines then compete with two compute streams)
     pix_ov = (not args.host_io) if args.pixel_overlap is None else bool(args.pixel_overlap)
-    pix_ov = pix_ov and not gated
-    if world > 1 or args.sharded or emu or gated or pix_ov:
+    shr2 = None
+    if world > 1 or args.sharded or pix_ov:
         from visiondepth3d_amd.sharded import MeasureReplaySharder
-        shr = MeasureReplaySharder(r, p, rank, emu or world, B)
-        shr2 = [shr, MeasureReplaySharder(r, p, rank, emu or world, B, slot_base=B)] if (gated or pix_ov) else None
+        shr2 = [MeasureReplaySharder(r, p, rank, world, B)]
         if pix_ov:
+            shr2.append(MeasureReplaySharder(r, p, rank, world, B, slot_base=B))
             r.set_pixel_overlap(True)
-        if emu:   # every "other rank" contributes a copy of this rank's planes: same kernel work as a real G-rank step, no fabric
-            for s_ in (shr2 or [shr]):
-                s_.gather = lambda t: t.repeat((emu,) + (1,) * (t.dim() - 1))
 
     pipe = None
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}[depth_dtype]
     if model_name:
-        from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
-        pipe = DepthPipe(model_name, device="cuda", dtype=torch.bfloat16, renderer=rh)   # fused image-processor front end
+        from visiondepth3d_amd.depth import DepthPipe
+        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh)   # fused front end + fused backbone glue
 
-    shr_one = shr
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
     gathered = [torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if world > 1 else None
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     done = [torch.cuda.Event() for _ in range(NBUF)]
-    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded or emu or pix_ov) else None
-    ev_pix = [None]          # gated schedule: completion of the most recently enqueued pixel pass
-    pending = [None]         # gated schedule: (sharder, ring slot or None) whose pixel pass has not been enqueued yet
+    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded) else None
+    net_ev = []   # (start, end) torch events around the depth net + hand-off of the timed steps
 
-    def pixel_pass():
-        """gated schedule: pixel kernels of the pending step on the DIBR stream (the caller has ordered them after the depth net)."""
-        if pending[0] is None:
-            return
-        sh_, kr_ = pending[0]
-        with torch.cuda.stream(dibr_stream):
-            o_ = outs
-            if ring is not None:
-                ring.reserve_output(kr_)
-                o_ = ring.d_out[kr_]
-            sh_.pixels(o_)
-            if ring is not None:
-                ring.download(kr_)
-            e_ = torch.cuda.Event()
-            e_.record(dibr_stream)
-        ev_pix[0] = e_
-        pending[0] = None
-
-    def step_gated(i):
-        """D(i) on the depth-net stream | pixels(i-1) alone | chain(i) on the DIBR stream, overlapping D(i+1)."""
+    def step(i, timed=False):
+        shr = shr2[i % len(shr2)] if shr2 else None    # pixel overlap: alternate slot sets so the next chain never waits for these pixels
         idx = [(i * B + j) % args.clip for j in range(B)]
         contiguous = idx == list(range(idx[0], idx[0] + B))
         fb = frames[idx[0]:idx[0] + B] if contiguous else frames[idx]
         k = i % NBUF
-        sh_ = shr2[i % 2]
-        kr = None
-        if ring is not None:
-            kr = i % ring.n
-            ring.upload(kr, h_clip[idx[0]:idx[0] + B] if contiguous else h_clip[idx])
-            fb = ring.d_in[kr]
-        cur = torch.cuda.current_stream()
-        if ev_pix[0] is not None:
-            cur.wait_event(ev_pix[0])          # the depth net of this batch starts after the previous pixel pass: no sharing
-        cur.wait_event(done[k])                # hand-off buffer k: its measurement chain (two steps ago) is finished
-        pred = pipe.infer_bgr_u8(fb, raw=True)
-        dloc = rh.depth_handoff(pred, sh, sw, out=dbuf[k])
-        ev = torch.cuda.Event()
-        ev.record()
-        dibr_stream.wait_event(ev)             # DIBR stream: everything below runs after this batch's depth net
-        if ring is not None:
-            dibr_stream.wait_event(ring.ev_in[kr])
-        pixel_pass()                           # pixels(i-1): between D(i) and D(i+1), with the GPU to themselves
-        with torch.cuda.stream(dibr_stream):
-            dall = dloc
-            if world > 1:
-                dist.all_gather_into_tensor(gathered[k], dloc.contiguous())
-                dall = gathered[k]
-            elif emu:
-                dall = sh_.gather(dloc)
-        sh_.p1(fb, dall)
-        with torch.cuda.stream(dibr_stream):
-            sh_.r.shard2_r1(sh_._frame_order(sh_.gather(sh_.q_local)))
-        sh_.p3()
-        with torch.cuda.stream(dibr_stream):
-            sh_.replay(sh_._frame_order(sh_.gather(sh_.m_local)))
-        done[k].record(dibr_stream)
-        pending[0] = (sh_, kr)
-
-    def drain():
-        """gated schedule: the pixel pass of the last enqueued step (so that a timed region holds exactly its own steps)."""
-        if gated and pending[0] is not None:
-            if ev_pix[0] is not None:
-                pass
-            pixel_pass()
-
-    def step(i):
-        # this rank's B frames of the step; global frame order inside a step: (j, g) for j in range(B) for g in range(world)
-        shr = shr2[i % 2] if pix_ov else shr_one    # pixel overlap: alternate slot sets so the next chain never waits for these pixels
-        idx = [(i * B + j) % args.clip for j in range(B)]
-        fb = frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
-        k = i % NBUF
         outs_k = outs
         if ring is not None:
             kr = i % ring.n
-            ring.upload(kr, h_clip[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else h_clip[idx])
+            ring.upload(kr, h_clip[idx[0]:idx[0] + B] if contiguous else h_clip[idx])
             fb, outs_k = ring.d_in[kr], ring.d_out[kr]
         if overlap:
             torch.cuda.current_stream().wait_event(done[k])  # hand-off buffer k is free again (no-op until first recorded)
+        dloc = None
         if pipe is not None:
-            pred = pipe.infer_bgr_u8(fb, raw=True)       # [B,518,924] f32 on device
+            if timed and profile:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            pred = pipe.infer_bgr_u8(fb, raw=True)              # [B,518,924] f32 on device
             dloc = rh.depth_handoff(pred, sh, sw, out=dbuf[k])  # the reference's 8-bit depth hand-off (a24), fused, no disk hop
-        else:
-            dloc = None
+            if timed and profile:
+                e1.record()
+                net_ev.append((e0, e1))
         if shr is not None and dloc is None:
-            dsrc = depths if (pix_ov and world == 1 and not emu and not args.sharded) else depths_u8   # 1 GPU: the precomputed f32 planes
-            dloc = dsrc[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else dsrc[idx]
+            dsrc = depths if depths_u8 is None else depths_u8   # 1 GPU: the precomputed f32 planes
+            dloc = dsrc[idx[0]:idx[0] + B] if contiguous else dsrc[idx]
         if overlap:  # hand the batch to the DIBR stream; this (torch) stream goes on to the next batch's depth inference
             ev = torch.cuda.Event()
             ev.record()
             dibr_stream.wait_event(ev)
-        if world > 1:   # data-path collective 1: uint8 depth planes [world*B,h,w]; ordered on the DIBR stream so that the ring
-                        # transfer overlaps the next batch's depth inference instead of stalling the depth-net stream
+        if world > 1:   # data-path collective: ordered on the DIBR stream so that it overlaps the next batch's depth inference
             with (torch.cuda.stream(dibr_stream) if overlap else contextlib.nullcontext()):
                 dist.all_gather_into_tensor(gathered[k], dloc.contiguous())
         if ring is not None:
             if overlap:
                 dibr_stream.wait_event(ring.ev_in[kr])
-            # the stream that writes d_out[kr] waits until its previous content has left for the host
             ring.reserve_output(kr, compute_stream=r.pixel_stream if pix_ov else dibr_stream)
         if shr is None:
             for j in range(B):
                 r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs_k[j])
-        else:  # measure / replay sharding: P1 over all world*B frames (foreign: plane EMA only), exchange of 2 floats per frame, EMA
-               # replay, P3 on own frames, exchange of 4 x int64 per frame, tracker replay, pixel pass (sharded.MeasureReplaySharder)
-            shr.p1(fb, gathered[k] if world > 1 else (shr.gather(dloc) if emu else dloc))
+        else:
+            shr.p1(fb, gathered[k] if world > 1 else dloc)
             on_dibr = (lambda: torch.cuda.stream(dibr_stream)) if overlap else contextlib.nullcontext
-            with on_dibr():   # the small collectives (and the torch ops that reorder their results) are enqueued on the DIBR stream,
-                              # where the records are produced and consumed -- not on the depth net's stream
+            with on_dibr():   # the small collectives (and the torch ops that reorder their results) run on the DIBR stream
                 shr.r.shard2_r1(shr._frame_order(shr.gather(shr.q_local)))
             shr.p3()
             with on_dibr():
@@ -317,27 +258,18 @@ def main():
             shr.finish(m_ord, outs_k, ordered=True)
         if overlap:
             done[k].record(dibr_stream)
-        if ring is not None:   # D2H behind the stream that produced the muxed frames (the pixel stream when the passes are overlapped)
+        if ring is not None:   # D2H behind the stream that produced the muxed frames
             ring.download(kr, compute_stream=r.pixel_stream if pix_ov else dibr_stream)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_step = step_gated if gated else step
-    for i in range(args.warmup):
-        run_step(i)
-    drain()
-    fence()
-    if not args.no_profile:
+    for i in range(warmup):
+        step(i)
+    env.fence()
+    if profile:
         r.set_profiling(True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(args.warmup + i)
-    drain()
-    fence()
+    for i in range(steps):
+        step(warmup + i, timed=True)
+    env.fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -345,112 +277,252 @@ def main():
         dt = float(t.item())
 
     stage_ms = {}
-    if not args.no_profile:
+    if profile:
         for name in ("frame", "ingest", "select_eye", "select_dc", "shape", "select_s1", "shift", "w1", "warp", "finish",
-                     "p1_own", "p1_foreign", "p3_own", "replay"):   # the last four: measure / replay schedule (one replay per step)
-            stage_ms[name] = round(r.stage_ms(name), 5)
+                     "p1_own", "p3_own", "replay"):
+            v = r.stage_ms(name)
+            if v >= 0:
+                stage_ms[name] = round(v, 5)
         r.set_profiling(False)
+    net_ms = None
+    if net_ev:
+        net_ms = sum(a.elapsed_time(b) for a, b in net_ev) / len(net_ev)
 
-    # W1 / E1 without the depth net sharing the CUs: a short DIBR-only pass AFTER the timed region (same frames, same kernels), so that
-    # the contention of the overlapped end-to-end step can be told apart from the kernel itself (reported as roofline.isolated_*)
+    # W1 / E1 alone on the GPU: a short sequential DIBR-only pass AFTER the timed region (same frames, same kernels)
     iso_ms = {}
-    if rank == 0 and (pipe is not None or pix_ov) and not args.no_profile and (shr is None or gated or pix_ov) and world == 1 and not emu:
+    if rank == 0 and profile and isolated_pass and world == 1:
         r.set_profiling(True)   # clears the accumulators of the timed region (already read above)
         for j in range(min(B, 8, len(depths))):
             r.render_frame(frames[j], depths[j], p, out=outs[j])
         r.sync()
-        iso_ms = {"w1": round(r.stage_ms("w1"), 5), "finish": round(r.stage_ms("finish"), 5)}
+        iso_ms = {"w1": round(r.stage_ms("w1"), 5), "finish": round(r.stage_ms("finish"), 5), "frame": round(r.stage_ms("frame"), 5)}
         r.set_profiling(False)
 
-    # measured streaming-copy yardstick: device-to-device copy of 1 GiB through the same library
-    copy_gbs = None
-    if rank == 0:
-        nbytes = 1 << 30
-        a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        b = torch.empty_like(a)
-        for _ in range(3):
-            r._L.vd3d_stream_copy(r._ctx, a.data_ptr(), b.data_ptr(), nbytes)
-        r.set_profiling(True)
-        for _ in range(10):
-            r._L.vd3d_stream_copy(r._ctx, a.data_ptr(), b.data_ptr(), nbytes)
-        ms = r.stage_ms("stream_copy")
-        r.set_profiling(False)
-        copy_gbs = 2 * nbytes / (ms * 1e-3) / 1e9
-        del a, b
+    flops = pipe.flops_per_frame(sh, sw) if (pipe is not None and rank == 0) else None
+    res = dict(workload=workload, desc=desc, sh=sh, sw=sw, model=model_name, B=B, steps=steps, warmup=warmup, dt=dt,
+               frames_total=world * steps * B, stage_ms=stage_ms, iso_ms=iso_ms, net_ms=net_ms, flops_per_frame=flops,
+               N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), depth_dtype=depth_dtype if model_name else None,
+               host_io=bool(args.host_io))
+    del pipe
+    r.close()
+    if rh is not r:
+        rh.close()
+    torch.cuda.empty_cache()
+    return res
 
-    if rank == 0:
-        frames_total = world * args.steps * B
-        value = frames_total / dt
-        N = p.warp_h * p.warp_w
+
+def copy_yardstick(env):
+    """measured streaming-copy rate: device-to-device copy of 1 GiB through the library's own copy kernel"""
+    torch = env.torch
+    from visiondepth3d_amd.render_3d import Renderer
+    r = Renderer(env.local_rank)
+    nbytes = 1 << 30
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(3):
+        r._L.vd3d_stream_copy(r._ctx, a.data_ptr(), b.data_ptr(), nbytes)
+    r.set_profiling(True)
+    for _ in range(10):
+        r._L.vd3d_stream_copy(r._ctx, a.data_ptr(), b.data_ptr(), nbytes)
+    ms = r.stage_ms("stream_copy")
+    r.set_profiling(False)
+    r.close()
+    return 2 * nbytes / (ms * 1e-3) / 1e9
+
+
+def _pmc(workload):
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        return pm.get(workload)
+    except Exception:
+        return None
+
+
+def rooflines(res, copy_gbs=None, pmc_workload=None):
+    """roofline objects of one measured workload: W1 (north_star's kernel), E1, the whole DIBR frame, the depth net."""
+    out = {}
+    N, st, iso = res["N"], res["stage_ms"], res["iso_ms"]
+    pm = _pmc(pmc_workload or res["workload"]) or {}
+    w1_ms = st.get("w1", -1)
+    if w1_ms > 0:
+        alg = 13 * N  # SURVEY 8(d): W1 = read RGB 3N + read depth 4N + write two u8 eyes 6N per stereo pair
+        ach = alg / (w1_ms * 1e-3) / 1e9
+        w1 = pm.get("k_warp_fused", pm if "corrected_bytes_per_launch" in pm else {})
+        lane = w1.get("valu_lane_instr_per_launch")
+        rf = {"bound": "valu" if lane else "hbm", "kernel": "k_warp_fused (W1: feather mask + pool + warp + blend, one launch)",
+              "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+              "traffic": w1.get("corrected_bytes_per_launch"), "traffic_source": w1.get("source"),
+              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": w1_ms,
+              "isolated_avg_launch_ms": iso.get("w1"),
+              "isolated_frac": round(alg / (iso["w1"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso.get("w1", 0) > 0 else None,
+              "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
+              "note": "frac prices SURVEY 8(d)'s 13 N algorithmic bytes against the 8 TB/s HBM spec (north_star's yardstick); the kernel is "
+                      "VALU-issue-bound, not HBM-bound (the reference's nested-bilinear arithmetic is kept bit-exact): `valu` prices the "
+                      "PMC-counted VALU lane-instructions of one launch against the chip's VALU issue peak. avg_launch_ms = HIP events "
+                      "inside the timed region (the kernel shares the CUs with the overlapped streams); isolated_* = the same kernel in a "
+                      "sequential DIBR-only pass after the timed region"}
+        if lane:
+            t = (iso.get("w1") or w1_ms) * 1e-3
+            rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                          "frac_of_valu_peak_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4), "source": w1.get("source")}
+        out["roofline"] = rf
+    fin_ms = st.get("finish", -1)
+    if fin_ms > 0:  # E1: 6N eyes in + N eye-res depth + 3N Half-SBS out
+        alg = 10 * N
+        ach = alg / (fin_ms * 1e-3) / 1e9
+        e1 = pm.get("k_finish_fused", {})
+        lane = e1.get("valu_lane_instr_per_launch")
+        rf = {"bound": "valu" if lane else "hbm", "kernel": "k_finish_fused (E1: DOF + grade + sharpen + fit + mux, both eyes)",
+              "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+              "traffic": e1.get("corrected_bytes_per_launch"), "algorithmic_bytes_per_launch": alg, "avg_launch_ms": fin_ms,
+              "isolated_avg_launch_ms": iso.get("finish"),
+              "isolated_frac": round(alg / (iso["finish"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso.get("finish", 0) > 0 else None}
+        if lane:   # SURVEY 8(d): E1 against BOTH bounds (HBM above, fp32 ALU here)
+            t = (iso.get("finish") or fin_ms) * 1e-3
+            rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                          "frac_of_valu_peak_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4), "source": e1.get("source")}
+        out["roofline_e1"] = rf
+    fr_ms, note = st.get("frame", -1), "sequential frame: K1-K6, k_shift, W1, E1"
+    if fr_ms <= 0 and all(st.get(k, -1) > 0 for k in ("p1_own", "p3_own", "warp", "finish")):
+        fr_ms = st["p1_own"] + st["p3_own"] + st["warp"] + st["finish"] + max(st.get("replay", 0.0), 0.0) / res["B"]
+        note = "sum of the frame's stage durations: P1 + P3 (K1-K6 in measure mode) + replay/B + k_shift + W1 + E1, on two streams"
+    if fr_ms > 0:  # whole DIBR chain = RGB 3N + depth 4N twice + two u8 eyes 6N = 17 N per stereo pair
+        ch = 17 * N / (fr_ms * 1e-3) / 1e9
+        out["roofline_chain"] = {"bound": "latency", "kernel": "whole DIBR frame (" + note + ")", "achieved": round(ch, 2),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ch / HBM_PEAK_GBS, 5),
+                                 "algorithmic_bytes_per_frame": 17 * N, "avg_frame_ms": round(fr_ms, 5),
+                                 "isolated_avg_frame_ms": iso.get("frame")}
+    if res.get("net_ms") and res.get("flops_per_frame"):
+        tf = res["flops_per_frame"] * res["B"] / (res["net_ms"] * 1e-3) / 1e12
+        pk = MFMA_PEAK_TFLOPS[res["depth_dtype"]]
+        out["roofline_depthnet"] = {"bound": "mfma", "kernel": f"{res['model']} forward + hand-off ({res['depth_dtype']}; hipBLASLt / AOTriton / "
+                                    "MIOpen through PyTorch-ROCm, glue fused in HIP)", "achieved": round(tf, 2), "peak": pk,
+                                    "unit": "TFLOP/s", "frac": round(tf / pk, 4), "flops_per_frame": res["flops_per_frame"],
+                                    "avg_batch_ms": round(res["net_ms"], 3), "frames_per_batch": res["B"],
+                                    "note": "torch-event time of depth inference + 8-bit hand-off per batch inside the timed region, "
+                                            "while the DIBR streams of the previous batch share the GPU"}
+    return out
+
+
+def sub_record(res, extra=None):
+    d = {"workload": res["workload"], "description": res["desc"], "value": round(res["frames_total"] / res["dt"], 3),
+         "unit": "stereo-pairs/s", "steps": res["steps"], "warmup": res["warmup"], "frames_timed": res["frames_total"],
+         "ms_per_step": round(res["dt"] / res["steps"] * 1e3, 4),
+         "dtype": "f32" if res["depth_dtype"] in (None, "f32") else "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)"}
+    if extra:
+        d.update(extra)
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="measure ONLY this workload (profiling runs); default: the headline + the sub-records described above")
+    ap.add_argument("--depth-dtype", default="f32", choices=("f32", "bf16"), help="depth-net precision of the measured workload "
+                    "(f32 = the reference's; bf16 is labelled reduced precision)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per step")
+    ap.add_argument("--clip", type=int, default=16, help="distinct synthetic frames resident in HBM (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true", help="headline only")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
+    ap.add_argument("--sharded", action="store_true", help="use the measure / replay step protocol even at N=1 without pixel overlap")
+    ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
+                    "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
+    ap.add_argument("--pixel-overlap", dest="pixel_overlap", action="store_true", default=None,
+                    help="two slot sets + vd3d_set_pixel_overlap: the pixel kernels of step i run on a second stream of the renderer while "
+                    "the (latency-bound) measurement chain of step i+1 runs on the first (the default)")
+    ap.add_argument("--no-pixel-overlap", dest="pixel_overlap", action="store_false")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
+    args = ap.parse_args()
+
+    env = Env(args)
+    single = args.workload is not None
+    wl = args.workload or HEADLINE
+    prof = not args.no_profile
+    head = run_workload(env, args, wl, args.steps, args.warmup, depth_dtype=args.depth_dtype, profile=prof)
+    subs, roof_src = {}, head
+    if env.rank == 0 and env.world == 1 and not single and not args.no_sub_records:
+        nroof = max(2, math.ceil(200 / args.batch))   # >= 200 timed frames (SURVEY 8(d) config 3), >= 20 warm-up frames
+        r4 = run_workload(env, args, "4k-dibr", nroof, max(2, math.ceil(20 / args.batch)), profile=prof)
+        r1e = run_workload(env, args, "1080p-dav2s-dibr", 10, 3, depth_dtype="f32", profile=prof)
+        r1d = run_workload(env, args, "1080p-dibr", 10, 3, profile=prof)
+        rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
+        subs = {"4k-dibr": (r4, None), "1080p-dav2s-dibr": (r1e, None), "1080p-dibr": (r1d, None), "4k-dav2b-dibr-bf16": (rbf, None)}
+        roof_src = r4
+
+    if env.rank == 0:
+        copy_gbs = copy_yardstick(env)
+        sh, sw, model_name, desc = WORKLOADS[wl]
+        value = head["frames_total"] / head["dt"]
+        reduced = model_name is not None and args.depth_dtype != "f32"
         res = {
             "metric": "stereo-pairs/sec end-to-end (depth+warp+fill+mux)",
-            "value": round(value, 3), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 DIBR kernels (u8 in/out)" + (" + bf16 depth net" if pipe is not None else ""),
-            "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)" if ring is None else
+            "value": round(value, 3), "unit": "stereo-pairs/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not reduced else "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)",
+            "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)" if not args.host_io else
                     "synthetic; frames start in pinned host memory and muxed frames are copied back to pinned host memory (PCIe-inclusive run)",
-            "config": {"workload": args.workload, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
-                       "frames_per_step": B, "depth_model": model_name, "emulated_world": emu or None,
-                       "pixel_overlap": bool(pix_ov),
-                       "sharding": "frames of one clip round-robin over ranks; all-gather of uint8 depth planes; foreign frames cost one plane-EMA launch; "
-                                   "owners measure, 2 floats + 4 int64 per frame are all-gathered, scalar trackers replayed on every rank "
-                                   "(bit-identical to 1 GPU)",
+            "config": {"workload": wl, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
+                       "frames_per_step": args.batch, "depth_model": model_name,
+                       "depth_net_dtype": ({"f32": "float32 (the reference's precision)", "bf16": "bfloat16"}[args.depth_dtype]
+                                           if model_name else None),
+                       "arithmetic": "u8 in/out, float32 DIBR kernels, float64 scalar trackers",
+                       "pixel_overlap": head["pix_ov"],
+                       "sharding": "contiguous frame chunks per rank; scalar records all-gathered and trackers replayed on every rank "
+                                   "(bit-identical to 1 GPU)" if env.world > 1 else None,
                        "params": "render_cli.py defaults + dof_strength 2.0"},
         }
-        if stage_ms:
-            warp_ms = stage_ms["w1"] if stage_ms.get("w1", -1) > 0 else stage_ms["warp"]
-            alg_bytes = 13 * N  # warp kernel W1 = read RGB 3N + read depth 4N + write two u8 eyes 6N per stereo pair
-            achieved = alg_bytes / (warp_ms * 1e-3) / 1e9 if warp_ms > 0 else None
-            traffic, traffic_src = None, None
-            try:  # HBM bytes per launch from the committed PMC passes (only when they were taken on this workload)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-                if args.workload in pm:
-                    traffic, traffic_src = pm[args.workload]["corrected_bytes_per_launch"], pm[args.workload]["source"]
-            except Exception:
-                pass
-            res["roofline"] = {"bound": "hbm", "kernel": "k_warp_fused (W1: feather mask + pool + warp + blend, one launch)",
-                               "achieved": round(achieved, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                               "traffic": traffic, "traffic_source": traffic_src,
-                               "note": "measured VALU-issue-bound (~690 VALU lane-instr/pixel = ~95% of the SIMD issue cycles of the launch; "
-                                       "profiles/r01_pmc_4k_dibr.md), not HBM-bound: the reference's nested bilinear arithmetic is kept exact. "
-                                       "avg_launch_ms is taken inside the timed region, where the kernel shares the CUs with the overlapped depth "
-                                       "net; isolated_* is the same kernel in a DIBR-only pass after the timed region",
-                               "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": warp_ms,
-                               "isolated_avg_launch_ms": iso_ms.get("w1"),
-                               "isolated_frac": round(alg_bytes / (iso_ms["w1"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso_ms.get("w1", 0) > 0 else None,
-                               "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
-                               "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None}
-            fin_ms = stage_ms.get("finish", -1)
-            if fin_ms > 0:  # E1 (fused DOF/grade/sharpen/fit/mux): 6N eyes in + N eye-res depth + 3N Half-SBS out
-                e1_bytes = 10 * N
-                e1 = e1_bytes / (fin_ms * 1e-3) / 1e9
-                res["roofline_e1"] = {"bound": "hbm", "kernel": "k_finish_fused (E1)", "achieved": round(e1, 2), "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": round(e1 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": e1_bytes,
-                                      "avg_launch_ms": fin_ms}
-            fr_ms = stage_ms.get("frame", -1)
-            chain_note = "9 launches: K1-K6, k_shift, W1, E1"
-            if fr_ms <= 0 and min(stage_ms.get(k, -1) for k in ("p1_own", "p3_own", "warp", "finish")) > 0:
-                # measure / replay schedule: the frame's stages run on two streams; their HIP-event durations are summed
-                fr_ms = round(stage_ms["p1_own"] + stage_ms["p3_own"] + stage_ms["warp"] + stage_ms["finish"] +
-                              max(stage_ms.get("replay", 0.0), 0.0) / B, 5)
-                chain_note = "sum of the frame's stage durations: P1 + P3 (K1-K6 in measure mode) + replay/B + k_shift + W1 + E1, on two streams"
-            if fr_ms > 0:  # whole DIBR chain = RGB 3N + depth 4N twice + two u8 eyes 6N = 17 N per stereo pair
-                ch = 17 * N / (fr_ms * 1e-3) / 1e9
-                res["roofline_chain"] = {"bound": "hbm", "kernel": "whole DIBR frame (" + chain_note + ")", "achieved": round(ch, 2),
-                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ch / HBM_PEAK_GBS, 5),
-                                         "algorithmic_bytes_per_frame": 17 * N, "avg_frame_ms": fr_ms}
-            res["stage_ms"] = stage_ms
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sh, sw, seconds_budget=12.0)
+        hr = rooflines(head, copy_gbs)
+        if roof_src is not head:   # the section-8(d) roofline run: 4K, DIBR only, >= 200 timed frames
+            rr = rooflines(roof_src, copy_gbs)
+            for k in ("roofline", "roofline_e1", "roofline_chain"):
+                if k in rr:
+                    rr[k]["measured_on"] = f"sub-record 4k-dibr ({roof_src['frames_total']} timed frames, DIBR only)"
+                    if k in hr and "avg_launch_ms" in hr[k]:
+                        rr[k]["in_headline_avg_launch_ms"] = hr[k]["avg_launch_ms"]   # same kernel while the depth net shares the CUs
+                    res[k] = rr[k]
+            if "roofline_depthnet" in hr:
+                res["roofline_depthnet"] = hr["roofline_depthnet"]
+        else:
+            res.update(hr)
+        res["stage_ms"] = head["stage_ms"]
+        if subs:
+            sr = {}
+            for name, (rs, _) in subs.items():
+                extra = {"stage_ms": rs["stage_ms"]}
+                rf = rooflines(rs, copy_gbs, pmc_workload=None)
+                if "roofline_depthnet" in rf:
+                    extra["roofline_depthnet"] = rf["roofline_depthnet"]
+                if name == "4k-dav2b-dibr-bf16":
+                    extra["note"] = ("same workload as the headline with the depth net in bfloat16: NOT like-for-like with the reference "
+                                     "(float32); its uint8 depth-plane deviation is measured by tests/test_hip_depth_e2e.py")
+                sr[name] = sub_record(rs, extra)
+            res["sub_records"] = sr
+        if env.world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(sh, sw, seconds_budget=12.0, max_frames=8 if sh > 1080 else 30)
+            if subs and wl == HEADLINE:
+                cb["gpu_same_work"] = {"workload": "4k-dibr", "value": sub_record(subs["4k-dibr"][0])["value"], "unit": "stereo-pairs/s",
+                                       "note": "DIBR chain only on one MI355X: the same work as this CPU figure (`value` also holds the depth net)"}
+            res["cpu_baseline"] = cb
+            if subs:
+                c1 = cpu_baseline(1080, 1920, seconds_budget=8.0)
+                c1["gpu_same_work"] = {"workload": "1080p-dibr", "value": sub_record(subs["1080p-dibr"][0])["value"], "unit": "stereo-pairs/s"}
+                res["cpu_baseline_1080p"] = c1
+                try:
+                    res["cpu_depth_net"] = cpu_depth_net(model_name, sh, sw) if model_name else None
+                except Exception as e:
+                    res["cpu_depth_net"] = {"error": str(e)[:200]}
             try:   # same port on all host cores (bounded: a few frames per core)
-                res["cpu_baseline_allcores"] = cpu_baseline_allcores(sh, sw, 4 if sh <= 1080 else 2)
+                res["cpu_baseline_allcores"] = cpu_baseline_allcores(1080, 1920, 4)
             except Exception as e:   # the single-core figure above is the contract's baseline; this one is additional context
                 res["cpu_baseline_allcores"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
-    r.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if env.world > 1:
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VD3D_ABI_VERSION 2
+#define VD3D_ABI_VERSION 3
 
 typedef enum vd3d_status {
   VD3D_OK = 0,
@@ -250,21 +250,26 @@ int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slo
  * Replaces the reference's 8-bit depth video on disk while keeping its quantisation. */
 int vd3d_depth_handoff(vd3d_ctx* ctx, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint8_t* out_gray);
 
+/* element type of the depth network's activations (a25).  The reference loads its Hugging Face depth models with
+ * AutoModelForDepthEstimation.from_pretrained(checkpoint) and no dtype, i.e. float32 (core/render_depth.py:758-759,823-824):
+ * VD3D_DT_F32 is the like-for-like precision, VD3D_DT_BF16 the optional reduced-precision mode. */
+typedef enum vd3d_dtype { VD3D_DT_BF16 = 0, VD3D_DT_F32 = 1 } vd3d_dtype;
+
 /* ---- depth-net input preparation (a25, core/render_depth.py:1106-1119 -> DPTImageProcessor): B uint8 BGR frames
- * [B][H][W][3] -> antialiased bicubic resize to (th,tw), 1/255, (x-mean)/std, RGB, bfloat16, NHWC [B][th][tw][3].
+ * [B][H][W][3] -> antialiased bicubic resize to (th,tw), 1/255, (x-mean)/std, RGB, `dtype`, NHWC [B][th][tw][3].
  * Returns VD3D_E_UNSUPPORTED when the down-scale factor exceeds the kernel's tap budget (scale > ~5.5). */
 int vd3d_depth_preprocess(vd3d_ctx* ctx, const uint8_t* frames_bgr, int B, int H, int W, int th, int tw,
-                          const float* mean3_host, const float* std3_host, void* out_bf16_nhwc);
+                          const float* mean3_host, const float* std3_host, int dtype, void* out_nhwc);
 
-/* Transformer-block glue of the depth network (a25): s = x + y, n = LayerNorm(s)*gamma + beta on bfloat16 [rows][cols]
- * device arrays in one pass (y == NULL: LayerNorm only, out_sum unused).  cols in {384, 768, 1024} (DA-V2 S/B/L), else
+/* Transformer-block glue of the depth network (a25): s = x + y, n = LayerNorm(s)*gamma + beta on [rows][cols] device arrays
+ * of `dtype` in one pass (y == NULL: LayerNorm only, out_sum unused).  cols in {384, 768, 1024} (DA-V2 S/B/L), else
  * VD3D_E_UNSUPPORTED.  Replaces torch's add + layer_norm kernel pair inside DepthPipe's fused backbone. */
-int vd3d_add_layernorm_bf16(vd3d_ctx* ctx, const void* x, const void* y_or_null, const void* gamma, const void* beta,
-                            float eps, int64_t rows, int cols, void* out_sum, void* out_norm);
+int vd3d_add_layernorm(vd3d_ctx* ctx, int dtype, const void* x, const void* y_or_null, const void* gamma, const void* beta,
+                       float eps, int64_t rows, int cols, void* out_sum, void* out_norm);
 
-/* F.interpolate(mode="bilinear", align_corners=True) of a bfloat16 NHWC (channels_last) tensor [B][ih][iw][C] ->
- * [B][oh][ow][C], C a multiple of 8: the up-samplings of the DPT neck / head (a25). */
-int vd3d_upsample_bilinear_nhwc_bf16(vd3d_ctx* ctx, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
+/* F.interpolate(mode="bilinear", align_corners=True) of an NHWC (channels_last) tensor [B][ih][iw][C] -> [B][oh][ow][C] of
+ * `dtype`, C a multiple of 8 (bf16) / 4 (f32): the up-samplings of the DPT neck / head (a25). */
+int vd3d_upsample_bilinear_nhwc(vd3d_ctx* ctx, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
 
 /* ---- preview visualisers: generate_preview_image, core/preview_utils.py:23-84, the exactly defined types.
  * left / right: uint8 BGR [h][w][3] eyes (outputs of vd3d_pixel_shift).  out: [h][w][3], except HSBS: [h][2*(w/2)][3].

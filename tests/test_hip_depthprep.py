@@ -21,6 +21,23 @@ def _ref(frames_u8, th, tw):
     return ((x / 255.0) - mean) / std
 
 
+@pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840), (270, 480)])
+def test_depth_preprocess_f32_matches_torch(hw):
+    """float32 output (the reference's precision): only the association of the 2-D filter sums differs from ATen's."""
+    from visiondepth3d_amd.render_3d import Renderer
+    H, W = hw
+    r = Renderer(0)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(i, H, W)[0] for i in range(2)])).cuda()
+    th, tw = dpt_resize_target(H, W)
+    got = r.depth_preprocess(frames, th, tw, IMAGENET_MEAN, IMAGENET_STD, dtype=torch.float32)
+    assert got.shape == (2, 3, th, tw) and got.dtype == torch.float32
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    ref = _ref(frames, th, tw)
+    err = (got - ref).abs()
+    assert float(err.max()) < 2e-4, float(err.max())     # values are O(1): ~1e-5 relative filter-sum noise times 1/std
+    r.close()
+
+
 @pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840), (270, 480), (518, 924), (101, 333)])
 def test_depth_preprocess_matches_torch(hw):
     from visiondepth3d_amd.render_3d import Renderer
@@ -28,7 +45,7 @@ def test_depth_preprocess_matches_torch(hw):
     r = Renderer(0)
     frames = torch.from_numpy(np.stack([synth.synth_frame(i, H, W)[0] for i in range(2)])).cuda()
     th, tw = dpt_resize_target(H, W)
-    got = r.depth_preprocess(frames, th, tw, IMAGENET_MEAN, IMAGENET_STD)
+    got = r.depth_preprocess(frames, th, tw, IMAGENET_MEAN, IMAGENET_STD, dtype=torch.bfloat16)
     assert got.shape == (2, 3, th, tw) and got.dtype == torch.bfloat16
     assert got.is_contiguous(memory_format=torch.channels_last)
     ref = _ref(frames, th, tw)
@@ -46,8 +63,8 @@ def test_depth_pipe_uses_fused_front_end():
     from visiondepth3d_amd.render_3d import Renderer
     r = Renderer(0)
     frames = torch.from_numpy(np.stack([synth.synth_frame(i, 270, 480)[0] for i in range(2)])).cuda()
-    pa = DepthPipe("depth-anything-v2-small", device="cuda")
-    pb = DepthPipe("depth-anything-v2-small", device="cuda", renderer=r)
+    pa = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.bfloat16)
+    pb = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.bfloat16, renderer=r)
     a = pa.infer_bgr_u8(frames, raw=True)
     r.set_profiling(True)
     b = pb.infer_bgr_u8(frames, raw=True)
@@ -55,7 +72,7 @@ def test_depth_pipe_uses_fused_front_end():
     rel = ((a - b).abs().mean() / a.abs().mean()).item()
     assert rel < 2e-2, rel                    # bf16 network: inputs differ in a few last bf16 bits
     # the stock HF module graph (separate q/k/v, LayerScale modules, unpadded token sequence) gives the same prediction
-    pc = DepthPipe("depth-anything-v2-small", device="cuda", fuse_backbone=False)
+    pc = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.bfloat16, fuse_backbone=False)
     c = pc.infer_bgr_u8(frames, raw=True)
     rel = ((a - c).abs().mean() / c.abs().mean()).item()
     assert rel < 2e-2, rel
@@ -101,4 +118,41 @@ def test_upsample_bilinear_nhwc_matches_torch(shape):
     assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all()), float(err.max())
     same = (got == F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True)).float().mean().item()
     assert same > 0.99, same        # bit-identical to ATen's bf16 kernel on (almost) every element
+    r.close()
+
+
+@pytest.mark.parametrize("cols", [384, 768, 1024])
+def test_add_layernorm_f32_matches_torch(cols):
+    from visiondepth3d_amd.render_3d import Renderer
+    r = Renderer(0)
+    g = torch.Generator(device="cuda").manual_seed(cols)
+    x = torch.randn(2, 1237, cols, device="cuda", generator=g) * 2
+    y = torch.randn(2, 1237, cols, device="cuda", generator=g)
+    ln = torch.nn.LayerNorm(cols, eps=1e-6).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(cols, device="cuda", generator=g))
+        ln.bias.copy_(0.1 * torch.randn(cols, device="cuda", generator=g))
+        s, n = r.add_layernorm(x, y, ln)
+        assert torch.equal(s, x + y)                                   # float32 add is exactly ATen's
+        n_ref = torch.nn.functional.layer_norm((x + y).double(), (cols,), ln.weight.double(), ln.bias.double(), 1e-6)
+        assert float((n.double() - n_ref).abs().max()) < 5e-6
+        x2, n2 = r.add_layernorm(x, None, ln)
+        assert x2 is x
+        n2_ref = torch.nn.functional.layer_norm(x.double(), (cols,), ln.weight.double(), ln.bias.double(), 1e-6)
+        assert float((n2.double() - n2_ref).abs().max()) < 5e-6
+    r.close()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 19, 33, 37, 66), (1, 32, 37, 66, 70, 126), (1, 4, 3, 3, 2, 2)])
+def test_upsample_bilinear_nhwc_f32_matches_torch(shape):
+    from visiondepth3d_amd.render_3d import Renderer
+    import torch.nn.functional as F
+    B, Cc, ih, iw, oh, ow = shape
+    r = Renderer(0)
+    g = torch.Generator(device="cuda").manual_seed(ih * iw)
+    x = torch.randn(B, Cc, ih, iw, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    got = r.upsample_bilinear(x, (oh, ow))
+    ref = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True)
+    assert got.shape == ref.shape and got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
+    assert float((got - ref).abs().max()) < 1e-5
     r.close()

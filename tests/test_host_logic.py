@@ -176,3 +176,80 @@ def test_depth_pipe_protocol_against_the_transformers_pipeline():
     got2 = pipe([img], inference_size=(112, 70))[0]["predicted_depth"]
     assert tuple(got2.shape) == tuple(exp2.shape) == (70, 112)
     assert float((got2 - exp2).abs().mean() / exp2.abs().mean()) < 5e-2
+
+
+def test_depth_pipe_from_pretrained_round_trip(tmp_path):
+    """B3 checkpoint loading (core/render_depth.py:756-760: AutoModelForDepthEstimation.from_pretrained(local folder)): a stock
+    DepthAnythingForDepthEstimation saved with save_pretrained (safetensors + config.json + preprocessor_config.json) comes back
+    through DepthPipe.from_pretrained, gets the fused-weight rewrites (one QKV GEMM, folded LayerScale) and predicts the same
+    depth as the stock graph to 1e-6 (mean, relative to the output range; max 1e-5) on CPU / float32."""
+    import torch
+    transformers = pytest.importorskip("transformers")
+    from visiondepth3d_amd.depth import IMAGENET_MEAN, IMAGENET_STD, DepthPipe, build_config, synthetic_weights_
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    model = transformers.DepthAnythingForDepthEstimation(build_config("depth-anything-v2-small")).eval()
+    synthetic_weights_(model, 3)
+    model.save_pretrained(tmp_path)
+    transformers.DPTImageProcessor(do_resize=True, size={"height": 518, "width": 518}, keep_aspect_ratio=True, ensure_multiple_of=14,
+                                   resample=3, image_mean=IMAGENET_MEAN, image_std=IMAGENET_STD).save_pretrained(tmp_path)
+    assert (tmp_path / "model.safetensors").exists() and (tmp_path / "preprocessor_config.json").exists()
+    pipe = DepthPipe.from_pretrained(str(tmp_path), device="cpu")
+    assert pipe.dtype == torch.float32 and pipe.arch == "da"
+    assert pipe.proc["size"] == (518, 518) and pipe.proc["multiple"] == 14 and pipe.proc["keep_aspect_ratio"] is True
+    assert pipe.resize_target(1080, 1920) == (518, 924)
+    g = torch.Generator().manual_seed(5)
+    pv = torch.randn(1, 3, 70, 126, generator=g)
+    with torch.no_grad():
+        a = pipe.model(pixel_values=pv).predicted_depth
+        b = model(pixel_values=pv).predicted_depth
+    # float32 association noise of the rewrites (LayerScale folded into the weights, one QKV GEMM): mean 1e-6, max 1e-5 of range
+    assert float((a - b).abs().mean() / b.abs().max()) < 1e-6
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-5
+    # the fused weights really are derived from the LOADED checkpoint: a different seed gives a different prediction
+    other = DepthPipe("depth-anything-v2-small", device="cpu", seed=4)
+    with torch.no_grad():
+        c = other.model(pixel_values=pv).predicted_depth
+    assert float((c - b).abs().max() / b.abs().max()) > 1e-3
+    with pytest.raises(FileNotFoundError):
+        DepthPipe.from_pretrained(str(tmp_path / "missing"))
+
+
+def test_depth_pipe_model_zoo_covers_the_reference_hf_families():
+    """core/render_depth.py:686-712: Depth-Anything V1 / V2 and Distill-Any-Depth are one architecture family (DepthAnything on
+    DINOv2); MiDaS 3.0 / DPT-Large is DPTForDepthEstimation.  Shapes only (no weights exist here)."""
+    from visiondepth3d_amd.depth import MODEL_ZOO, build_config
+    for fam in ("depth-anything-v2", "depth-anything-v1"):
+        for size in ("small", "base", "large"):
+            assert f"{fam}-{size}" in MODEL_ZOO
+    assert MODEL_ZOO["distill-any-depth-large"] is MODEL_ZOO["depth-anything-v2-large"]
+    cfg = build_config("dpt-large")
+    assert type(cfg).__name__ == "DPTConfig" and cfg.hidden_size == 1024 and cfg.num_hidden_layers == 24
+
+
+def test_depth_pipe_generic_architecture_dpt_protocol():
+    """A non-DepthAnything Hugging Face depth model (DPTForDepthEstimation = the MiDaS 3.0 / Intel dpt-* family of the reference's
+    list, core/render_depth.py:706-709) behind the same B3 protocol: its own image-processor constants (384 x 384, no aspect
+    keeping, mean = std = 0.5), stock module graph.  Tiny configuration (2 layers) so the CPU test stays fast."""
+    import torch
+    transformers = pytest.importorskip("transformers")
+    from PIL import Image
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import PROCESSORS, DepthPipe, synthetic_weights_
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg = transformers.DPTConfig(hidden_size=64, num_hidden_layers=4, num_attention_heads=4, intermediate_size=128, image_size=64,
+                                 patch_size=16, backbone_out_indices=[0, 1, 2, 3], neck_hidden_sizes=[16, 32, 64, 64],
+                                 fusion_hidden_size=32, readout_type="project")
+    model = transformers.DPTForDepthEstimation(cfg).eval()
+    synthetic_weights_(model, 1)
+    proc_kw = dict(PROCESSORS["dpt"], size=(64, 64))
+    pipe = DepthPipe("tiny-dpt", device="cpu", model=model, processor=proc_kw)
+    assert pipe.arch == "generic" and pipe.resize_target(126, 224) == (64, 64)
+    proc = transformers.DPTImageProcessor(do_resize=True, size={"height": 64, "width": 64}, keep_aspect_ratio=False, ensure_multiple_of=1,
+                                          resample=3, do_rescale=True, rescale_factor=1 / 255, do_normalize=True,
+                                          image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5], do_pad=False)
+    img = Image.fromarray(synth.synth_frame(2, 126, 224)[0][..., ::-1].copy())
+    hf = transformers.pipeline("depth-estimation", model=model, image_processor=proc, device="cpu")
+    exp = hf([img])[0]["predicted_depth"].squeeze()
+    got = pipe([img])[0]["predicted_depth"]
+    assert tuple(got.shape) == tuple(exp.shape) == (126, 224)
+    assert float((got - exp).abs().mean() / exp.abs().mean()) < 3e-2   # 8-bit rounding of the resized image in the PIL front end

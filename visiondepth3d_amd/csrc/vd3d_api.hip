@@ -883,30 +883,33 @@ VD3D_EXPORT int vd3d_depth_handoff(vd3d_ctx* c, const float* pred, int B, int ph
 }
 
 VD3D_EXPORT int vd3d_depth_preprocess(vd3d_ctx* c, const uint8_t* frames_bgr, int B, int H, int W, int th, int tw,
-                                      const float* mean3_host, const float* std3_host, void* out_bf16_nhwc) {
-  if (!c || !frames_bgr || !mean3_host || !std3_host || !out_bf16_nhwc || B < 1 || H < 1 || W < 1 || th < 1 || tw < 1)
+                                      const float* mean3_host, const float* std3_host, int dtype, void* out_nhwc) {
+  if (dtype != VD3D_DT_BF16 && dtype != VD3D_DT_F32) return set_err(VD3D_E_INVALID, "bad dtype %d", dtype);
+  if (!c || !frames_bgr || !mean3_host || !std3_host || !out_nhwc || B < 1 || H < 1 || W < 1 || th < 1 || tw < 1)
     return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   StageTimer t(c, "depth_prep");
-  if (!vd_launch_depth_prep(c->stream, frames_bgr, B, H, W, th, tw, mean3_host, std3_host, out_bf16_nhwc))
+  if (!vd_launch_depth_prep(c->stream, frames_bgr, B, H, W, th, tw, mean3_host, std3_host, dtype, out_nhwc))
     return set_err(VD3D_E_UNSUPPORTED, "depth_preprocess: %dx%d -> %dx%d exceeds the antialias tap budget", W, H, tw, th);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-VD3D_EXPORT int vd3d_add_layernorm_bf16(vd3d_ctx* c, const void* x, const void* y_or_null, const void* gamma, const void* beta,
-                                        float eps, int64_t rows, int cols, void* out_sum, void* out_norm) {
+VD3D_EXPORT int vd3d_add_layernorm(vd3d_ctx* c, int dtype, const void* x, const void* y_or_null, const void* gamma, const void* beta,
+                                   float eps, int64_t rows, int cols, void* out_sum, void* out_norm) {
+  if (dtype != VD3D_DT_BF16 && dtype != VD3D_DT_F32) return set_err(VD3D_E_INVALID, "bad dtype %d", dtype);
   if (!c || !x || !gamma || !beta || !out_norm || rows < 1 || (y_or_null && !out_sum)) return set_err(VD3D_E_INVALID, "bad argument");
-  if (!vd_launch_add_layernorm(c->stream, x, y_or_null, gamma, beta, eps, (long long)rows, cols, out_sum, out_norm))
+  if (!vd_launch_add_layernorm(c->stream, dtype, x, y_or_null, gamma, beta, eps, (long long)rows, cols, out_sum, out_norm))
     return set_err(VD3D_E_UNSUPPORTED, "add_layernorm: cols %d not in {384,768,1024}", cols);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-VD3D_EXPORT int vd3d_upsample_bilinear_nhwc_bf16(vd3d_ctx* c, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C) {
+VD3D_EXPORT int vd3d_upsample_bilinear_nhwc(vd3d_ctx* c, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C) {
+  if (dtype != VD3D_DT_BF16 && dtype != VD3D_DT_F32) return set_err(VD3D_E_INVALID, "bad dtype %d", dtype);
   if (!c || !in || !out || B < 1 || ih < 1 || iw < 1) return set_err(VD3D_E_INVALID, "bad argument");
-  if (!vd_launch_upsample_bilinear_nhwc(c->stream, in, out, B, ih, iw, oh, ow, C))
-    return set_err(VD3D_E_UNSUPPORTED, "upsample_bilinear_nhwc: C %% 8 != 0 or output smaller than 2x2");
+  if (!vd_launch_upsample_bilinear_nhwc(c->stream, dtype, in, out, B, ih, iw, oh, ow, C))
+    return set_err(VD3D_E_UNSUPPORTED, "upsample_bilinear_nhwc: C not a multiple of 8 (bf16) / 4 (f32) or output smaller than 2x2");
   HIPCHK(hipGetLastError());
   return 0;
 }

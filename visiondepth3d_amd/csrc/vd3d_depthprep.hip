@@ -48,7 +48,11 @@ VD_DEV uint16_t dp_bf16(float f) {   // round-to-nearest-even, finite inputs
   return (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
 }
 
-__global__ __launch_bounds__(256) void k_depth_prep(const uint8_t* __restrict__ frames, vd_prep_args a, uint16_t* __restrict__ out) {
+VD_DEV void dp_store(uint16_t* o, float f) { *o = dp_bf16(f); }
+VD_DEV void dp_store(float* o, float f) { *o = f; }
+
+template <typename OT>   // uint16_t = bfloat16 bits, float = float32 (the reference's precision)
+__global__ __launch_bounds__(256) void k_depth_prep(const uint8_t* __restrict__ frames, vd_prep_args a, OT* __restrict__ out) {
   extern __shared__ unsigned char smem[];
   float* wx = reinterpret_cast<float*>(smem);                  // [DP_TX][DP_KMAX]
   float* wy = wx + DP_TX * DP_KMAX;                            // [DP_TY][DP_KMAX]
@@ -107,15 +111,16 @@ __global__ __launch_bounds__(256) void k_depth_prep(const uint8_t* __restrict__ 
       const float wj = w[j];
       s[0] += h[0] * wj; s[1] += h[1] * wj; s[2] += h[2] * wj;
     }
-    uint16_t* o = out + (((size_t)b * a.th + (oy0 + oy)) * a.tw + (ox0 + ox)) * 3;   // NHWC
+    OT* o = out + (((size_t)b * a.th + (oy0 + oy)) * a.tw + (ox0 + ox)) * 3;   // NHWC
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = dp_bf16(((s[c] / 255.0f) - a.mean[c]) / a.stdv[c]);
+    for (int c = 0; c < 3; ++c) dp_store(o + c, ((s[c] / 255.0f) - a.mean[c]) / a.stdv[c]);
   }
 }
 
 // returns false when the filter footprint exceeds the kernel's tap budget (caller keeps the ATen path)
 bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, int W, int th, int tw, const float mean[3],
-                          const float stdv[3], void* out_bf16_nhwc) {
+                          const float stdv[3], int dtype, void* out_nhwc) {
+  if (dtype != VD3D_DT_BF16 && dtype != VD3D_DT_F32) return false;
   vd_prep_args a;
   a.B = B; a.H = H; a.W = W; a.th = th; a.tw = tw;
   a.scale_h = (float)H / (float)th; a.scale_w = (float)W / (float)tw;
@@ -131,8 +136,13 @@ bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, in
   static bool attr[64] = {false};   // per device: the attribute belongs to the device's copy of the code object
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64 && !attr[dev]) { (void)hipFuncSetAttribute((const void*)k_depth_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; }
+  if (dev >= 0 && dev < 64 && !attr[dev]) {
+    (void)hipFuncSetAttribute((const void*)k_depth_prep<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_depth_prep<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr[dev] = true;
+  }
   dim3 g((tw + DP_TX - 1) / DP_TX, (th + DP_TY - 1) / DP_TY, B);
-  hipLaunchKernelGGL(k_depth_prep, g, dim3(256), lds, s, frames, a, reinterpret_cast<uint16_t*>(out_bf16_nhwc));
+  if (dtype == VD3D_DT_F32) hipLaunchKernelGGL(k_depth_prep<float>, g, dim3(256), lds, s, frames, a, reinterpret_cast<float*>(out_nhwc));
+  else hipLaunchKernelGGL(k_depth_prep<uint16_t>, g, dim3(256), lds, s, frames, a, reinterpret_cast<uint16_t*>(out_nhwc));
   return true;
 }

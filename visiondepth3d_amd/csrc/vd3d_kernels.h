@@ -140,11 +140,11 @@ void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const 
 bool vd_launch_preview(hipStream_t s, int type, const uint8_t* L, const uint8_t* R, int h, int w, uint8_t* out);
 // ---- vd3d_depthprep.hip
 bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, int W, int th, int tw, const float mean[3],
-                          const float stdv[3], void* out_bf16_nhwc);
+                          const float stdv[3], int dtype, void* out_nhwc);
 // ---- vd3d_netops.hip
-bool vd_launch_add_layernorm(hipStream_t s, const void* x, const void* y, const void* gamma, const void* beta, float eps,
+bool vd_launch_add_layernorm(hipStream_t s, int dtype, const void* x, const void* y, const void* gamma, const void* beta, float eps,
                              long long rows, int cols, void* out_sum, void* out_norm);
-bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
+bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
 // ---- vd3d_handoff.hip
 void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint32_t* mm,
                              uint8_t* out);

@@ -53,9 +53,57 @@ __global__ __launch_bounds__(256) void k_add_layernorm(const uint32_t* __restric
   }
 }
 
-bool vd_launch_add_layernorm(hipStream_t s, const void* x, const void* y, const void* gamma, const void* beta, float eps,
+// float32 variant (the reference runs its HF depth models in float32, core/render_depth.py:758-759): x + y is ATen's exact float32 add,
+// LayerNorm statistics two-pass in float32.  One wave per row, float2 per lane per step (cols = NJ * 128).
+template <int NJ>
+__global__ __launch_bounds__(256) void k_add_layernorm_f32(const float2* __restrict__ x, const float2* __restrict__ y,
+                                                           const float2* __restrict__ gamma, const float2* __restrict__ beta,
+                                                           float eps, long long rows, float2* __restrict__ out_sum,
+                                                           float2* __restrict__ out_norm) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t base = (size_t)row * (NJ * 64);   // in float2
+  float v[2 * NJ];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float2 a = x[base + lane + 64 * j];
+    if (y) {
+      const float2 b = y[base + lane + 64 * j];
+      a.x += b.x; a.y += b.y;
+      out_sum[base + lane + 64 * j] = a;
+    }
+    v[2 * j] = a.x; v[2 * j + 1] = a.y;
+    sum += a.x + a.y;
+  }
+  const float n = (float)(NJ * 128);
+  const float mean = wave_sum_f(sum) / n;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2 * NJ; ++j) { const float d = v[j] - mean; sq += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum_f(sq) / n + eps);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float2 g = gamma[lane + 64 * j], b = beta[lane + 64 * j];
+    out_norm[base + lane + 64 * j] = make_float2((v[2 * j] - mean) * rstd * g.x + b.x, (v[2 * j + 1] - mean) * rstd * g.y + b.y);
+  }
+}
+
+bool vd_launch_add_layernorm(hipStream_t s, int dtype, const void* x, const void* y, const void* gamma, const void* beta, float eps,
                              long long rows, int cols, void* out_sum, void* out_norm) {
   const dim3 g((unsigned)((rows + 3) / 4)), b(256);
+  if (dtype == VD3D_DT_F32) {
+    const float2 *xx = (const float2*)x, *yy = (const float2*)y, *gg = (const float2*)gamma, *bb = (const float2*)beta;
+    float2 *os = (float2*)out_sum, *on = (float2*)out_norm;
+    switch (cols) {
+      case 384: hipLaunchKernelGGL(k_add_layernorm_f32<3>, g, b, 0, s, xx, yy, gg, bb, eps, rows, os, on); return true;
+      case 768: hipLaunchKernelGGL(k_add_layernorm_f32<6>, g, b, 0, s, xx, yy, gg, bb, eps, rows, os, on); return true;
+      case 1024: hipLaunchKernelGGL(k_add_layernorm_f32<8>, g, b, 0, s, xx, yy, gg, bb, eps, rows, os, on); return true;
+      default: return false;
+    }
+  }
+  if (dtype != VD3D_DT_BF16) return false;
   const uint32_t *xx = (const uint32_t*)x, *yy = (const uint32_t*)y, *gg = (const uint32_t*)gamma, *bb = (const uint32_t*)beta;
   uint32_t *os = (uint32_t*)out_sum, *on = (uint32_t*)out_norm;
   switch (cols) {
@@ -99,7 +147,41 @@ __global__ __launch_bounds__(256) void k_upsample_bilinear_nhwc(const uint4* __r
   }
   out[idx] = make_uint4(o[0], o[1], o[2], o[3]);
 }
-bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C) {
+// float32 variant: one thread = 4 channels (16 B), ATen's association
+__global__ __launch_bounds__(256) void k_upsample_bilinear_nhwc_f32(const float4* __restrict__ in, float4* __restrict__ out, int ih, int iw,
+                                                                    int oh, int ow, int c4, float sh, float sw, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % c4);
+  long long r = idx / c4;
+  const int x = (int)(r % ow); r /= ow;
+  const int y = (int)(r % oh);
+  const long long b = r / oh;
+  const float fy = sh * (float)y, fx = sw * (float)x;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < ih - 1 ? 1 : 0), x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+  const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+  const float4* base = in + (size_t)b * ih * iw * c4 + c;
+  const float4 p00 = base[((size_t)y0 * iw + x0) * c4], p01 = base[((size_t)y0 * iw + x1) * c4];
+  const float4 p10 = base[((size_t)y1 * iw + x0) * c4], p11 = base[((size_t)y1 * iw + x1) * c4];
+  float4 o;
+  o.x = ly0 * (lx0 * p00.x + lx1 * p01.x) + ly1 * (lx0 * p10.x + lx1 * p11.x);
+  o.y = ly0 * (lx0 * p00.y + lx1 * p01.y) + ly1 * (lx0 * p10.y + lx1 * p11.y);
+  o.z = ly0 * (lx0 * p00.z + lx1 * p01.z) + ly1 * (lx0 * p10.z + lx1 * p11.z);
+  o.w = ly0 * (lx0 * p00.w + lx1 * p01.w) + ly1 * (lx0 * p10.w + lx1 * p11.w);
+  out[idx] = o;
+}
+bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C) {
+  if (dtype == VD3D_DT_F32) {
+    if (C % 4 || oh < 2 || ow < 2) return false;
+    const int c4 = C / 4;
+    const long long total = (long long)B * oh * ow * c4;
+    const float sh = (float)(ih - 1) / (float)(oh - 1), sw = (float)(iw - 1) / (float)(ow - 1);
+    hipLaunchKernelGGL(k_upsample_bilinear_nhwc_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)in, (float4*)out,
+                       ih, iw, oh, ow, c4, sh, sw, total);
+    return true;
+  }
+  if (dtype != VD3D_DT_BF16) return false;
   if (C % 8 || oh < 2 || ow < 2) return false;
   const int c8 = C / 8;
   const long long total = (long long)B * oh * ow * c8;

@@ -9,33 +9,59 @@ so the 2D->3D stage can start without the reference's host round trip and 8-bit 
 truncation (``depth_to_u8``, a24) so the DIBR stage sees the same quantised values.
 
 MFMA work (DINOv2 GEMMs / attention, DPT convs) goes through PyTorch-ROCm (hipBLASLt / MIOpen / SDPA): per
-BASELINE.json:north_star the depth net is NOT hand-written.  No network and no checkpoints exist in this
-environment, so weights are deterministic synthetic tensors (NumPy PCG64 keyed by parameter name).
+BASELINE.json:north_star the depth net is NOT hand-written.
+
+Precision: the reference loads ``AutoModelForDepthEstimation.from_pretrained(checkpoint)`` with no dtype, i.e. float32
+(core/render_depth.py:758-759,823-824); float32 is the DEFAULT here (f32-input MFMA on gfx950) and bfloat16 is an opt-in
+whose uint8 depth-plane deviation is measured by tests/test_hip_depth_e2e.py.
+
+Checkpoints: ``DepthPipe.from_pretrained(dir)`` loads a local Hugging Face folder (config.json + model.safetensors +
+preprocessor_config.json) exactly like the reference's local-model branch (:756-760) and then applies the fused-weight
+rewrites.  No network and no checkpoints exist in the build environment, so benchmarks and tests use deterministic
+synthetic weights (NumPy PCG64 keyed by parameter name) on the real architectures.
 """
 from __future__ import annotations
 
+import json
+import os
 import zlib
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-# Depth-Anything-V2 family (HF configs of depth-anything/Depth-Anything-V2-{Small,Base,Large}-hf)
+# Architectures of the reference's model list (core/render_depth.py:686-712) that go through its Hugging Face branch
+# (AutoModelForDepthEstimation, :756-760,823-824).  "da" = DepthAnythingForDepthEstimation on a DINOv2 backbone: Depth-Anything V1
+# (LiheYoung/depth-anything-*-hf), V2 (depth-anything/Depth-Anything-V2-*-hf) and Distill-Any-Depth
+# (xingyang1/Distill-Any-Depth-*-hf) share these three shapes and differ only in their weights.  "dpt" = DPTForDepthEstimation
+# (MiDaS 3.0 family: Intel/dpt-large).  Marigold / DepthCrafter / ONNX entries are other pipelines (SURVEY section 2: out of scope).
+_DA_S = dict(arch="da", hidden=384, layers=12, heads=6, out_indices=[9, 10, 11, 12], neck=[48, 96, 192, 384], fusion=64, head=32)
+_DA_B = dict(arch="da", hidden=768, layers=12, heads=12, out_indices=[9, 10, 11, 12], neck=[96, 192, 384, 768], fusion=128, head=32)
+_DA_L = dict(arch="da", hidden=1024, layers=24, heads=16, out_indices=[21, 22, 23, 24], neck=[256, 512, 1024, 1024], fusion=256, head=32)
 MODEL_ZOO = {
-    "depth-anything-v2-small": dict(hidden=384, layers=12, heads=6, out_indices=[9, 10, 11, 12],
-                                    neck=[48, 96, 192, 384], fusion=64, head=32),
-    "depth-anything-v2-base": dict(hidden=768, layers=12, heads=12, out_indices=[9, 10, 11, 12],
-                                   neck=[96, 192, 384, 768], fusion=128, head=32),
-    "depth-anything-v2-large": dict(hidden=1024, layers=24, heads=16, out_indices=[21, 22, 23, 24],
-                                    neck=[256, 512, 1024, 1024], fusion=256, head=32),
+    "depth-anything-v2-small": _DA_S, "depth-anything-v2-base": _DA_B, "depth-anything-v2-large": _DA_L,
+    "depth-anything-v1-small": _DA_S, "depth-anything-v1-base": _DA_B, "depth-anything-v1-large": _DA_L,
+    "distill-any-depth-small": _DA_S, "distill-any-depth-large": _DA_L,
+    "dpt-large": dict(arch="dpt", hidden=1024, layers=24, heads=16, out_indices=[5, 11, 17, 23], neck=[256, 512, 1024, 1024], fusion=256),
 }
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
+# image-processor constants (preprocessor_config.json of the checkpoints): DA = DPTImageProcessor(size 518, keep_aspect_ratio,
+# ensure_multiple_of 14, bicubic, ImageNet mean/std); DPT-Large = 384 x 384, no aspect keeping, mean = std = 0.5
+PROCESSORS = {
+    "da": dict(size=(518, 518), keep_aspect_ratio=True, multiple=14, mean=IMAGENET_MEAN, std=IMAGENET_STD),
+    "dpt": dict(size=(384, 384), keep_aspect_ratio=False, multiple=1, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)),
+}
 
 
 def build_config(name: str):
     from transformers import DepthAnythingConfig, Dinov2Config
     z = MODEL_ZOO[name]
+    if z["arch"] == "dpt":
+        from transformers import DPTConfig
+        return DPTConfig(hidden_size=z["hidden"], num_hidden_layers=z["layers"], num_attention_heads=z["heads"],
+                         intermediate_size=4 * z["hidden"], image_size=384, patch_size=16, backbone_out_indices=z["out_indices"],
+                         neck_hidden_sizes=z["neck"], fusion_hidden_size=z["fusion"], readout_type="project")
     bc = Dinov2Config(hidden_size=z["hidden"], num_hidden_layers=z["layers"], num_attention_heads=z["heads"], patch_size=14,
                       image_size=518, out_indices=z["out_indices"], reshape_hidden_states=False, apply_layernorm=True)
     return DepthAnythingConfig(backbone_config=bc, reassemble_hidden_size=z["hidden"], neck_hidden_sizes=z["neck"],
@@ -63,13 +89,15 @@ def synthetic_weights_(model: torch.nn.Module, seed: int = 0) -> None:
         p.copy_(torch.from_numpy(v).to(p.dtype))
 
 
-def dpt_resize_target(h: int, w: int, size: int = 518, multiple: int = 14):
+def dpt_resize_target(h: int, w: int, size=518, multiple: int = 14, keep_aspect_ratio: bool = True):
     """DPTImageProcessor.get_resize_output_image_size (keep_aspect_ratio, ensure_multiple_of=14): 1080x1920 -> 518x924."""
-    sh, sw = size / h, size / w
-    if abs(1 - sw) < abs(1 - sh):
-        sh = sw
-    else:
-        sw = sh
+    size_h, size_w = (size, size) if isinstance(size, int) else size
+    sh, sw = size_h / h, size_w / w
+    if keep_aspect_ratio:
+        if abs(1 - sw) < abs(1 - sh):
+            sh = sw
+        else:
+            sw = sh
 
     def snap(v):
         return max(int(round(v / multiple)) * multiple, multiple)
@@ -94,28 +122,75 @@ class DepthPipe:
     """``pipe(images, inference_size=None) -> [{"predicted_depth": Tensor[h, w]}]`` (reference protocol) plus a
     device-resident batch path."""
 
-    def __init__(self, name: str = "depth-anything-v2-small", device="cuda", dtype=torch.bfloat16, seed: int = 0,
-                 channels_last: bool = True, renderer=None, fuse_backbone: bool = True):
-        """``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream);
-        when given (and dtype is bf16) the image-processor front end runs as one fused HIP launch
-        (``vd3d_depth_preprocess``) instead of ~8 ATen kernels."""
-        from transformers import DepthAnythingForDepthEstimation
+    def __init__(self, name: str = "depth-anything-v2-small", device="cuda", dtype=torch.float32, seed: int = 0,
+                 channels_last: bool = True, renderer=None, fuse_backbone: bool = True, model=None, processor: dict | None = None):
+        """``dtype``: float32 (the reference's precision, default) or bfloat16.
+        ``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream); when given the
+        image-processor front end, the residual-add + LayerNorm pairs and the DPT up-samplings run as fused HIP launches.
+        ``model`` / ``processor``: an already constructed Hugging Face depth model and its image-processor constants
+        (``from_pretrained``); otherwise the architecture ``name`` is built from MODEL_ZOO with synthetic weights."""
         self.name, self.device, self.dtype = name, torch.device(device), dtype
-        cfg = build_config(name)
-        model = DepthAnythingForDepthEstimation(cfg).eval()
-        synthetic_weights_(model, seed)
-        self.model = model.to(self.device, dtype)
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("DepthPipe runs in float32 (reference precision) or bfloat16")
+        if model is None:
+            cfg = build_config(name)
+            if MODEL_ZOO[name]["arch"] == "dpt":
+                from transformers import DPTForDepthEstimation as Net
+            else:
+                from transformers import DepthAnythingForDepthEstimation as Net
+            model = Net(cfg).eval()
+            synthetic_weights_(model, seed)
+            processor = processor or PROCESSORS[MODEL_ZOO[name]["arch"]]
+        self.arch = "da" if type(model).__name__ == "DepthAnythingForDepthEstimation" else "generic"
+        self.proc = dict(PROCESSORS["da"] if processor is None else processor)
+        self.model = model.eval().to(self.device, dtype)
         if channels_last and self.device.type == "cuda":
             self.model = self.model.to(memory_format=torch.channels_last)
-        self.mean = torch.tensor(IMAGENET_MEAN, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
-        self.std = torch.tensor(IMAGENET_STD, device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
+        self.mean = torch.tensor(self.proc["mean"], device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
+        self.std = torch.tensor(self.proc["std"], device=self.device, dtype=torch.float32).view(1, 3, 1, 1)
         self.n_params = sum(p.numel() for p in self.model.parameters())
-        self.renderer = renderer if (renderer is not None and dtype == torch.bfloat16 and self.device.type == "cuda") else None
-        self._cache_position_embeddings()
-        if fuse_backbone:
-            self._fuse_backbone_layers()
-        if self.renderer is not None:
-            self._patch_dpt_upsampling()
+        self.renderer = renderer if (renderer is not None and self.device.type == "cuda") else None
+        dino = self.arch == "da" and type(self.model.backbone).__name__ == "Dinov2Backbone"
+        if dino:
+            self._cache_position_embeddings()
+            if fuse_backbone:
+                self._fuse_backbone_layers()
+            if self.renderer is not None:
+                self._patch_dpt_upsampling()
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda", dtype=torch.float32, **kw) -> "DepthPipe":
+        """A local Hugging Face checkpoint folder (config.json + model.safetensors [+ preprocessor_config.json]) -- the reference's
+        local-model branch, ``AutoModelForDepthEstimation.from_pretrained(checkpoint)`` + ``AutoProcessor.from_pretrained(checkpoint)``
+        (core/render_depth.py:756-760).  DepthAnything / DINOv2 checkpoints (Depth-Anything V1 / V2, Distill-Any-Depth) then get the
+        fused-weight rewrites (one QKV GEMM, LayerScale folded into the projections); any other depth architecture
+        (DPT / MiDaS 3.0, ZoeDepth ...) runs its stock module graph behind the same protocol."""
+        from transformers import AutoModelForDepthEstimation
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path}: not a local checkpoint folder (this build environment has no network)")
+        model = AutoModelForDepthEstimation.from_pretrained(path, local_files_only=True)
+        proc = dict(PROCESSORS["da" if type(model).__name__ == "DepthAnythingForDepthEstimation" else "dpt"])
+        pc = os.path.join(path, "preprocessor_config.json")
+        if os.path.exists(pc):
+            with open(pc) as f:
+                j = json.load(f)
+            sz = j.get("size") or {}
+            if isinstance(sz, dict) and "height" in sz:
+                proc["size"] = (int(sz["height"]), int(sz["width"]))
+            elif isinstance(sz, int):
+                proc["size"] = (sz, sz)
+            proc["keep_aspect_ratio"] = bool(j.get("keep_aspect_ratio", proc["keep_aspect_ratio"]))
+            proc["multiple"] = int(j.get("ensure_multiple_of", proc["multiple"]))
+            if j.get("image_mean") is not None:
+                proc["mean"] = tuple(float(v) for v in j["image_mean"])
+            if j.get("image_std") is not None:
+                proc["std"] = tuple(float(v) for v in j["image_std"])
+            if int(j.get("resample", 3)) != 3:
+                raise NotImplementedError("image processors other than bicubic (PIL resample 3) are not built")
+        return cls(os.path.basename(os.path.normpath(path)), device=device, dtype=dtype, model=model, processor=proc, **kw)
+
+    def resize_target(self, h: int, w: int):
+        return dpt_resize_target(h, w, self.proc["size"], self.proc["multiple"], self.proc["keep_aspect_ratio"])
 
     def _cache_position_embeddings(self):
         """DINOv2 re-interpolates its position embedding (bicubic 37x37 -> patch grid) on EVERY forward; for a fixed
@@ -135,12 +210,12 @@ class DepthPipe:
 
     def _patch_dpt_upsampling(self):
         """Route the align_corners=True bilinear up-samplings of the DPT neck / head (transformers
-        DepthAnythingFeatureFusionLayer / DepthAnythingDepthEstimationHead) through vd3d_upsample_bilinear_nhwc_bf16; the
+        DepthAnythingFeatureFusionLayer / DepthAnythingDepthEstimationHead) through vd3d_upsample_bilinear_nhwc; the
         module graphs are otherwise reproduced verbatim."""
         R = self.renderer
 
         def up(x, size):
-            if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+            if x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last):
                 return R.upsample_bilinear(x, size)
             return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
@@ -208,8 +283,8 @@ class DepthPipe:
             def fwd(x, wqkv=wqkv, bqkv=bqkv, wo=wo, bo=bo, fc1=fc1, w2=w2, b2=b2, nh=nh, hd=hd, scaling=scaling, n1=n1, n2=n2,
                     act=act, nxt=nxt):
                 B, T, d = x.shape
-                hip = R is not None and x.dtype == torch.bfloat16 and x.is_contiguous() and d in (384, 768, 1024)
-                if hip:   # residual add + LayerNorm pairs as single HIP launches (vd3d_add_layernorm_bf16)
+                hip = R is not None and x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous() and d in (384, 768, 1024)
+                if hip:   # residual add + LayerNorm pairs as single HIP launches (vd3d_add_layernorm)
                     h = stash["h"] if stash["x"] is x else R.add_layernorm(x, None, n1)[1]
                     stash["x"] = stash["h"] = None
                 else:
@@ -245,10 +320,10 @@ class DepthPipe:
         else:
             oH, oW = H, W
         if self.renderer is not None and inference_size is None and frames_bgr.dtype == torch.uint8:
-            th, tw = dpt_resize_target(H, W)
+            th, tw = self.resize_target(H, W)
             x = None
             try:
-                x = self.renderer.depth_preprocess(frames_bgr, th, tw, IMAGENET_MEAN, IMAGENET_STD)
+                x = self.renderer.depth_preprocess(frames_bgr, th, tw, self.proc["mean"], self.proc["std"], dtype=self.dtype)
             except Exception as e:   # down-scale beyond the kernel's tap budget: the ATen path below is the same math
                 if getattr(e, "code", None) != -4:
                     raise
@@ -261,7 +336,7 @@ class DepthPipe:
         if inference_size is not None:  # hf_batch_safe_pipe: img.resize(inference_size, BICUBIC) first (:1113-1116)
             x = F.interpolate(x, size=(int(inference_size[1]), int(inference_size[0])), mode="bicubic", antialias=True,
                               align_corners=False).clamp_(0, 255)
-        th, tw = dpt_resize_target(x.shape[2], x.shape[3])
+        th, tw = self.resize_target(x.shape[2], x.shape[3])
         x = F.interpolate(x, size=(th, tw), mode="bicubic", antialias=True, align_corners=False)
         x = ((x / 255.0) - self.mean) / self.std
         x = x.to(self.dtype)
@@ -289,10 +364,11 @@ class DepthPipe:
     def flops_per_frame(self, h: int, w: int) -> float:
         """Dense-GEMM flop estimate for MFMA accounting: 2*params_linear*tokens + 4*T^2*d per layer
         for the backbone, measured conv flops for the DPT head via a counting hook."""
-        th, tw = dpt_resize_target(h, w)
-        T = (th // 14) * (tw // 14) + 1
-        z = MODEL_ZOO[self.name]
-        d, L = z["hidden"], z["layers"]
+        th, tw = self.resize_target(h, w)
+        bcfg = getattr(self.model.config, "backbone_config", None) or self.model.config
+        ps = int(bcfg.patch_size)
+        T = (th // ps) * (tw // ps) + 1
+        d, L = int(bcfg.hidden_size), int(bcfg.num_hidden_layers)
         lin = L * (4 * d * d + 8 * d * d)  # qkv+proj, mlp 4x
         backbone = 2.0 * lin * T + 4.0 * T * T * d * L
         total = [0.0]

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, FrameScalars, RenderParams, ShiftParams, State
+from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, DT_BF16, DT_F32, FrameScalars, RenderParams, ShiftParams, State
 from .geometry import aspect_ratios  # noqa: F401  (re-exported like the reference module does)
 from .params import render_kwargs_to_params, shift_params_from_kwargs
 
@@ -276,32 +276,40 @@ class Renderer:
         _lib.check(self._L.vd3d_subject_depth(self._ctx, _ptr(p), H, W, C.byref(o)))
         return float(o.value)
 
-    def depth_preprocess(self, frames_bgr: torch.Tensor, th: int, tw: int, mean, std) -> torch.Tensor:
-        """DPT image-processor front end fused in one launch: uint8 BGR [B,H,W,3] -> bf16 tensor of logical shape
+    @staticmethod
+    def _dt(dtype) -> int:
+        if dtype == torch.float32:
+            return DT_F32
+        if dtype == torch.bfloat16:
+            return DT_BF16
+        raise TypeError(f"depth-net glue kernels are built for float32 and bfloat16, not {dtype}")
+
+    def depth_preprocess(self, frames_bgr: torch.Tensor, th: int, tw: int, mean, std, dtype=torch.float32) -> torch.Tensor:
+        """DPT image-processor front end fused in one launch: uint8 BGR [B,H,W,3] -> ``dtype`` tensor of logical shape
         [B,3,th,tw] in channels_last memory (antialiased bicubic resize, 1/255, ImageNet normalise)."""
         f = frames_bgr.to(self.device, torch.uint8).contiguous()
         B, H, W, _ = f.shape
-        out = torch.empty((B, th, tw, 3), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((B, th, tw, 3), dtype=dtype, device=self.device)
         m = (C.c_float * 3)(*[float(v) for v in mean]); s = (C.c_float * 3)(*[float(v) for v in std])
-        _lib.check(self._L.vd3d_depth_preprocess(self._ctx, _ptr(f), B, H, W, int(th), int(tw), m, s, _ptr(out)))
+        _lib.check(self._L.vd3d_depth_preprocess(self._ctx, _ptr(f), B, H, W, int(th), int(tw), m, s, self._dt(dtype), _ptr(out)))
         return out.permute(0, 3, 1, 2)   # NCHW view of NHWC storage == torch.channels_last
 
     def add_layernorm(self, x: torch.Tensor, y, norm: torch.nn.LayerNorm):
-        """(x + y, LayerNorm(x + y)) for contiguous bf16 [..., cols] tensors in one launch; y=None -> (x, LayerNorm(x))."""
+        """(x + y, LayerNorm(x + y)) for contiguous float32 / bf16 [..., cols] tensors in one launch; y=None -> (x, LayerNorm(x))."""
         cols = x.shape[-1]
         rows = x.numel() // cols
         out_n = torch.empty_like(x)
         out_s = torch.empty_like(x) if y is not None else x
-        _lib.check(self._L.vd3d_add_layernorm_bf16(self._ctx, _ptr(x), _ptr(y) if y is not None else None, _ptr(norm.weight), _ptr(norm.bias),
-                                                   float(norm.eps), rows, cols, _ptr(out_s) if y is not None else None, _ptr(out_n)))
+        _lib.check(self._L.vd3d_add_layernorm(self._ctx, self._dt(x.dtype), _ptr(x), _ptr(y) if y is not None else None, _ptr(norm.weight),
+                                              _ptr(norm.bias), float(norm.eps), rows, cols, _ptr(out_s) if y is not None else None, _ptr(out_n)))
         return out_s, out_n
 
     def upsample_bilinear(self, x: torch.Tensor, size) -> torch.Tensor:
-        """F.interpolate(x, size, mode="bilinear", align_corners=True) for a bf16 channels_last [B,C,h,w] tensor."""
+        """F.interpolate(x, size, mode="bilinear", align_corners=True) for a float32 / bf16 channels_last [B,C,h,w] tensor."""
         B, Cc, ih, iw = x.shape
         oh, ow = int(size[0]), int(size[1])
         out = torch.empty((B, Cc, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        _lib.check(self._L.vd3d_upsample_bilinear_nhwc_bf16(self._ctx, _ptr(x), _ptr(out), B, ih, iw, oh, ow, Cc))
+        _lib.check(self._L.vd3d_upsample_bilinear_nhwc(self._ctx, self._dt(x.dtype), _ptr(x), _ptr(out), B, ih, iw, oh, ow, Cc))
         return out
 
     def detect_black_bars(self, frame_bgr: torch.Tensor):
