@@ -167,7 +167,7 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     sh, sw, model_name, desc = WORKLOADS[workload]
     p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
     overlap = (not args.no_overlap) and model_name is not None
-    r = Renderer(local_rank, private_stream=overlap)   # DIBR chain on its own stream when a depth net shares the GPU
+    r = Renderer(local_rank, private_stream=overlap, auto_order=False)   # bench orders its streams by hand; DIBR chain on its own stream when a depth net shares the GPU
     rh = Renderer(local_rank) if overlap else r        # depth hand-off stays on the depth net's (torch) stream
     dibr_stream = r.stream if overlap else None
     r.new_clip()

@@ -170,6 +170,9 @@ int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out);
 int vd3d_ctx_destroy(vd3d_ctx* ctx);
 int vd3d_sync(vd3d_ctx* ctx);                            /* hipStreamSynchronize */
 void* vd3d_ctx_stream(vd3d_ctx* ctx);
+/* re-target a context created on a caller-owned stream (not VD3D_STREAM_PRIVATE): later calls enqueue on `stream`, which is first
+ * ordered behind everything the context has enqueued so far */
+int vd3d_ctx_set_stream(vd3d_ctx* ctx, void* stream);
 void* vd3d_ctx_pixel_stream(vd3d_ctx* ctx);              /* second stream of vd3d_set_pixel_overlap (NULL before it was enabled) */
 
 /* ---- tracker state (replaces the module singletons; lets ranks exchange it) -- */
@@ -244,6 +247,14 @@ int vd3d_shard2_p1_foreign(vd3d_ctx* ctx, const void* const* depth_ptrs_host, in
 int vd3d_shard2_r1(vd3d_ctx* ctx, const float* q_all_dev, int n);
 int vd3d_shard2_p3(vd3d_ctx* ctx, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev);
 int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);
+
+/* ---- heal_missing_pixels(warped_frame, warped_depth, original_frame, edge_mask, heal_strength=0.5), core/render_3d.py:431-459 (a23):
+ * the gradient-based hole fill.  warped_chw / original_chw / out_chw: float32 [3][H][W] (rgb_chw), edge_mask_or_null: float32 [H][W]
+ * or NULL; the reference's warped_depth argument is unused by the reference and has no counterpart.  The reference's render
+ * loop never calls this function, so it is an optional stage here too: callers that want it run it between B1 and the
+ * finishing stage.  out may not alias the inputs. */
+int vd3d_heal_missing_pixels(vd3d_ctx* ctx, const float* warped_chw, const float* original_chw, const float* edge_mask_or_null,
+                             int H, int W, double heal_strength, float* out_chw);
 
 /* ---- depth hand-off (a24): transformers' bicubic post-process to (H,W) + convert_depth_to_grayscale
  * (core/render_depth.py:585-611,1914-1916) for a batch of B predictions [B][ph][pw] float32 -> uint8 [B][H][W].

@@ -152,6 +152,19 @@ def shape_depth_for_pop(d, subject, stretch_lo=0.05, stretch_hi=0.95, depth_mid=
     return out, lo.value, hi.value
 
 
+def heal_missing_pixels(warped, orig, edge_mask=None, heal_strength=0.5):
+    """heal_missing_pixels(warped_frame, warped_depth, original_frame, edge_mask, heal_strength) (core/render_3d.py:431-459)."""
+    w, pw = _f(warped)
+    o, po = _f(orig)
+    _, H, W = w.shape
+    out = np.empty_like(w)
+    pe = None
+    if edge_mask is not None:
+        e, pe = _f(np.reshape(edge_mask, (H, W)))
+    lib().vo_heal_missing_pixels(pw, po, pe, H, W, C.c_double(float(heal_strength)), out.ctypes.data_as(_f32p))
+    return out
+
+
 def gaussian_kernel1d(k, sigma):
     out = np.empty(k, np.float32)
     lib().vo_gaussian_kernel1d(k, C.c_float(np.float32(sigma)), out.ctypes.data_as(_f32p))

@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import ref_loader as rl  # noqa: E402
 import ref_stubs  # noqa: E402
+from cases import HEAL_CASES, heal_inputs  # noqa: E402
 from visiondepth3d_amd import synth  # noqa: E402
 
 r = rl.load()
@@ -439,8 +440,22 @@ def gen_blank():
     save("blank.npz", **out)
 
 
+def gen_heal():
+    """a23 heal_missing_pixels (core/render_3d.py:431-459), pure torch: pinned directly."""
+    out = {"cases": np.frombuffer(json.dumps(HEAL_CASES).encode(), dtype=np.uint8)}
+    for i, case in enumerate(HEAL_CASES):
+        warped, orig, edge, hs = heal_inputs(case)
+        res = r.heal_missing_pixels(torch.from_numpy(warped), None, torch.from_numpy(orig),
+                                    None if edge is None else torch.from_numpy(edge), hs).numpy()
+        out[f"healed_{i}"] = res
+        out[f"sha_{i}"] = np.frombuffer(sha(res).encode(), dtype=np.uint8)
+    save("heal.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal"]
+    if "heal" in which:
+        gen_heal()
     if "blank" in which:
         gen_blank()
     if "previews" in which:

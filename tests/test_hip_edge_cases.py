@@ -169,3 +169,33 @@ def test_unsupported_features_fail_loudly():
         r.render_frame(torch.zeros(54, 96, 3, dtype=torch.uint8).cuda(), torch.zeros(54, 96).cuda(), p)
     assert e.value.code == -4
     r.close()
+
+
+def test_heal_missing_pixels_vs_oracle_and_golden(oracle):
+    """a23 heal_missing_pixels (core/render_3d.py:431-459) through the C ABI: bit-exact against the reference goldens (float32
+    planes), against the oracle on ragged sizes (tile edges, 1-pixel images), and on a full 1080p plane."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from cases import HEAL_CASES, heal_inputs
+    from conftest import load_golden
+    from visiondepth3d_amd.render_3d import Renderer
+    r = Renderer(0)
+    g = load_golden("heal.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for i, case in enumerate(HEAL_CASES):
+        warped, orig, edge, hs = heal_inputs(case)
+        got = r.heal_missing_pixels(T(warped), T(orig), None if edge is None else T(edge), hs).cpu().numpy()
+        assert np.array_equal(got, g[f"healed_{i}"]), i
+    rng = np.random.default_rng(3)
+    for (H, W) in ((1, 1), (1, 7), (5, 1), (17, 65), (16, 64), (31, 129), (1080, 1920)):
+        warped = np.clip(rng.random((3, H, W)) * 0.1 + np.linspace(0, 0.9, W)[None, None, :], 0, 1).astype(np.float32)
+        orig = rng.random((3, H, W)).astype(np.float32)
+        edge = rng.random((1, H, W)).astype(np.float32) if (H * W) % 2 else None
+        got = r.heal_missing_pixels(T(warped), T(orig), None if edge is None else T(edge), 0.5).cpu().numpy()
+        exp = oracle.heal_missing_pixels(warped, orig, edge, 0.5)
+        assert np.array_equal(got, exp), (H, W)
+    with pytest.raises(AssertionError):
+        r.heal_missing_pixels(torch.zeros(3, 4, 4), torch.zeros(3, 4, 5))
+    r.close()

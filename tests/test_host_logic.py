@@ -1,3 +1,4 @@
+import os
 """CPU-only tests of the host logic that mirrors the reference's Python: geometry, kwargs mapping, synth."""
 import numpy as np
 import pytest
@@ -88,23 +89,167 @@ def test_u8_unit_is_the_exact_division():
     assert math.isfinite(float(rc))
 
 
-def test_blackdetect_log_parsing(tmp_path):
-    """The skip_blank_frames side channel (core/ffmpeg_blackdetect.py:23-81): start times -> int(t * fps), cache file, and the
-    reference's behaviours kept as they are (only black_start frames, 'd.d' pattern, [] when ffmpeg is missing)."""
-    from visiondepth3d_amd import blackdetect as bd
-    log = ("[blackdetect @ 0x1] black_start:0.5 black_end:1.25 black_duration:0.75\n"
-           "[blackdetect @ 0x1] black_start:12.041667 black_end:12.5 black_duration:0.458333\n"
-           "[blackdetect @ 0x1] black_start:3 black_end:4 black_duration:1\n")          # integral seconds: not matched (:65)
-    assert bd.parse_blackdetect_log(log, 24.0) == [12, 289]
-    assert bd.parse_blackdetect_log(log, 23.976) == [11, 288]
-    assert bd.blackdetect_filter("black", 0.1, 0.10) == "blackdetect=d=0.1:pix_th=0.1"
-    assert "{duration_threshold}" in bd.blackdetect_filter("white", 0.1, 0.1)    # the reference's raw string (:51)
-    with pytest.raises(ValueError):
-        bd.blackdetect_filter("grey", 0.1, 0.1)
-    vid = str(tmp_path / "clip.mp4")
-    (tmp_path / "clip.mp4.blankcache.json").write_text("[7, 3, 9]")
-    assert bd.detect_black_white_frames(vid) == [7, 3, 9]                           # cache is returned as stored (:38-41)
-    assert bd.detect_black_white_frames(str(tmp_path / "none.mp4"), cache=False) == []   # no ffmpeg here -> [] like :79-81
+class _FakeRenderer:
+    """Host-logic stand-in for Renderer (no GPU): records what the shell asks for and returns recognisable frames."""
+
+    def __init__(self):
+        import torch
+        self.device = torch.device("cpu")
+        self.calls, self.clips = [], 0
+
+    def new_clip(self):
+        self.clips += 1
+
+    def render_frame(self, frame, depth, params, blank=False):
+        import torch
+        self.calls.append((int(frame[0, 0, 0]), bool(blank)))
+        out = torch.zeros((params.out_h, params.out_w, 3), dtype=torch.uint8)
+        out[...] = int(frame[0, 0, 0])
+        return out
+
+
+def _fake_clip(n, h=54, w=96):
+    import numpy as np
+    frames = [np.full((h, w, 3), i, np.uint8) for i in range(n)]     # frame i carries its own index in every byte
+    return frames, [f.copy() for f in frames]
+
+
+def _shell_args(**over):
+    import threading
+    a = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0, output_width=96,
+             output_height=54, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, output_format="Half-SBS",
+             selected_aspect_ratio="Default (16:9)", aspect_ratios={"Default (16:9)": 16 / 9}, dof_strength=2.0,
+             suspend_flag=threading.Event(), cancel_flag=threading.Event())
+    a.update(over)
+    return a
+
+
+def test_render_sbs_3d_signature_is_the_references_51_parameters():
+    """B2's Python face (core/render_3d.py:933-985): same parameter names, order and defaults (+ one keyword-only extension)."""
+    import inspect
+    from visiondepth3d_amd.params import RENDER_DEFAULTS
+    from visiondepth3d_amd.render_3d import render_sbs_3d
+    ps = list(inspect.signature(render_sbs_3d).parameters.values())
+    pos = [p for p in ps if p.kind is p.POSITIONAL_OR_KEYWORD]
+    assert len(pos) == 51
+    assert [p.name for p in pos[:15]] == ["input_path", "depth_path", "output_path", "selected_codec", "fps", "output_width", "output_height",
+                                          "fg_shift", "mg_shift", "bg_shift", "sharpness_factor", "output_format", "selected_aspect_ratio",
+                                          "aspect_ratios", "dof_strength"]
+    assert all(p.default is p.empty for p in pos[:15])
+    assert {p.name: p.default for p in pos[15:]} == RENDER_DEFAULTS and [p.name for p in pos[15:]] == list(RENDER_DEFAULTS)
+    assert [p.name for p in ps if p.kind is p.KEYWORD_ONLY] == ["renderer"]
+
+
+def test_render_sbs_3d_shell_read_order_writer_and_window(monkeypatch):
+    """The capture / writer shell with an in-memory video backend (the fake cv2 of tests/golden/ref_stubs.py) and a fake renderer:
+    the window's first frame is decoded twice and never rendered (:1024-1028,1184-1189), rendering starts with the next frame,
+    the writer is opened with the reference's writer size (:1134-1138) and gets every muxed frame; start_s / end_s resolve
+    to frames as :1008-1011 and the loop stops at end_frame_idx (:1432-1435)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_stubs
+    from visiondepth3d_amd import video_io
+    monkeypatch.setattr(video_io, "video_backend", ref_stubs)
+    frames, depths = _fake_clip(10)
+    ref_stubs._Clip.clips["in.mp4"], ref_stubs._Clip.clips["depth.mp4"] = frames, depths
+    caps = []
+    real_cap = ref_stubs.VideoCapture
+
+    class Cap(real_cap):
+        def __init__(self, path):
+            super().__init__(path)
+            caps.append(self)
+    monkeypatch.setattr(ref_stubs, "VideoCapture", Cap)
+    fr = _FakeRenderer()
+    video_io.render_sbs_3d(**_shell_args(), renderer=fr)
+    assert caps[0].log == [0, 0] + list(range(1, 10))             # frame 0 decoded twice, then 1..9
+    assert [c[0] for c in fr.calls] == list(range(1, 10)) and fr.clips == 1
+    written = ref_stubs._Clip.written["out.avi"]
+    assert len(written) == 9 and written[0].shape == (54, 96, 3) and int(written[3][0, 0, 0]) == 4
+    # Full-SBS: the writer is opened 2 x 1920 wide whatever the source is (:1099-1101)
+    sizes = []
+    real_wr = ref_stubs.VideoWriter
+
+    class Wr(real_wr):
+        def __init__(self, path, fourcc, fps, size):
+            super().__init__(path, fourcc, fps, size)
+            sizes.append((fourcc, size))
+    monkeypatch.setattr(ref_stubs, "VideoWriter", Wr)
+    video_io.render_sbs_3d(**_shell_args(output_format="Full-SBS", output_height=1080), renderer=_FakeRenderer())
+    assert sizes == [("XVID", (3840, 1080))]
+    # clip window: fps 24, start 0.125 s -> frame 3, end 0.25 s -> frame 6: frame 3 consumed, 4 and 5 rendered
+    fr = _FakeRenderer()
+    video_io.render_sbs_3d(**_shell_args(start_s=0.125, end_s=0.25), renderer=fr)
+    assert [c[0] for c in fr.calls] == [4, 5]
+    fr = _FakeRenderer()
+    video_io.render_sbs_3d(**_shell_args(start_s=5.0), renderer=fr)        # empty window: nothing rendered, no writer
+    assert fr.calls == []
+    # unreadable inputs return silently like the reference (:988-989)
+    assert video_io.render_sbs_3d(**_shell_args(input_path="missing.mp4"), renderer=_FakeRenderer()) is None
+
+
+def test_render_sbs_3d_shell_cancel_blank_and_ffmpeg_pipe(monkeypatch):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_stubs
+    from visiondepth3d_amd import video_io
+    monkeypatch.setattr(video_io, "video_backend", ref_stubs)
+    frames, depths = _fake_clip(8)
+    ref_stubs._Clip.clips["in.mp4"], ref_stubs._Clip.clips["depth.mp4"] = frames, depths
+    # cancel: tested before a frame is decoded (:1196-1197) -> a flag set from the start renders nothing
+    args = _shell_args()
+    args["cancel_flag"].set()
+    fr = _FakeRenderer()
+    video_io.render_sbs_3d(**args, renderer=fr)
+    assert fr.calls == []
+
+    # cancel raised while frame 3 is being rendered: frame 3 is still written, nothing after it is decoded
+    args = _shell_args()
+
+    class Cancelling(_FakeRenderer):
+        def render_frame(self, frame, depth, params, blank=False):
+            if int(frame[0, 0, 0]) == 3:
+                args["cancel_flag"].set()
+            return super().render_frame(frame, depth, params, blank)
+    fr = Cancelling()
+    video_io.render_sbs_3d(**args, renderer=fr)
+    assert [c[0] for c in fr.calls] == [1, 2, 3] and len(ref_stubs._Clip.written["out.avi"]) == 3
+    # skip_blank_frames: absolute indices from the plugged-in detector, offset by the window start (:1063,1278)
+    monkeypatch.setattr(video_io, "blank_frame_detector", lambda path: [2, 5])
+    fr = _FakeRenderer()
+    video_io.render_sbs_3d(**_shell_args(skip_blank_frames=True), renderer=fr)
+    assert [c for c in fr.calls if c[1]] == [(3, True), (6, True)]       # loop index 2 / 5 = frames 3 / 6 (the loop starts at frame 1)
+    monkeypatch.setattr(video_io, "blank_frame_detector", None)         # no detector: every frame rendered normally (:1058-1060)
+    fr = _FakeRenderer()
+    video_io.render_sbs_3d(**_shell_args(skip_blank_frames=True), renderer=fr)
+    assert not any(b for _, b in fr.calls) and len(fr.calls) == 7
+
+    # ffmpeg pipe (:1143-1163,1422-1427): rawvideo bgr24 of the writer size on stdin, unknown encoders fall back to libx264
+    class Pipe:
+        def __init__(self):
+            self.buf, self.closed = bytearray(), False
+        def write(self, b):
+            self.buf += b
+        def close(self):
+            self.closed = True
+
+    class Proc:
+        def __init__(self, cmd, stdin=None):
+            self.cmd, self.stdin, self.waited = cmd, Pipe(), False
+            procs.append(self)
+        def wait(self, timeout=None):
+            self.waited = True
+        def kill(self):
+            pass
+    procs = []
+    monkeypatch.setattr(video_io, "popen", Proc)
+    video_io.render_sbs_3d(**_shell_args(use_ffmpeg=True, selected_ffmpeg_codec="not-a-codec", crf_value=19), renderer=_FakeRenderer())
+    cmd = procs[0].cmd
+    assert cmd[:2] == ["ffmpeg", "-y"] and cmd[cmd.index("-s") + 1] == "96x54" and cmd[cmd.index("-pix_fmt") + 1] == "bgr24"
+    assert cmd[cmd.index("-c:v") + 1] == "libx264" and cmd[cmd.index("-crf") + 1] == "19" and cmd[-1] == "out.avi"
+    assert len(procs[0].stdin.buf) == 7 * 54 * 96 * 3 and procs[0].stdin.closed and procs[0].waited
+    assert video_io.ffmpeg_pipe_command(8, 4, 30.0, "hevc_nvenc", 21, "o.mp4")[-5:] == ["-cq", "21", "-b:v", "0", "o.mp4"]
+    assert "-crf" not in video_io.ffmpeg_pipe_command(8, 4, 30.0, "h264_amf", 21, "o.mp4")
 
 
 def test_dpt_front_end_matches_the_real_image_processor():

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -132,6 +133,11 @@ static int ensure_eye(vd3d_ctx* c, int eh, int ew) {
   HIPCHK(re_alloc(&c->tdf, ne));
   HIPCHK(re_alloc(&c->dn[0], ne));
   HIPCHK(re_alloc(&c->dn[1], ne));
+  if (c->eye_h != 0) {   // the planes were reallocated: TemporalDepthFilter.prev_depth / prev_depth_tensor no longer exist
+    const int32_t zero2[2] = {0, 0};
+    static_assert(offsetof(vd3d_state, prev_depth_valid) == offsetof(vd3d_state, tdf_valid) + sizeof(int32_t), "adjacent flags");
+    HIPCHK(hipMemcpyAsync(&c->work->st.tdf_valid, zero2, sizeof zero2, hipMemcpyHostToDevice, c->stream));
+  }
   c->eye_h = eh; c->eye_w = ew; c->dn_cur = 0;
   return 0;
 }
@@ -215,6 +221,23 @@ VD3D_EXPORT int vd3d_sync(vd3d_ctx* c) {
   return 0;
 }
 VD3D_EXPORT void* vd3d_ctx_stream(vd3d_ctx* c) { return (void*)c->stream; }
+// Re-target a context that enqueues on a caller-owned stream (e.g. whatever stream is current in PyTorch at call time).  Work already
+// enqueued stays on the old stream; the new stream is ordered behind it with an event, so the context's planes are never raced.
+VD3D_EXPORT int vd3d_ctx_set_stream(vd3d_ctx* c, void* stream) {
+  if (!c) return set_err(VD3D_E_INVALID, "NULL context");
+  if (c->own_stream) return set_err(VD3D_E_INVALID, "the context owns a private stream (VD3D_STREAM_PRIVATE)");
+  if ((hipStream_t)stream == c->stream) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  int rc = join_pixels(c);
+  if (rc) return rc;
+  hipEvent_t e;
+  HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(e, c->stream));
+  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+  HIPCHK(hipEventDestroy(e));
+  c->stream = (hipStream_t)stream;
+  return 0;
+}
 VD3D_EXPORT void* vd3d_ctx_pixel_stream(vd3d_ctx* c) { return c ? (void*)c->pix_stream : nullptr; }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -463,7 +486,11 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.n_eye = ne;
   { const char* e = getenv("VD3D_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.shard = shard; a.shard_idx = step_idx; a.s1_out = s1_out; a.blank = blank ? 1 : 0;
-  float* const save_D = c->D; float* const save_rgb = c->rgb_eye;
+  struct PlaneSwap {   // restores the context's own planes on EVERY exit path (an early HIPCHK return must not leave slot memory in c->D)
+    vd3d_ctx* c; float* D; float* rgb;
+    explicit PlaneSwap(vd3d_ctx* ctx) : c(ctx), D(ctx->D), rgb(ctx->rgb_eye) {}
+    ~PlaneSwap() { c->D = D; c->rgb_eye = rgb; }
+  } plane_swap(c);
   if (shard == 1) { c->D = c->slot_D[slot]; c->rgb_eye = c->slot_rgb[slot]; }
   a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a.ipd_factor = p->ipd_factor; a.shift = sp;
@@ -497,7 +524,7 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   // a blank frame still runs the whole select chain (its eye-res half carries the filters and the bars; the work-res half only
   // computes unused pop-shaping constants -- blank frames are rare and this keeps one code path), but no shift map and no warp
   rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, state_only || blank);
-  c->D = save_D; c->rgb_eye = save_rgb;
+  c->D = plane_swap.D; c->rgb_eye = plane_swap.rgb;
   if (rc) return rc;
   if (shard == 1) {  // keep what the deferred pixel pass needs: this frame's normalised depth and all per-frame constants
     HIPCHK(hipMemcpyAsync(c->slot_dn[slot], dn_cur, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -868,6 +895,19 @@ VD3D_EXPORT int vd3d_subject_depth(vd3d_ctx* c, const float* plane, int H, int W
   a.stage = VD_ST_BS; vd_launch_scalar_stage(c->stream, c->work, c->histA, c->histB, a);
   HIPCHK(hipMemcpyAsync(out_host, &c->work->fs.s1, sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// a23: heal_missing_pixels, core/render_3d.py:431-459 (optional stage; the reference's loop never calls it)
+VD3D_EXPORT int vd3d_heal_missing_pixels(vd3d_ctx* c, const float* warped_chw, const float* original_chw, const float* edge_mask_or_null,
+                                         int H, int W, double heal_strength, float* out_chw) {
+  if (!c || !warped_chw || !original_chw || !out_chw || H < 1 || W < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  if (out_chw == warped_chw || out_chw == original_chw) return set_err(VD3D_E_INVALID, "out may not alias an input (3x3 neighbourhood reads)");
+  if ((long long)H * W * 3 >= (1ll << 31)) return set_err(VD3D_E_INVALID, "frame too large");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "heal");
+  vd_launch_heal(c->stream, warped_chw, original_chw, edge_mask_or_null, H, W, (float)heal_strength, out_chw);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

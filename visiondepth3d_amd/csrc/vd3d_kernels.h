@@ -154,6 +154,9 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
                             int use_override, int bar_w, int bar_s, uint8_t* out);
 
+// ---- vd3d_heal.hip
+void vd_launch_heal(hipStream_t s, const float* warped, const float* orig, const float* edge_or_null, int H, int W, float hs, float* out);
+
 // ---- frame sharding (vd3d_select.hip)
 void vd_launch_shard_replay(hipStream_t s, vd_dev_work* w, const float* s1_all, const int* own_slot, int n, vd_dev_work* slot_work,
                             const vd_stage_args& a);

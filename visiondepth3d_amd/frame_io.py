@@ -34,9 +34,12 @@ class PinnedRing:
         self.ev_done = [torch.cuda.Event() for _ in range(depth)]
         self.ev_out = [torch.cuda.Event() for _ in range(depth)]
         self.used = [False] * depth
+        self.staged = [False] * depth   # an H2D copy out of h_in[k] / h_x[k] has been enqueued at least once
 
     def upload(self, k: int, frames_host, extra_host=None, compute_stream=None):
         """Stage (host memcpy into pinned memory) and enqueue the H2D copy of slot k; the compute stream waits for it."""
+        if self.staged[k]:
+            self.ev_in[k].synchronize()               # HOST: the previous H2D out of the pinned slot has executed before it is restaged
         if self.used[k]:
             self.s_in.wait_event(self.ev_done[k])     # the previous occupant of d_in[k] has been consumed by its kernels
         def stage(src, pinned_slot):   # a decoder that writes into pinned memory itself skips the staging memcpy
@@ -52,6 +55,7 @@ class PinnedRing:
             if src_x is not None:
                 self.d_x[k].copy_(src_x, non_blocking=True)
             self.ev_in[k].record(self.s_in)
+        self.staged[k] = True
         (compute_stream or torch.cuda.current_stream(self.device)).wait_event(self.ev_in[k])
 
     def download(self, k: int, compute_stream=None):

@@ -27,6 +27,7 @@ def preview_image(renderer: Renderer, preview_type: str, left: torch.Tensor, rig
     h, w = int(l_.shape[0]), int(l_.shape[1])
     t = PREVIEW_TYPES[preview_type]
     out = torch.empty((h, 2 * (w // 2) if t == 1 else w, 3), dtype=torch.uint8, device=renderer.device)
+    renderer._enter(l_, r_, out)
     _lib.check(renderer._L.vd3d_preview_image(renderer._ctx, t, _ptr(l_), _ptr(r_), h, w, _ptr(out)))
     return out
 

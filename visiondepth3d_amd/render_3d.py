@@ -6,7 +6,7 @@ streams.  There is no CPU fallback: without the HIP library / a GPU these functi
     pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg, mg, bg, **kw)   # core/render_3d.py:561-712
     Renderer.render_frame(frame_bgr_u8, depth, params)                              # loop body :1227-1419
     render_clip(frames, depths, **render_sbs_3d kwargs)                             # loop :1194-1464 (first frame skipped)
-    render_sbs_3d(input_path, depth_path, output_path, ...)                         # :933-985 signature (needs cv2 for I/O)
+    render_sbs_3d(input_path, depth_path, output_path, ...)                         # :933-985, video_io.py (capture / writer shell)
 """
 from __future__ import annotations
 
@@ -30,7 +30,13 @@ def _ptr(t: torch.Tensor):
 class Renderer:
     """One vd3d_ctx on one GPU.  Holds the tracker state the reference keeps in module globals."""
 
-    def __init__(self, device: int | torch.device | None = None, private_stream: bool = False):
+    def __init__(self, device: int | torch.device | None = None, private_stream: bool = False, auto_order: bool = True):
+        """``private_stream=False`` (default): every call enqueues on the stream that is current in PyTorch AT CALL TIME (the context
+        is re-targeted when it changes), so tensor ops and vd3d kernels stay ordered like two torch ops.
+        ``private_stream=True``: the context owns a non-blocking stream.  With ``auto_order`` (default) each call first orders that
+        stream behind torch's current stream (event) and marks the tensors it touches with ``record_stream`` so the caching allocator
+        does not recycle them early; consumers order themselves behind ``Renderer.stream`` (``ordered_after()``).  Callers that
+        pipeline by hand (bench.py) pass ``auto_order=False`` and own all the events."""
         if not torch.cuda.is_available():
             raise RuntimeError("visiondepth3d_amd needs a ROCm GPU (MI355X); there is no CPU path")
         L = _lib.lib()
@@ -43,6 +49,36 @@ class Renderer:
             # default: enqueue on torch's current stream so tensor ops and vd3d kernels stay ordered
             stream = C.c_void_p(-1) if private_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             _lib.check(L.vd3d_ctx_create(self.device.index, stream, C.byref(self._ctx)))
+            self._private, self._auto_order = bool(private_stream), bool(auto_order)
+            self._bound = None if private_stream else int(torch.cuda.current_stream(self.device).cuda_stream)
+        self._stream_obj = None
+
+    def _enter(self, *tensors):
+        """Order this call against PyTorch's current stream (see __init__)."""
+        cur = torch.cuda.current_stream(self.device)
+        if not self._private:
+            h = int(cur.cuda_stream)
+            if h != self._bound:
+                _lib.check(self._L.vd3d_ctx_set_stream(self._ctx, C.c_void_p(h)))
+                self._bound = h
+            return
+        if self._auto_order:
+            st = self.stream
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            st.wait_event(ev)
+            for t in tensors:
+                if t is not None and torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(st)
+
+    def ordered_after(self, stream=None):
+        """Make ``stream`` (default: torch's current stream) wait for everything this renderer has enqueued so far."""
+        st = self.stream
+        tgt = stream or torch.cuda.current_stream(self.device)
+        if int(tgt.cuda_stream) != int(st.cuda_stream):
+            ev = torch.cuda.Event()
+            ev.record(st)
+            tgt.wait_event(ev)
 
     @property
     def stream(self) -> "torch.cuda.Stream":
@@ -50,7 +86,9 @@ class Renderer:
         ptr = self._L.vd3d_ctx_stream(self._ctx)
         if not ptr:
             return torch.cuda.default_stream(self.device)
-        return torch.cuda.ExternalStream(int(ptr), device=self.device)
+        if self._stream_obj is None or int(self._stream_obj.cuda_stream) != int(ptr):
+            self._stream_obj = torch.cuda.ExternalStream(int(ptr), device=self.device)
+        return self._stream_obj
 
     @property
     def pixel_stream(self):
@@ -119,6 +157,7 @@ class Renderer:
         L = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         R = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         S = torch.empty((1, H, W), dtype=torch.float32, device=self.device) if want_shift else None
+        self._enter(ft, dt, L, R, S)
         _lib.check(self._L.vd3d_pixel_shift(self._ctx, _ptr(ft), _ptr(dt), ih, iw, W, H, C.byref(params), _ptr(L), _ptr(R),
                                             _ptr(S) if want_shift else None))
         return (L, R, S) if want_shift else (L, R)
@@ -148,6 +187,7 @@ class Renderer:
         if out is None:
             out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
         fn = self._L.vd3d_render_frame_blank if blank else self._L.vd3d_render_frame
+        self._enter(f, d, out)
         _lib.check(fn(self._ctx, _ptr(f), _ptr(d), fmt, C.byref(params), _ptr(out)))
         return out
 
@@ -192,15 +232,18 @@ class Renderer:
     # measure / replay protocol (include/vd3d.h vd3d_shard2_*)
     def shard2_p0(self, frame, params: RenderParams, crop_out: torch.Tensor):
         f = frame.to(self.device).contiguous()
+        self._enter(f, crop_out)
         _lib.check(self._L.vd3d_shard2_p0(self._ctx, _ptr(f), C.byref(params), _ptr(crop_out)))
 
     def shard2_set_crops(self, crops_all: torch.Tensor):
         cr = crops_all.to(self.device, torch.int32).contiguous()
+        self._enter(cr)
         _lib.check(self._L.vd3d_shard2_set_crops(self._ctx, _ptr(cr), cr.numel() // 4))
 
     def shard2_p1(self, frame, depth, params: RenderParams, step_idx: int, slot: int = -1, q_out: torch.Tensor | None = None):
         d = depth.to(self.device).contiguous()
         f = frame.to(self.device).contiguous() if frame is not None else None
+        self._enter(f, d, q_out)
         _lib.check(self._L.vd3d_shard2_p1(self._ctx, _ptr(f) if f is not None else None, _ptr(d), self._depth_fmt(d), C.byref(params),
                                           int(step_idx), int(slot), _ptr(q_out) if q_out is not None else None))
 
@@ -212,15 +255,18 @@ class Renderer:
 
     def shard2_r1(self, q_all: torch.Tensor):
         q = q_all.to(self.device, torch.float32).contiguous()
+        self._enter(q)
         _lib.check(self._L.vd3d_shard2_r1(self._ctx, _ptr(q), q.numel() // 2))
 
     def shard2_p3(self, slot: int, step_idx: int, params: RenderParams, m_out: torch.Tensor):
+        self._enter(m_out)
         _lib.check(self._L.vd3d_shard2_p3(self._ctx, int(slot), int(step_idx), C.byref(params), _ptr(m_out)))
 
     def shard2_r2(self, m_all: torch.Tensor, own_slots, params: RenderParams):
         n = len(own_slots)
         arr = (C.c_int * n)(*[int(v) for v in own_slots])
         m = m_all.to(self.device, torch.int64).contiguous()
+        self._enter(m)
         _lib.check(self._L.vd3d_shard2_r2(self._ctx, _ptr(m), arr, n, C.byref(params)))
 
     def set_pixel_overlap(self, on: bool):
@@ -239,6 +285,7 @@ class Renderer:
     def shard_pixels(self, slot: int, params: RenderParams, out: torch.Tensor | None = None):
         if out is None:
             out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
+        self._enter(out)
         _lib.check(self._L.vd3d_shard_pixels(self._ctx, int(slot), C.byref(params), _ptr(out)))
         return out
 
@@ -250,14 +297,35 @@ class Renderer:
         B, ph, pw = p.shape
         if out is None:
             out = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
+        self._enter(p, out)
         _lib.check(self._L.vd3d_depth_handoff(self._ctx, _ptr(p), B, ph, pw, int(H), int(W), int(bool(invert)), _ptr(out)))
+        return out
+
+    def heal_missing_pixels(self, warped_frame, original_frame, edge_mask=None, heal_strength=0.5) -> torch.Tensor:
+        """a23 (core/render_3d.py:431-459) on device: float32 [3,H,W] tensors (+ optional [1,H,W] edge mask) -> healed [3,H,W]."""
+        if warped_frame.dim() != 3 or warped_frame.shape[0] != 3 or warped_frame.shape != original_frame.shape:
+            raise AssertionError("warped_frame and original_frame must both be [3,H,W]")
+        w = warped_frame.to(self.device, torch.float32).contiguous()
+        o = original_frame.to(self.device, torch.float32).contiguous()
+        H, W = int(w.shape[1]), int(w.shape[2])
+        e = None
+        if edge_mask is not None:
+            if edge_mask.numel() != H * W:
+                raise AssertionError("edge_mask must be [1,H,W]")
+            e = edge_mask.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(w)
+        self._enter(w, o, e, out)
+        _lib.check(self._L.vd3d_heal_missing_pixels(self._ctx, _ptr(w), _ptr(o), _ptr(e) if e is not None else None, H, W,
+                                                    float(heal_strength), _ptr(out)))
         return out
 
     def finish_frame(self, left, right, depth_norm, params: RenderParams, focal_depth, bar_width=0, bar_side=0):
         out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
         dn = depth_norm.to(self.device, torch.float32).contiguous()
         eh, ew = dn.shape[-2:]
-        _lib.check(self._L.vd3d_finish_frame(self._ctx, _ptr(left.contiguous()), _ptr(right.contiguous()), _ptr(dn), eh, ew,
+        left, right = left.to(self.device).contiguous(), right.to(self.device).contiguous()
+        self._enter(left, right, dn, out)
+        _lib.check(self._L.vd3d_finish_frame(self._ctx, _ptr(left), _ptr(right), _ptr(dn), eh, ew,
                                              C.byref(params), float(focal_depth), int(bar_width), int(bar_side), _ptr(out)))
         return out
 
@@ -266,6 +334,7 @@ class Renderer:
         p = plane.to(self.device, torch.float32).contiguous()
         q = (C.c_float * len(qs))(*[float(np.float32(v)) for v in qs])
         o = (C.c_float * len(qs))()
+        self._enter(p)
         _lib.check(self._L.vd3d_quantiles(self._ctx, _ptr(p), p.numel(), q, len(qs), o))
         return [float(v) for v in o]
 
@@ -273,6 +342,7 @@ class Renderer:
         p = plane.to(self.device, torch.float32).contiguous()
         H, W = p.shape[-2:]
         o = C.c_float()
+        self._enter(p)
         _lib.check(self._L.vd3d_subject_depth(self._ctx, _ptr(p), H, W, C.byref(o)))
         return float(o.value)
 
@@ -291,6 +361,7 @@ class Renderer:
         B, H, W, _ = f.shape
         out = torch.empty((B, th, tw, 3), dtype=dtype, device=self.device)
         m = (C.c_float * 3)(*[float(v) for v in mean]); s = (C.c_float * 3)(*[float(v) for v in std])
+        self._enter(f, out)
         _lib.check(self._L.vd3d_depth_preprocess(self._ctx, _ptr(f), B, H, W, int(th), int(tw), m, s, self._dt(dtype), _ptr(out)))
         return out.permute(0, 3, 1, 2)   # NCHW view of NHWC storage == torch.channels_last
 
@@ -300,6 +371,7 @@ class Renderer:
         rows = x.numel() // cols
         out_n = torch.empty_like(x)
         out_s = torch.empty_like(x) if y is not None else x
+        self._enter(x, y, out_s, out_n)
         _lib.check(self._L.vd3d_add_layernorm(self._ctx, self._dt(x.dtype), _ptr(x), _ptr(y) if y is not None else None, _ptr(norm.weight),
                                               _ptr(norm.bias), float(norm.eps), rows, cols, _ptr(out_s) if y is not None else None, _ptr(out_n)))
         return out_s, out_n
@@ -309,6 +381,7 @@ class Renderer:
         B, Cc, ih, iw = x.shape
         oh, ow = int(size[0]), int(size[1])
         out = torch.empty((B, Cc, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        self._enter(x, out)
         _lib.check(self._L.vd3d_upsample_bilinear_nhwc(self._ctx, self._dt(x.dtype), _ptr(x), _ptr(out), B, ih, iw, oh, ow, Cc))
         return out
 
@@ -316,6 +389,7 @@ class Renderer:
         """detect_black_bars(frame_to_tensor(frame)) (core/render_3d.py:293-316) on a uint8 BGR frame -> (top, bottom)."""
         f = frame_bgr.to(self.device, torch.uint8).contiguous()
         t, b = C.c_int(), C.c_int()
+        self._enter(f)
         _lib.check(self._L.vd3d_detect_black_bars(self._ctx, _ptr(f), f.shape[0], f.shape[1], C.byref(t), C.byref(b)))
         return t.value, b.value
 
@@ -370,26 +444,37 @@ def pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg_shift, mg_shi
     return res[0].cpu().numpy(), res[1].cpu().numpy()
 
 
-def render_clip(frames, depths, *, renderer: Renderer | None = None, target_ratio=16 / 9, keep_on_device=False,
-                blank_frames=None, start_frame_idx=0, **kw):
+def heal_missing_pixels(warped_frame, warped_depth, original_frame, edge_mask, heal_strength=0.5):
+    """Same signature as the reference (core/render_3d.py:431): ``warped_depth`` is accepted and unused, exactly like there."""
+    return default_renderer().heal_missing_pixels(warped_frame, original_frame, edge_mask, heal_strength)
+
+
+def render_clip(frames, depths, **kw):
     """The render_sbs_3d frame loop over in-memory frames (uint8 BGR arrays/tensors) and depths
     (float32 [h,w] or uint8 depth-video frames).  Yields muxed frames.  Mirrors the reference's read
     order: the first frame of the clip is consumed before the loop and never rendered (:1026,1184,1222).
+    Keywords: see ``render_pairs``."""
+    return render_pairs(zip(frames, depths), **kw)
 
-    ``skip_blank_frames=True`` uses ``blank_frames`` (absolute frame indices, what
+
+def render_pairs(pairs, *, renderer: Renderer | None = None, target_ratio=16 / 9, keep_on_device=False,
+                 blank_frames=None, start_frame_idx=0, skip_first=True, **kw):
+    """``render_clip`` over ONE iterable of (frame, depth) pairs.  ``skip_first=False``: the caller has already consumed the
+    clip's first frame (render_sbs_3d's capture shell does, like the reference).
+
+    ``skip_blank_frames=True`` uses ``blank_frames`` (absolute frame indices, what the reference's
     ``detect_black_white_frames`` returns; tested as ``start_frame_idx + loop index`` like :1063,1278); without a
     list it renders every frame, which is what the reference does when its detection fails (:1058-1060)."""
     r = renderer or default_renderer()
     blank = set(blank_frames or ()) if kw.get("skip_blank_frames") else set()
-    it = iter(zip(frames, depths))
-    first = next(it, None)
-    if first is None:
+    it = iter(pairs)
+    if skip_first and next(it, None) is None:
         return
-    f0 = first[0]
-    sh, sw = int(f0.shape[0]), int(f0.shape[1])
-    params = render_kwargs_to_params(sw, sh, target_ratio=target_ratio, **kw)
-    r.new_clip()
+    params = None
     for idx, (f, d) in enumerate(it):
+        if params is None:
+            params = render_kwargs_to_params(int(f.shape[1]), int(f.shape[0]), target_ratio=target_ratio, **kw)
+            r.new_clip()
         ft = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
         dt = d if torch.is_tensor(d) else torch.from_numpy(np.ascontiguousarray(d))
         out = r.render_frame(ft.to(r.device, non_blocking=True), dt.to(r.device, non_blocking=True), params,
@@ -397,62 +482,4 @@ def render_clip(frames, depths, *, renderer: Renderer | None = None, target_rati
         yield out if keep_on_device else out.cpu().numpy()
 
 
-def render_sbs_3d(input_path, depth_path, output_path, selected_codec, fps, output_width, output_height, fg_shift,
-                  mg_shift, bg_shift, sharpness_factor, output_format, selected_aspect_ratio, aspect_ratios, dof_strength,
-                  **kw):
-    """Reference signature (core/render_3d.py:933-985).  Video I/O goes through OpenCV exactly like the
-    reference; this build environment has no cv2, so the I/O shell raises ImportError there while
-    ``render_clip`` carries the whole per-frame path."""
-    try:
-        import cv2
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("render_sbs_3d needs OpenCV for VideoCapture/VideoWriter; use render_clip() for in-memory frames") from e
-    cancel_flag, suspend_flag = kw.pop("cancel_flag", None), kw.pop("suspend_flag", None)
-    progress, progress_label = kw.pop("progress", None), kw.pop("progress_label", None)
-    for k in ("use_ffmpeg", "selected_ffmpeg_codec", "crf_value"):
-        kw.pop(k, None)
-    start_s, end_s = kw.pop("start_s", None), kw.pop("end_s", None)
-    cap, dcap = cv2.VideoCapture(input_path), cv2.VideoCapture(depth_path)
-    if not cap.isOpened() or not dcap.isOpened():
-        return
-    total = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
-    fps = cap.get(cv2.CAP_PROP_FPS) or fps or 30.0
-    start_idx = int(round(max(0.0, (start_s or 0.0)) * fps))
-    end_idx = total if end_s is None else min(total, int(round(end_s * fps)))
-    cap.set(cv2.CAP_PROP_POS_FRAMES, start_idx)
-    dcap.set(cv2.CAP_PROP_POS_FRAMES, start_idx)
-
-    def gen(c):
-        n = 0
-        while n < max(0, end_idx - start_idx):
-            ok, fr = c.read()
-            if not ok:
-                return
-            n += 1
-            yield fr
-
-    target_ratio = aspect_ratios.get(selected_aspect_ratio.get(), 16 / 9)
-    writer = None
-    blank_frames = None
-    if kw.get("skip_blank_frames"):   # :1046-1060
-        from .blackdetect import detect_black_white_frames
-        try:
-            blank_frames = detect_black_white_frames(input_path, mode="black", duration_threshold=0.1, pixel_threshold=0.10, cache=True)
-        except Exception as e:
-            print(f"Blank frame detection failed: {e}")
-    for i, out in enumerate(render_clip(gen(cap), gen(dcap), target_ratio=target_ratio, blank_frames=blank_frames,
-                                        start_frame_idx=start_idx, output_height=output_height,
-                                        fg_shift=fg_shift, mg_shift=mg_shift, bg_shift=bg_shift,
-                                        sharpness_factor=sharpness_factor, output_format=output_format,
-                                        dof_strength=dof_strength, **kw)):
-        if cancel_flag is not None and cancel_flag.is_set():
-            break
-        if writer is None:
-            writer = cv2.VideoWriter(output_path, cv2.VideoWriter_fourcc(*selected_codec), fps, (out.shape[1], out.shape[0]))
-        writer.write(out)
-        if progress is not None:
-            progress["value"] = 100.0 * i / max(total, 1)
-    cap.release()
-    dcap.release()
-    if writer is not None:
-        writer.release()
+from .video_io import render_sbs_3d  # noqa: E402,F401  (the reference module exports it, core/render_3d.py:933)
