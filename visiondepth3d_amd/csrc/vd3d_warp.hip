@@ -4,14 +4,18 @@
 // (core/render_3d.py:684-712): warped-depth gradient mask -> k x k separable window average -> RGB warp of both
 // eyes -> feather blend -> tensor_to_frame truncation, with NO intermediate planes in HBM.
 //
-// Per 64x32 output tile (512 threads, 3 workgroups per CU at 4K / k = 9: the LDS buffers alias, see the kernel):
+// Per 64x32 output tile (512 threads = 8 waves, 3 workgroups per CU at 4K / k = 9: the LDS buffers alias, see the kernel):
 //   tables  row taps (wave-uniform) and column taps of the resize, grid_sample row parts -> LDS, once per tile
-//   phase A warped depth of BOTH eyes (one packed-f32 vector) on the (TH+k) x (TW+k) halo: S loads, then D gathers (L2)
+//   phase A warped depth of BOTH eyes (one packed-f32 vector) on the (TH+k) x (TW+k) halo.  Mapping: ONE WAVE = ONE ROW, lane =
+//           column, so everything that depends on y (sample row, its weights, the south flag, all row base addresses) is
+//           scalar and everything that depends on x only (the linspace coordinate) is computed once per lane; the k leftover
+//           columns right of the first 64 are walked transposed (wave = column, lane = row).  ~35 VALU per position, was ~150.
 //   phase B e2 = clamp(|grad WD| * fs, 0, 1)            phase C horizontal k-sums (ascending x)
-//           (the eye-res RGB tile is prefetched into registers during B / C and lands over the dead wd / e2 buffers)
-//   phase D vertical k-sums -> b, RGB samples = nested bilinear (resize of :595 inside the grid_sample of :697)
-//           read from the LDS eye tile, one row per wave (row-uniform taps; exact skip of the south samples when the
-//           sample row is integral), blend, truncate, shuffle-packed 12-byte stores per 4 lanes.
+//           (the eye-res RGB tile is prefetched into registers during B / C -- one wave = one tile row, scalar row addresses --
+//           and lands over the dead wd / e2 buffers)
+//   phase D vertical k-sums -> b (exact 3-operation division by k*k), RGB samples = nested bilinear (resize of :595 inside the
+//           grid_sample of :697) read from the LDS eye tile, one row per wave (row-uniform taps; exact skip of the south samples
+//           when the sample row is integral), blend, truncate, shuffle-packed 12-byte stores per 4 lanes.
 // Arithmetic is identical to the unfused v0 kernels (same helpers, same association) => bit-exact vs the oracle.
 //
 // Algorithmic HBM bytes per stereo pair: read RGB 3N (eye-res f32 x3 at N/4) + D 4N + S 4N, write 6N.
@@ -21,16 +25,21 @@
 #define WF_TW 64
 #define WF_TH 32
 #define WF_NT 512
-#define WF_PF 16  // RGB tile elements prefetched per thread (registers) while phase A runs
+#define WF_NW (WF_NT / 64)
+#define WF_AB 3   // halo rows of phase A a wave walks together (loads of all of them in flight)
+#define WF_PF 16  // RGB tile row-chunks prefetched per wave (registers) while phases B / C run
 
 struct vd_wf_args {
   int ih, iw, H, W, k, feather, bound;  // bound: rigorous host-side bound on |pixel shift| (+ margin)
   int er_max, ec_max;                   // eye tile capacity (rows, cols) when resizing
+  int nc;                               // 64-column chunks per tile row = ceil(ec_max / 64)
   int ncol;                             // entries of the column-tap table (WF_TW + 2*bound + 6)
   int tab_off;                          // float offset of the tables in LDS
-  uint32_t m_ww, m_ew, m_ec, m_erec;    // ceil(2^32/d) reciprocals: q = umulhi(t, m) is exact for t, d < 2^16
+  int fastdiv;                          // 1: x / (k*k) as q0 = x*rc, r = fma(-q0, kk, x), q = fma(r, rc, q0) -- verified exhaustively
+  uint32_t m_ew;                        // ceil(2^32/d) reciprocal: q = umulhi(t, m) is exact for t, d < 2^16
   float fs, scale_h, scale_w;
   float step_x, step_y;                 // linspace steps (1-(-1))/(float)(W-1), .../(H-1): vd_lin11_step
+  float kk, rc_kk;                      // (float)(k*k) and its correctly rounded reciprocal
 };
 // LDS tables (built once per tile, so the per-pixel phases only do table look-ups):
 //   rowA[wh][4]   per halo row of phase A : yn, n, 1-n, south flag                      (grid_sample row part)
@@ -39,6 +48,8 @@ struct vd_wf_args {
 //                                           keeps a duplicate of the last image column)
 #define WF_RD 16
 VD_DEV int wf_div(int t, uint32_t m) { return (int)__umulhi((uint32_t)t, m); }
+VD_DEV int wf_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+VD_DEV float wf_unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 VD_DEV vd_tap wf_tap(int in, int out, float scale, int o) {  // vd_interp_tap with the scale hoisted
   vd_tap t;
@@ -75,21 +86,61 @@ VD_DEV void wf_gs_row(float gy, int H, int* yn, float* n, float* sr, bool* s_ok)
   const float f = floorf(iy);
   *n = iy - f; *sr = 1.f - (iy - f); *yn = (int)f; *s_ok = ((int)f + 1) < H;
 }
-// RGB tile: prefetched registers -> LDS (+ the rare overflow elements straight from global)
-#define WF_STORE_TILE                                                                                                   \
-  {                                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < WF_PF; ++j) {                                                                 \
-      const int t = tid + j * WF_NT;                                                                                    \
-      if (t < 3 * er * ec) tile[t] = pf[j];                                                                             \
-    }                                                                                                                   \
-    const unsigned ni_ = (unsigned)a.ih * (unsigned)a.iw;                                                               \
-    for (int t = tid + WF_PF * WF_NT; t < 3 * er * ec; t += WF_NT) { /* only for very large shift bounds */            \
-      const int c = t / (er * ec), rem = t - c * er * ec, ty = rem / ec, tx = rem - ty * ec;                            \
-      tile[t] = rgb[(unsigned)c * ni_ + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + tx, a.iw - 1)];    \
-    }                                                                                                                   \
+// warped depth of both eyes at one position (grid_sample of D with the shift S, :700-701): the caller supplies the row part
+// (drow = D + yn * W, n, sr, south) and the column part (gx); in the main block of phase A the former is scalar and the latter is
+// loop-invariant per lane, in the leftover block it is the other way round.
+VD_DEV vd_f2 wf_warped_depth(const float* __restrict__ drow, float s, float gx, float n, float sr, bool south, int W) {
+  const wf_gs2 g = wf_gs_params2(gx, s, n, sr, W);
+  const float* r0 = drow + g.xw[0];
+  const float* r1 = drow + g.xw[1];
+  const vd_f2 vnw = {r0[0], r1[0]};
+  const vd_f2 vne = {g.e_ok[0] ? r0[1] : 0.f, g.e_ok[1] ? r1[1] : 0.f};
+  // vd_gs_combine; when n == 0 (or no south row) sw = se = 0 exactly and the south samples add +0
+  vd_f2 acc = vd_vfma(vne, g.ne, vnw * g.nw);
+  if (south) {
+    const vd_f2 vsw = {r0[W], r1[W]};
+    const vd_f2 vse = {g.e_ok[0] ? r0[W + 1] : 0.f, g.e_ok[1] ? r1[W + 1] : 0.f};
+    acc = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, acc));
   }
+  return acc;
+}
+
+// The same in two halves, so that a wave can have the gathers of several positions in flight before it combines any of them.
+struct wf_wdl { vd_f2 w, vnw, vne, vsw, vse; bool e0, e1; };   // vne / vse: RAW east samples, zeroed by e0 / e1 in the combine
+VD_DEV wf_wdl wf_wd_issue(const float* __restrict__ drow, float s, float gx, bool south, int W) {
+  wf_wdl l;
+  const vd_f2 g = {gx + s, gx - s};
+  vd_f2 ix = (g + 1.f) * ((float)(W - 1) / 2.f);
+  ix.x = fminf((float)(W - 1), fmaxf(ix.x, 0.f)); ix.y = fminf((float)(W - 1), fmaxf(ix.y, 0.f));
+  const vd_f2 xw = {floorf(ix.x), floorf(ix.y)};
+  l.w = ix - xw;
+  const int x0 = (int)xw.x, x1 = (int)xw.y;
+  const bool e0 = (x0 + 1) < W, e1 = (x1 + 1) < W;
+  const float* r0 = drow + x0;
+  const float* r1 = drow + x1;
+  // branch-free per lane (the east neighbour of the last column is read as the column itself and then zeroed), so that the
+  // loads of several positions stay in flight together; `south` is wave-uniform where this is used
+  const int o0 = e0 ? 1 : 0, o1 = e1 ? 1 : 0;
+  l.vnw = vd_f2{r0[0], r1[0]};
+  l.vne = vd_f2{r0[o0], r1[o1]};
+  l.vsw = vd_f2{0.f, 0.f}; l.vse = vd_f2{0.f, 0.f};
+  if (south) {
+    l.vsw = vd_f2{r0[W], r1[W]};
+    l.vse = vd_f2{r0[W + o0], r1[W + o1]};
+  }
+  l.e0 = e0; l.e1 = e1;   // nothing above consumes a loaded value: no s_waitcnt in the issue half
+  return l;
+}
+// Unconditional on purpose (no `if (south)`): with the south samples zero-filled the two extra fused multiply-adds add +0 to a
+// non-negative accumulator, i.e. nothing -- and a branch here would let the optimiser fuse this half back onto the issue half.
+VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
+  const vd_f2 e = 1.f - l.w;
+  const vd_f2 vne = {l.e0 ? l.vne.x : 0.f, l.e1 ? l.vne.y : 0.f}, vse = {l.e0 ? l.vse.x : 0.f, l.e1 ? l.vse.y : 0.f};
+  const vd_f2 acc = vd_vfma(vne, sr * l.w, l.vnw * (sr * e));
+  return vd_vfma(vse, n * l.w, vd_vfma(l.vsw, n * e, acc));
+}
+
 // LDS map (floats):  wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2] | tile[3*er*ec] | rowD | rowA | colT      ([..][2] = eyes)
-#define WF_AI 6  // phase-A positions per thread ((TH+k)(TW+k) <= WF_AI*WF_NT for k <= 9; larger k loops)
 template <bool RESIZE, bool FEATHER>
 __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
@@ -109,39 +160,69 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   float* rowA = rowD + WF_TH * WF_RD;                               // [wh][4]
   float* colT = rowA + wh * 4;                                      // [ncol][2]
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = wf_uni(tid >> 6);
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
   const int cb = max(x0 - a.bound - 2, 0);                          // first warp-res column of colT
 
-  // eye-res RGB tile: global -> registers now, registers -> LDS after phase A (latency hidden behind phase A)
+  // eye-res RGB tile geometry (block-uniform)
   int er0 = 0, ec0 = 0, er = 0, ec = 0;
-  float pf[WF_PF];
   if (RESIZE) {
     const int ya = max(y0 - 1, 0), yb = min(y0 + WF_TH, H - 1);
-    const int xa = max(x0 - a.bound - 1, 0), xb = min(x0 + WF_TW + a.bound + 1, W - 1);
+    const int xa = max(x0 - a.bound - 1, 0);
     er0 = wf_tap(a.ih, H, a.scale_h, ya).i0; er = wf_tap(a.ih, H, a.scale_h, yb).i1 - er0 + 1;
-    ec0 = wf_tap(a.iw, W, a.scale_w, xa).i0; ec = wf_tap(a.iw, W, a.scale_w, xb).i1 - ec0 + 1;
-    er = min(er, a.er_max); ec = a.ec_max;  // fixed row pitch (host constant) so the reciprocals apply
+    ec0 = wf_tap(a.iw, W, a.scale_w, xa).i0;
+    er = min(er, a.er_max); ec = a.ec_max;  // fixed row pitch (host constant)
     ec0 = min(ec0, a.iw + 1 - ec); ec0 = max(ec0, 0);   // tile column iw - ec0 (if inside) duplicates the last image column
-    if (!FEATHER) {
-    const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
-    // element t = tid + j*WF_NT of the [3*er][ec] tile, (row, tx) advanced incrementally (no integer division / 32-bit multiply)
-    const int pq = WF_NT / ec, pr = WF_NT - pq * ec;
-    int prow = wf_div(tid, a.m_ec), ptx = tid - prow * ec;
-#pragma unroll
-    for (int j = 0; j < WF_PF; ++j) {
-      float v = 0.f;
-      if (prow < 3 * er) {
-        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);
-        const int ty = prow - c * er;
-        const unsigned pb = c == 2 ? 2u * ni : (c == 1 ? ni : 0u);
-        v = rgb[pb + __umul24((unsigned)(er0 + ty), (unsigned)a.iw) + (unsigned)min(ec0 + ptx, a.iw - 1)];
-      }
-      pf[j] = v;
-      prow += pq; ptx += pr;
-      if (ptx >= ec) { ptx -= ec; ++prow; }
-    }
-      }
   }
+  const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
+  // The tile as NR = 3*er rows of NC = a.nc 64-column chunks; wave wv owns the row-chunks q = wv + 8*j.  (row, chunk) advance
+  // incrementally (no division); everything but the lane's column is scalar.
+  const int NR = 3 * er, NC = a.nc;
+  const int pq = WF_NW / NC, pr = WF_NW - pq * NC;     // q += 8  ==  (row, chunk) += (pq, pr) with carry
+  int prow0 = 0, pch0 = wv;
+  if (RESIZE) { while (pch0 >= NC) { pch0 -= NC; ++prow0; } }
+  float pf[WF_PF];
+  // global -> registers (one row-chunk per j): scalar row base, per-lane clamped column
+#define WF_LOAD_TILE                                                                                                    \
+  {                                                                                                                     \
+    int prow = prow0, pch = pch0;                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < WF_PF; ++j) {                                                                 \
+      float v = 0.f;                                                                                                    \
+      if (prow < NR) {                                                                                                  \
+        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);                                                        \
+        const int ty = prow - c * er;                                                                                   \
+        const float* srow = rgb + ((unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw);                           \
+        const int cx = pch * 64 + lane;                                                                                 \
+        if (cx < ec) v = srow[min(ec0 + cx, a.iw - 1)];                                                                 \
+      }                                                                                                                 \
+      pf[j] = v;                                                                                                        \
+      prow += pq; pch += pr;                                                                                            \
+      if (pch >= NC) { pch -= NC; ++prow; }                                                                             \
+    }                                                                                                                   \
+  }
+  // registers -> LDS (+ the rare row-chunks beyond the register budget straight from global)
+#define WF_STORE_TILE                                                                                                   \
+  {                                                                                                                     \
+    int prow = prow0, pch = pch0;                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < WF_PF; ++j) {                                                                 \
+      const int cx = pch * 64 + lane;                                                                                   \
+      if (prow < NR && cx < ec) {                                                                                       \
+        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);                                                        \
+        tile[((prow - c * er) * ec + cx) * 3 + c] = pf[j];                                                              \
+      }                                                                                                                 \
+      prow += pq; pch += pr;                                                                                            \
+      if (pch >= NC) { pch -= NC; ++prow; }                                                                             \
+    }                                                                                                                   \
+    for (; prow < NR;) { /* only for very large shift bounds */                                                        \
+      const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);                                                          \
+      const int ty = prow - c * er;                                                                                     \
+      const int cx = pch * 64 + lane;                                                                                   \
+      if (cx < ec) tile[(ty * ec + cx) * 3 + c] = rgb[(unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + cx, a.iw - 1)]; \
+      prow += pq; pch += pr;                                                                                            \
+      if (pch >= NC) { pch -= NC; ++prow; }                                                                             \
+    }                                                                                                                   \
+  }
+  if (RESIZE && !FEATHER) WF_LOAD_TILE
   // ---- tables
   if (tid < wh) {   // phase-A rows
     const int y = wy0 + tid;
@@ -149,90 +230,92 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     if (y >= 0 && y < H) wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
     float* t = rowA + tid * 4;
     t[0] = __int_as_float(yn); t[1] = n; t[2] = sr; t[3] = __int_as_float((s_ok && n != 0.f) ? 1 : 0);
-  } else if (tid >= 64 && tid < 64 + WF_TH) {   // phase-D rows
-    const int ty = tid - 64, y = min(y0 + ty, H - 1);
+  } else if (tid >= 128 && tid < 128 + WF_TH) {   // phase-D rows
+    const int ty = tid - 128, y = min(y0 + ty, H - 1);
     int yn; float n, sr; bool s_ok;
     wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
     float* t = rowD + ty * WF_RD;
     const vd_tap to = wf_tap(a.ih, H, a.scale_h, y), t0 = wf_tap(a.ih, H, a.scale_h, yn), t1 = wf_tap(a.ih, H, a.scale_h, min(yn + 1, H - 1));
-    t[0] = __int_as_float((to.i0 - er0) * ec); t[1] = __int_as_float((to.i1 - er0) * ec); t[2] = to.w0; t[3] = to.w1;
-    t[4] = __int_as_float((t0.i0 - er0) * ec); t[5] = __int_as_float((t0.i1 - er0) * ec); t[6] = t0.w0; t[7] = t0.w1;
-    t[8] = __int_as_float((t1.i0 - er0) * ec); t[9] = __int_as_float((t1.i1 - er0) * ec); t[10] = t1.w0; t[11] = t1.w1;
+    const int rp = ec * 12;   // bytes per tile row: [ec][3] floats
+    t[0] = __int_as_float((to.i0 - er0) * rp); t[1] = __int_as_float((to.i1 - er0) * rp); t[2] = to.w0; t[3] = to.w1;
+    t[4] = __int_as_float((t0.i0 - er0) * rp); t[5] = __int_as_float((t0.i1 - er0) * rp); t[6] = t0.w0; t[7] = t0.w1;
+    t[8] = __int_as_float((t1.i0 - er0) * rp); t[9] = __int_as_float((t1.i1 - er0) * rp); t[10] = t1.w0; t[11] = t1.w1;
     t[12] = n; t[13] = sr; t[14] = __int_as_float((s_ok && n != 0.f) ? 1 : 0); t[15] = __int_as_float(yn);
   }
   if (RESIZE) {
     for (int j = tid; j < a.ncol; j += WF_NT) {
       const vd_tap t = wf_tap(a.iw, W, a.scale_w, min(cb + j, W - 1));
-      colT[2 * j] = __int_as_float(t.i0 - ec0); colT[2 * j + 1] = t.w1;
+      colT[2 * j] = __int_as_float((t.i0 - ec0) * 12); colT[2 * j + 1] = t.w1;   // byte offset of the tap's column in a tile row
     }
   }
   __syncthreads();
   if (FEATHER) {
-    // phase A: warped depth of both eyes on the (TH+k) x (TW+k) halo region (grid_sample of D, :700-701).
-    // Two passes with a fixed unroll so all S loads, then all D gathers, are in flight together.
-    for (int base = 0; base < wh * ww; base += WF_AI * WF_NT) {
-      float sv[WF_AI];
+    // phase A, main block: wave = halo row (scalar row part), lane = the first 64 halo columns (gx once per lane).  The phase is
+    // LATENCY-bound (two dependent global round trips per position: S, then the D gathers), so WF_AB rows are walked together: all
+    // their S loads are issued first, then all their D gathers, then the combines (measured: 12 -> 4 exposed round trips per wave).
+    {
+      const int x = wx0 + lane;
+      const bool xin = x >= 0 && x < W;
+      const int xc = min(max(x, 0), W - 1);              // lanes left / right of the image load a valid column and are zeroed below
+      const float gx = vd_lin11_step(a.step_x, W, xc);
+      for (int tb = wv; tb < wh; tb += WF_AB * WF_NW) {
+        float sv[WF_AB];
 #pragma unroll
-      for (int j = 0; j < WF_AI; ++j) {
-        const int t = base + tid + j * WF_NT;
-        const int ty = wf_div(t, a.m_ww), tx = t - ty * ww;
-        const int y = wy0 + ty, x = wx0 + tx;
-        sv[j] = (t < wh * ww && y >= 0 && y < H && x >= 0 && x < W) ? S[__umul24((unsigned)y, (unsigned)W) + (unsigned)x] : 0.f;
-      }
+        for (int j = 0; j < WF_AB; ++j) {
+          const int ty = tb + j * WF_NW, y = wy0 + ty;
+          sv[j] = (ty < wh && y >= 0 && y < H) ? S[(unsigned)y * (unsigned)W + (unsigned)xc] : 0.f;   // wave-uniform guard
+        }
+        wf_wdl ld[WF_AB];
+        float rn[WF_AB], rsr[WF_AB]; bool rso[WF_AB], rok[WF_AB];
 #pragma unroll
-      for (int j = 0; j < WF_AI; ++j) {
-        const int t = base + tid + j * WF_NT;
-        if (t < wh * ww) {
-          const int ty = wf_div(t, a.m_ww), tx = t - ty * ww;
-          const int y = wy0 + ty, x = wx0 + tx;
-          vd_f2 v = {0.f, 0.f};
-          if (y >= 0 && y < H && x >= 0 && x < W) {
-            const float gx = vd_lin11_step(a.step_x, W, x);
+        for (int j = 0; j < WF_AB; ++j) {
+          const int ty = tb + j * WF_NW, y = wy0 + ty;
+          rok[j] = ty < wh && y >= 0 && y < H;   // wave-uniform
+          rn[j] = 0.f; rsr[j] = 1.f; rso[j] = false;
+          ld[j].w = ld[j].vnw = ld[j].vne = ld[j].vsw = ld[j].vse = vd_f2{0.f, 0.f}; ld[j].e0 = ld[j].e1 = false;
+          if (rok[j]) {
             const vd_f4 rt = *reinterpret_cast<const vd_f4*>(rowA + ty * 4);
-            const int yn = __float_as_int(rt.x);
-            const wf_gs2 g = wf_gs_params2(gx, sv[j], rt.y, rt.z, W);
-            const unsigned rb = __umul24((unsigned)yn, (unsigned)W);
-            const float* r0 = D + (rb + (unsigned)g.xw[0]);
-            const float* r1 = D + (rb + (unsigned)g.xw[1]);
-            const vd_f2 vnw = {r0[0], r1[0]};
-            const vd_f2 vne = {g.e_ok[0] ? r0[1] : 0.f, g.e_ok[1] ? r1[1] : 0.f};
-            // vd_gs_combine; when n == 0 (or no south row) sw = se = 0 exactly and the south samples add +0
-            vd_f2 acc = vd_vfma(vne, g.ne, vnw * g.nw);
-            if (__float_as_int(rt.w)) {
-              const vd_f2 vsw = {r0[W], r1[W]};
-              const vd_f2 vse = {g.e_ok[0] ? r0[W + 1] : 0.f, g.e_ok[1] ? r1[W + 1] : 0.f};
-              acc = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, acc));
-            }
-            v = acc;
+            const int yn = wf_uni(__float_as_int(rt.x));
+            rn[j] = wf_unif(rt.y); rsr[j] = wf_unif(rt.z);
+            rso[j] = wf_uni(__float_as_int(rt.w)) != 0;
+            ld[j] = wf_wd_issue(D + (unsigned)yn * (unsigned)W, sv[j], gx, rso[j], W);
           }
-          wd[t] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        vd_f2 vv[WF_AB];
+#pragma unroll
+        for (int j = 0; j < WF_AB; ++j) {   // rows outside the image hold zero-filled samples -> 0
+          const vd_f2 v = wf_wd_combine(ld[j], rn[j], rsr[j]);
+          vv[j].x = xin ? v.x : 0.f; vv[j].y = xin ? v.y : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < WF_AB; ++j) {
+          const int ty = tb + j * WF_NW;
+          if (ty < wh) wd[ty * ww + lane] = vv[j];
         }
       }
     }
-  }
-  if (RESIZE && !FEATHER) {
-    WF_STORE_TILE
-  }
-  __syncthreads();
-  if (FEATHER && RESIZE) {   // tile prefetch: in flight during phases B and C only (keeps the register footprint of phase A small)
-    const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
-    // element t = tid + j*WF_NT of the [3*er][ec] tile, (row, tx) advanced incrementally (no integer division / 32-bit multiply)
-    const int pq = WF_NT / ec, pr = WF_NT - pq * ec;
-    int prow = wf_div(tid, a.m_ec), ptx = tid - prow * ec;
-#pragma unroll
-    for (int j = 0; j < WF_PF; ++j) {
-      float v = 0.f;
-      if (prow < 3 * er) {
-        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);
-        const int ty = prow - c * er;
-        const unsigned pb = c == 2 ? 2u * ni : (c == 1 ? ni : 0u);
-        v = rgb[pb + __umul24((unsigned)(er0 + ty), (unsigned)a.iw) + (unsigned)min(ec0 + ptx, a.iw - 1)];
+    // phase A, leftover block: the k halo columns right of the first 64, transposed (wave = column, lane = halo row)
+    for (int c = wv; c < ww - 64; c += WF_NW) {
+      const int tx = 64 + c, x = wx0 + tx;          // wave-uniform
+      const bool xin = x >= 0 && x < W;
+      const float gx = vd_lin11_step(a.step_x, W, min(max(x, 0), W - 1));
+      for (int ty = lane; ty < wh; ty += 64) {
+        const int y = wy0 + ty;
+        vd_f2 v = {0.f, 0.f};
+        if (xin && y >= 0 && y < H) {
+          const vd_f4 rt = *reinterpret_cast<const vd_f4*>(rowA + ty * 4);
+          const int yn = __float_as_int(rt.x);
+          v = wf_warped_depth(D + (unsigned)yn * (unsigned)W, S[(unsigned)y * (unsigned)W + (unsigned)x], gx, rt.y, rt.z,
+                              __float_as_int(rt.w) != 0, W);
+        }
+        wd[ty * ww + tx] = v;
       }
-      pf[j] = v;
-      prow += pq; ptx += pr;
-      if (ptx >= ec) { ptx -= ec; ++prow; }
     }
-    }
+  }
+  if (RESIZE && !FEATHER) WF_STORE_TILE
+  __syncthreads();
+  if (FEATHER && RESIZE) WF_LOAD_TILE   // tile prefetch: in flight during phases B and C only (keeps the register footprint of phase A small)
   if (FEATHER) {
     // phase B: e2 = clamp(|grad WD| * fs, 0, 1) (:347-352), zero outside the image (avg_pool2d zero padding)
     const int bq = WF_NT / ew, br = WF_NT - bq * ew;
@@ -241,11 +324,11 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       const int y = y0 - r + ty, x = x0 - r + tx;
       vd_f2 e = {0.f, 0.f};
       if (y >= 0 && y < H && x >= 0 && x < W) {
-        const vd_f2* wv = wd + __umul24((unsigned)(ty + 1), (unsigned)ww) + (tx + 1);
-        const vd_f2 c = wv[0];
+        const vd_f2* wvp = wd + __umul24((unsigned)(ty + 1), (unsigned)ww) + (tx + 1);
+        const vd_f2 c = wvp[0];
         const vd_f2 z = {0.f, 0.f};
-        const vd_f2 gx = x > 0 ? c - wv[-1] : z;
-        const vd_f2 gy = y > 0 ? c - wv[-ww] : z;
+        const vd_f2 gx = x > 0 ? c - wvp[-1] : z;
+        const vd_f2 gy = y > 0 ? c - wvp[-ww] : z;
         const vd_f2 q = gx * gx + gy * gy;
         const vd_f2 m = vd_f2{sqrtf(q.x), sqrtf(q.y)} * a.fs;
         e.x = vd_clamp_fin(m.x, 0.f, 1.f); e.y = vd_clamp_fin(m.y, 0.f, 1.f);
@@ -255,19 +338,25 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       if (tx >= ew) { tx -= ew; ++ty; }
     }
     __syncthreads();
-    // phase C: horizontal window sums (ascending x) into the dead wd buffer
+    // phase C: horizontal window sums (ascending x) into the dead wd buffer; wave = e2 row, lane = tile column
     vd_f2* hs = wd;
-    for (int t = tid; t < eh * WF_TW; t += WF_NT) {
-      const int ty = t >> 6, tx = t & 63;
-      const vd_f2* row = e2 + ty * ew + tx;
+    for (int ty = wv; ty < eh; ty += WF_NW) {
+      const vd_f2* row = e2 + ty * ew + lane;
       vd_f2 sacc = {0.f, 0.f};
       for (int j = 0; j < k; ++j) sacc += row[j];
-      hs[t] = sacc;
+      hs[ty * WF_TW + lane] = sacc;
     }
     if (RESIZE) {
       __syncthreads();   // every read of e2 is done: the tile may overwrite it
       WF_STORE_TILE
     }
+  }
+  // the shift values of this wave's phase-D rows: issued before the barrier so that their latency overlaps the tile store
+  float sD[WF_TH / WF_NW];
+#pragma unroll
+  for (int j = 0; j < WF_TH / WF_NW; ++j) {
+    const int y = y0 + wv + j * WF_NW, x = x0 + lane;
+    sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
   }
   __syncthreads();
   // phase D: one wave = 64 consecutive pixels of ONE row per iteration, so everything that depends on y only
@@ -275,29 +364,36 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
   // have an exactly integral sample row (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 ->
   // skipped (bit-exact: fma(v, 0, acc) == acc for finite v).
   const vd_f2* hs = wd;
-  const float div = (float)(k * k);
-  const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
-  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int ty = wv; ty < WF_TH; ty += WF_NT / 64) {
+#pragma unroll 1
+  for (int ty = wv; ty < WF_TH; ty += WF_NW) {
     const int y = y0 + ty;
     if (y >= H) break;
+    const float s_row = sD[0];   // rotate the prefetched shift values (static register indices, compact loop body)
+#pragma unroll
+    for (int j = 0; j + 1 < WF_TH / WF_NW; ++j) sD[j] = sD[j + 1];
     const vd_f4* rt = reinterpret_cast<const vd_f4*>(rowD + ty * WF_RD);
     const vd_f4 ro = rt[0], ra = rt[1], rb = rt[2], rs = rt[3];
-    const float n = rs.x, sr = rs.y;
-    const bool south = __float_as_int(rs.z) != 0;
-    const int yn = __float_as_int(rs.w);
+    const float n = wf_unif(rs.x), sr = wf_unif(rs.y);
+    const bool south = wf_uni(__float_as_int(rs.z)) != 0;
+    const int yn = wf_uni(__float_as_int(rs.w));
     const int x = x0 + lane;
     uint32_t pL = 0, pR = 0;
     if (x < W) {
-      const unsigned o = __umul24((unsigned)y, (unsigned)W) + (unsigned)x;
+      const unsigned o = (unsigned)y * (unsigned)W + (unsigned)x;
       vd_f2 b = {0.f, 0.f};
       if (FEATHER) {
         const vd_f2* col = hs + ty * WF_TW + lane;
         vd_f2 sacc = {0.f, 0.f};
         for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
-        b.x = sacc.x / div; b.y = sacc.y / div;
+        if (a.fastdiv) {   // correctly rounded sacc / (k*k) in three packed operations (tools/verify_fastdiv.c: exhaustive)
+          const vd_f2 q0 = sacc * a.rc_kk;
+          const vd_f2 rr = vd_vfma(-q0, (vd_f2)(a.kk), sacc);
+          b = vd_vfma(rr, (vd_f2)(a.rc_kk), q0);
+        } else {
+          b.x = sacc.x / a.kk; b.y = sacc.y / a.kk;
+        }
       }
-      const float s = S[o];
+      const float s = s_row;
       const float gx0 = vd_lin11_step(a.step_x, W, x);
       const wf_gs2 g = wf_gs_params2(gx0, s, n, sr, W);
       const vd_f2 omb = 1.0f - b;
@@ -311,32 +407,42 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         const vd_f2 wa0 = 1.f - wa1, wb0 = 1.f - wb1;
         const int io = __float_as_int(eo.x);
         const float wo1 = eo.y, wo0 = 1.f - eo.y;
+        // tile row offsets of the three resize taps are wave-uniform
+        const int o_r0 = wf_uni(__float_as_int(ro.x)), o_r1 = wf_uni(__float_as_int(ro.y));
+        const int a_r0 = wf_uni(__float_as_int(ra.x)), a_r1 = wf_uni(__float_as_int(ra.y));
+        const int b_r0 = wf_uni(__float_as_int(rb.x)), b_r1 = wf_uni(__float_as_int(rb.y));
+        const float o_w0 = wf_unif(ro.z), o_w1 = wf_unif(ro.w), a_w0 = wf_unif(ra.z), a_w1 = wf_unif(ra.w);
+        const float b_w0 = wf_unif(rb.z), b_w1 = wf_unif(rb.w);
+        // The tile is [er][ec][3] floats, so the channel and the next column are IMMEDIATE offsets (+4c, +12 bytes) of one address
+        // per (row tap, column tap): 18 address adds per row.  The loads are volatile ds_read_b32 on purpose: the optimiser would
+        // otherwise merge column i / i+1 into ds_read2 pairs, and re-pairing those into (left eye, right eye) operands costs more
+        // v_mov than the merge saves (measured: 80 of 386 VALU instructions per row).
+        typedef const __attribute__((address_space(3))) char* wf_lds_cp;              // explicit LDS pointers: ds_read_b32 with an
+        typedef const volatile __attribute__((address_space(3))) float* wf_lds_vfp;   // immediate offset, never flat_load
+        const wf_lds_cp tb = (wf_lds_cp)tile;
+        auto ld = [&](int byte_off) { return *(wf_lds_vfp)(tb + byte_off); };
+        const int ao0 = o_r0 + io, ao1 = o_r1 + io;
+        const int aa0L = a_r0 + iaL, aa0R = a_r0 + iaR, ab0L = a_r0 + ibL, ab0R = a_r0 + ibR;
+        const int aa1L = a_r1 + iaL, aa1R = a_r1 + iaR, ab1L = a_r1 + ibL, ab1R = a_r1 + ibR;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float* tc = tile + c * er * ec;
-          // nested bilinear sample of BOTH eyes: tile rows r0o / r1o (wave-uniform), tile columns i (and i+1) per eye
-          auto smp2 = [&](const vd_f4& rw, int iL, int iR, const vd_f2& w0, const vd_f2& w1) {
-            const float* q0 = tc + __float_as_int(rw.x);
-            const float* q1 = tc + __float_as_int(rw.y);
-            const vd_f2 p00 = {q0[iL], q0[iR]}, p01 = {q0[iL + 1], q0[iR + 1]};
-            const vd_f2 p10 = {q1[iL], q1[iR]}, p11 = {q1[iL + 1], q1[iR + 1]};
+          // nested bilinear sample of BOTH eyes: tile rows r0 / r1 (wave-uniform), tile columns i (and i+1) per eye
+          auto smp2 = [&](int q0L, int q0R, int q1L, int q1R, float wy0, float wy1, const vd_f2& w0, const vd_f2& w1) {
+            const vd_f2 p00 = {ld(q0L + 4 * c), ld(q0R + 4 * c)}, p01 = {ld(q0L + 12 + 4 * c), ld(q0R + 12 + 4 * c)};
+            const vd_f2 p10 = {ld(q1L + 4 * c), ld(q1R + 4 * c)}, p11 = {ld(q1L + 12 + 4 * c), ld(q1R + 12 + 4 * c)};
             const vd_f2 ua = vd_vfma(p00, w0, w1 * p01);
             const vd_f2 ub = vd_vfma(p10, w0, w1 * p11);
-            return vd_vfma(ua, (vd_f2)(rw.z), rw.w * ub);
+            return vd_vfma(ua, (vd_f2)(wy0), wy1 * ub);
           };
-          float orig;
-          {
-            const float* q0 = tc + __float_as_int(ro.x);
-            const float* q1 = tc + __float_as_int(ro.y);
-            orig = vd_bilerp(q0[io], q0[io + 1], q1[io], q1[io + 1], wo0, wo1, ro.z, ro.w);
-          }
-          const vd_f2 vnw = smp2(ra, iaL, iaR, wa0, wa1);
-          vd_f2 vne = smp2(ra, ibL, ibR, wb0, wb1);
+          const float orig = vd_bilerp(ld(ao0 + 4 * c), ld(ao0 + 12 + 4 * c), ld(ao1 + 4 * c), ld(ao1 + 12 + 4 * c), wo0, wo1, o_w0, o_w1);
+          const vd_f2 vnw = smp2(aa0L, aa0R, aa1L, aa1R, a_w0, a_w1, wa0, wa1);
+          vd_f2 vne = smp2(ab0L, ab0R, ab1L, ab1R, a_w0, a_w1, wb0, wb1);
           vne.x = g.e_ok[0] ? vne.x : 0.f; vne.y = g.e_ok[1] ? vne.y : 0.f;
           vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
           if (south) {
-            const vd_f2 vsw = smp2(rb, iaL, iaR, wa0, wa1);
-            vd_f2 vse = smp2(rb, ibL, ibR, wb0, wb1);
+            const int d0 = b_r0 - a_r0, d1 = b_r1 - a_r1;   // wave-uniform row deltas
+            const vd_f2 vsw = smp2(aa0L + d0, aa0R + d0, aa1L + d1, aa1R + d1, b_w0, b_w1, wa0, wa1);
+            vd_f2 vse = smp2(ab0L + d0, ab0R + d0, ab1L + d1, ab1R + d1, b_w0, b_w1, wb0, wb1);
             vse.x = g.e_ok[0] ? vse.x : 0.f; vse.y = g.e_ok[1] ? vse.y : 0.f;
             v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
@@ -350,7 +456,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
         for (int c = 0; c < 3; ++c) {
           const float* pl = rgb + (unsigned)c * ni;
           const float orig = pl[o];
-          const float* r0 = pl + __umul24((unsigned)yn, (unsigned)W);
+          const float* r0 = pl + (unsigned)yn * (unsigned)W;
           const vd_f2 vnw = {r0[g.xw[0]], r0[g.xw[1]]};
           const vd_f2 vne = {g.e_ok[0] ? r0[g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[g.xw[1] + 1] : 0.f};
           vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
@@ -370,7 +476,7 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
     const uint32_t nL = (uint32_t)__shfl_down((int)pL, 1, 64), nR = (uint32_t)__shfl_down((int)pR, 1, 64);
     const int q = lane & 3;
     const int xq = x0 + (lane & ~3);
-    const unsigned ob = (__umul24((unsigned)y, (unsigned)W) + (unsigned)xq) * 3u;
+    const unsigned ob = ((unsigned)y * (unsigned)W + (unsigned)xq) * 3u;
     const bool full = (xq + 3 < W) && (ob % 4u == 0);
     if (full) {
       if (q < 3) {
@@ -389,6 +495,14 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
       orr[0] = (uint8_t)pR; orr[1] = (uint8_t)(pR >> 8); orr[2] = (uint8_t)(pR >> 16);
     }
   }
+#undef WF_LOAD_TILE
+#undef WF_STORE_TILE
+}
+
+// blur_ksize values whose k*k passed tools/verify_fastdiv.c (all floats in [0, k*k], 3-operation division == IEEE division)
+static bool wf_fastdiv_ok(int k) {
+  static const char ok[34] = {0, /*1..*/ 1, 1, 1, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, 0, /*15..*/ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  return k >= 1 && k <= 33 && ok[k];
 }
 
 // returns false when the fused kernel cannot be used (tiles would not fit the 160 KB LDS): caller falls back to v0
@@ -405,6 +519,7 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   const bool resize = !(ih == H && iw == W);
   a.er_max = a.ec_max = 0;
   const int k = a.k;
+  a.kk = (float)(k * k); a.rc_kk = 1.0f / a.kk; a.fastdiv = wf_fastdiv_ok(k) ? 1 : 0;
   size_t sz_tile = 0;
   if (resize) {
     a.er_max = (int)ceil((WF_TH + 2) * (double)a.scale_h) + 3;
@@ -414,6 +529,8 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
     if (a.ec_max > iw + 1) a.ec_max = iw + 1;
     sz_tile = (size_t)3 * a.er_max * a.ec_max;
   }
+  a.nc = a.ec_max > 0 ? (a.ec_max + 63) / 64 : 1;
+  if (a.nc > WF_NW) return false;        // the (row, chunk) walk advances 8 row-chunks at a time
   // aliased layout (see the kernel): max(wd2 + e2_2, hs2 + tile) when feathering, else the tile alone
   size_t fl = sz_tile;
   if (a.feather) {
@@ -428,9 +545,9 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   if (fl & 3) fl += 4 - (fl & 3);
   a.step_x = (1.f - (-1.f)) / (float)(W - 1); a.step_y = (1.f - (-1.f)) / (float)(H - 1);
   auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
-  a.m_ww = magic(WF_TW + k); a.m_ew = magic(WF_TW + k - 1); a.m_ec = magic(a.ec_max > 0 ? a.ec_max : 1); a.m_erec = 0;
+  a.m_ew = magic(WF_TW + k - 1);
   if ((WF_TH + k) * (WF_TW + k) >= 65536 || 3 * a.er_max * a.ec_max >= 65536) return false;
-  if (H >= (1 << 24) || W >= (1 << 24) || (unsigned long long)H * W * 3ull >= (1ull << 32) || (unsigned long long)ih * iw * 3ull >= (1ull << 32)) return false;  // 24-bit multiplies, 32-bit offsets
+  if (H >= (1 << 24) || W >= (1 << 24) || (unsigned long long)H * W * 3ull >= (1ull << 32) || (unsigned long long)ih * iw * 3ull >= (1ull << 32)) return false;  // 32-bit offsets
   const size_t bytes = fl * sizeof(float);
   if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 53.1 KB)
   dim3 g((W + WF_TW - 1) / WF_TW, (H + WF_TH - 1) / WF_TH);
