@@ -188,10 +188,11 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     pix_ov = (not args.host_io) if args.pixel_overlap is None else bool(args.pixel_overlap)
     shr2 = None
     if world > 1 or args.sharded or pix_ov:
-        from visiondepth3d_amd.sharded import MeasureReplaySharder
-        shr2 = [MeasureReplaySharder(r, p, rank, world, B)]
+        from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
+        be = HipChunkBackend(r, p)
+        shr2 = [ChunkSharder(be, rank, world, B)]
         if pix_ov:
-            shr2.append(MeasureReplaySharder(r, p, rank, world, B, slot_base=B))
+            shr2.append(ChunkSharder(be, rank, world, B, slot_base=B, twin_of=shr2[0]))
             r.set_pixel_overlap(True)
 
     pipe = None
@@ -201,11 +202,10 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
         pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh)   # fused front end + fused backbone glue
 
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
-    gathered = [torch.empty((world * B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)] if world > 1 else None
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
     done = [torch.cuda.Event() for _ in range(NBUF)]
-    depths_u8 = (depths * 255).to(torch.uint8) if pipe is None and (world > 1 or args.sharded) else None
     net_ev = []   # (start, end) torch events around the depth net + hand-off of the timed steps
+    step_no = [0]
 
     def step(i, timed=False):
         shr = shr2[i % len(shr2)] if shr2 else None    # pixel overlap: alternate slot sets so the next chain never waits for these pixels
@@ -231,15 +231,11 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
                 e1.record()
                 net_ev.append((e0, e1))
         if shr is not None and dloc is None:
-            dsrc = depths if depths_u8 is None else depths_u8   # 1 GPU: the precomputed f32 planes
-            dloc = dsrc[idx[0]:idx[0] + B] if contiguous else dsrc[idx]
+            dloc = depths[idx[0]:idx[0] + B] if contiguous else depths[idx]   # the precomputed f32 planes
         if overlap:  # hand the batch to the DIBR stream; this (torch) stream goes on to the next batch's depth inference
             ev = torch.cuda.Event()
             ev.record()
             dibr_stream.wait_event(ev)
-        if world > 1:   # data-path collective: ordered on the DIBR stream so that it overlaps the next batch's depth inference
-            with (torch.cuda.stream(dibr_stream) if overlap else contextlib.nullcontext()):
-                dist.all_gather_into_tensor(gathered[k], dloc.contiguous())
         if ring is not None:
             if overlap:
                 dibr_stream.wait_event(ring.ev_in[kr])
@@ -247,15 +243,19 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
         if shr is None:
             for j in range(B):
                 r.render_frame(fb[j], dloc[j] if dloc is not None else depths[idx[j]], p, out=outs_k[j])
-        else:
-            shr.p1(fb, gathered[k] if world > 1 else dloc)
+        else:   # chunked sharding (visiondepth3d_amd/sharded.py): the point-to-point plane hand-off and the two record all-gathers
+                # are enqueued on the DIBR stream, where the planes / records are produced and consumed
             on_dibr = (lambda: torch.cuda.stream(dibr_stream)) if overlap else contextlib.nullcontext
-            with on_dibr():   # the small collectives (and the torch ops that reorder their results) run on the DIBR stream
-                shr.r.shard2_r1(shr._frame_order(shr.gather(shr.q_local)))
+            with on_dibr():
+                shr.p1(fb, dloc, first_step=(step_no[0] == 0), more_steps=True)
+                q_all = shr.gather(shr.q_local)
+            shr.r1(q_all)
             shr.p3()
             with on_dibr():
-                m_ord = shr._frame_order(shr.gather(shr.m_local))
-            shr.finish(m_ord, outs_k, ordered=True)
+                m_all = shr.gather(shr.m_local)
+            shr.r2(m_all)
+            shr.pixels(outs_k)
+        step_no[0] += 1
         if overlap:
             done[k].record(dibr_stream)
         if ring is not None:   # D2H behind the stream that produced the muxed frames
@@ -428,7 +428,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="headline only")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
-    ap.add_argument("--sharded", action="store_true", help="use the measure / replay step protocol even at N=1 without pixel overlap")
+    ap.add_argument("--sharded", action="store_true", help="use the chunk-sharding step protocol even at N=1 without pixel overlap")
     ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
                     "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
     ap.add_argument("--pixel-overlap", dest="pixel_overlap", action="store_true", default=None,

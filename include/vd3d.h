@@ -107,6 +107,14 @@ typedef struct vd3d_render_params {
   double sharpness_factor;       /* apply_sharpening factor (:1406) */
   double color_saturation, color_contrast, color_brightness; /* apply_color_grade (:1362-1365) */
   double target_ratio;           /* aspect_ratios[selected_aspect_ratio] (:1072); used when auto_crop_black_bars */
+  /* Association of the DOF Gaussian levels (apply_dof_cuda -> torchvision gaussian_blur, core/render_3d.py:806).  The reference
+   * blurs with a dense k x k depthwise convolution whose summation order belongs to the convolution library of the machine it
+   * runs on.  0 (default): separable columns-then-rows sums -- 4x less arithmetic, identical to <= 6e-7 in float, which the
+   * reference's own uint8 truncation turns into +-1 LSB on ~0.5 % of samples before the sharpen stage (gain ~4.5).
+   * 1: the dense convolution in the order PyTorch's CPU build (oneDNN) uses -- row-major taps, one fused multiply-add per tap --
+   * which reproduces the CPU reference's blur BIT FOR BIT (tests/test_oracle_vs_golden.py::test_b2_attribution*). */
+  int32_t dof_dense_conv;
+  int32_t reserved0;
 } vd3d_render_params;
 
 /*
@@ -204,23 +212,23 @@ int vd3d_render_frame(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth
 int vd3d_render_frame_blank(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
                             const vd3d_render_params* p, uint8_t* out_bgr);
 
-/* Advance all temporal state (TemporalDepthFilter / percentile EMA / trackers) over one frame exactly as
- * vd3d_render_frame does, without rendering pixels; needs only the depth.  Frame sharding across GPUs:
- * every rank advances over all frames, and renders only its own. */
-int vd3d_advance_state(vd3d_ctx* ctx, const void* depth, int depth_fmt, const vd3d_render_params* p);
-
-/* ---- frame sharding, three-phase protocol (one clip over G GPUs, bit-identical to 1 GPU) -------------
- * A "step" is a window of n <= 512 consecutive frames dealt round-robin to the ranks.  Every rank calls
- *   vd3d_shard_pass1 for EVERY frame of the step in order (slot >= 0 for its own frames, -1 for foreign ones: only the
- *     depth plane is needed there and only the cheap eye-res chain runs, so all eye-res trackers advance identically),
- *   exchanges the measured s1 of its frames (one float per frame; all-gather over RCCL),
- *   vd3d_shard_pass2 to replay the FloatingWindowTracker over the whole step from the gathered s1 values,
- *   vd3d_shard_pixels for each of its own frames (shift plane, warp, DOF, grade, sharpen, mux). */
+/* ---- frame sharding: ONE clip over G GPUs, bit-identical to 1 GPU --------------------------------------------
+ * The reference renders strictly frame by frame (core/render_3d.py:1194-1463); its temporal state is a plane EMA
+ * (TemporalDepthFilter :220-229), a percentile EMA (:233-262) and non-linear scalar trackers (:463-511,895-922).  Here a "step" is
+ * a window of n <= 512 consecutive frames cut into G contiguous chunks, one per rank.  Per step every rank runs
+ *   [vd3d_tdf_plane_import]   the filtered plane of the frame before its chunk, received from the previous chunk's owner
+ *                             (one eye-size float32 plane per chunk boundary, point to point);
+ *   vd3d_shard2_p1            per own frame, in order: ingest + plane EMA + exact q.02 / q.98 of the filtered plane;
+ *   [vd3d_tdf_plane_export]   the plane after its last frame, sent on to the next chunk's owner;
+ *   all-gather of 2 floats per frame, vd3d_shard2_r1: DepthPercentileEMA replayed on every rank;
+ *   vd3d_shard2_p3            per own frame: every other measurement (4 x int64 per frame), planes kept in the frame's slot;
+ *   all-gather of 4 x int64 per frame, vd3d_shard2_r2: the remaining trackers replayed in frame order, own slots patched;
+ *   vd3d_shard_pixels[_blank] per own frame: shift plane, warp, DOF, grade, sharpen, mux.
+ * Data-path traffic per step and rank: <= 40 B per frame of records + one plane per chunk boundary. */
 int vd3d_shard_begin(vd3d_ctx* ctx, const vd3d_render_params* p, int n_slots);
-int vd3d_shard_pass1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void* depth, int depth_fmt,
-                     const vd3d_render_params* p, int step_idx, int slot, float* s1_out_dev);
-int vd3d_shard_pass2(vd3d_ctx* ctx, const float* s1_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);
 int vd3d_shard_pixels(vd3d_ctx* ctx, int slot, const vd3d_render_params* p, uint8_t* out_bgr);
+/* the pixel pass of an own frame listed by skip_blank_frames (core/render_3d.py:1278-1281): both eyes are the source frame */
+int vd3d_shard_pixels_blank(vd3d_ctx* ctx, int slot, const uint8_t* frame_bgr, const vd3d_render_params* p, uint8_t* out_bgr);
 /* Overlapped pixel passes (no reference counterpart: the reference renders strictly frame by frame, core/render_3d.py:1194-1463).
  * enable != 0: vd3d_shard_pixels is enqueued on a second stream of the context, ordered after all work enqueued so far; the
  * measurement chain of the next step (vd3d_shard2_p1 .. r2; latency-bound scans) then overlaps the pixel kernels of this one.  A call
@@ -230,23 +238,22 @@ int vd3d_set_pixel_overlap(vd3d_ctx* ctx, int enable);
 int vd3d_join_pixels(vd3d_ctx* ctx);
 int vd3d_wait_pixels(vd3d_ctx* ctx, int slot);   /* host waits for the outstanding overlapped pixel pass of `slot` (no-op if none) */
 
-/* Measure / replay variant (the one bench.py uses for N > 1): the only replicated work per foreign frame is the
- * TemporalDepthFilter plane EMA.  Per step: vd3d_shard2_p1 for every frame in order (own frames also measure q.02/q.98);
- * all-gather of 2 floats per frame; vd3d_shard2_r1 (DepthPercentileEMA replay); vd3d_shard2_p3 per own frame (all other
- * measurements, 4 x int64 per frame); all-gather; vd3d_shard2_r2 (remaining trackers replayed in frame order, own slots
- * patched); vd3d_shard_pixels per own frame.  Bit-identical to the sequential render. */
 /* with auto_crop_black_bars: vd3d_shard2_p0 per own frame (crop rectangle {x,y,w,h} -> device int[4]), all-gather of the
  * rectangles, vd3d_shard2_set_crops(frame order) -- before vd3d_shard2_p1 of the step */
 int vd3d_shard2_p0(vd3d_ctx* ctx, const uint8_t* frame_bgr, const vd3d_render_params* p, int* crop_out_dev);
 int vd3d_shard2_set_crops(vd3d_ctx* ctx, const int* crops_all_dev, int n);
-int vd3d_shard2_p1(vd3d_ctx* ctx, const uint8_t* frame_bgr_or_null, const void* depth, int depth_fmt,
+int vd3d_shard2_p1(vd3d_ctx* ctx, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
                    const vd3d_render_params* p, int step_idx, int slot, float* q_out_dev);
-/* a run of `count` consecutive FOREIGN frames in one launch (== count calls of vd3d_shard2_p1 with slot = -1) */
-int vd3d_shard2_p1_foreign(vd3d_ctx* ctx, const void* const* depth_ptrs_host, int count, int depth_fmt,
-                           const vd3d_render_params* p, int step_idx_first);
+/* TemporalDepthFilter.prev_depth (float32 [eye_h][eye_w]) out of / into the context: the chunk-boundary hand-off.  import with
+ * valid = 0 installs "no previous frame" (what a fresh clip starts from). */
+int vd3d_tdf_plane_export(vd3d_ctx* ctx, float* dst_dev, int eye_h, int eye_w);
+int vd3d_tdf_plane_import(vd3d_ctx* ctx, const float* src_dev, int eye_h, int eye_w, int valid);
 int vd3d_shard2_r1(vd3d_ctx* ctx, const float* q_all_dev, int n);
 int vd3d_shard2_p3(vd3d_ctx* ctx, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev);
-int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p);
+/* blank_host_or_null[t] != 0: frame t of the step is in the skip_blank_frames set (no ipd scaling, no focal / FloatingWindowTracker
+ * update for it, core/render_3d.py:1278-1281,1334-1337) */
+int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slot_host, const uint8_t* blank_host_or_null, int n,
+                   const vd3d_render_params* p);
 
 /* ---- heal_missing_pixels(warped_frame, warped_depth, original_frame, edge_mask, heal_strength=0.5), core/render_3d.py:431-459 (a23):
  * the gradient-based hole fill.  warped_chw / original_chw / out_chw: float32 [3][H][W] (rgb_chw), edge_mask_or_null: float32 [H][W]

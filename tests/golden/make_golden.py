@@ -440,6 +440,109 @@ def gen_blank():
     save("blank.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 9. B2 attribution: the reference's OWN stage outputs inside the loop (eyes out of pixel_shift_cuda, the normalised depth,
+#    the focal depth, the side-mask decision) next to its final muxed frame, so that the finishing stage (DOF + grade + bars +
+#    sharpen + fit + mux) can be checked in isolation: feed the reference's eyes, compare with the reference's frame.
+# ------------------------------------------------------------------------------------------
+ATTRIB_CASES = {
+    "half_sbs_cli": LOOP_CASES["half_sbs_cli"],
+    "half_sbs_graded": (108, 192, 4, dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0,
+                                         sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0, blur_ksize=9,
+                                         use_subject_tracking=True, use_floating_window=True, color_saturation=1.2,
+                                         color_contrast=1.05, color_brightness=0.02)),
+    "full_sbs_preserve": LOOP_CASES["full_sbs_preserve"],
+}
+
+
+def run_loop_capturing(sh, sw, n, kw, depth_as_u8=True):
+    """render_sbs_3d through the fake cv2 with taps on pixel_shift_cuda / FocalDepthTracker.update / compute_motion_metric /
+    apply_side_mask.  Returns (written frames, per-frame captures)."""
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ref_stubs._Clip.clips["in.mp4"] = frames
+    ref_stubs._Clip.clips["depth.mp4"] = [synth.depth_to_u8_bgr(d) for d in depths]
+    rl.reset_state()
+    caps = []
+    cur = {}
+    orig_ps, orig_mm, orig_fu, orig_sm = r.pixel_shift_cuda, r.compute_motion_metric, r.FocalDepthTracker.update, r.apply_side_mask
+
+    def ps(*a, **k):
+        out = orig_ps(*a, **k)
+        cur.clear()
+        cur["L"], cur["R"] = np.array(out[0], copy=True), np.array(out[1], copy=True)
+        cur["side"], cur["bar"] = 0, 0
+        caps.append(cur.copy())
+        return out
+
+    def mm(prev, d):
+        caps[-1]["dn"] = d.detach().cpu().numpy().copy()
+        return orig_mm(prev, d)
+
+    def fu(self_, cand):
+        v = orig_fu(self_, cand)
+        caps[-1]["focal"] = float(v)
+        return v
+
+    def sm(img, side="right", width=40):
+        caps[-1]["side"], caps[-1]["bar"] = (1 if side == "right" else 2), int(width)
+        return orig_sm(img, side=side, width=width)
+
+    r.pixel_shift_cuda, r.compute_motion_metric, r.FocalDepthTracker.update, r.apply_side_mask = ps, mm, fu, sm
+    try:
+        args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0,
+                    output_width=sw, selected_aspect_ratio=_Aspect("Default (16:9)"), aspect_ratios=r.aspect_ratios,
+                    suspend_flag=threading.Event(), cancel_flag=threading.Event())
+        args.update(kw)
+        with contextlib.redirect_stdout(io.StringIO()) as so:
+            r.render_sbs_3d(**args)
+        if "crashed" in so.getvalue():
+            raise RuntimeError(so.getvalue())
+    finally:
+        r.pixel_shift_cuda, r.compute_motion_metric, r.FocalDepthTracker.update, r.apply_side_mask = orig_ps, orig_mm, orig_fu, orig_sm
+    return ref_stubs._Clip.written["out.avi"], caps
+
+
+def gen_attrib():
+    out = {"cases_json": np.frombuffer(json.dumps(ATTRIB_CASES).encode(), dtype=np.uint8)}
+    for name, (sh, sw, n, kw) in ATTRIB_CASES.items():
+        written, caps = run_loop_capturing(sh, sw, n, kw)
+        assert len(written) == len(caps)
+        out[f"{name}__final"] = np.stack(written)
+        out[f"{name}__L"] = np.stack([c["L"] for c in caps])
+        out[f"{name}__R"] = np.stack([c["R"] for c in caps])
+        out[f"{name}__dn"] = np.stack([c["dn"] for c in caps])
+        out[f"{name}__focal"] = np.array([c["focal"] for c in caps], np.float64)
+        out[f"{name}__bar"] = np.array([[c["side"], c["bar"]] for c in caps], np.int32)
+        print(f"  attrib {name}: {len(written)} frames, eyes {caps[0]['L'].shape}, dn {caps[0]['dn'].shape}")
+    save("attrib.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# 10. BASELINE configs[0] at REAL size: one 1920x1080 clip (3 decoded frames -> 2 rendered), CLI defaults + DOF 2.0, Half-SBS.
+#     The muxed frames are 6.2 MB each, so the fixture keeps row bands + per-row / per-column channel sums (like widen.npz).
+# ------------------------------------------------------------------------------------------
+REAL_KW = dict(output_format="Half-SBS", output_height=1080, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+               dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+REAL_BANDS = [(0, 8), (268, 276), (536, 544), (804, 812), (1072, 1080)]
+
+
+def gen_real1080():
+    sh, sw, n = 1080, 1920, 3
+    written, _ = run_loop_capturing(sh, sw, n, REAL_KW)
+    out = {"kw_json": np.frombuffer(json.dumps(REAL_KW).encode(), dtype=np.uint8),
+           "bands_json": np.frombuffer(json.dumps(REAL_BANDS).encode(), dtype=np.uint8)}
+    for i, fr in enumerate(written):
+        assert fr.shape == (1080, 1920, 3)
+        out[f"bands_{i}"] = np.concatenate([fr[a:b] for a, b in REAL_BANDS])
+        out[f"rowsum_{i}"] = fr.astype(np.int64).sum(axis=1)      # [1080, 3]
+        out[f"colsum_{i}"] = fr.astype(np.int64).sum(axis=0)      # [1920, 3]
+        out[f"sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+        # a 1-in-8 decimated copy: every 8th row and column, all channels (16 KB) -- localises a difference the sums only detect
+        out[f"dec8_{i}"] = fr[::8, ::8].copy()
+    print(f"  real1080: {len(written)} frames")
+    save("real1080.npz", **out)
+
+
 def gen_heal():
     """a23 heal_missing_pixels (core/render_3d.py:431-459), pure torch: pinned directly."""
     out = {"cases": np.frombuffer(json.dumps(HEAL_CASES).encode(), dtype=np.uint8)}
@@ -453,7 +556,11 @@ def gen_heal():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080"]
+    if "attrib" in which:
+        gen_attrib()
+    if "real1080" in which:
+        gen_real1080()
     if "heal" in which:
         gen_heal()
     if "blank" in which:

@@ -242,192 +242,96 @@ def test_render_frame_f32_depth_and_collapse(R, oracle):
         assert np.array_equal(got, exp), (i, u8_diff_stats(got, exp))
 
 
-def test_frame_sharding_two_contexts_equals_sequential(R, oracle):
-    """vd3d_advance_state: two contexts playing rank 0 / rank 1 of a frame-sharded clip reproduce the sequential
-    render bit for bit and end in the same tracker state; orchestration itself is covered on CPU/gloo."""
-    from visiondepth3d_amd.render_3d import Renderer
-    from visiondepth3d_amd.sharded import FrameShardedRenderer, HipBackend
-    g = load_golden("render_loop.npz")
-    sh, sw, n, kw = golden_json(g, "cases_json")["half_sbs_cli"]
-    frames, depths = synth.synth_clip(n, sh, sw)
-    gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
-    p = render_kwargs_to_params(sw, sh, **kw)
-    R.reset_state(); R.new_clip()
-    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
-    st_seq = R.export_state().as_dict()
-    ranks = [Renderer(0), Renderer(0)]
-    for rr in ranks:
-        rr.reset_state(); rr.new_clip()
-    for t, (f, d) in enumerate(zip(frames, gray)):
-        for g_, rr in enumerate(ranks):
-            if t % 2 == g_:
-                out = rr.render_frame(T(f), T(d), p).cpu().numpy()
-                assert np.array_equal(out, seq[t]), t
-            else:
-                rr.advance_state(T(d), p)
-    assert ranks[0].export_state().as_dict() == ranks[1].export_state().as_dict() == st_seq
-    sr = FrameShardedRenderer(HipBackend(ranks[0], p), 0, 1)
-    ranks[0].reset_state()
-    got = [o.cpu().numpy() for _, o in sr.render_clip(n, lambda t: T(frames[t]), lambda t: T(gray[t]))]
-    assert all(np.array_equal(a, b) for a, b in zip(got, seq))
-    for rr in ranks:
-        rr.close()
+KW_CLI = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
+              feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
 
 
-def test_three_phase_sharding_equals_sequential(R, oracle):
-    """StepShardedRenderer protocol (pass1 own/foreign, s1 exchange, tracker replay, pixel pass): two contexts play
-    rank 0 / rank 1 with the exchanges done by hand; output and final state must equal the sequential render bit for bit.
-    Two steps so state carried across steps is covered; world = 1 degenerate case as well."""
-    from visiondepth3d_amd.render_3d import Renderer
-    from visiondepth3d_amd.sharded import StepShardedRenderer
-    sh, sw, B, G = 108, 192, 3, 2
-    kw = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
-              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
-    p = render_kwargs_to_params(sw, sh, **kw)
-    n = 2 * B * G
-    frames, depths = synth.synth_clip(n, sh, sw)
-    gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
+def _seq_render(R, p, frames, depths, blank=()):
     R.reset_state(); R.new_clip()
-    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
-    st_seq = R.export_state().as_dict()
-    ranks = [Renderer(0), Renderer(0)]
-    sh_r = []
+    out, sc = [], []
+    for t, (f, d) in enumerate(zip(frames, depths)):
+        out.append(R.render_frame(f, d, p, blank=t in blank).cpu().numpy())
+        sc.append(R.last_scalars().as_dict())
+    return out, sc, R.export_state().as_dict(), R.tdf_plane_export(p).cpu().numpy()
+
+
+def _emulated_ranks(p, G, B):
+    from shard_emul import Emu
+    from visiondepth3d_amd.render_3d import Renderer
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
+    ranks = [Renderer(0) for _ in range(G)]
+    shd = []
     for g_, rr in enumerate(ranks):
         rr.reset_state(); rr.new_clip()
-        sh_r.append(StepShardedRenderer(rr, p, g_, G, B))
-    for step in range(2):
-        base = step * B * G
-        loc_f = [[T(frames[base + j * G + g_]) for j in range(B)] for g_ in range(G)]
-        loc_d = [torch.stack([T(gray[base + j * G + g_]) for j in range(B)]) for g_ in range(G)]
-        depth_all = torch.cat(loc_d)                      # what the all-gather would return (rank-major)
-        for g_ in range(G):
-            sh_r[g_].pass1(loc_f[g_], depth_all)
-        s1_all = torch.cat([sh_r[g_].s1_local for g_ in range(G)])
-        for g_ in range(G):
-            outs = sh_r[g_].finish(s1_all.clone())
-            for j in range(B):
-                t = base + j * G + g_
-                assert np.array_equal(outs[j].cpu().numpy(), seq[t]), (step, g_, j)
-    assert ranks[0].export_state().as_dict() == ranks[1].export_state().as_dict() == st_seq
-    # world == 1: the protocol degenerates to the sequential render
-    R.reset_state(); R.new_clip()
-    one = StepShardedRenderer(R, p, 0, 1, 4)
-    outs = one.render_step([T(f) for f in frames[:4]], torch.stack([T(d) for d in gray[:4]]))
-    assert all(np.array_equal(o.cpu().numpy(), s_) for o, s_ in zip(outs, seq[:4]))
-    for rr in ranks:
-        rr.close()
+        shd.append(ChunkSharder(HipChunkBackend(rr, p), g_, G, B))
+    return ranks, Emu(shd)
 
 
 @pytest.mark.parametrize("G,B", [(2, 3), (3, 2), (4, 1)])
-def test_measure_replay_sharding_equals_sequential(R, oracle, G, B):
-    """MeasureReplaySharder (vd3d_shard2_*): G contexts play the ranks, the three all-gathers are done by hand.  Muxed frames, the
-    per-frame scalars of every own frame and the final tracker state must equal the sequential render bit for bit.  Three steps
-    (state carried across steps, first step starts a clip), plus the world = 1 degenerate case."""
-    from visiondepth3d_amd.render_3d import Renderer
-    from visiondepth3d_amd.sharded import MeasureReplaySharder
+def test_chunk_sharding_equals_sequential(R, oracle, G, B):
+    """ChunkSharder (contiguous chunks, vd3d_shard2_* + vd3d_tdf_plane_export / import): G contexts play the ranks, the plane
+    hand-off and the two all-gathers are done by hand (tests/shard_emul.py).  Muxed frames, the final tracker state and the final
+    plane state of EVERY rank must equal the sequential render bit for bit.  Three steps (state carried across steps and chunk
+    boundaries, first step starts a clip), incl. a frame whose depth collapses (DepthPercentileEMA guard path)."""
     sh, sw = 108, 192
-    kw = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
-              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
-    p = render_kwargs_to_params(sw, sh, **kw)
-    steps = 3
-    n = steps * B * G
+    p = render_kwargs_to_params(sw, sh, output_height=108, **KW_CLI)
+    n = 3 * B * G
     frames, depths = synth.synth_clip(n, sh, sw)
     gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
-    gray[2 * B * G - 1][:] = 77          # a frame whose depth collapses (hi - lo < 1e-5): DepthPercentileEMA guard path
-    R.reset_state(); R.new_clip()
-    seq, seq_sc = [], []
-    for f, d in zip(frames, gray):
-        seq.append(R.render_frame(T(f), T(d), p).cpu().numpy())
-        seq_sc.append(R.last_scalars().as_dict())
-    st_seq = R.export_state().as_dict()
-    ranks = [Renderer(0) for _ in range(G)]
-    shd = []
-    for g_, rr in enumerate(ranks):
-        rr.reset_state(); rr.new_clip()
-        shd.append(MeasureReplaySharder(rr, p, g_, G, B))
-    for step in range(steps):
-        base = step * B * G
-        loc_f = [[T(frames[base + j * G + g_]) for j in range(B)] for g_ in range(G)]
-        depth_all = torch.cat([torch.stack([T(gray[base + j * G + g_]) for j in range(B)]) for g_ in range(G)])   # rank-major
-        for g_ in range(G):
-            shd[g_].p1(loc_f[g_], depth_all)
-        q_all = torch.cat([shd[g_].q_local for g_ in range(G)])
-        for g_ in range(G):
-            shd[g_].world = G   # _frame_order uses world/B
-            shd[g_].r.shard2_r1(shd[g_]._frame_order(q_all.clone()))
-            shd[g_].p3()
-        m_all = torch.cat([shd[g_].m_local for g_ in range(G)])
-        for g_ in range(G):
-            outs = shd[g_].finish(m_all.clone())
-            for j in range(B):
-                t = base + j * G + g_
-                assert np.array_equal(outs[j].cpu().numpy(), seq[t]), (step, g_, j, u8_diff_stats(outs[j].cpu().numpy(), seq[t]))
-    states = [rr.export_state().as_dict() for rr in ranks]
-    assert all(st == st_seq for st in states), [{k: (st[k], st_seq[k]) for k in st if st[k] != st_seq[k]} for st in states]
+    gray[2 * B * G - 1][:] = 77
+    ft, dt = [T(f) for f in frames], [T(d) for d in gray]
+    seq, _, st_seq, plane_seq = _seq_render(R, p, ft, dt)
+    ranks, emu = _emulated_ranks(p, G, B)
+    got = emu.run_clip(ft, dt, B)
+    assert sorted(got) == list(range(n))
+    for t in range(n):
+        assert np.array_equal(got[t].cpu().numpy(), seq[t]), (t, u8_diff_stats(got[t].cpu().numpy(), seq[t]))
     for rr in ranks:
+        st = rr.export_state().as_dict()
+        assert st == st_seq, {k: (st[k], st_seq[k]) for k in st if st[k] != st_seq[k]}
+        assert np.array_equal(rr.tdf_plane_export(p).cpu().numpy(), plane_seq)
         rr.close()
 
 
-def test_measure_replay_partial_last_step(R, oracle):
-    """A clip whose length is not a multiple of world * B: the last step is partial (n_valid), frames past the end are skipped."""
-    from visiondepth3d_amd.render_3d import Renderer
-    from visiondepth3d_amd.sharded import MeasureReplaySharder
+def test_chunk_sharding_partial_last_step_and_blank_frames(R, oracle):
+    """A clip whose length is not a multiple of world * B (the last step is partial: one rank has a short chunk, one has none and
+    only forwards the plane) with skip_blank_frames hits in both steps: blank own frames take the blank pixel pass, the replay skips
+    the ipd scaling / focal tracker / FloatingWindowTracker for them on EVERY rank (core/render_3d.py:1278-1281,1334-1337)."""
     sh, sw, G, B = 108, 192, 3, 2
-    kw = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
-              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
-    p = render_kwargs_to_params(sw, sh, **kw)
-    n = G * B + 4                    # one full step + a partial one with 4 of 6 frames
+    p = render_kwargs_to_params(sw, sh, output_height=108, skip_blank_frames=True, ipd_factor=1.15, **KW_CLI)
+    n = G * B + 3                    # one full step + a partial one: rank 0 two frames, rank 1 one, rank 2 none
     frames, depths = synth.synth_clip(n, sh, sw)
     gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
-    R.reset_state(); R.new_clip()
-    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
-    st_seq = R.export_state().as_dict()
-    ranks = [Renderer(0) for _ in range(G)]
-    shd = []
-    for g_, rr in enumerate(ranks):
-        rr.reset_state(); rr.new_clip()
-        shd.append(MeasureReplaySharder(rr, p, g_, G, B))
-    zero_f, zero_d = T(np.zeros_like(frames[0])), T(np.zeros_like(gray[0]))
-    for base, nv in ((0, G * B), (G * B, 4)):
-        def fr(t):
-            return (T(frames[base + t]), T(gray[base + t])) if t < nv else (zero_f, zero_d)
-        loc_f = [[fr(j * G + g_)[0] for j in range(B)] for g_ in range(G)]
-        depth_all = torch.cat([torch.stack([fr(j * G + g_)[1] for j in range(B)]) for g_ in range(G)])
-        for g_ in range(G):
-            shd[g_].p1(loc_f[g_], depth_all, nv)
-        q_all = torch.cat([shd[g_].q_local for g_ in range(G)])
-        for g_ in range(G):
-            shd[g_].r.shard2_r1(shd[g_]._frame_order(q_all.clone())[:nv])
-            shd[g_].p3(nv)
-        m_all = torch.cat([shd[g_].m_local for g_ in range(G)])
-        for g_ in range(G):
-            outs = shd[g_].finish(m_all.clone(), n_valid=nv)
-            own = [j * G + g_ for j in range(B) if j * G + g_ < nv]
-            assert len(outs) == len(own)
-            for o, t in zip(outs, own):
-                assert np.array_equal(o.cpu().numpy(), seq[base + t]), (base, g_, t)
-    assert all(rr.export_state().as_dict() == st_seq for rr in ranks)
+    blank = {1, 4, 7}
+    for t in blank:
+        frames[t][:] = (frames[t] // 16)        # dark frames, like the ones ffmpeg's blackdetect reports
+    ft, dt = [T(f) for f in frames], [T(d) for d in gray]
+    seq, _, st_seq, plane_seq = _seq_render(R, p, ft, dt, blank)
+    ranks, emu = _emulated_ranks(p, G, B)
+    got = emu.run_clip(ft, dt, B, blank_frames=blank)
+    assert sorted(got) == list(range(n))
+    for t in range(n):
+        assert np.array_equal(got[t].cpu().numpy(), seq[t]), t
     for rr in ranks:
+        assert rr.export_state().as_dict() == st_seq
+        assert np.array_equal(rr.tdf_plane_export(p).cpu().numpy(), plane_seq)
         rr.close()
 
 
-def test_measure_replay_world1_and_continuation(R, oracle):
+def test_chunk_sharding_world1_and_continuation(R, oracle):
     """world = 1 degenerates to the sequential render; a sequential frame rendered AFTER sharded steps continues exactly."""
-    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
     sh, sw = 108, 192
-    kw = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
-              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
-    p = render_kwargs_to_params(sw, sh, **kw)
-    frames, depths = synth.synth_clip(8, sh, sw)
+    p = render_kwargs_to_params(sw, sh, output_height=108, **KW_CLI)
+    frames, depths = synth.synth_clip(9, sh, sw)
     gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]
+    ft, dt = [T(f) for f in frames], [T(d) for d in gray]
+    seq, _, st_seq, _ = _seq_render(R, p, ft, dt)
     R.reset_state(); R.new_clip()
-    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
-    st_seq = R.export_state().as_dict()
-    R.reset_state(); R.new_clip()
-    one = MeasureReplaySharder(R, p, 0, 1, 4)
-    outs = one.render_step([T(f) for f in frames[:4]], torch.stack([T(d) for d in gray[:4]]))
-    outs = [o.cpu().numpy() for o in outs]
-    outs += [o.cpu().numpy() for o in one.render_step([T(f) for f in frames[4:]], torch.stack([T(d) for d in gray[4:]]))]
+    one = ChunkSharder(HipChunkBackend(R, p), 0, 1, 4)
+    outs = [o.cpu().numpy() for o in one.render_step(ft[:4], dt[:4], first_step=True)]
+    outs += [o.cpu().numpy() for o in one.render_step(ft[4:8], dt[4:8])]
+    outs.append(R.render_frame(ft[8], dt[8], p).cpu().numpy())
     assert all(np.array_equal(a, b) for a, b in zip(outs, seq))
     assert R.export_state().as_dict() == st_seq
 
@@ -437,24 +341,22 @@ def test_overlapped_pixel_passes_equal_sequential(R, oracle, two_sets):
     """vd3d_set_pixel_overlap: pixel passes on the context's second stream while the next step's measurement chain runs on the
     first.  Two alternating slot sets (real overlap) and ONE reused slot set (every chain call first waits for the pixel pass that
     still reads its slot) both reproduce the sequential render bit for bit; an unsharded frame afterwards continues exactly."""
-    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
     sh, sw, B, steps = 270, 480, 3, 4
-    kw = dict(output_format="Half-SBS", output_height=sh, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
-              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
-    p = render_kwargs_to_params(sw, sh, **kw)
+    p = render_kwargs_to_params(sw, sh, output_height=sh, **KW_CLI)
     n = B * steps + 1
     frames, depths = synth.synth_clip(n, sh, sw)
     ft, dt = [T(f) for f in frames], [T(d) for d in depths]
+    seq, _, st_seq, _ = _seq_render(R, p, ft, dt)
     R.reset_state(); R.new_clip()
-    seq = [R.render_frame(f, d, p).cpu().numpy() for f, d in zip(ft, dt)]
-    st_seq = R.export_state().as_dict()
-    R.reset_state(); R.new_clip()
-    sets = [MeasureReplaySharder(R, p, 0, 1, B), MeasureReplaySharder(R, p, 0, 1, B, slot_base=B)] if two_sets else [MeasureReplaySharder(R, p, 0, 1, B)] * 2
+    be = HipChunkBackend(R, p)
+    first = ChunkSharder(be, 0, 1, B)
+    sets = [first, ChunkSharder(be, 0, 1, B, slot_base=B, twin_of=first)] if two_sets else [first] * 2
     R.set_pixel_overlap(True)
     try:
         outs = []
         for i in range(steps):
-            outs += sets[i % 2].render_step(ft[i * B:(i + 1) * B], torch.stack(dt[i * B:(i + 1) * B]))
+            outs += sets[i % 2].render_step(ft[i * B:(i + 1) * B], dt[i * B:(i + 1) * B], first_step=(i == 0))
         last = R.render_frame(ft[-1], dt[-1], p)     # joins the outstanding pixel passes before it touches L / R / S
         R.sync()
         got = [o.cpu().numpy() for o in outs] + [last.cpu().numpy()]
@@ -465,27 +367,28 @@ def test_overlapped_pixel_passes_equal_sequential(R, oracle, two_sets):
 
 
 def test_render_clip_overlapped_pixels(R, oracle):
-    """MeasureReplaySharder.render_clip(overlap_pixels=True): frames are yielded one step late, after a host wait on their
-    pixel pass; whole clip incl. a partial last step == the sequential render, and the context is left in sequential mode."""
-    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    """ChunkSharder.render_clip(overlap_pixels=True): frames are yielded one step late, after a host wait on their pixel pass; whole
+    clip incl. a partial last step and a blank frame == the sequential render, and the context is left in sequential mode.  A second
+    clip on the same sharder starts from fresh per-clip state (render_clip calls new_clip itself)."""
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
     sh, sw, B, n = 270, 480, 3, 11
-    kw = dict(output_format="Half-SBS", output_height=sh, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
-              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
-    p = render_kwargs_to_params(sw, sh, **kw)
+    p = render_kwargs_to_params(sw, sh, output_height=sh, skip_blank_frames=True, **KW_CLI)
     frames, depths = synth.synth_clip(n, sh, sw)
     ft, dt = [T(f) for f in frames], [T(d) for d in depths]
-    R.reset_state(); R.new_clip()
-    seq = [R.render_frame(f, d, p).cpu().numpy() for f, d in zip(ft, dt)]
-    st_seq = R.export_state().as_dict()
-    R.reset_state(); R.new_clip()
-    shr = MeasureReplaySharder(R, p, 0, 1, B)
-    got = [(t, o.cpu().numpy()) for t, o in shr.render_clip(n, lambda t: ft[t], lambda t: dt[t], overlap_pixels=True)]
+    seq, _, st_seq, _ = _seq_render(R, p, ft, dt, {5})
+    R.reset_state()
+    shr = ChunkSharder(HipChunkBackend(R, p), 0, 1, B)
+    got = [(t, o.cpu().numpy()) for t, o in shr.render_clip(n, lambda t: ft[t], lambda t: dt[t], blank_frames={5}, overlap_pixels=True)]
     assert [t for t, _ in got] == list(range(n))
     assert all(np.array_equal(o, seq[t]) for t, o in got)
     assert R.export_state().as_dict() == st_seq
-    R.reset_state(); R.new_clip()
-    again = [o.cpu().numpy() for _, o in shr.render_clip(n, lambda t: ft[t], lambda t: dt[t])]   # sequential mode still works after
-    assert all(np.array_equal(a, b) for a, b in zip(again, seq))
+    # a second clip on the same sharder (sequential mode): fresh per-clip state, the never-reset singletons carry over (:500)
+    again = [o.cpu().numpy() for _, o in shr.render_clip(n, lambda t: ft[t], lambda t: dt[t], blank_frames={5})]
+    R.reset_state()
+    for _rep in range(2):
+        R.new_clip()
+        seq2 = [R.render_frame(ft[t], dt[t], p, blank=(t == 5)).cpu().numpy() for t in range(n)]
+    assert all(np.array_equal(a, b) for a, b in zip(again, seq2))
 
 
 # ------------------------------------------------------------------------------------------ full-size
@@ -522,3 +425,41 @@ def test_full_size_properties(R, oracle, hw):
         ro = oracle.RenderOracle(p); ro.new_clip()
         exp = ro.render(f, d, 0)
         assert np.array_equal(a.cpu().numpy(), exp), u8_diff_stats(a.cpu().numpy(), exp)
+
+
+# ------------------------------------------------------------------------------------------ B2 attribution on the GPU
+def test_b2_attribution_hip_finish_stage_vs_reference_frames(R):
+    """vd3d_finish_frame fed with the REFERENCE's own eyes (tests/golden/attrib.npz) against the reference's own muxed frames: with
+    dof_dense_conv every sample of all 11 frames is EXACT; with the separable default the committed, measured deviation holds
+    (tests/test_oracle_vs_golden.py::test_b2_attribution_finish_stage_separable_is_measured)."""
+    from test_oracle_vs_golden import attrib_stats
+
+    def finish(L, R_, dn, p, focal, bar_w, bar_side):
+        return R.finish_frame(T(L), T(R_), T(dn), p, focal, bar_w, bar_side).cpu().numpy()
+    for name, (mx, ne, n1, tot) in attrib_stats(finish, True).items():
+        assert (mx, ne) == (0, 0), (name, mx, ne, tot)
+    st = attrib_stats(finish, False)
+    assert st["half_sbs_cli"][0] <= 4 and st["half_sbs_cli"][1] <= 2000 and st["half_sbs_cli"][2] <= 800, st
+    assert st["half_sbs_graded"][1] <= 20 and st["full_sbs_preserve"][1] <= 60, st
+
+
+def test_configs0_real_size_1080p_hip_vs_reference_fixture_and_oracle(R, oracle):
+    """BASELINE configs[0] at real size through the C ABI: vs the reference's frames (real1080.npz; same bars as the oracle test) in
+    both DOF modes, and bit-exact vs the oracle in the dense mode (the separable mode is covered at 1080p by test_full_size_properties)."""
+    from test_oracle_vs_golden import real1080_stats
+    kept = {}
+
+    def render(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        outs = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
+        kept[int(p.dof_dense_conv)] = (p, frames, dbgr, outs)
+        return outs
+    stats = real1080_stats(render)
+    for s in stats(True):
+        assert s["max"] <= 2 and s["ne"] <= 16 and s["n1"] <= 6 and s["rowsum"] <= 8, s
+    for s in stats(False):
+        assert s["max"] <= 4 and s["ne"] <= 3000 and s["n1"] <= 1300, s
+    p, frames, dbgr, outs = kept[1]
+    ro = oracle.RenderOracle(p)
+    ro.new_clip()
+    assert np.array_equal(outs[0], ro.render(frames[0], dbgr[0], 1))

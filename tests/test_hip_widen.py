@@ -88,14 +88,6 @@ def test_autocrop_other_formats_and_unfused(R, oracle, fmt, monkeypatch):
     assert np.array_equal(got, exp), u8_diff_stats(got, exp)
 
 
-def test_autocrop_needs_the_frame(R):
-    p = render_kwargs_to_params(192, 120, output_format="Half-SBS", output_height=108, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
-                                sharpness_factor=0.2, dof_strength=0.0, auto_crop_black_bars=True)
-    d = T(np.zeros((120, 192), np.float32))
-    with pytest.raises(Vd3dError):
-        R.advance_state(d, p)       # depth-only state advance cannot detect bars: loud, not silently uncropped
-
-
 def test_fractional_fit_finish_vs_oracle(R, oracle):
     """finish stage with fractional / mixed INTER_AREA ratios and pad offsets (small canvases, every format that pads)."""
     rng = np.random.default_rng(11)
@@ -161,10 +153,11 @@ def test_pinned_ring_clip_equals_sequential(R, oracle):
 
 
 def test_autocrop_in_sharded_steps_equals_sequential(R):
-    """auto_crop_black_bars inside measure/replay sharded steps: owners detect the bars (P0), the crop rectangles are exchanged,
-    every rank's plane EMA uses frame t's rectangle.  Two emulated ranks (one context each) vs the sequential render."""
+    """auto_crop_black_bars inside chunk-sharded steps: every owner detects the bars of its own frames (P0) and ingests them with
+    that rectangle -- no exchange is needed, only owners ingest.  Two emulated ranks (one context each) vs the sequential render."""
+    from shard_emul import Emu
     from visiondepth3d_amd.render_3d import Renderer
-    from visiondepth3d_amd.sharded import MeasureReplaySharder
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
     sh, sw, G, B, steps = 120, 192, 2, 2, 2
     n = steps * G * B
     frames, depth_bgr = synth.letterbox_clip(n, sh, sw, 10, 14)
@@ -172,38 +165,21 @@ def test_autocrop_in_sharded_steps_equals_sequential(R):
     p = render_kwargs_to_params(sw, sh, output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0,
                                 sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0, blur_ksize=9,
                                 use_subject_tracking=True, use_floating_window=True, auto_crop_black_bars=True)
+    ft, dt = [T(f) for f in frames], [T(d) for d in gray]
     R.reset_state(); R.new_clip()
-    seq = [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, gray)]
+    seq = [R.render_frame(f, d, p).cpu().numpy() for f, d in zip(ft, dt)]
     st_seq = R.export_state().as_dict()
     ranks = [Renderer(0) for _ in range(G)]
     shd = []
     for g_, rr in enumerate(ranks):
         rr.reset_state(); rr.new_clip()
-        shd.append(MeasureReplaySharder(rr, p, g_, G, B))
+        shd.append(ChunkSharder(HipChunkBackend(rr, p), g_, G, B))
     assert all(s_.auto_crop for s_ in shd)
-    for step in range(steps):
-        base = step * B * G
-        loc_f = [[T(frames[base + j * G + g_]) for j in range(B)] for g_ in range(G)]
-        depth_all = torch.cat([torch.stack([T(gray[base + j * G + g_]) for j in range(B)]) for g_ in range(G)])
-        for g_ in range(G):
-            for j in range(B):
-                shd[g_].r.shard2_p0(loc_f[g_][j], p, shd[g_].c_local[j])
-        c_all = torch.cat([shd[g_].c_local for g_ in range(G)])
-        for g_ in range(G):
-            shd[g_].r.shard2_set_crops(shd[g_]._frame_order(c_all.clone()))
-            shd[g_].p1(loc_f[g_], depth_all)
-        q_all = torch.cat([shd[g_].q_local for g_ in range(G)])
-        for g_ in range(G):
-            shd[g_].r.shard2_r1(shd[g_]._frame_order(q_all.clone()))
-            shd[g_].p3()
-        m_all = torch.cat([shd[g_].m_local for g_ in range(G)])
-        for g_ in range(G):
-            outs = shd[g_].finish(m_all.clone())
-            for j in range(B):
-                t = base + j * G + g_
-                assert np.array_equal(outs[j].cpu().numpy(), seq[t]), (step, g_, j)
+    got = Emu(shd).run_clip(ft, dt, B)
+    for t in range(n):
+        assert np.array_equal(got[t].cpu().numpy(), seq[t]), t
     assert all(rr.export_state().as_dict() == st_seq for rr in ranks)
-    crops = c_all.view(G, B, 4).transpose(0, 1).reshape(-1, 4).cpu().numpy()
+    crops = torch.cat([s_.crops[g_ * B:(g_ + 1) * B] for g_, s_ in enumerate(shd)]).cpu().numpy()   # the last step's rectangles
     assert (crops[:, 1] >= 10).all() and (crops[:, 3] <= 96).all()      # the letterbox rows are gone from every frame's rectangle
     for rr in ranks:
         rr.close()

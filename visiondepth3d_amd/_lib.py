@@ -16,9 +16,9 @@ EXPORTS = (
     "vd3d_abi_version", "vd3d_last_error", "vd3d_shift_params_default", "vd3d_render_params_default",
     "vd3d_ctx_create", "vd3d_ctx_destroy", "vd3d_sync", "vd3d_ctx_stream", "vd3d_ctx_set_stream", "vd3d_ctx_pixel_stream",
     "vd3d_state_reset", "vd3d_state_new_clip", "vd3d_state_export", "vd3d_state_import", "vd3d_state_planes",
-    "vd3d_last_scalars", "vd3d_pixel_shift", "vd3d_render_frame", "vd3d_render_frame_blank", "vd3d_advance_state", "vd3d_depth_handoff", "vd3d_heal_missing_pixels",
-    "vd3d_shard_begin", "vd3d_shard_pass1", "vd3d_shard_pass2", "vd3d_shard_pixels", "vd3d_set_pixel_overlap", "vd3d_join_pixels", "vd3d_wait_pixels", "vd3d_finish_frame", "vd3d_quantiles",
-    "vd3d_subject_depth", "vd3d_shard2_p0", "vd3d_shard2_set_crops", "vd3d_shard2_p1", "vd3d_shard2_p1_foreign", "vd3d_shard2_r1", "vd3d_shard2_p3", "vd3d_shard2_r2", "vd3d_depth_preprocess", "vd3d_add_layernorm", "vd3d_upsample_bilinear_nhwc", "vd3d_preview_image", "vd3d_detect_black_bars", "vd3d_stream_copy", "vd3d_set_profiling", "vd3d_last_stage_ms", "vd3d_stage_calls",
+    "vd3d_last_scalars", "vd3d_pixel_shift", "vd3d_render_frame", "vd3d_render_frame_blank", "vd3d_depth_handoff", "vd3d_heal_missing_pixels",
+    "vd3d_shard_begin", "vd3d_shard_pixels", "vd3d_shard_pixels_blank", "vd3d_tdf_plane_export", "vd3d_tdf_plane_import", "vd3d_set_pixel_overlap", "vd3d_join_pixels", "vd3d_wait_pixels", "vd3d_finish_frame", "vd3d_quantiles",
+    "vd3d_subject_depth", "vd3d_shard2_p0", "vd3d_shard2_set_crops", "vd3d_shard2_p1", "vd3d_shard2_r1", "vd3d_shard2_p3", "vd3d_shard2_r2", "vd3d_depth_preprocess", "vd3d_add_layernorm", "vd3d_upsample_bilinear_nhwc", "vd3d_preview_image", "vd3d_detect_black_bars", "vd3d_stream_copy", "vd3d_set_profiling", "vd3d_last_stage_ms", "vd3d_stage_calls",
     "vd3d_debug_planes",
 )
 
@@ -60,11 +60,11 @@ def lib():
     L.vd3d_pixel_shift.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, C.POINTER(ShiftParams), u8p, u8p, f32p]
     L.vd3d_render_frame.argtypes = [vp, u8p, vp, i32, C.POINTER(RenderParams), u8p]
     L.vd3d_render_frame_blank.argtypes = [vp, u8p, vp, i32, C.POINTER(RenderParams), u8p]
-    L.vd3d_advance_state.argtypes = [vp, vp, i32, C.POINTER(RenderParams)]
     L.vd3d_shard_begin.argtypes = [vp, C.POINTER(RenderParams), i32]
-    L.vd3d_shard_pass1.argtypes = [vp, u8p, vp, i32, C.POINTER(RenderParams), i32, i32, f32p]
-    L.vd3d_shard_pass2.argtypes = [vp, f32p, C.POINTER(C.c_int), i32, C.POINTER(RenderParams)]
     L.vd3d_shard_pixels.argtypes = [vp, i32, C.POINTER(RenderParams), u8p]
+    L.vd3d_shard_pixels_blank.argtypes = [vp, i32, u8p, C.POINTER(RenderParams), u8p]
+    L.vd3d_tdf_plane_export.argtypes = [vp, f32p, i32, i32]
+    L.vd3d_tdf_plane_import.argtypes = [vp, f32p, i32, i32, i32]
     L.vd3d_set_pixel_overlap.argtypes = [vp, i32]
     L.vd3d_join_pixels.argtypes = [vp]
     L.vd3d_wait_pixels.argtypes = [vp, i32]
@@ -76,10 +76,9 @@ def lib():
     L.vd3d_shard2_p0.argtypes = [vp, vp, vp, vp]
     L.vd3d_shard2_set_crops.argtypes = [vp, vp, i32]
     L.vd3d_shard2_p1.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
-    L.vd3d_shard2_p1_foreign.argtypes = [vp, C.POINTER(C.c_void_p), i32, i32, vp, i32]
     L.vd3d_shard2_r1.argtypes = [vp, vp, i32]
     L.vd3d_shard2_p3.argtypes = [vp, i32, i32, vp, vp]
-    L.vd3d_shard2_r2.argtypes = [vp, vp, C.POINTER(C.c_int), i32, vp]
+    L.vd3d_shard2_r2.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_uint8), i32, vp]
     L.vd3d_depth_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp]
     L.vd3d_add_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, C.c_float, C.c_int64, i32, vp, vp]
     L.vd3d_upsample_bilinear_nhwc.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32]

@@ -283,7 +283,7 @@ static int check_shift_params(const vd3d_shift_params* p, int H, int W) {
 }
 
 static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_plane, int ih, int iw, int W, int H,
-                              const vd3d_shift_params& sp, vd_stage_args a, bool state_only = false) {
+                              const vd3d_shift_params& sp, vd_stage_args a, bool skip_pixels = false) {
   hipStream_t s = c->stream;
   if (c->use_fused) {
     StageTimer t(c, "select_dc");   // fused chain: stage1 (A1), b1 (B1), shape (+A2), b2 (B2)
@@ -309,7 +309,7 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     a.stage = VD_ST_B2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
   }
   }
-  if (!state_only) { StageTimer t(c, "warp");
+  if (!skip_pixels) { StageTimer t(c, "warp");
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
     bool fused = false;
     if (c->use_fused) { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R); }
@@ -417,12 +417,13 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
                       uint8_t* out, const vd_dev_work* wk = nullptr) {
   StageTimer t(c, "finish");
   if (!wk) wk = c->work;
-  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out)) {
+  const int dense = (p->dof_dense_conv && fc.nlev) ? 1 : 0;   // the reference's dense k x k conv order: unfused kernels only
+  if (c->use_fused && !dense && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out)) {
     HIPCHK(hipGetLastError());
     return 0;
   }
-  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL);
-  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR);
+  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense);
+  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense);
   vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
   HIPCHK(hipGetLastError());
   return 0;
@@ -444,18 +445,14 @@ VD3D_EXPORT int vd3d_finish_frame(vd3d_ctx* c, const uint8_t* left_bgr, const ui
 
 // ---- B2 ---------------------------------------------------------------------------------------
 static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
-                             const vd3d_render_params* p, uint8_t* out_bgr, bool state_only, int shard = 0, int step_idx = 0,
-                             int slot = -1, float* s1_out = nullptr, bool blank = false) {
-  if (!c || !depth || !p || (!state_only && (!frame_bgr || !out_bgr))) return set_err(VD3D_E_INVALID, "NULL argument");
+                             const vd3d_render_params* p, uint8_t* out_bgr, bool blank) {
+  if (!c || !depth || !p || !frame_bgr || !out_bgr) return set_err(VD3D_E_INVALID, "NULL argument");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
   if (!p->auto_crop_black_bars &&
       (p->crop_x < 0 || p->crop_y < 0 || p->crop_w < 1 || p->crop_h < 1 || p->crop_x + p->crop_w > p->src_w || p->crop_y + p->crop_h > p->src_h))
     return set_err(VD3D_E_INVALID, "crop window outside the frame");
-  if (p->auto_crop_black_bars) {
-    if (!frame_bgr) return set_err(VD3D_E_UNSUPPORTED, "auto_crop_black_bars needs the frame of EVERY step (detect_black_bars runs on the "
-                                   "RGB frame): frame-sharded steps and depth-only state advances cannot derive the crop");
-    if (!(p->target_ratio > 0.0) || p->src_w < 1 || p->src_h < 1) return set_err(VD3D_E_INVALID, "auto_crop_black_bars needs target_ratio > 0");
-  }
+  if (p->auto_crop_black_bars && (!(p->target_ratio > 0.0) || p->src_w < 1 || p->src_h < 1))
+    return set_err(VD3D_E_INVALID, "auto_crop_black_bars needs target_ratio > 0");
   if (p->eye_w < 2 || p->eye_h < 2) return set_err(VD3D_E_INVALID, "eye size too small");
   int rc = check_fit(p);
   if (rc) return rc;
@@ -474,24 +471,17 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   vd_finish_consts fc;
   if ((rc = make_finish_consts(p, &fc))) return rc;
   HIPCHK(hipSetDevice(c->device));
-  if (!state_only && (rc = join_pixels(c))) return rc;   // the unsharded pixel pass shares L / R / S with overlapped ones
-  if (shard == 1 && (rc = wait_slot(c, slot))) return rc;
+  if ((rc = join_pixels(c))) return rc;   // the unsharded pixel pass shares L / R / S with overlapped ones
   if ((rc = ensure_eye(c, p->eye_h, p->eye_w))) return rc;
   if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
   hipStream_t s = c->stream;
   const long long ne = (long long)p->eye_h * p->eye_w;
-  StageTimer tf(c, state_only ? "advance" : "frame");
+  StageTimer tf(c, "frame");
   vd_stage_args a;
   memset(&a, 0, sizeof a);
   a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.n_eye = ne;
   { const char* e = getenv("VD3D_DBG"); a.dbg = e ? atoi(e) : 0; }
-  a.shard = shard; a.shard_idx = step_idx; a.s1_out = s1_out; a.blank = blank ? 1 : 0;
-  struct PlaneSwap {   // restores the context's own planes on EVERY exit path (an early HIPCHK return must not leave slot memory in c->D)
-    vd3d_ctx* c; float* D; float* rgb;
-    explicit PlaneSwap(vd3d_ctx* ctx) : c(ctx), D(ctx->D), rgb(ctx->rgb_eye) {}
-    ~PlaneSwap() { c->D = D; c->rgb_eye = rgb; }
-  } plane_swap(c);
-  if (shard == 1) { c->D = c->slot_D[slot]; c->rgb_eye = c->slot_rgb[slot]; }
+  a.blank = blank ? 1 : 0;
   a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a.ipd_factor = p->ipd_factor; a.shift = sp;
   float* dn_cur = c->dn[c->dn_cur];
@@ -523,21 +513,16 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   }
   // a blank frame still runs the whole select chain (its eye-res half carries the filters and the bars; the work-res half only
   // computes unused pop-shaping constants -- blank frames are rare and this keeps one code path), but no shift map and no warp
-  rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, state_only || blank);
-  c->D = plane_swap.D; c->rgb_eye = plane_swap.rgb;
+  rc = run_shift_and_warp(c, c->rgb_eye, dn_cur, p->eye_h, p->eye_w, p->warp_w, p->warp_h, sp, a, blank);
   if (rc) return rc;
-  if (shard == 1) {  // keep what the deferred pixel pass needs: this frame's normalised depth and all per-frame constants
-    HIPCHK(hipMemcpyAsync(c->slot_dn[slot], dn_cur, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(&c->slot_work[slot], c->work, sizeof(vd_dev_work), hipMemcpyDeviceToDevice, s));
-  }
-  if (!state_only && blank) {
+  if (blank) {
     StageTimer t(c, "finish");
     const size_t nb = (size_t)p->src_h * p->src_w * 3;
     if (nb > c->blank_cap) { HIPCHK(re_alloc(&c->blank_eye, nb)); c->blank_cap = nb; }
     vd_launch_blank_eye(s, frame_bgr, p->src_h, p->src_w, c->work, c->blank_eye);
     vd_launch_sharp_mux(s, c->blank_eye, c->blank_eye, pb, fc, out_bgr);
     HIPCHK(hipGetLastError());
-  } else if (!state_only) {
+  } else {
     rc = run_finish(c, c->L, c->R, dn_cur, p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr);
     if (rc) return rc;
   }
@@ -555,14 +540,7 @@ VD3D_EXPORT int vd3d_render_frame(vd3d_ctx* c, const uint8_t* frame_bgr, const v
 // the ipd scaling, the focal tracker, DOF and the colour grade do not run.  Sharpen / fit / mux work on the source-sized frame.
 VD3D_EXPORT int vd3d_render_frame_blank(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
                                         const vd3d_render_params* p, uint8_t* out_bgr) {
-  return render_frame_impl(c, frame_bgr, depth, depth_fmt, p, out_bgr, false, 0, 0, -1, nullptr, true);
-}
-
-// Advance every temporal tracker (planes + scalars) exactly as vd3d_render_frame would for this frame, WITHOUT producing
-// pixels: only the depth is needed.  This is what lets frames of one clip be sharded across GPUs with bit-identical
-// results: every rank advances the state over all frames and renders the pixels of its own frames.
-VD3D_EXPORT int vd3d_advance_state(vd3d_ctx* c, const void* depth, int depth_fmt, const vd3d_render_params* p) {
-  return render_frame_impl(c, nullptr, depth, depth_fmt, p, nullptr, true);
+  return render_frame_impl(c, frame_bgr, depth, depth_fmt, p, out_bgr, true);
 }
 
 // ---- frame sharding, three-phase protocol (visiondepth3d_amd/sharded.py) ----------------------------------
@@ -598,38 +576,17 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
   c->n_slots = n_slots; c->slot_eh = p->eye_h; c->slot_ew = p->eye_w; c->slot_H = p->warp_h; c->slot_W = p->warp_w;
   return 0;
 }
-// phase 1, called for EVERY frame of the step in order.  slot >= 0: this rank owns the frame (frame_bgr required): full
-// measurement incl. the warp-res select, s1 written to *s1_out_dev, planes kept in the slot.  slot < 0: foreign frame
-// (only the depth is needed): eye-res chain only, so all eye-res trackers advance identically on every rank.
-VD3D_EXPORT int vd3d_shard_pass1(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt,
-                                 const vd3d_render_params* p, int step_idx, int slot, float* s1_out_dev) {
-  if (!c || step_idx < 0 || step_idx >= VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad step index");
-  if (slot >= c->n_slots) return set_err(VD3D_E_INVALID, "slot %d out of range (vd3d_shard_begin)", slot);
-  if (slot >= 0 && (!frame_bgr || !s1_out_dev)) return set_err(VD3D_E_INVALID, "own frame needs the frame and an s1 destination");
-  return render_frame_impl(c, slot >= 0 ? frame_bgr : nullptr, depth, depth_fmt, p, nullptr, true, slot >= 0 ? 1 : 2, step_idx, slot, s1_out_dev);
-}
-// phase 2: replay the FloatingWindowTracker over the n frames of the step from the exchanged s1 values (device array in
-// frame order); own_slot_host[t] = slot of frame t on this rank or -1.
-VD3D_EXPORT int vd3d_shard_pass2(vd3d_ctx* c, const float* s1_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p) {
-  if (!c || !s1_all_dev || !own_slot_host || !p || n < 1 || n > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
-  HIPCHK(hipSetDevice(c->device));
-  vd3d_shift_params sp = p->shift;
-  sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
-  sp.depth_stretch_hi = 0.95; sp.fg_pop_multiplier = 1.20; sp.bg_push_multiplier = 1.10; sp.subject_lock_strength = 1.00;
-  vd_stage_args a;
-  memset(&a, 0, sizeof a);
-  a.have_eye = 1; a.W = p->warp_w; a.H = p->warp_h; a.shift = sp;
-  for (int t = 0; t < n; ++t) { int rc = wait_slot(c, own_slot_host[t]); if (rc) return rc; }
-  StageTimer t(c, "replay");
-  vd_launch_shard_replay(c->stream, c->work, s1_all_dev, own_slot_host, n, c->slot_work, a);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
 // phase 3: shift plane, fused warp and finishing kernels of one owned frame from its slot -> muxed frame
-VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_params* p, uint8_t* out_bgr) {
+static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p, uint8_t* out_bgr, const uint8_t* blank_frame_bgr) {
   if (!c || !p || !out_bgr || slot < 0 || slot >= c->n_slots) return set_err(VD3D_E_INVALID, "bad argument");
   int rc = check_fit(p);
   if (rc) return rc;
+  vd3d_render_params pb = *p;
+  if (blank_frame_bgr) {   // the source-sized frame itself goes through sharpen / fit / mux (:1279-1281, :1406-1419)
+    pb.warp_w = p->src_w; pb.warp_h = p->src_h;
+    if (p->src_w < 1 || p->src_h < 1) return set_err(VD3D_E_INVALID, "bad source size");
+    if ((rc = check_fit(&pb))) return rc;
+  }
   vd3d_shift_params sp = p->shift;
   sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
   sp.depth_stretch_hi = 0.95; sp.fg_pop_multiplier = 1.20; sp.bg_push_multiplier = 1.10; sp.subject_lock_strength = 1.00;
@@ -656,6 +613,14 @@ VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_param
   hipStream_t s = c->stream;
   const int H = p->warp_h, W = p->warp_w;
   const vd_dev_work* wk = &c->slot_work[slot];
+  if (blank_frame_bgr) {
+    StageTimer t(c, "finish");
+    const size_t nb = (size_t)p->src_h * p->src_w * 3;
+    if (nb > c->blank_cap) { HIPCHK(re_alloc(&c->blank_eye, nb)); c->blank_cap = nb; }
+    vd_launch_blank_eye(s, blank_frame_bgr, p->src_h, p->src_w, wk, c->blank_eye);
+    vd_launch_sharp_mux(s, c->blank_eye, c->blank_eye, pb, fc, out_bgr);
+    HIPCHK(hipGetLastError());
+  } else {
   { StageTimer t(c, "warp");
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, c->S); }
     bool fused;
@@ -671,12 +636,22 @@ VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_param
   HIPCHK(hipGetLastError());
   rc = run_finish(c, c->L, c->R, c->slot_dn[slot], p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr, wk);
   if (rc) return rc;
+  }
   if (c->pix_overlap) {
     HIPCHK(hipEventRecord(c->slot_done[slot], c->pix_stream));
     HIPCHK(hipEventRecord(c->ev_pix_last, c->pix_stream));
     c->slot_busy[slot] = 1; c->pix_pending = true;
   }
   return 0;
+}
+
+VD3D_EXPORT int vd3d_shard_pixels(vd3d_ctx* c, int slot, const vd3d_render_params* p, uint8_t* out_bgr) {
+  return shard_pixels_impl(c, slot, p, out_bgr, nullptr);
+}
+// the pixel pass of an own frame that is in the skip_blank_frames set (core/render_3d.py:1278-1281): both eyes are the source frame
+VD3D_EXPORT int vd3d_shard_pixels_blank(vd3d_ctx* c, int slot, const uint8_t* frame_bgr, const vd3d_render_params* p, uint8_t* out_bgr) {
+  if (!frame_bgr) return set_err(VD3D_E_INVALID, "NULL frame");
+  return shard_pixels_impl(c, slot, p, out_bgr, frame_bgr);
 }
 
 // Overlapped pixel passes: with enable != 0, vd3d_shard_pixels is enqueued on a second stream of the context, ordered after all work
@@ -724,14 +699,15 @@ static void shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args*
   a->n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a->ipd_factor = p->ipd_factor; a->shift = *sp; a->etab = c->etab;
 }
-// P1, for EVERY frame of the step in order.  slot < 0: foreign frame -> plane EMA only.  slot >= 0: own frame -> ingest (RGB kept
-// in the slot), plane EMA, exact q.02 / q.98 of the filtered plane written to q_out_dev[0..1]; the filtered planes of this frame
-// and of the frame before it are kept in the slot.
+// P1, for every OWN frame of the step in frame order (a rank owns a contiguous chunk of the step): ingest (RGB kept in the slot),
+// TemporalDepthFilter plane EMA, exact q.02 / q.98 of the filtered plane written to q_out_dev[0..1]; the filtered planes of this
+// frame and of the frame before it are kept in the slot.  The plane EMA carries over from the previous frame of the clip, wherever
+// it was rendered: vd3d_tdf_plane_import installs the plane the previous chunk's owner exported.
 VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params* p,
                                int step_idx, int slot, float* q_out_dev) {
   if (!c || !depth || !p || step_idx < 0 || step_idx >= VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
-  if (slot >= c->n_slots) return set_err(VD3D_E_INVALID, "slot %d out of range (vd3d_shard_begin)", slot);
-  if (slot >= 0 && (!frame_bgr || !q_out_dev)) return set_err(VD3D_E_INVALID, "own frame needs the frame and a destination for its quantiles");
+  if (slot < 0 || slot >= c->n_slots) return set_err(VD3D_E_INVALID, "slot %d out of range (vd3d_shard_begin)", slot);
+  if (!frame_bgr || !q_out_dev) return set_err(VD3D_E_INVALID, "an own frame needs the frame and a destination for its quantiles");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
   if (p->auto_crop_black_bars && !c->crop_tab_set)
     return set_err(VD3D_E_INVALID, "auto_crop_black_bars in a sharded step: call vd3d_shard2_p0 on the own frames and vd3d_shard2_set_crops first");
@@ -744,20 +720,30 @@ VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void
   a.shard_idx = step_idx;
   a.crop_tab = p->auto_crop_black_bars ? c->crop_tab : nullptr;
   const size_t ne = (size_t)p->eye_h * p->eye_w;
-  StageTimer t(c, slot >= 0 ? "p1_own" : "p1_foreign");
-  if (slot < 0) {
-    a.shard = 4;
-    const long long nel = (long long)ne;
-    (void)nel;
-    vd_launch_chain_eye_lite(s, depth, depth_fmt, *p, c->work, c->tdf, a);
-  } else {
-    a.shard = 3; a.q_out = q_out_dev;
-    HIPCHK(hipMemcpyAsync(c->slot_tdfp[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
-    vd_launch_chain_eye(s, frame_bgr, depth, depth_fmt, *p, c->work, c->slot_rgb[slot], c->tdf, c->histA, c->histB, a);
-    HIPCHK(hipMemcpyAsync(c->slot_tdf[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
-  }
+  StageTimer t(c, "p1_own");
+  a.shard = 3; a.q_out = q_out_dev;
+  HIPCHK(hipMemcpyAsync(c->slot_tdfp[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
+  vd_launch_chain_eye(s, frame_bgr, depth, depth_fmt, *p, c->work, c->slot_rgb[slot], c->tdf, c->histA, c->histB, a);
+  HIPCHK(hipMemcpyAsync(c->slot_tdf[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipGetLastError());
+  return 0;
+}
+// The chunk hand-off of the plane state (one eye-size float32 plane per chunk boundary): export copies
+// TemporalDepthFilter.prev_depth to a caller buffer (which the caller sends to the owner of the next chunk), import installs a
+// received plane and marks it valid (valid = 0: "no previous frame", the state of a fresh clip).
+VD3D_EXPORT int vd3d_tdf_plane_export(vd3d_ctx* c, float* dst_dev, int eye_h, int eye_w) {
+  if (!c || !dst_dev || !c->tdf || eye_h != c->eye_h || eye_w != c->eye_w) return set_err(VD3D_E_INVALID, "bad argument (vd3d_shard_begin first)");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dst_dev, c->tdf, (size_t)eye_h * eye_w * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+VD3D_EXPORT int vd3d_tdf_plane_import(vd3d_ctx* c, const float* src_dev, int eye_h, int eye_w, int valid) {
+  if (!c || !src_dev || !c->tdf || eye_h != c->eye_h || eye_w != c->eye_w) return set_err(VD3D_E_INVALID, "bad argument (vd3d_shard_begin first)");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->tdf, src_dev, (size_t)eye_h * eye_w * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  const int32_t v = valid ? 1 : 0;
+  HIPCHK(hipMemcpyAsync(&c->work->st.tdf_valid, &v, sizeof v, hipMemcpyHostToDevice, c->stream));   // pageable 4-byte source: staged by the runtime
   return 0;
 }
 // P0 (only with auto_crop_black_bars), own frames: detect_black_bars + the per-frame aspect crop -> crop_out_dev[0..3] = {x, y, w, h}.
@@ -777,33 +763,6 @@ VD3D_EXPORT int vd3d_shard2_set_crops(vd3d_ctx* c, const int* crops_all_dev, int
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpyAsync(c->crop_tab, crops_all_dev, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
   c->crop_tab_set = true;
-  return 0;
-}
-// P1 for a RUN of consecutive foreign frames (step indices step_idx_first .. +count-1): one launch instead of `count`
-// (depth_ptrs_host: `count` device pointers to the depth planes, same depth_fmt).  Equivalent to `count` vd3d_shard2_p1(slot = -1) calls.
-VD3D_EXPORT int vd3d_shard2_p1_foreign(vd3d_ctx* c, const void* const* depth_ptrs_host, int count, int depth_fmt,
-                                       const vd3d_render_params* p, int step_idx_first) {
-  if (!c || !depth_ptrs_host || !p || count < 1 || step_idx_first < 0 || step_idx_first + count > VD_MAX_STEP)
-    return set_err(VD3D_E_INVALID, "bad argument");
-  if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
-  if (p->auto_crop_black_bars && !c->crop_tab_set)
-    return set_err(VD3D_E_INVALID, "auto_crop_black_bars in a sharded step: call vd3d_shard2_p0 / vd3d_shard2_set_crops first");
-  if (!c->tdf || c->eye_h != p->eye_h || c->eye_w != p->eye_w) return set_err(VD3D_E_INVALID, "vd3d_shard_begin first");
-  HIPCHK(hipSetDevice(c->device));
-  vd_stage_args a; vd3d_shift_params sp;
-  shard2_args(c, p, &a, &sp);
-  a.shard = 4;
-  a.crop_tab = p->auto_crop_black_bars ? c->crop_tab : nullptr;
-  StageTimer t(c, "p1_foreign");
-  for (int done = 0; done < count; done += VD_MULTI_MAX) {
-    const int m = count - done < VD_MULTI_MAX ? count - done : VD_MULTI_MAX;
-    vd_depth_list dl;
-    for (int k = 0; k < VD_MULTI_MAX; ++k) dl.d[k] = k < m ? depth_ptrs_host[done + k] : nullptr;
-    if (!dl.d[0]) return set_err(VD3D_E_INVALID, "NULL depth plane");
-    a.shard_idx = step_idx_first + done;
-    vd_launch_tdf_multi(c->stream, dl, m, depth_fmt, *p, c->work, c->tdf, a);
-  }
-  HIPCHK(hipGetLastError());
   return 0;
 }
 // R1: replay DepthPercentileEMA over the n frames of the step from the exchanged quantiles q_all_dev[n][2] (frame order)
@@ -836,14 +795,15 @@ VD3D_EXPORT int vd3d_shard2_p3(vd3d_ctx* c, int slot, int step_idx, const vd3d_r
 }
 // R2: replay every remaining tracker over the n frames of the step from the exchanged measurements m_all_dev[n][4] (frame order);
 // own_slot_host[t] = slot of frame t on this rank or -1.  Afterwards vd3d_shard_pixels(slot) renders the own frames.
-VD3D_EXPORT int vd3d_shard2_r2(vd3d_ctx* c, const long long* m_all_dev, const int* own_slot_host, int n, const vd3d_render_params* p) {
+VD3D_EXPORT int vd3d_shard2_r2(vd3d_ctx* c, const long long* m_all_dev, const int* own_slot_host, const uint8_t* blank_host_or_null, int n,
+                               const vd3d_render_params* p) {
   if (!c || !m_all_dev || !own_slot_host || !p || n < 1 || n > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   vd_stage_args a; vd3d_shift_params sp;
   shard2_args(c, p, &a, &sp);
   for (int t = 0; t < n; ++t) { int rc = wait_slot(c, own_slot_host[t]); if (rc) return rc; }
   StageTimer t(c, "replay");
-  vd_launch_shard2_r2(c->stream, c->work, m_all_dev, c->etab, own_slot_host, n, c->slot_work, a);
+  vd_launch_shard2_r2(c->stream, c->work, m_all_dev, c->etab, own_slot_host, blank_host_or_null, n, c->slot_work, a);
   HIPCHK(hipGetLastError());
   return 0;
 }

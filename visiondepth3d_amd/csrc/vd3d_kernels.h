@@ -5,7 +5,7 @@
 #include "vd3d_work.h"
 
 enum { VD_ST_A0 = 0, VD_ST_B0, VD_ST_A1, VD_ST_B1, VD_ST_A2, VD_ST_B2,
-       VD_ST_AQ, VD_ST_BQ, VD_ST_BS, VD_ST_B2_LITE };  // AQ/BQ: generic quantile pair, BS: bare subject depth (test entry points)
+       VD_ST_AQ, VD_ST_BQ, VD_ST_BS };  // AQ/BQ: generic quantile pair, BS: bare subject depth (test entry points)
 #define PL_KMAX_HOST 33   // largest blur_ksize the pool kernel's LDS tile is sized for
 #define DF_RMAX_HOST 15   // largest Gaussian radius of the DOF kernel
 
@@ -17,10 +17,8 @@ struct vd_stage_args {
   long long n_eye;     // eye_h*eye_w
   long long n_crop;    // centre-crop population of compute_dynamic_parallax_scale
   double ipd_factor;
-  int shard;           // frame sharding: 0 = normal frame, 1 = own frame (s1 measured, tracker deferred), 2 = foreign frame;
-                       // measure/replay protocol: 3 = own frame (measurements only, no tracker touched), 4 = foreign frame (tdf EMA only)
+  int shard;           // 0 = sequential frame; 3 = own frame of a sharded step (measurements only, no tracker touched)
   int shard_idx;       // frame index inside the sharded step
-  float* s1_out;       // shard == 1: where the measured s1 goes (device)
   float* q_out;        // shard == 3: {q_lo, q_hi} of this frame (device, 2 floats)
   long long* m_out;    // shard == 3: {sum1, sum2, sum_mad, (s_norm | s1 << 32)} of this frame (device, 4 x int64)
   const int* crop_tab; // shard 3/4 with auto_crop_black_bars: per-frame crop rectangles {x, y, w, h} of the step (device), else NULL
@@ -86,21 +84,15 @@ VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __re
 
 // ---- vd3d_select.hip (fused chain)
 void vd_launch_shard2_r1(hipStream_t s, vd_dev_work* w, const float* q_all, int n, float* etab);
-void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, const float* etab, const int* own_slot_host, int n,
-                         vd_dev_work* slot_work, const vd_stage_args& a);
+void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, const float* etab, const int* own_slot_host,
+                         const uint8_t* blank_host_or_null, int n, vd_dev_work* slot_work, const vd_stage_args& a);
 void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w,
                         int* crop_out = nullptr);   // crop_out: optional device int[4] copy of the rectangle (sharded steps)
 void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w,
                          float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a);
-void vd_launch_chain_eye_lite(hipStream_t s, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
-                              const vd_stage_args& a);   // a.shard == 4: the plane EMA of a foreign frame, nothing else
-#define VD_MULTI_MAX 15
-struct vd_depth_list { const void* d[VD_MULTI_MAX]; };
-void vd_launch_tdf_multi(hipStream_t s, const vd_depth_list& dl, int count, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
-                         const vd_stage_args& a);   // plane EMA over `count` consecutive foreign frames in one launch
 void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
                           vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
-                          const vd_stage_args& a);   // a.shard == 2 (foreign frame): eye-res part only, no warp-res select
+                          const vd_stage_args& a);
 
 // ---- vd3d_select.hip
 void vd_launch_hist_eye_d(hipStream_t s, bool passB, const float* tdf, long long n, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
@@ -131,7 +123,7 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
                           const vd3d_shift_params& p, uint8_t* L, uint8_t* R);
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
-                         int bar_width, int bar_side, uint8_t* eye_out);
+                         int bar_width, int bar_side, uint8_t* eye_out, int dense = 0);
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
                          const vd_finish_consts& fc, uint8_t* out);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
@@ -156,7 +148,3 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
 
 // ---- vd3d_heal.hip
 void vd_launch_heal(hipStream_t s, const float* warped, const float* orig, const float* edge_or_null, int H, int W, float hs, float* out);
-
-// ---- frame sharding (vd3d_select.hip)
-void vd_launch_shard_replay(hipStream_t s, vd_dev_work* w, const float* s1_all, const int* own_slot, int n, vd_dev_work* slot_work,
-                            const vd_stage_args& a);

@@ -299,6 +299,10 @@ void vd_launch_warp(hipStream_t s, const float* rgb, int ih, int iw, const float
 #define DF_TW 32
 #define DF_TH 16
 #define DF_RMAX 15
+// DENSE = true: the Gaussian levels as the reference's dense k x k depthwise convolution in the order PyTorch's CPU build runs it
+// (row-major taps, one fused multiply-add per tap from 0, 2-D kernel = float32 outer product): bit-exact against the CPU
+// reference, 4x the arithmetic of the separable default (vd3d_render_params::dof_dense_conv).
+template <bool DENSE>
 __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ eye_in, const float* __restrict__ dn, int eh, int ew,
                                                    int H, int W, vd_finish_consts fc, const vd_dev_work* __restrict__ w,
                                                    float focal_override, int use_override, int bar_width_o, int bar_side_o,
@@ -307,8 +311,17 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
   float* tile = lds;                        // [3][th][tw]
-  float* vb = lds + (size_t)3 * th * tw;    // [3][DF_TH][tw]   vertical sums (the vertical pass runs first)
+  float* vb = lds + (size_t)3 * th * tw;    // separable: [3][DF_TH][tw] vertical sums (the vertical pass runs first)
+                                            // dense    : [nlev][k*k] 2-D kernels (outer products ky[i] * kx[j])
   const int x0 = blockIdx.x * DF_TW, y0 = blockIdx.y * DF_TH;
+  if (DENSE) {
+    int off = 0;
+    for (int l = 0; l < fc.nlev; ++l) {
+      const int k = fc.ksz[l];
+      for (int t = threadIdx.x; t < k * k; t += 512) vb[off + t] = fc.kern[l][t / k] * fc.kern[l][t - (t / k) * k];
+      off += k * k;
+    }
+  }
   for (int t = threadIdx.x; t < th * tw; t += 512) {
     const int ty = t / tw, tx = t - ty * tw;
     const int y = vd_reflect(y0 - R + ty, H), x = vd_reflect(x0 - R + tx, W);
@@ -344,6 +357,23 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) { vlo[c] = tile[c * th * tw + (ty + R) * tw + tx + R]; vhi[c] = vlo[c]; }
+  if (DENSE) {
+    int off = 0;
+    for (int l = 0; l < fc.nlev; ++l) {
+      const int k = fc.ksz[l], r = k / 2;
+      if (l + 1 == lo || l + 1 == lo + 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float* t0 = tile + (size_t)c * th * tw + (ty + R - r) * tw + tx + R - r;
+          float acc = 0.f;
+          for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) acc = vd_fma(t0[i * tw + j], vb[off + i * k + j], acc);
+          if (l + 1 == lo) vlo[c] = acc; else vhi[c] = acc;
+        }
+      }
+      off += k * k;
+    }
+  } else
   for (int l = 0; l < fc.nlev; ++l) {  // level l+1 of the reference's stack
     const int k = fc.ksz[l], r = k / 2;
     __syncthreads();
@@ -387,12 +417,21 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
 }
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
-                         int bar_width, int bar_side, uint8_t* eye_out) {
+                         int bar_width, int bar_side, uint8_t* eye_out, int dense) {
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
-  size_t lds = sizeof(float) * 3 * ((size_t)th * tw + (size_t)DF_TH * tw);
-  hipLaunchKernelGGL(k_dof_grade, dim3((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH), dim3(512), lds, s, eye_in, dn, eh, ew, H, W,
-                     fc, w, focal_override, use_override, bar_width, bar_side, eye_out);
+  const dim3 g((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH);
+  if (dense) {
+    size_t k2 = 0;
+    for (int l = 0; l < fc.nlev; ++l) k2 += (size_t)fc.ksz[l] * fc.ksz[l];
+    const size_t lds = sizeof(float) * (3 * (size_t)th * tw + k2);
+    hipLaunchKernelGGL(k_dof_grade<true>, g, dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w, focal_override, use_override, bar_width,
+                       bar_side, eye_out);
+    return;
+  }
+  const size_t lds = sizeof(float) * 3 * ((size_t)th * tw + (size_t)DF_TH * tw);
+  hipLaunchKernelGGL(k_dof_grade<false>, g, dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w, focal_override, use_override, bar_width,
+                     bar_side, eye_out);
 }
 
 // ------------------------------------------------------------------------------------------------

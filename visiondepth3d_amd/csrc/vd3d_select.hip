@@ -435,18 +435,14 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
     } break;
     case VD_ST_A1:
       if (a.have_eye) scan_a_job(&lcs[VD_J_EYE_SUBJ], histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
-      if (a.shard != 2) {
-        scan_a_job(&lcs[VD_J_WORK_Q], histA + (size_t)VD_J_WORK_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
-                   (float)a.shift.depth_stretch_hi, sm);
-        scan_a_job(&lcs[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
-      }
+      scan_a_job(&lcs[VD_J_WORK_Q], histA + (size_t)VD_J_WORK_Q * VD_NB_A, SEL_QUANT, (float)a.shift.depth_stretch_lo,
+                 (float)a.shift.depth_stretch_hi, sm);
+      scan_a_job(&lcs[VD_J_WORK_S0], histA + (size_t)VD_J_WORK_S0 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
       break;
     case VD_ST_B1: {
       if (a.have_eye) scan_b_job(&lcs[VD_J_EYE_SUBJ], histB + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_EYE_SUBJ * VD_MAX_T * VD_NB_BC, sm);
-      if (a.shard != 2) {
-        scan_b_job(&lcs[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_BC, sm);
-        scan_b_job(&lcs[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_BC, sm);
-      }
+      scan_b_job(&lcs[VD_J_WORK_Q], histB + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_Q * VD_MAX_T * VD_NB_BC, sm);
+      scan_b_job(&lcs[VD_J_WORK_S0], histB + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S0 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
         vd_sel_ctl* cq = &lcs[VD_J_WORK_Q];
         const float lo = quantile_lerp(cq->val[0], cq->val[1], cq->w[0]);
@@ -489,9 +485,6 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           fg *= (double)scale; mg *= (double)scale; bg *= (double)scale;
           if (a.ipd_factor != 0.0 && !a.blank) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
           w->fg_d = fg; w->mg_d = mg; w->bg_d = bg;
-          if (a.shard && a.shard_idx >= 0 && a.shard_idx < VD_MAX_STEP) {
-            w->step_fg[a.shard_idx] = fg; w->step_mg[a.shard_idx] = mg; w->step_bg[a.shard_idx] = bg;
-          }
           // compute_motion_metric :924-929
           w->fs.mad = 0.f;
           double motion = 0.0;
@@ -529,16 +522,13 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
     case VD_ST_A2:
       scan_a_job(&lcs[VD_J_WORK_S1], histA + (size_t)VD_J_WORK_S1 * VD_NB_A, SEL_SUBJECT, 0.f, 0.f, sm);
       break;
-    case VD_ST_B2:
-    case VD_ST_B2_LITE: {
-      if (a.stage == VD_ST_B2)
-        scan_b_job(&lcs[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
+    case VD_ST_B2: {
+      scan_b_job(&lcs[VD_J_WORK_S1], histB + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_B, vd_histbc(histB) + (size_t)VD_J_WORK_S1 * VD_MAX_T * VD_NB_BC, sm);
       if (tid == 0) {
-        if (a.stage == VD_ST_B2) {
+        {
           const float s1 = subject_from_job(&lcs[VD_J_WORK_S1]);
           w->fs.s1 = s1;
-          if (a.shard == 1) { if (a.s1_out) *a.s1_out = s1; }  // sharded: the FloatingWindowTracker is replayed after the exchange
-          else if (a.shard == 3) reinterpret_cast<float*>(&a.m_out[3])[1] = s1;
+          if (a.shard == 3) reinterpret_cast<float*>(&a.m_out[3])[1] = s1;   // sharded: every tracker is replayed after the exchange
           else if (!a.blank) shift_scalars(w, a.shift, a.W, s1, w->fg_d, w->mg_d, w->bg_d);   // blank: pixel_shift_cuda never runs
         }
         if (a.have_eye && a.shard != 3) {  // floating-window bars :1390-1403
@@ -716,7 +706,6 @@ __global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict
     const int* cr = a.crop_tab ? a.crop_tab + 4 * a.shard_idx : w->acrop;
     p.crop_x = cr[0]; p.crop_y = cr[1]; p.crop_w = cr[2]; p.crop_h = cr[3];
   }
-  const bool lite = a.shard == 4;   // foreign frame of the measure/replay protocol: the plane EMA only (no histogram, no scan)
   for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
     const long long i = base + threadIdx.x;
     float v = 0.f;
@@ -724,14 +713,11 @@ __global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict
       const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
       v = vd_ingest_pixel(frame, depth, fmt, p, tdf_valid, rgb_eye, tdf, ey, ex);
     }
-    if (!lite) vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
+    vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
   }
   __syncthreads();
-  if (!lite) lds_hist_flush(h0, histA + (size_t)VD_J_EYE_Q * VD_NB_A);
-  if (last_workgroup(&w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) {
-    if (lite) { if (threadIdx.x == 0) w->st.tdf_valid = 1; }
-    else { a.stage = VD_ST_A0; run_scalar_stage(w, histA, histB, a, sm); }
-  }
+  lds_hist_flush(h0, histA + (size_t)VD_J_EYE_Q * VD_NB_A);
+  if (last_workgroup(&w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A0; run_scalar_stage(w, histA, histB, a, sm); }
 }
 
 // K2: pass B of J0; last workgroup: scan B0 + DepthPercentileEMA
@@ -994,50 +980,6 @@ void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth,
   hipLaunchKernelGGL(k_chain_b0, dim3(chain_grid(ne, 4096, 256)), dim3(1024), 0, s, tdf, ne, w, histA, histB, a);
 }
 
-void vd_launch_chain_eye_lite(hipStream_t s, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
-                              const vd_stage_args& a) {
-  const long long ne = (long long)p.eye_h * p.eye_w;
-  hipLaunchKernelGGL(k_chain_ingest, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, (const uint8_t*)nullptr, depth, fmt, p, w,
-                     (float*)nullptr, tdf, (uint32_t*)nullptr, (const uint32_t*)nullptr, a);
-}
-
-// TemporalDepthFilter (:220-229) over `count` CONSECUTIVE foreign frames of a sharded step in one launch: each eye-res pixel's EMA
-// chain is independent of every other pixel, so the frames are walked per pixel in registers (same float32 expression per frame as
-// vd_ingest_pixel: nv = 0.5f*prev + (float)(1-0.5)*cur), one read of each depth plane, one read + one write of the filtered plane.
-__global__ __launch_bounds__(1024) void k_tdf_multi(vd_depth_list dl, int count, int fmt, vd3d_render_params p, vd_dev_work* w,
-                                                    float* __restrict__ tdf, vd_stage_args a) {
-  __shared__ uint32_t sflag;
-  const long long n = (long long)p.eye_h * p.eye_w;
-  const int tdf_valid = w->st.tdf_valid;
-  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
-    const long long i = base + threadIdx.x;
-    if (i >= n) continue;
-    const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
-    float prev = tdf_valid ? tdf[i] : 0.f;
-    int valid = tdf_valid;
-    for (int k = 0; k < count; ++k) {
-      int cx = p.crop_x, cy = p.crop_y, cw = p.crop_w, ch = p.crop_h;
-      if (p.auto_crop_black_bars) { const int* cr = a.crop_tab + 4 * (a.shard_idx + k); cx = cr[0]; cy = cr[1]; cw = cr[2]; ch = cr[3]; }
-      const vd_tap ty = vd_interp_tap(ch, p.eye_h, ey), tx = vd_interp_tap(cw, p.eye_w, ex);
-      const size_t i00 = (size_t)(ty.i0 + cy) * p.src_w + (tx.i0 + cx), i01 = (size_t)(ty.i0 + cy) * p.src_w + (tx.i1 + cx);
-      const size_t i10 = (size_t)(ty.i1 + cy) * p.src_w + (tx.i0 + cx), i11 = (size_t)(ty.i1 + cy) * p.src_w + (tx.i1 + cx);
-      const void* dk = dl.d[k];
-      const float cur = vd_bilerp(vd_depth_at(dk, fmt, i00), vd_depth_at(dk, fmt, i01), vd_depth_at(dk, fmt, i10), vd_depth_at(dk, fmt, i11),
-                                  tx.w0, tx.w1, ty.w0, ty.w1);
-      const float pv = valid ? prev : cur;
-      prev = 0.5f * pv + (float)(1 - 0.5) * cur;
-      valid = 1;
-    }
-    tdf[i] = prev;
-  }
-  if (last_workgroup(&w->ticket[0], &sflag, a.dbg) && threadIdx.x == 0) w->st.tdf_valid = 1;
-}
-void vd_launch_tdf_multi(hipStream_t s, const vd_depth_list& dl, int count, int fmt, const vd3d_render_params& p, vd_dev_work* w, float* tdf,
-                         const vd_stage_args& a) {
-  const long long ne = (long long)p.eye_h * p.eye_w;
-  hipLaunchKernelGGL(k_tdf_multi, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, dl, count, fmt, p, w, tdf, a);
-}
-
 // src = the filtered plane (render path: have_eye) or the caller's depth plane (bare pixel_shift_cuda)
 void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
                           vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
@@ -1048,26 +990,19 @@ void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* 
   f.step_x = W > 1 ? (1.f - (-1.f)) / (float)(W - 1) : 0.f; f.step_y = H > 1 ? (1.f - (-1.f)) / (float)(H - 1) : 0.f;
   const long long ne = (long long)ih * iw, n = (long long)H * W;
   const int eye_wg = have_eye ? chain_grid(ne, 4096, 128) : 0;
-  const bool foreign = a.shard == 2;                // sharded foreign frame: eye-res part only
-  const int work_wg = foreign ? 0 : chain_grid(n, 8192, 256);     // K3: 130 KB of LDS histograms -> one resident workgroup per CU
+  const int work_wg = chain_grid(n, 8192, 256);     // K3: 130 KB of LDS histograms -> one resident workgroup per CU
   const int eye_wg_b = eye_wg;
-  const int work_wg_b = foreign ? 0 : chain_grid(n, 4096, 512);   // K4: streams the stored curved-depth plane (one release fence per workgroup)
+  const int work_wg_b = chain_grid(n, 4096, 512);   // K4: streams the stored curved-depth plane (one release fence per workgroup)
   // K3's warp-res workgroups must not read the dn plane its eye-res workgroups are writing: they read the filtered plane
   // and apply the (device-scalar) normalisation per tap; K4/K5 read the stored plane, complete by then.
   hipLaunchKernelGGL(k_chain_stage1, dim3(eye_wg + work_wg), dim3(1024), 0, s, src, dn_cur, dn_prev, ih, iw, eye_wg, f, dc, w, histA, histB, a);
   f.src = have_eye ? dn_cur : src; f.norm = 0;
   hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b), dim3(1024), 0, s, dn_cur, ih, iw, eye_wg_b, f, dc, w, histA, histB, a);
-  if (foreign) {  // no shaped depth, no s1: only the bar/convergence recurrences of stage B2
-    vd_stage_args b = a;
-    b.stage = VD_ST_B2_LITE;
-    hipLaunchKernelGGL(k_scalar_stage, dim3(1), dim3(1024), 0, s, w, histA, histB, b);
-    return;
-  }
   hipLaunchKernelGGL(k_chain_shape, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, f, dc, w, mid, gamma, D, histA, histB, a);
   hipLaunchKernelGGL(k_chain_b2, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, D, H, W, w, histA, histB, a);
 }
 
-struct vd_own_slots { short v[VD_MAX_STEP]; };  // passed by value in the kernel arguments (1 KB): no staging copy, no sync
+struct vd_own_slots { short v[VD_MAX_STEP]; unsigned char blank[VD_MAX_STEP]; };  // by value in the kernel arguments (1.5 KB): no staging copy
 // ================================================================================================
 // Measure / replay frame sharding: owners measure, every rank replays the scalar recurrences.
 // k_shard2_r1: DepthPercentileEMA (:249-261) over the exchanged (q_lo, q_hi) of ALL frames of the step, in frame order.
@@ -1127,23 +1062,26 @@ __global__ void k_shard2_r2(vd_dev_work* w, const long long* __restrict__ m_all,
       st->sm_mg = al * mg + (1 - al) * st->sm_mg;
       st->sm_bg = al * bg + (1 - al) * st->sm_bg;
     }
+    const bool blank = own.blank[t] != 0;   // skip_blank_frames hit (:1278-1281): no ipd scaling, no focal / FloatingWindowTracker update
     fg = st->sm_fg; mg = st->sm_mg; bg = st->sm_bg;
     fg *= (double)scale; mg *= (double)scale; bg *= (double)scale;
-    if (a.ipd_factor != 0.0) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
+    if (a.ipd_factor != 0.0 && !blank) { fg *= a.ipd_factor; mg *= a.ipd_factor; bg *= a.ipd_factor; }
     w->fg_d = fg; w->mg_d = mg; w->bg_d = bg;
     w->fs.mad = 0.f;
     double motion = 0.0;
-    if (have_prev) {
+    if (have_prev && !blank) {
       const float mad = (float)(((double)sum_mad / VD_FX) / (double)a.n_eye);
       w->fs.mad = mad;
       const double m = (double)mad * 4.0;
       motion = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
     }
-    w->fs.focal = focal_update(st, motion, (double)s_norm);
+    if (!blank) w->fs.focal = focal_update(st, motion, (double)s_norm);
+    else w->fs.focal = st->focal;
     w->focal = (float)w->fs.focal;
     // ---- stage B2
-    w->fs.s1 = s1;
-    shift_scalars(w, a.shift, a.W, s1, fg, mg, bg);
+    w->fs.s1 = blank ? 0.f : s1;
+    if (!blank) shift_scalars(w, a.shift, a.W, s1, fg, mg, bg);
+    else { w->fs.zpo_raw = 0.f; w->fs.zpo = 0.0; }
     {
       const float s = s_norm;
       const float rz = ((((-s) * (float)w->fg_d) + ((-s) * (float)w->mg_d)) + (s * (float)w->bg_d)) / (float)((double)a.W / 2 + 1e-6);
@@ -1172,7 +1110,7 @@ __global__ void k_shard2_r2(vd_dev_work* w, const long long* __restrict__ m_all,
       vd3d_frame_scalars* fs = &d->fs;   // diagnostics of the slot = what vd3d_last_scalars reports for a sequential frame
       fs->ema_lo = e[0]; fs->ema_hi = e[4]; fs->collapse = (int)e[2];
       fs->mean_c = mean; fs->var_c = var; fs->dyn_scale = (double)scale; fs->s_norm = s_norm; fs->mad = w->fs.mad;
-      fs->s1 = s1; fs->zpo_raw = w->fs.zpo_raw; fs->zpo = w->fs.zpo; fs->focal = w->fs.focal; fs->stable_zero = w->fs.stable_zero;
+      fs->s1 = w->fs.s1; fs->zpo_raw = w->fs.zpo_raw; fs->zpo = w->fs.zpo; fs->focal = w->fs.focal; fs->stable_zero = w->fs.stable_zero;
       fs->bar_width = w->bar_width; fs->bar_side = w->bar_side;
     }
   }
@@ -1180,33 +1118,12 @@ __global__ void k_shard2_r2(vd_dev_work* w, const long long* __restrict__ m_all,
   w->ema_lo = e[0]; w->ema_den = e[1]; w->collapse = (int)e[2];
   st->prev_depth_valid = 1;
 }
-void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, const float* etab, const int* own_slot_host, int n,
-                         vd_dev_work* slot_work, const vd_stage_args& a) {
+void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, const float* etab, const int* own_slot_host,
+                         const uint8_t* blank_host_or_null, int n, vd_dev_work* slot_work, const vd_stage_args& a) {
   vd_own_slots own;
-  for (int t = 0; t < VD_MAX_STEP; ++t) own.v[t] = (short)(t < n ? own_slot_host[t] : -1);
-  hipLaunchKernelGGL(k_shard2_r2, dim3(1), dim3(64), 0, s, w, m_all, etab, own, n, slot_work, a);
-}
-
-// Tracker replay of a sharded step: the FloatingWindowTracker (and everything shift_scalars derives from s1) is advanced over
-// ALL frames of the step in order from the exchanged s1 values; own frames get their final constants patched into their slot.
-__global__ void k_shard_replay(vd_dev_work* w, const float* __restrict__ s1_all, vd_own_slots own, int n,
-                               vd_dev_work* slot_work, vd_stage_args a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int t = 0; t < n; ++t) {
-    shift_scalars(w, a.shift, a.W, s1_all[t], w->step_fg[t], w->step_mg[t], w->step_bg[t]);
-    const int sl = own.v[t];
-    if (sl >= 0) {
-      vd_dev_work* d = &slot_work[sl];
-      d->fg = w->fg; d->mg = w->mg; d->bg = w->bg;
-      d->zpo_f = w->zpo_f; d->have_zpo = w->have_zpo; d->msn = w->msn; d->conv = w->conv; d->have_conv = w->have_conv;
-      d->fs.s1 = s1_all[t]; d->fs.zpo_raw = w->fs.zpo_raw; d->fs.zpo = w->fs.zpo;
-      d->st = w->st;  // snapshot for diagnostics (vd3d_last_scalars on a slot is not exposed; kept for debugging)
-    }
+  for (int t = 0; t < VD_MAX_STEP; ++t) {
+    own.v[t] = (short)(t < n ? own_slot_host[t] : -1);
+    own.blank[t] = (unsigned char)((blank_host_or_null && t < n && blank_host_or_null[t]) ? 1 : 0);
   }
-}
-void vd_launch_shard_replay(hipStream_t s, vd_dev_work* w, const float* s1_all, const int* own_slot_host, int n, vd_dev_work* slot_work,
-                            const vd_stage_args& a) {
-  vd_own_slots own;
-  for (int t = 0; t < VD_MAX_STEP; ++t) own.v[t] = (short)(t < n ? own_slot_host[t] : -1);
-  hipLaunchKernelGGL(k_shard_replay, dim3(1), dim3(64), 0, s, w, s1_all, own, n, slot_work, a);
+  hipLaunchKernelGGL(k_shard2_r2, dim3(1), dim3(64), 0, s, w, m_all, etab, own, n, slot_work, a);
 }

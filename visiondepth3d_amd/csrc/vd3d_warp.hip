@@ -500,9 +500,11 @@ __global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ 
 }
 
 // blur_ksize values whose k*k passed tools/verify_fastdiv.c (all floats in [0, k*k], 3-operation division == IEEE division)
-static bool wf_fastdiv_ok(int k) {
-  static const char ok[34] = {0, /*1..*/ 1, 1, 1, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, 0, /*15..*/ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  return k >= 1 && k <= 33 && ok[k];
+static bool wf_fastdiv_ok(int k) {   // every float in [0, k*k] checked; inexact for k in {6, 10, 12, 14, 18, 20, 22, 24, 26, 28, 30}
+  if (k < 1 || k > 33) return false;
+  static const unsigned long long bad = (1ull << 6) | (1ull << 10) | (1ull << 12) | (1ull << 14) | (1ull << 18) | (1ull << 20) | (1ull << 22) |
+                                        (1ull << 24) | (1ull << 26) | (1ull << 28) | (1ull << 30);
+  return !((bad >> k) & 1ull);
 }
 
 // returns false when the fused kernel cannot be used (tiles would not fit the 160 KB LDS): caller falls back to v0

@@ -55,6 +55,4 @@ struct vd_dev_work {
   float focal;
   int32_t bar_width, bar_side;
   int32_t acrop[4];        // crop_x, crop_y, crop_w, crop_h of THIS frame when auto_crop_black_bars is on (k_autocrop)
-  // per-frame layer shifts of the current sharded step (after smoother * dyn_scale * ipd): inputs of the tracker replay
-  double step_fg[VD_MAX_STEP], step_mg[VD_MAX_STEP], step_bg[VD_MAX_STEP];
 };

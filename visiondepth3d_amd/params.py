@@ -35,8 +35,10 @@ def shift_params_from_kwargs(fg_shift, mg_shift, bg_shift, **kw) -> ShiftParams:
 
 
 def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, mg_shift, bg_shift,
-                            sharpness_factor, output_format, dof_strength, target_ratio=16 / 9,
+                            sharpness_factor, output_format, dof_strength, target_ratio=16 / 9, dof_dense_conv=False,
                             **kw) -> RenderParams:
+    """``dof_dense_conv`` (extension, not a render_sbs_3d parameter): the DOF Gaussian levels in the reference's dense k x k
+    association instead of the separable default (include/vd3d.h vd3d_render_params::dof_dense_conv)."""
     unknown = set(kw) - set(RENDER_DEFAULTS) - {"output_width", "input_path", "depth_path", "output_path",
                                                 "selected_codec", "fps", "selected_aspect_ratio", "aspect_ratios"}
     if unknown:
@@ -59,4 +61,5 @@ def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, 
                            color_contrast=o["color_contrast"], color_brightness=o["color_brightness"])
     p.auto_crop_black_bars = 1 if o["auto_crop_black_bars"] else 0   # :1230-1234, crop decided per frame on device
     p.target_ratio = float(target_ratio)
+    p.dof_dense_conv = 1 if dof_dense_conv else 0
     return p

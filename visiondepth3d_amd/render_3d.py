@@ -191,19 +191,6 @@ class Renderer:
         _lib.check(fn(self._ctx, _ptr(f), _ptr(d), fmt, C.byref(params), _ptr(out)))
         return out
 
-    def advance_state(self, depth: torch.Tensor, params: RenderParams) -> None:
-        """Advance the temporal state over one frame without rendering it (frame sharding)."""
-        if depth.dtype == torch.float32 and depth.dim() == 2:
-            fmt = DEPTH_F32
-        elif depth.dtype == torch.uint8 and depth.dim() == 3 and depth.shape[2] == 3:
-            fmt = DEPTH_BGR_U8
-        elif depth.dtype == torch.uint8 and depth.dim() == 2:
-            fmt = DEPTH_GRAY_U8
-        else:
-            raise AssertionError("depth must be float32 [h,w], uint8 [h,w,3] or uint8 [h,w]")
-        d = depth.to(self.device).contiguous()
-        _lib.check(self._L.vd3d_advance_state(self._ctx, _ptr(d), fmt, C.byref(params)))
-
     # ---- frame sharding, three-phase protocol (include/vd3d.h; orchestrated by visiondepth3d_amd.sharded) ----
     def _depth_fmt(self, depth):
         if depth.dtype == torch.float32 and depth.dim() == 2:
@@ -217,18 +204,6 @@ class Renderer:
     def shard_begin(self, params: RenderParams, n_slots: int):
         _lib.check(self._L.vd3d_shard_begin(self._ctx, C.byref(params), int(n_slots)))
 
-    def shard_pass1(self, frame, depth, params: RenderParams, step_idx: int, slot: int = -1, s1_out: torch.Tensor | None = None):
-        d = depth.to(self.device).contiguous()
-        f = frame.to(self.device).contiguous() if frame is not None else None
-        _lib.check(self._L.vd3d_shard_pass1(self._ctx, _ptr(f) if f is not None else None, _ptr(d), self._depth_fmt(d), C.byref(params),
-                                            int(step_idx), int(slot), _ptr(s1_out) if s1_out is not None else None))
-
-    def shard_pass2(self, s1_all: torch.Tensor, own_slots, params: RenderParams):
-        n = len(own_slots)
-        arr = (C.c_int * n)(*[int(v) for v in own_slots])
-        s1 = s1_all.to(self.device, torch.float32).contiguous()
-        _lib.check(self._L.vd3d_shard_pass2(self._ctx, _ptr(s1), arr, n, C.byref(params)))
-
     # measure / replay protocol (include/vd3d.h vd3d_shard2_*)
     def shard2_p0(self, frame, params: RenderParams, crop_out: torch.Tensor):
         f = frame.to(self.device).contiguous()
@@ -240,18 +215,25 @@ class Renderer:
         self._enter(cr)
         _lib.check(self._L.vd3d_shard2_set_crops(self._ctx, _ptr(cr), cr.numel() // 4))
 
-    def shard2_p1(self, frame, depth, params: RenderParams, step_idx: int, slot: int = -1, q_out: torch.Tensor | None = None):
+    def shard2_p1(self, frame, depth, params: RenderParams, step_idx: int, slot: int, q_out: torch.Tensor):
         d = depth.to(self.device).contiguous()
-        f = frame.to(self.device).contiguous() if frame is not None else None
+        f = frame.to(self.device).contiguous()
         self._enter(f, d, q_out)
-        _lib.check(self._L.vd3d_shard2_p1(self._ctx, _ptr(f) if f is not None else None, _ptr(d), self._depth_fmt(d), C.byref(params),
-                                          int(step_idx), int(slot), _ptr(q_out) if q_out is not None else None))
+        _lib.check(self._L.vd3d_shard2_p1(self._ctx, _ptr(f), _ptr(d), self._depth_fmt(d), C.byref(params), int(step_idx), int(slot),
+                                          _ptr(q_out)))
 
-    def shard2_p1_foreign(self, depths, params: RenderParams, step_idx_first: int):
-        """A run of consecutive foreign frames (list of device depth planes of one format) in one launch."""
-        ds = [d.to(self.device).contiguous() for d in depths]
-        arr = (C.c_void_p * len(ds))(*[d.data_ptr() for d in ds])
-        _lib.check(self._L.vd3d_shard2_p1_foreign(self._ctx, arr, len(ds), self._depth_fmt(ds[0]), C.byref(params), int(step_idx_first)))
+    def tdf_plane_export(self, params: RenderParams, out: torch.Tensor | None = None) -> torch.Tensor:
+        """TemporalDepthFilter.prev_depth -> float32 [eye_h, eye_w] tensor (the chunk-boundary hand-off of a sharded clip)."""
+        if out is None:
+            out = torch.empty((params.eye_h, params.eye_w), dtype=torch.float32, device=self.device)
+        self._enter(out)
+        _lib.check(self._L.vd3d_tdf_plane_export(self._ctx, _ptr(out), params.eye_h, params.eye_w))
+        return out
+
+    def tdf_plane_import(self, plane: torch.Tensor, params: RenderParams, valid: bool = True):
+        pl = plane.to(self.device, torch.float32).contiguous()
+        self._enter(pl)
+        _lib.check(self._L.vd3d_tdf_plane_import(self._ctx, _ptr(pl), params.eye_h, params.eye_w, 1 if valid else 0))
 
     def shard2_r1(self, q_all: torch.Tensor):
         q = q_all.to(self.device, torch.float32).contiguous()
@@ -262,12 +244,13 @@ class Renderer:
         self._enter(m_out)
         _lib.check(self._L.vd3d_shard2_p3(self._ctx, int(slot), int(step_idx), C.byref(params), _ptr(m_out)))
 
-    def shard2_r2(self, m_all: torch.Tensor, own_slots, params: RenderParams):
+    def shard2_r2(self, m_all: torch.Tensor, own_slots, params: RenderParams, blank=None):
         n = len(own_slots)
         arr = (C.c_int * n)(*[int(v) for v in own_slots])
+        bl = (C.c_uint8 * n)(*[1 if b else 0 for b in blank]) if blank is not None else None
         m = m_all.to(self.device, torch.int64).contiguous()
         self._enter(m)
-        _lib.check(self._L.vd3d_shard2_r2(self._ctx, _ptr(m), arr, n, C.byref(params)))
+        _lib.check(self._L.vd3d_shard2_r2(self._ctx, _ptr(m), arr, bl, n, C.byref(params)))
 
     def set_pixel_overlap(self, on: bool):
         """Run ``shard_pixels`` on a second stream of the context, behind the measurement chain of the next step
@@ -282,9 +265,15 @@ class Renderer:
         """Block the host until the overlapped pixel pass of ``slot`` (if any) has written its frame."""
         _lib.check(self._L.vd3d_wait_pixels(self._ctx, int(slot)))
 
-    def shard_pixels(self, slot: int, params: RenderParams, out: torch.Tensor | None = None):
+    def shard_pixels(self, slot: int, params: RenderParams, out: torch.Tensor | None = None, blank_frame: torch.Tensor | None = None):
+        """Pixel pass of an own frame; ``blank_frame``: the frame is in the skip_blank_frames set -> its source frame is both eyes."""
         if out is None:
             out = torch.empty((params.out_h, params.out_w, 3), dtype=torch.uint8, device=self.device)
+        if blank_frame is not None:
+            f = blank_frame.to(self.device, torch.uint8).contiguous()
+            self._enter(out, f)
+            _lib.check(self._L.vd3d_shard_pixels_blank(self._ctx, int(slot), _ptr(f), C.byref(params), _ptr(out)))
+            return out
         self._enter(out)
         _lib.check(self._L.vd3d_shard_pixels(self._ctx, int(slot), C.byref(params), _ptr(out)))
         return out
