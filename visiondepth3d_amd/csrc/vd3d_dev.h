@@ -38,6 +38,48 @@ VD_DEV float vd_lin11_step(float step, int steps, int i) {
 // correctly-rounded float32 pow / exp through float64 (device libm is < 1 ULP in float64)
 VD_DEV float vd_pow_cr(float x, float e) { return (float)pow((double)x, (double)e); }
 VD_DEV float vd_exp_cr(float x) { return (float)exp((double)x); }
+// Table-driven float64 pow for x in (0, 1]: log2 by a 128-entry table + degree-7 polynomial, 2^f by a 64-entry table + degree-6
+// polynomial, ~30 float64 operations instead of libm's ~200.  Relative error < 2^-45; whenever the float64 result lies within
+// 2^-39 of a float32 rounding boundary (3e-5 of the inputs) the function reports "ambiguous" and the caller uses vd_pow_cr, so the
+// value is ALWAYS the float32 rounding of the libm result.  tools/verify_fastpow.c restates these exact operations on the CPU and
+// checks every float in (0, 1] for g = 0.85 (the only exponent render_sbs_3d passes), 0.3, 0.5, 0.999, 1, 1.5, 2.2: 0 mismatches.
+// tab: [0,128) 1/c_i, [128,256) log2 c_i, [256,320) 2^(j/64)  (vd3d_pow_tables.h; the kernels stage it in LDS).
+VD_DEV bool vd_pow_fast(float x, double g, const double* __restrict__ tab, float* out) {
+  const uint32_t b = __float_as_uint(x);
+  if (b < 0x00800000u || b > 0x3f800000u) return false;          // zero, subnormal, > 1: exact path
+  const int e = (int)(b >> 23) - 127;
+  const int i = (int)((b >> 16) & 0x7fu);
+  const double m = (double)__uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+  const double r = __builtin_fma(m, tab[i], -1.0);               // |r| <= 2^-8
+  const double C1 = 1.4426950408889634074, C2 = -0.72134752044448170368, C3 = 0.48089834696298780245, C4 = -0.36067376022224085184,
+               C5 = 0.28853900817779268147, C6 = -0.24044917348149390123, C7 = 0.20609929155556620106;
+  double p = __builtin_fma(r, C7, C6); p = __builtin_fma(r, p, C5); p = __builtin_fma(r, p, C4); p = __builtin_fma(r, p, C3);
+  p = __builtin_fma(r, p, C2); p = __builtin_fma(r, p, C1);
+  const double L = ((double)e + tab[128 + i]) + r * p;
+  const double y = g * L;
+  if (!(y > -120.0)) return false;
+  const double k = __builtin_rint(y * 64.0);
+  const double f = __builtin_fma(k, -1.0 / 64.0, y);             // |f| <= 2^-7
+  const long long ki = (long long)k;
+  const int j = (int)(ki & 63);
+  const int n = (int)((ki - j) / 64);
+  const double t = f * 0.69314718055994530942;
+  double q = __builtin_fma(t, 1.0 / 6.0, 1.0); q = __builtin_fma(t * (1.0 / 5.0), q, 1.0); q = __builtin_fma(t * (1.0 / 4.0), q, 1.0);
+  q = __builtin_fma(t * (1.0 / 3.0), q, 1.0); q = __builtin_fma(t * 0.5, q, 1.0); q = __builtin_fma(t, q, 1.0);
+  const double res = ldexp(tab[256 + j] * q, n);
+  const uint32_t low = (uint32_t)((unsigned long long)__double_as_longlong(res) & 0x1fffffffull);   // mantissa bits below float32 precision
+  const uint32_t half = 0x10000000u;
+  const uint32_t dist = low > half ? low - half : half - low;
+  if (dist < (1u << 13)) return false;                           // within 2^-39 of a rounding boundary
+  *out = (float)res;
+  return true;
+}
+VD_DEV float vd_pow_cr_fast(float x, float e, const double* __restrict__ tab) {   // == vd_pow_cr(x, e) for every x
+  float v;
+  if (vd_pow_fast(x, (double)e, tab, &v)) return v;
+  return vd_pow_cr(x, e);
+}
+
 // x^1.5 == x*sqrt(x): float64 sqrt is correctly rounded, product error < 1 ULP(float64) => same float32 as pow
 VD_DEV float vd_pow15_cr(float x) {
   double d = (double)x;

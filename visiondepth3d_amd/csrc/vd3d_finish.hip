@@ -116,7 +116,10 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
   }
 }
 
-__global__ __launch_bounds__(FF_NT) void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
+#ifndef FF_OCC_ATTR
+#define FF_OCC_ATTR   // A/B builds: -DFF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))' forces the 64-VGPR budget
+#endif
+__global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
                                                         const vd_dev_work* __restrict__ w, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];

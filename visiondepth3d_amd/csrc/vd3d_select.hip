@@ -17,6 +17,7 @@
 // the two frame-sharding protocols.
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
+#include "vd3d_pow_tables.h"
 
 #define NBL 16272  // LDS bins per job (>= 0x3F80 + 1)
 
@@ -614,7 +615,7 @@ VD_DEV unsigned key_a(float v) { unsigned k = __float_as_uint(v) >> 16; return k
 // thread (16 dependent round trips per thread at 4K).  body(valid, y, x, v) is called uniformly by every lane (it may ballot).
 // VEC4 = false for the pass-B kernels: their hits are one value band of a smooth plane, i.e. spatially clustered, and the
 // 16-byte walk would put a band on 4x fewer workgroups (measured 2x slower).
-template <bool VEC4, class Body>
+template <bool VEC4, int NT = 1024, class Body>
 VD_DEV void vd_plane_walk(const float* __restrict__ p, long long n, int W, int wg, int nwg, Body body) {
   if (VEC4 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
     const long long n4 = n >> 2;
@@ -631,12 +632,26 @@ VD_DEV void vd_plane_walk(const float* __restrict__ p, long long n, int W, int w
       body(ok, y, x, v.x); body(ok, y, x + 1, v.y); body(ok, y, x + 2, v.z); body(ok, y, x + 3, v.w);
     }
   } else {
-    for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
-      const long long i = base + threadIdx.x;
-      const bool ok = i < n;
-      float v = 0.f; int y = 0, x = 0;
-      if (ok) { v = p[i]; y = (int)((unsigned)i / (unsigned)W); x = (int)((unsigned)i - (unsigned)y * (unsigned)W); }
-      body(ok, y, x, v);
+    // four grid-strided elements per trip, their loads issued together: with one 4-byte load in flight per thread these passes
+    // were pure latency (a thread walks n / (nwg * 1024) ~ 16 dependent round trips at 4K); the visiting ORDER is irrelevant to
+    // a histogram, the spatial spread over workgroups stays what the pass-B kernels want (VEC4 = false, see above)
+    constexpr int U = 4;
+    const long long stride = (long long)nwg * NT;
+    for (long long base = (long long)wg * NT; base < n; base += U * stride) {
+      float v[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long i = base + u * stride + threadIdx.x;
+        ok[u] = i < n;
+        v[u] = ok[u] ? p[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long i = base + u * stride + threadIdx.x;
+        int y = 0, x = 0;
+        if (ok[u]) { y = (int)((unsigned)i / (unsigned)W); x = (int)((unsigned)i - (unsigned)y * (unsigned)W); }
+        body(ok[u], y, x, v[u]);
+      }
     }
   }
 }
@@ -878,6 +893,7 @@ VD_DEV void hist_b_add(uint32_t* histB, int job, const vd_targets& c, float v, b
   const unsigned bits = __float_as_uint(v);
   bool hit = false; unsigned key = 0;
   for (uint32_t t = 0; t < c.nt; ++t) if (member && (bits >> 16) == c.tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
+  if (!__any(hit)) return;   // the hits are one value band of a smooth plane: most waves have none
   vd_hist_add_agg(histB + (size_t)job * VD_MAX_T * VD_NB_B, key, hit);
   vd_hist_add_agg(vd_histbc(histB) + (size_t)job * VD_MAX_T * VD_NB_BC, key >> 8, hit);
 }
@@ -902,13 +918,19 @@ __global__ __launch_bounds__(1024) void k_chain_b1(const float* __restrict__ dn_
   if (last_workgroup(&w->ticket[3], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B1; run_scalar_stage(w, histA, histB, a, sm); }
 }
 
+#define VD_X_NONE(v)
+#define VD_X_VAL(v) v,
+__constant__ double c_pow_tab[320] = {VD_POW_TABLES(VD_X_VAL, VD_X_NONE, VD_X_NONE) VD_POW_TABLES(VD_X_NONE, VD_X_VAL, VD_X_NONE)
+                                      VD_POW_TABLES(VD_X_NONE, VD_X_NONE, VD_X_VAL)};
 // K5: shape_depth_for_pop -> D plane + pass A of J4 ; last workgroup: scan A2
 __global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* __restrict__ dc, vd_dev_work* w, float mid, float gamma,
                                                       float* __restrict__ D,
                                                       uint32_t* histA, const uint32_t* histB, vd_stage_args a) {
   __shared__ uint32_t h1[NBL];
   __shared__ uint32_t sm[128];
+  __shared__ double ptab[320];   // vd_pow_fast tables
   for (int b = threadIdx.x; b < NBL; b += 1024) h1[b] = 0;
+  if (threadIdx.x < 320) ptab[threadIdx.x] = c_pow_tab[threadIdx.x];
   __syncthreads();
   const long long n = (long long)f.H * f.W;
   const int stretch = w->shp_stretch;
@@ -918,7 +940,7 @@ __global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* _
     const float centered = (ds - subj_s) + mid;
     const float t = centered - mid;
     const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
-    return vd_clamp(sgn * vd_pow_cr(fabsf(t), gamma) + mid, 0.f, 1.f);
+    return vd_clamp(sgn * vd_pow_cr_fast(fabsf(t), gamma, ptab) + mid, 0.f, 1.f);
   };
   if ((f.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(dc) | reinterpret_cast<uintptr_t>(D)) & 15) == 0) {
     const long long n4 = n >> 2;   // 4 pixels per thread: one 16-byte load / store, one integer division, 4 independent pow chains

@@ -141,8 +141,11 @@ VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
 }
 
 // LDS map (floats):  wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2] | tile[3*er*ec] | rowD | rowA | colT      ([..][2] = eyes)
+#ifndef WF_OCC_ATTR
+#define WF_OCC_ATTR   // A/B builds: -DWF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))'
+#endif
 template <bool RESIZE, bool FEATHER>
-__global__ __launch_bounds__(WF_NT) void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
+__global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
                                                       uint8_t* __restrict__ R) {
   extern __shared__ float lds[];
