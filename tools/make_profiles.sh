@@ -1,0 +1,26 @@
+# Collects the rocprofv3 evidence that profiles/ keeps (run on the GPU box through gpurun; outputs under gpurun_out/profiles_rXX/):
+#   1. kernel-trace --stats of the 4K DIBR-only roofline run (configs[2]) and of the headline (4K + DA-V2-Base float32)
+#   2. three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters) of the 4K DIBR-only run -- never combined with trace domains
+#      other than --kernel-trace (MI355X_MICROARCH.md HBM / rocprofv3 section)
+# usage: bash tools/make_profiles.sh r02
+export TMPDIR=/tmp
+TAG=${1:-r02}
+R=$PWD; O=$R/gpurun_out/profiles_$TAG; mkdir -p $O
+cd /tmp
+DIBR="python $R/bench.py --workload 4k-dibr --steps 6 --warmup 2 --no-cpu-baseline --no-profile"
+HEAD="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-sub-records --no-profile"
+run_stats() {  # name, cmd
+  rm -rf $O/t_$1; rocprofv3 --kernel-trace --stats -d $O/t_$1 -o p -- $2 > $O/t_$1.log 2>&1
+  DB=$(find $O/t_$1 -name "*_results.db" | head -1)
+  python $R/tools/rocpd_summary.py $DB 30 > $O/${TAG}_$1_kernel_stats.md; rm -rf $O/t_$1
+}
+run_stats 4k_dibr "$DIBR"
+run_stats 4k_dav2b_f32 "$HEAD"
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU"; do
+  n=$(echo $c | cut -d" " -f1)
+  rm -rf $O/p_$n; rocprofv3 --kernel-trace --pmc $c -d $O/p_$n -o p -- $DIBR > /dev/null 2>&1
+done
+python $R/tools/pmc_summary.py $(find $O/p_FETCH_SIZE $O/p_WRITE_SIZE $O/p_SQ_WAVES -name "*_results.db") > $O/${TAG}_pmc_4k_dibr_raw.md
+python $R/tools/pmc_to_json.py $TAG $(find $O/p_FETCH_SIZE $O/p_WRITE_SIZE $O/p_SQ_WAVES -name "*_results.db") > $O/pmc_latest.json
+rm -rf $O/p_FETCH_SIZE $O/p_WRITE_SIZE $O/p_SQ_WAVES
+ls -la $O

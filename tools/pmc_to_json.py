@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes (rocpd databases) of the 4K DIBR-only run -> profiles/pmc_latest.json, the per-launch figures bench.py
+attaches to its roofline objects: corrected HBM/fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, KB -> B; the x2 read correction is the
+gfx950 one calibrated on k_stream_copy, MI355X_MICROARCH.md "HBM") and VALU lane-instructions (SQ_INSTS_VALU x 64).
+
+    python tools/pmc_to_json.py r02 fetch.db write.db sq.db > profiles/pmc_latest.json"""
+import json
+import sqlite3
+import sys
+from collections import defaultdict
+
+tag, paths = sys.argv[1], sys.argv[2:]
+acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for p in paths:
+    for name, counter, value in sqlite3.connect(p).execute("select kernel_name, counter_name, value from counters_collection"):
+        a = acc[name][counter]
+        a[0] += value; a[1] += 1
+avg = lambda n, c: (acc[n][c][0] / acc[n][c][1]) if acc[n].get(c) and acc[n][c][1] else None
+out = {}
+for key, prefix in (("k_warp_fused", "void k_warp_fused<true, true>"), ("k_finish_fused", "k_finish_fused")):
+    n = next((k for k in acc if k.startswith(prefix)), None)
+    if n is None:
+        continue
+    f, w, v = avg(n, "FETCH_SIZE"), avg(n, "WRITE_SIZE"), avg(n, "SQ_INSTS_VALU")
+    out[key] = {"kernel": n[:60], "fetch_size_kb_raw": f, "write_size_kb": w,
+                "corrected_bytes_per_launch": int(2 * f * 1024 + w * 1024) if f is not None and w is not None else None,
+                "valu_wave_instr_per_launch": v, "valu_lane_instr_per_launch": v * 64 if v is not None else None,
+                "lds_wave_instr_per_launch": avg(n, "SQ_INSTS_LDS"), "lds_bank_conflict_cycles": avg(n, "SQ_LDS_BANK_CONFLICT"),
+                "source": f"profiles/{tag}_pmc_4k_dibr.md"}
+print(json.dumps({"4k-dibr": out, "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in three separate passes over "
+                  "`bench.py --workload 4k-dibr`; read side x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request; calibrated on k_stream_copy)"}, indent=1))
