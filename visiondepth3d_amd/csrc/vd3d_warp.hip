@@ -27,13 +27,11 @@
 #define WF_NT 512
 #define WF_NW (WF_NT / 64)
 #define WF_AB 3   // halo rows of phase A a wave walks together (loads of all of them in flight)
-#define WF_PF 16  // RGB tile row-chunks prefetched per wave (registers) while phases B / C run
 
 struct vd_wf_args {
   int ih, iw, H, W, k, feather, bound;  // bound: rigorous host-side bound on |pixel shift| (+ margin)
-  int er_max, ec_max;                   // eye tile capacity (rows, cols) when resizing
-  int nc;                               // 64-column chunks per tile row = ceil(ec_max / 64)
-  int ncol;                             // entries of the column-tap table (WF_TW + 2*bound + 6)
+  int er_max;                           // eye-res rows one tile touches (exact maximum over the tile rows, host-computed)
+  int nch;                              // warp-res columns of the pre-interpolated rows Hh: WF_TW + 2*bound + 2
   int tab_off;                          // float offset of the tables in LDS
   int fastdiv;                          // 1: x / (k*k) as q0 = x*rc, r = fma(-q0, kk, x), q = fma(r, rc, q0) -- verified exhaustively
   uint32_t m_ew;                        // ceil(2^32/d) reciprocal: q = umulhi(t, m) is exact for t, d < 2^16
@@ -43,9 +41,8 @@ struct vd_wf_args {
 };
 // LDS tables (built once per tile, so the per-pixel phases only do table look-ups):
 //   rowA[wh][4]   per halo row of phase A : yn, n, 1-n, south flag                      (grid_sample row part)
-//   rowD[TH][16]  per tile row of phase D : 3 resize taps (orig / yn / yn+1) as tile row offsets + weights, n, 1-n, south, yn
-//   colT[ncol][2] per warp-res column     : resize tap of that column as tile column offset + weight (i1 = i0+1: the tile
-//                                           keeps a duplicate of the last image column)
+//   rowD[TH][16]  per tile row of phase D : 3 resize taps (orig / yn / yn+1) as Hh row byte offsets + weights, n, 1-n, south, yn
+//   colT[nch][2]  per warp-res column     : resize tap of that column (absolute eye-res column, weight of the next one)
 #define WF_RD 16
 VD_DEV int wf_div(int t, uint32_t m) { return (int)__umulhi((uint32_t)t, m); }
 VD_DEV int wf_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -140,10 +137,12 @@ VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
   return vd_vfma(vse, n * l.w, vd_vfma(l.vsw, n * e, acc));
 }
 
-// LDS map (floats):  wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2] | tile[3*er*ec] | rowD | rowA | colT      ([..][2] = eyes)
+// LDS map (floats):  phases A-C: wd2[wh*ww][2] (later hs2[eh*TW][2]) | e2_2[eh*ew][2]      ([..][2] = eyes)
+//                    phase D   : Hh[3][er_max][nch] over the same region (RESIZE)   | then, never aliased: rowD | rowA / colT
 #ifndef WF_OCC_ATTR
 #define WF_OCC_ATTR   // A/B builds: -DWF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))'
 #endif
+#define WF_HB 6   // Hh rows a wave builds together (2 * WF_HB loads in flight)
 template <bool RESIZE, bool FEATHER>
 __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
@@ -153,79 +152,25 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
   const int x0 = blockIdx.x * WF_TW, y0 = blockIdx.y * WF_TH;
   const int ww = WF_TW + k, wh = WF_TH + k;          // wd region
   const int ew = WF_TW + k - 1, eh = WF_TH + k - 1;  // e2 region
-  // LDS aliasing (floats): wd2 [0, 2*wh*ww) is dead after phase B and becomes hs2 [0, 2*eh*TW); e2_2 follows wd2 and is dead
-  // after phase C; the RGB tile is parked in registers until then and lands at [2*eh*TW, ...) over the dead tail of wd2 and
-  // e2_2.  Live maximum = hs2 + tile (+ tables) = 53 KB at 4K / k = 9  =>  3 workgroups per CU instead of 2.
+  // LDS aliasing (floats): wd2 [0, 2*wh*ww) is dead after phase B and becomes hs2 [0, 2*eh*TW); e2_2 follows wd2 and is dead after
+  // phase C; hs2 is consumed into registers (the blend weights b of the wave's four rows) before the pre-interpolated RGB rows
+  // Hh land over the whole region.  Live maximum at 4K / k = 9: max(wd2 + e2_2 = 45.9 KB, Hh = 47.3 KB) + 3.8 KB of tables = 51 KB
+  // => 3 workgroups per CU.
   vd_f2* wd = reinterpret_cast<vd_f2*>(lds);                       // [wh*ww]   (later hs [eh*WF_TW])
   vd_f2* e2 = reinterpret_cast<vd_f2*>(lds + 2 * wh * ww);         // [eh*ew]
-  float* tile = FEATHER ? lds + 2 * eh * WF_TW : lds;              // [3][er][ec]
+  float* Hh = lds;                                                  // [3][er_max][nch]
   float* rowD = lds + a.tab_off;                                    // [WF_TH][WF_RD], 16 B aligned (host: after the aliased buffers)
-  float* rowA = rowD + WF_TH * WF_RD;                               // [wh][4]
-  float* colT = rowA + wh * 4;                                      // [ncol][2]
+  float* rowA = rowD + WF_TH * WF_RD;                               // [wh][4]        (phase A only)
+  float* colT = rowA;                                               // [nch][2]       (built after phase C: rowA is dead by then)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = wf_uni(tid >> 6);
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
-  const int cb = max(x0 - a.bound - 2, 0);                          // first warp-res column of colT
-
-  // eye-res RGB tile geometry (block-uniform)
-  int er0 = 0, ec0 = 0, er = 0, ec = 0;
-  if (RESIZE) {
-    const int ya = max(y0 - 1, 0), yb = min(y0 + WF_TH, H - 1);
-    const int xa = max(x0 - a.bound - 1, 0);
-    er0 = wf_tap(a.ih, H, a.scale_h, ya).i0; er = wf_tap(a.ih, H, a.scale_h, yb).i1 - er0 + 1;
-    ec0 = wf_tap(a.iw, W, a.scale_w, xa).i0;
-    er = min(er, a.er_max); ec = a.ec_max;  // fixed row pitch (host constant)
-    ec0 = min(ec0, a.iw + 1 - ec); ec0 = max(ec0, 0);   // tile column iw - ec0 (if inside) duplicates the last image column
-  }
+  const int cb = max(x0 - a.bound, 0);                              // first warp-res column of Hh / colT
+  const int nch = a.nch;
   const unsigned ni = (unsigned)a.ih * (unsigned)a.iw;
-  // The tile as NR = 3*er rows of NC = a.nc 64-column chunks; wave wv owns the row-chunks q = wv + 8*j.  (row, chunk) advance
-  // incrementally (no division); everything but the lane's column is scalar.
-  const int NR = 3 * er, NC = a.nc;
-  const int pq = WF_NW / NC, pr = WF_NW - pq * NC;     // q += 8  ==  (row, chunk) += (pq, pr) with carry
-  int prow0 = 0, pch0 = wv;
-  if (RESIZE) { while (pch0 >= NC) { pch0 -= NC; ++prow0; } }
-  float pf[WF_PF];
-  // global -> registers (one row-chunk per j): scalar row base, per-lane clamped column
-#define WF_LOAD_TILE                                                                                                    \
-  {                                                                                                                     \
-    int prow = prow0, pch = pch0;                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < WF_PF; ++j) {                                                                 \
-      float v = 0.f;                                                                                                    \
-      if (prow < NR) {                                                                                                  \
-        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);                                                        \
-        const int ty = prow - c * er;                                                                                   \
-        const float* srow = rgb + ((unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw);                           \
-        const int cx = pch * 64 + lane;                                                                                 \
-        if (cx < ec) v = srow[min(ec0 + cx, a.iw - 1)];                                                                 \
-      }                                                                                                                 \
-      pf[j] = v;                                                                                                        \
-      prow += pq; pch += pr;                                                                                            \
-      if (pch >= NC) { pch -= NC; ++prow; }                                                                             \
-    }                                                                                                                   \
-  }
-  // registers -> LDS (+ the rare row-chunks beyond the register budget straight from global)
-#define WF_STORE_TILE                                                                                                   \
-  {                                                                                                                     \
-    int prow = prow0, pch = pch0;                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < WF_PF; ++j) {                                                                 \
-      const int cx = pch * 64 + lane;                                                                                   \
-      if (prow < NR && cx < ec) {                                                                                       \
-        const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);                                                        \
-        tile[((prow - c * er) * ec + cx) * 3 + c] = pf[j];                                                              \
-      }                                                                                                                 \
-      prow += pq; pch += pr;                                                                                            \
-      if (pch >= NC) { pch -= NC; ++prow; }                                                                             \
-    }                                                                                                                   \
-    for (; prow < NR;) { /* only for very large shift bounds */                                                        \
-      const int c = prow >= 2 * er ? 2 : (prow >= er ? 1 : 0);                                                          \
-      const int ty = prow - c * er;                                                                                     \
-      const int cx = pch * 64 + lane;                                                                                   \
-      if (cx < ec) tile[(ty * ec + cx) * 3 + c] = rgb[(unsigned)c * ni + (unsigned)(er0 + ty) * (unsigned)a.iw + (unsigned)min(ec0 + cx, a.iw - 1)]; \
-      prow += pq; pch += pr;                                                                                            \
-      if (pch >= NC) { pch -= NC; ++prow; }                                                                             \
-    }                                                                                                                   \
-  }
-  if (RESIZE && !FEATHER) WF_LOAD_TILE
+
+  int er0 = 0;
+  if (RESIZE) er0 = wf_tap(a.ih, H, a.scale_h, max(y0 - 1, 0)).i0;  // first eye-res row the tile touches
   // ---- tables
   if (tid < wh) {   // phase-A rows
     const int y = wy0 + tid;
@@ -233,23 +178,17 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
     if (y >= 0 && y < H) wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
     float* t = rowA + tid * 4;
     t[0] = __int_as_float(yn); t[1] = n; t[2] = sr; t[3] = __int_as_float((s_ok && n != 0.f) ? 1 : 0);
-  } else if (tid >= 128 && tid < 128 + WF_TH) {   // phase-D rows
+  } else if (tid >= 128 && tid < 128 + WF_TH) {   // phase-D rows: the three resize taps as byte offsets of Hh rows + weights
     const int ty = tid - 128, y = min(y0 + ty, H - 1);
     int yn; float n, sr; bool s_ok;
     wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
     float* t = rowD + ty * WF_RD;
     const vd_tap to = wf_tap(a.ih, H, a.scale_h, y), t0 = wf_tap(a.ih, H, a.scale_h, yn), t1 = wf_tap(a.ih, H, a.scale_h, min(yn + 1, H - 1));
-    const int rp = ec * 12;   // bytes per tile row: [ec][3] floats
+    const int rp = nch * 4;   // bytes per Hh row
     t[0] = __int_as_float((to.i0 - er0) * rp); t[1] = __int_as_float((to.i1 - er0) * rp); t[2] = to.w0; t[3] = to.w1;
     t[4] = __int_as_float((t0.i0 - er0) * rp); t[5] = __int_as_float((t0.i1 - er0) * rp); t[6] = t0.w0; t[7] = t0.w1;
     t[8] = __int_as_float((t1.i0 - er0) * rp); t[9] = __int_as_float((t1.i1 - er0) * rp); t[10] = t1.w0; t[11] = t1.w1;
     t[12] = n; t[13] = sr; t[14] = __int_as_float((s_ok && n != 0.f) ? 1 : 0); t[15] = __int_as_float(yn);
-  }
-  if (RESIZE) {
-    for (int j = tid; j < a.ncol; j += WF_NT) {
-      const vd_tap t = wf_tap(a.iw, W, a.scale_w, min(cb + j, W - 1));
-      colT[2 * j] = __int_as_float((t.i0 - ec0) * 12); colT[2 * j + 1] = t.w1;   // byte offset of the tap's column in a tile row
-    }
   }
   __syncthreads();
   if (FEATHER) {
@@ -316,9 +255,7 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
       }
     }
   }
-  if (RESIZE && !FEATHER) WF_STORE_TILE
   __syncthreads();
-  if (FEATHER && RESIZE) WF_LOAD_TILE   // tile prefetch: in flight during phases B and C only (keeps the register footprint of phase A small)
   if (FEATHER) {
     // phase B: e2 = clamp(|grad WD| * fs, 0, 1) (:347-352), zero outside the image (avg_pool2d zero padding)
     const int bq = WF_NT / ew, br = WF_NT - bq * ew;
@@ -349,12 +286,8 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
       for (int j = 0; j < k; ++j) sacc += row[j];
       hs[ty * WF_TW + lane] = sacc;
     }
-    if (RESIZE) {
-      __syncthreads();   // every read of e2 is done: the tile may overwrite it
-      WF_STORE_TILE
-    }
   }
-  // the shift values of this wave's phase-D rows: issued before the barrier so that their latency overlaps the tile store
+  // the shift values of this wave's phase-D rows: issued early so that their latency overlaps the Hh build
   float sD[WF_TH / WF_NW];
 #pragma unroll
   for (int j = 0; j < WF_TH / WF_NW; ++j) {
@@ -362,18 +295,79 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
     sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
   }
   __syncthreads();
-  // phase D: one wave = 64 consecutive pixels of ONE row per iteration, so everything that depends on y only
-  // (sample rows yn / yn+1, their resize taps, the vertical weights) is wave-uniform and comes from rowD.  ~70 % of rows
-  // have an exactly integral sample row (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 ->
-  // skipped (bit-exact: fma(v, 0, acc) == acc for finite v).
-  const vd_f2* hs = wd;
+  // phase D0: the feather weights b of the wave's rows (vertical k-sums of hs2, / (k*k)) into registers -- hs2 dies here
+  vd_f2 bD[WF_TH / WF_NW];
+#pragma unroll
+  for (int j = 0; j < WF_TH / WF_NW; ++j) {
+    vd_f2 b = {0.f, 0.f};
+    if (FEATHER) {
+      const vd_f2* col = wd + (wv + j * WF_NW) * WF_TW + lane;
+      vd_f2 sacc = {0.f, 0.f};
+      for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
+      if (a.fastdiv) {   // correctly rounded sacc / (k*k) in three packed operations (tools/verify_fastdiv.c: exhaustive)
+        const vd_f2 q0 = sacc * a.rc_kk;
+        const vd_f2 rr = vd_vfma(-q0, (vd_f2)(a.kk), sacc);
+        b = vd_vfma(rr, (vd_f2)(a.rc_kk), q0);
+      } else {
+        b.x = sacc.x / a.kk; b.y = sacc.y / a.kk;
+      }
+    }
+    bD[j] = b;
+  }
+  if (RESIZE) {
+    // column taps of the warp-res columns cb .. cb + nch - 1: (absolute eye-res column i0, weight of i0 + 1)
+    for (int j = tid; j < nch; j += WF_NT) {
+      const vd_tap t = wf_tap(a.iw, W, a.scale_w, min(cb + j, W - 1));
+      colT[2 * j] = __int_as_float(t.i0); colT[2 * j + 1] = t.w1;
+    }
+    __syncthreads();   // hs2 fully consumed, colT complete
+    // phase D1: Hh[c][r][X] = the HORIZONTAL half of the resize of :595 for warp-res column cb + X and eye-res row er0 + r:
+    //   fma(p[i0], 1 - w1, w1 * p[i0 + 1])  -- exactly the first two operations of ATen's bilinear (rows, then columns), computed
+    // once and shared by every sample that needs it (~4.4 per element) instead of inside each of them.  One wave = one 64-column
+    // chunk (its column taps live in two registers), WF_HB rows of loads in flight.
+    {
+      const int nchk = (nch + 63) >> 6;
+      const int chunk = wv % nchk, rstart = wv / nchk, rstep = (WF_NW - chunk + nchk - 1) / nchk;
+      const int X = chunk * 64 + lane;
+      const bool xok = X < nch;
+      const vd_f2 ct = xok ? reinterpret_cast<const vd_f2*>(colT)[X] : vd_f2{0.f, 0.f};
+      const int i0 = __float_as_int(ct.x), i1 = min(i0 + 1, a.iw - 1);
+      const float w1 = ct.y, w0 = 1.f - ct.y;
+      const int er = a.er_max;
+      int c = 0, rr = rstart;
+      while (rr >= er) { rr -= er; ++c; }
+      while (c < 3) {
+        float p0[WF_HB], p1[WF_HB]; int dst[WF_HB];
+#pragma unroll
+        for (int j = 0; j < WF_HB; ++j) {
+          dst[j] = -1; p0[j] = 0.f; p1[j] = 0.f;
+          if (c < 3) {   // wave-uniform
+            const float* srow = rgb + ((unsigned)c * ni + (unsigned)min(er0 + rr, a.ih - 1) * (unsigned)a.iw);
+            if (xok) { p0[j] = srow[i0]; p1[j] = srow[i1]; }
+            dst[j] = (c * er + rr) * nch;
+            rr += rstep;
+            while (rr >= er && c < 3) { rr -= er; ++c; }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < WF_HB; ++j)
+          if (dst[j] >= 0 && xok) Hh[dst[j] + X] = vd_fma(p0[j], w0, w1 * p1[j]);
+      }
+    }
+  }
+  __syncthreads();
+  // phase D2: one wave = 64 consecutive pixels of ONE row per iteration, so everything that depends on y only (sample rows yn / yn+1,
+  // their resize taps, the vertical weights) is wave-uniform and comes from rowD.  ~70 % of rows have an exactly integral sample row
+  // (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 -> skipped (bit-exact: fma(v, 0, acc) == acc).
+  int jD = 0;
 #pragma unroll 1
-  for (int ty = wv; ty < WF_TH; ty += WF_NW) {
+  for (int ty = wv; ty < WF_TH; ty += WF_NW, ++jD) {
     const int y = y0 + ty;
     if (y >= H) break;
-    const float s_row = sD[0];   // rotate the prefetched shift values (static register indices, compact loop body)
+    const float s_row = sD[0];   // rotate the prefetched per-row values (static register indices, compact loop body)
+    const vd_f2 b = bD[0];
 #pragma unroll
-    for (int j = 0; j + 1 < WF_TH / WF_NW; ++j) sD[j] = sD[j + 1];
+    for (int j = 0; j + 1 < WF_TH / WF_NW; ++j) { sD[j] = sD[j + 1]; bD[j] = bD[j + 1]; }
     const vd_f4* rt = reinterpret_cast<const vd_f4*>(rowD + ty * WF_RD);
     const vd_f4 ro = rt[0], ra = rt[1], rb = rt[2], rs = rt[3];
     const float n = wf_unif(rs.x), sr = wf_unif(rs.y);
@@ -383,70 +377,40 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
     uint32_t pL = 0, pR = 0;
     if (x < W) {
       const unsigned o = (unsigned)y * (unsigned)W + (unsigned)x;
-      vd_f2 b = {0.f, 0.f};
-      if (FEATHER) {
-        const vd_f2* col = hs + ty * WF_TW + lane;
-        vd_f2 sacc = {0.f, 0.f};
-        for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
-        if (a.fastdiv) {   // correctly rounded sacc / (k*k) in three packed operations (tools/verify_fastdiv.c: exhaustive)
-          const vd_f2 q0 = sacc * a.rc_kk;
-          const vd_f2 rr = vd_vfma(-q0, (vd_f2)(a.kk), sacc);
-          b = vd_vfma(rr, (vd_f2)(a.rc_kk), q0);
-        } else {
-          b.x = sacc.x / a.kk; b.y = sacc.y / a.kk;
-        }
-      }
       const float s = s_row;
       const float gx0 = vd_lin11_step(a.step_x, W, x);
       const wf_gs2 g = wf_gs_params2(gx0, s, n, sr, W);
       const vd_f2 omb = 1.0f - b;
       if (RESIZE) {
-        // column taps from the table: entry j = resize tap of warp-res column cb + j; xw+1 is the next entry
-        const vd_f2* ct = reinterpret_cast<const vd_f2*>(colT);
-        const vd_f2 eo = ct[x - cb];
-        const vd_f2 eaL = ct[g.xw[0] - cb], ebL = ct[g.xw[0] - cb + 1], eaR = ct[g.xw[1] - cb], ebR = ct[g.xw[1] - cb + 1];
-        const int iaL = __float_as_int(eaL.x), ibL = __float_as_int(ebL.x), iaR = __float_as_int(eaR.x), ibR = __float_as_int(ebR.x);
-        const vd_f2 wa1 = {eaL.y, eaR.y}, wb1 = {ebL.y, ebR.y};
-        const vd_f2 wa0 = 1.f - wa1, wb0 = 1.f - wb1;
-        const int io = __float_as_int(eo.x);
-        const float wo1 = eo.y, wo0 = 1.f - eo.y;
-        // tile row offsets of the three resize taps are wave-uniform
+        typedef const __attribute__((address_space(3))) char* wf_lds_cp;
+        typedef const __attribute__((address_space(3))) float* wf_lds_fp;
+        const wf_lds_cp hb = (wf_lds_cp)Hh;
+        // byte offsets: column part per lane, row / channel part wave-uniform
+        const int cs = a.er_max * nch * 4;                            // channel stride
+        const int xo = (x - cb) * 4, xl = (g.xw[0] - cb) * 4, xr = (g.xw[1] - cb) * 4;
         const int o_r0 = wf_uni(__float_as_int(ro.x)), o_r1 = wf_uni(__float_as_int(ro.y));
         const int a_r0 = wf_uni(__float_as_int(ra.x)), a_r1 = wf_uni(__float_as_int(ra.y));
         const int b_r0 = wf_uni(__float_as_int(rb.x)), b_r1 = wf_uni(__float_as_int(rb.y));
         const float o_w0 = wf_unif(ro.z), o_w1 = wf_unif(ro.w), a_w0 = wf_unif(ra.z), a_w1 = wf_unif(ra.w);
         const float b_w0 = wf_unif(rb.z), b_w1 = wf_unif(rb.w);
-        // The tile is [er][ec][3] floats, so the channel and the next column are IMMEDIATE offsets (+4c, +12 bytes) of one address
-        // per (row tap, column tap): 18 address adds per row.  The loads are volatile ds_read_b32 on purpose: the optimiser would
-        // otherwise merge column i / i+1 into ds_read2 pairs, and re-pairing those into (left eye, right eye) operands costs more
-        // v_mov than the merge saves (measured: 80 of 386 VALU instructions per row).
-        typedef const __attribute__((address_space(3))) char* wf_lds_cp;              // explicit LDS pointers: ds_read_b32 with an
-        typedef const volatile __attribute__((address_space(3))) float* wf_lds_vfp;   // immediate offset, never flat_load
-        const wf_lds_cp tb = (wf_lds_cp)tile;
-        auto ld = [&](int byte_off) { return *(wf_lds_vfp)(tb + byte_off); };
-        const int ao0 = o_r0 + io, ao1 = o_r1 + io;
-        const int aa0L = a_r0 + iaL, aa0R = a_r0 + iaR, ab0L = a_r0 + ibL, ab0R = a_r0 + ibR;
-        const int aa1L = a_r1 + iaL, aa1R = a_r1 + iaR, ab1L = a_r1 + ibL, ab1R = a_r1 + ibR;
+        // one eye's sample pair (west, east) of one row tap: the vertical half of the resize on two adjacent Hh columns at once
+        auto pair = [&](int r0, int r1, float wy0, float wy1, int xoff) {
+          const vd_f2 A0 = {*(wf_lds_fp)(hb + r0 + xoff), *(wf_lds_fp)(hb + r0 + xoff + 4)};
+          const vd_f2 A1 = {*(wf_lds_fp)(hb + r1 + xoff), *(wf_lds_fp)(hb + r1 + xoff + 4)};
+          return vd_vfma(A0, (vd_f2)(wy0), wy1 * A1);
+        };
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          // nested bilinear sample of BOTH eyes: tile rows r0 / r1 (wave-uniform), tile columns i (and i+1) per eye
-          auto smp2 = [&](int q0L, int q0R, int q1L, int q1R, float wy0, float wy1, const vd_f2& w0, const vd_f2& w1) {
-            const vd_f2 p00 = {ld(q0L + 4 * c), ld(q0R + 4 * c)}, p01 = {ld(q0L + 12 + 4 * c), ld(q0R + 12 + 4 * c)};
-            const vd_f2 p10 = {ld(q1L + 4 * c), ld(q1R + 4 * c)}, p11 = {ld(q1L + 12 + 4 * c), ld(q1R + 12 + 4 * c)};
-            const vd_f2 ua = vd_vfma(p00, w0, w1 * p01);
-            const vd_f2 ub = vd_vfma(p10, w0, w1 * p11);
-            return vd_vfma(ua, (vd_f2)(wy0), wy1 * ub);
-          };
-          const float orig = vd_bilerp(ld(ao0 + 4 * c), ld(ao0 + 12 + 4 * c), ld(ao1 + 4 * c), ld(ao1 + 12 + 4 * c), wo0, wo1, o_w0, o_w1);
-          const vd_f2 vnw = smp2(aa0L, aa0R, aa1L, aa1R, a_w0, a_w1, wa0, wa1);
-          vd_f2 vne = smp2(ab0L, ab0R, ab1L, ab1R, a_w0, a_w1, wb0, wb1);
-          vne.x = g.e_ok[0] ? vne.x : 0.f; vne.y = g.e_ok[1] ? vne.y : 0.f;
+          const int co = c * cs;
+          const float orig = vd_fma(*(wf_lds_fp)(hb + co + o_r0 + xo), o_w0, o_w1 * *(wf_lds_fp)(hb + co + o_r1 + xo));
+          const vd_f2 nL = pair(co + a_r0, co + a_r1, a_w0, a_w1, xl), nR = pair(co + a_r0, co + a_r1, a_w0, a_w1, xr);
+          const vd_f2 vnw = {nL.x, nR.x};
+          const vd_f2 vne = {g.e_ok[0] ? nL.y : 0.f, g.e_ok[1] ? nR.y : 0.f};
           vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
           if (south) {
-            const int d0 = b_r0 - a_r0, d1 = b_r1 - a_r1;   // wave-uniform row deltas
-            const vd_f2 vsw = smp2(aa0L + d0, aa0R + d0, aa1L + d1, aa1R + d1, b_w0, b_w1, wa0, wa1);
-            vd_f2 vse = smp2(ab0L + d0, ab0R + d0, ab1L + d1, ab1R + d1, b_w0, b_w1, wb0, wb1);
-            vse.x = g.e_ok[0] ? vse.x : 0.f; vse.y = g.e_ok[1] ? vse.y : 0.f;
+            const vd_f2 sL = pair(co + b_r0, co + b_r1, b_w0, b_w1, xl), sR = pair(co + b_r0, co + b_r1, b_w0, b_w1, xr);
+            const vd_f2 vsw = {sL.x, sR.x};
+            const vd_f2 vse = {g.e_ok[0] ? sL.y : 0.f, g.e_ok[1] ? sR.y : 0.f};
             v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
           }
           if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f); }
@@ -454,7 +418,8 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
           pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
           pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
         }
-      } else {
+      } else
+      {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float* pl = rgb + (unsigned)c * ni;
@@ -498,8 +463,6 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
       orr[0] = (uint8_t)pR; orr[1] = (uint8_t)(pR >> 8); orr[2] = (uint8_t)(pR >> 16);
     }
   }
-#undef WF_LOAD_TILE
-#undef WF_STORE_TILE
 }
 
 // blur_ksize values whose k*k passed tools/verify_fastdiv.c (all floats in [0, k*k], 3-operation division == IEEE division)
@@ -522,39 +485,47 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   const double smax = ((double)W * p.max_pixel_shift_percent) / half_width + fabs(p.convergence_strength) / half_width;
   a.bound = (int)ceil(smax * (double)(W - 1) / 2.0 * 1.0001) + 2;
   const bool resize = !(ih == H && iw == W);
-  a.er_max = a.ec_max = 0;
   const int k = a.k;
   a.kk = (float)(k * k); a.rc_kk = 1.0f / a.kk; a.fastdiv = wf_fastdiv_ok(k) ? 1 : 0;
-  size_t sz_tile = 0;
+  a.er_max = 0; a.nch = 0;
+  size_t sz_hh = 0;
   if (resize) {
-    a.er_max = (int)ceil((WF_TH + 2) * (double)a.scale_h) + 3;
-    a.ec_max = (int)ceil((WF_TW + 2 * a.bound + 3) * (double)a.scale_w) + 3;
-    a.ec_max += 1;                       // room for the duplicate of the last image column (table taps use i1 = i0 + 1)
-    a.ec_max |= 1;                       // odd row pitch: the 4-rows-per-wave gathers of phase D land on distinct banks
-    if (a.ec_max > iw + 1) a.ec_max = iw + 1;
-    sz_tile = (size_t)3 * a.er_max * a.ec_max;
+    // exact number of eye-res rows a tile touches: the same float32 tap arithmetic as the kernel (wf_tap), over every tile row
+    auto tap_i0 = [&](int in, int out, float scale, int o) {
+      if (in == out) return o;
+      float src = fmaf(scale, (float)o + 0.5f, -0.5f);
+      if (src < 0.f) src = 0.f;
+      int i0 = (int)floorf(src);
+      return i0 > in - 1 ? in - 1 : i0;
+    };
+    for (int y0 = 0; y0 < H; y0 += WF_TH) {
+      const int ya = y0 - 1 > 0 ? y0 - 1 : 0, yb = y0 + WF_TH < H - 1 ? y0 + WF_TH : H - 1;
+      const int i0 = tap_i0(ih, H, a.scale_h, ya), j0 = tap_i0(ih, H, a.scale_h, yb);
+      const int i1 = j0 + (j0 < ih - 1 ? 1 : 0);
+      if (i1 - i0 + 1 > a.er_max) a.er_max = i1 - i0 + 1;
+    }
+    a.nch = WF_TW + 2 * a.bound + 2;
+    if ((a.nch + 63) / 64 > WF_NW) return false;   // one wave per 64-column chunk of the Hh build
+    sz_hh = (size_t)3 * a.er_max * a.nch;
   }
-  a.nc = a.ec_max > 0 ? (a.ec_max + 63) / 64 : 1;
-  if (a.nc > WF_NW) return false;        // the (row, chunk) walk advances 8 row-chunks at a time
-  // aliased layout (see the kernel): max(wd2 + e2_2, hs2 + tile) when feathering, else the tile alone
-  size_t fl = sz_tile;
+  // aliased layout (see the kernel): max(wd2 + e2_2, Hh) when feathering, else Hh alone
+  size_t fl = sz_hh;
   if (a.feather) {
     const size_t sz_wd = (size_t)2 * (WF_TH + k) * (WF_TW + k), sz_e2 = (size_t)2 * (WF_TH + k - 1) * (WF_TW + k - 1);
-    const size_t sz_hs = (size_t)2 * (WF_TH + k - 1) * WF_TW;
-    fl = sz_wd + sz_e2 > sz_hs + sz_tile ? sz_wd + sz_e2 : sz_hs + sz_tile;
+    fl = sz_wd + sz_e2 > sz_hh ? sz_wd + sz_e2 : sz_hh;
   }
-  a.ncol = WF_TW + 2 * a.bound + 6;
   fl = (fl + 3) & ~(size_t)3;            // tables start 16 B aligned (ds_read_b128)
   a.tab_off = (int)fl;
-  fl += (size_t)WF_TH * WF_RD + (size_t)(WF_TH + k) * 4 + (size_t)2 * a.ncol;
+  const size_t t_rowA = (size_t)(WF_TH + k) * 4, t_colT = (size_t)2 * a.nch;
+  fl += (size_t)WF_TH * WF_RD + (t_rowA > t_colT ? t_rowA : t_colT);
   if (fl & 3) fl += 4 - (fl & 3);
   a.step_x = (1.f - (-1.f)) / (float)(W - 1); a.step_y = (1.f - (-1.f)) / (float)(H - 1);
   auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
   a.m_ew = magic(WF_TW + k - 1);
-  if ((WF_TH + k) * (WF_TW + k) >= 65536 || 3 * a.er_max * a.ec_max >= 65536) return false;
+  if ((WF_TH + k) * (WF_TW + k) >= 65536) return false;
   if (H >= (1 << 24) || W >= (1 << 24) || (unsigned long long)H * W * 3ull >= (1ull << 32) || (unsigned long long)ih * iw * 3ull >= (1ull << 32)) return false;  // 32-bit offsets
   const size_t bytes = fl * sizeof(float);
-  if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 53.1 KB)
+  if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 51 KB)
   dim3 g((W + WF_TW - 1) / WF_TW, (H + WF_TH - 1) / WF_TH);
   static bool attr[64] = {false};   // per device: the attribute belongs to the device's copy of the code object
   int dev = 0;
