@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VD3D_ABI_VERSION 3
+#define VD3D_ABI_VERSION 4
 
 typedef enum vd3d_status {
   VD3D_OK = 0,
@@ -263,6 +263,29 @@ int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slo
 int vd3d_heal_missing_pixels(vd3d_ctx* ctx, const float* warped_chw, const float* original_chw, const float* edge_mask_or_null,
                              int H, int W, double heal_strength, float* out_chw);
 
+/* ---- cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC) on uint8 images with cn = 1 or 3 interleaved channels: the resize of
+ * the uint8 depth map back to the source size when the depth tab runs at an explicit inference size (a24,
+ * core/render_depth.py:1914-1917) and the size changes of the up-scale stage (core/merged_pipeline.py:260-264).  OpenCV's
+ * fixed-point bicubic (A = -0.75, 11-bit coefficients, replicate border, one rounding).  src != dst. */
+int vd3d_resize_cubic_u8(vd3d_ctx* ctx, const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw);
+/* cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) on uint8 BGR (3 interleaved channels): run_esrgan's input_res_pct < 100
+ * (core/merged_pipeline.py:246-248) and pad_to_aspect_ratio (core/render_3d.py:121).  Down-scale ratios up to 10. */
+int vd3d_resize_area_u8(vd3d_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, uint8_t* dst_bgr, int dh, int dw);
+
+/* ---- up-scale stage glue (core/merged_pipeline.py:219-236).  The network between the two calls is the caller's
+ * (visiondepth3d_amd.upscale runs it on PyTorch-ROCm).
+ *   preprocess : preprocess_esr :219-223 -- BGR uint8 rows (pitch_bytes apart, so a tile crop needs no copy) -> RGB / 255 as
+ *                float32, bf16 or fp16 (the reference's ONNX models are fp16), planar [3][h][w] or channels-last [h][w][3]
+ *   postprocess: postprocess_esr :225-229 -- RGB float32 [h][w] planes (or channels-last) -> clip(0,1) * 255 truncated, BGR uint8;
+ *                only the (cy, cx, ch, cw) window is written (the tile centre of _esrgan_tiled :266-284)
+ *   add_weighted: blend_images :231-236 -- cv2.addWeighted(a, alpha, b, beta, gamma) on uint8 */
+int vd3d_esr_preprocess(vd3d_ctx* ctx, int dtype, const uint8_t* frame_bgr, long long pitch_bytes, int h, int w, int channels_last,
+                        void* out_rgb);
+int vd3d_esr_postprocess(vd3d_ctx* ctx, const float* pred_rgb, int h, int w, int channels_last, int cy, int cx, int ch, int cw,
+                         uint8_t* out_bgr, long long pitch_bytes);
+int vd3d_add_weighted_u8(vd3d_ctx* ctx, const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma, long long n,
+                         uint8_t* out);
+
 /* ---- depth hand-off (a24): transformers' bicubic post-process to (H,W) + convert_depth_to_grayscale
  * (core/render_depth.py:585-611,1914-1916) for a batch of B predictions [B][ph][pw] float32 -> uint8 [B][H][W].
  * Replaces the reference's 8-bit depth video on disk while keeping its quantisation. */
@@ -271,7 +294,7 @@ int vd3d_depth_handoff(vd3d_ctx* ctx, const float* pred, int B, int ph, int pw, 
 /* element type of the depth network's activations (a25).  The reference loads its Hugging Face depth models with
  * AutoModelForDepthEstimation.from_pretrained(checkpoint) and no dtype, i.e. float32 (core/render_depth.py:758-759,823-824):
  * VD3D_DT_F32 is the like-for-like precision, VD3D_DT_BF16 the optional reduced-precision mode. */
-typedef enum vd3d_dtype { VD3D_DT_BF16 = 0, VD3D_DT_F32 = 1 } vd3d_dtype;
+typedef enum vd3d_dtype { VD3D_DT_BF16 = 0, VD3D_DT_F32 = 1, VD3D_DT_F16 = 2 /* vd3d_esr_preprocess only */ } vd3d_dtype;
 
 /* ---- depth-net input preparation (a25, core/render_depth.py:1106-1119 -> DPTImageProcessor): B uint8 BGR frames
  * [B][H][W][3] -> antialiased bicubic resize to (th,tw), 1/255, (x-mean)/std, RGB, `dtype`, NHWC [B][th][tw][3].

@@ -360,3 +360,37 @@ class RenderOracle:
         if rc:
             raise NotImplementedError("oracle: unsupported fit/format")
         return (out, L, R) if want_eyes else out
+
+
+def resize_cubic_u8(src, dh, dw):
+    """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC) on uint8 [h,w] or [h,w,3] (unpinned: OpenCV's published algorithm)."""
+    s = np.ascontiguousarray(src, np.uint8)
+    cn = 1 if s.ndim == 2 else s.shape[2]
+    out = np.empty((dh, dw) + (() if s.ndim == 2 else (cn,)), np.uint8)
+    lib().vo_resize_cubic_u8(s.ctypes.data_as(_u8p), s.shape[0], s.shape[1], cn, out.ctypes.data_as(_u8p), int(dh), int(dw))
+    return out
+
+
+def esr_pre(bgr):
+    """preprocess_esr (core/merged_pipeline.py:219-223) without the batch axis: [h,w,3] BGR uint8 -> [3,h,w] RGB float32."""
+    s = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty((3,) + s.shape[:2], np.float32)
+    lib().vo_esr_pre(s.ctypes.data_as(_u8p), s.shape[0], s.shape[1], out.ctypes.data_as(_f32p))
+    return out
+
+
+def esr_post(chw):
+    """postprocess_esr (core/merged_pipeline.py:225-229) without the batch axis: [3,h,w] RGB float32 -> [h,w,3] BGR uint8."""
+    t, pt = _f(chw)
+    out = np.empty(t.shape[1:] + (3,), np.uint8)
+    lib().vo_esr_post(pt, t.shape[1], t.shape[2], out.ctypes.data_as(_u8p))
+    return out
+
+
+def add_weighted_u8(a, alpha, b, beta, gamma=0.0):
+    """cv2.addWeighted(a, alpha, b, beta, gamma) on uint8 (unpinned: float32 fma form, round half to even)."""
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    out = np.empty_like(a)
+    lib().vo_add_weighted_u8(a.ctypes.data_as(_u8p), C.c_double(alpha), b.ctypes.data_as(_u8p), C.c_double(beta), C.c_double(gamma),
+                             C.c_longlong(a.size), out.ctypes.data_as(_u8p))
+    return out

@@ -1,0 +1,170 @@
+"""GPU parity of the up-scale stage glue (core/merged_pipeline.py:219-284) and of the uint8 INTER_CUBIC / INTER_AREA
+resizes: every HIP kernel against the oracle bit for bit, then ``run_esrgan`` end to end -- the network's own prediction is taken from
+the device, everything around it is recomputed with the oracle and must agree exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def R():
+    from visiondepth3d_amd.render_3d import Renderer
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("shape,dsize", [((37, 53), (74, 106)), ((37, 53), (91, 140)), ((64, 48), (48, 36)), ((30, 40, 3), (120, 160)),
+                                         ((50, 70, 3), (20, 33)), ((5, 4), (17, 9)), ((1, 9), (3, 27)), ((270, 480), (1080, 1920)),
+                                         ((540, 960, 3), (2160, 3840)), ((432, 768, 3), (108, 192)), ((33, 21, 3), (33, 21))])
+def test_resize_cubic_u8_bit_exact(R, oracle, shape, dsize):
+    rng = np.random.default_rng(shape[0] * 131 + dsize[1])
+    a = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = R.resize_cubic_u8(T(a), *dsize).cpu().numpy()
+    assert np.array_equal(got, oracle.resize_cubic_u8(a, *dsize))
+
+
+@pytest.mark.parametrize("shape,dsize", [((64, 96, 3), (32, 48)), ((64, 96, 3), (16, 24)), ((60, 90, 3), (45, 67)), ((1080, 1920, 3), (810, 1440)),
+                                         ((1080, 1920, 3), (270, 480)), ((40, 60, 3), (50, 30)), ((21, 33, 3), (21, 33))])
+def test_resize_area_u8_bit_exact(R, oracle, shape, dsize):
+    rng = np.random.default_rng(shape[0] + dsize[0])
+    a = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = R.resize_area_u8(T(a), *dsize).cpu().numpy()
+    assert np.array_equal(got, oracle.resize_area(a, dsize[1], dsize[0]))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16", "bfloat16"])
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_esr_preprocess_crop(R, oracle, dtype, channels_last):
+    rng = np.random.default_rng(3)
+    f = rng.integers(0, 256, (41, 57, 3), dtype=np.uint8)
+    td = getattr(torch, dtype)
+    for (y0, x0, h, w) in [(0, 0, 41, 57), (5, 9, 20, 31), (40, 56, 1, 1)]:
+        x = R.esr_preprocess(T(f), y0, x0, h, w, dtype=td, channels_last=channels_last)
+        assert tuple(x.shape) == (1, 3, h, w)
+        assert x.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        want = torch.from_numpy(oracle.esr_pre(f[y0:y0 + h, x0:x0 + w])).to(td)      # one rounding from float32, like the kernel
+        assert torch.equal(x[0].cpu(), want)
+
+
+def test_esr_postprocess_window_and_layouts(R, oracle):
+    rng = np.random.default_rng(4)
+    p = (rng.standard_normal((1, 3, 36, 52)) * 0.6 + 0.5).astype(np.float32)
+    p[0, 1, 3, 4] = np.nan
+    want = oracle.esr_post(p[0])
+    for cl in (False, True):
+        t = T(p)
+        if cl:
+            t = t.contiguous(memory_format=torch.channels_last)
+        assert np.array_equal(R.esr_postprocess(t).cpu().numpy(), want)
+        canvas = torch.full((30, 40, 3), 7, dtype=torch.uint8, device="cuda")
+        R.esr_postprocess(t, out=canvas, window=(8, 12, 10, 20), dst_yx=(15, 5))
+        c = canvas.cpu().numpy()
+        assert np.array_equal(c[15:25, 5:25], want[8:18, 12:32])
+        c[15:25, 5:25] = 7
+        assert np.all(c == 7)
+    with pytest.raises(AssertionError):
+        R.esr_postprocess(T(p), out=torch.empty((10, 10, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_add_weighted_u8_bit_exact(R, oracle):
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (90, 121, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (90, 121, 3), dtype=np.uint8)
+    for alpha in (0.85, 0.5, 0.25, 1.0):
+        got = R.add_weighted_u8(T(a), alpha, T(b), 1 - alpha).cpu().numpy()
+        assert np.array_equal(got, oracle.add_weighted_u8(a, alpha, b, 1 - alpha))
+
+
+def _run_esrgan_with_oracle_glue(up, oracle, frame, blend_mode, input_res_pct, target_size, tile, tile_pad):
+    """run_esrgan (core/merged_pipeline.py:237-284) with numpy / oracle glue; only ``net(x)`` runs on the device."""
+    def session(crop):
+        x = torch.from_numpy(oracle.esr_pre(crop))[None].to("cuda", up.dtype).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            return up.net(x).float().cpu().numpy()[0]
+
+    original = frame
+    if input_res_pct != 100:
+        h, w = frame.shape[:2]
+        nh, nw = int(h * input_res_pct / 100), int(w * input_res_pct / 100)
+        frame = oracle.resize_area(frame, nw, nh) if input_res_pct < 100 else oracle.resize_cubic_u8(frame, nh, nw)
+    if tile:
+        h, w = frame.shape[:2]
+        out = np.zeros_like(frame)
+        for y in range(0, h, tile):
+            for x in range(0, w, tile):
+                y0, x0 = max(0, y - tile_pad), max(0, x - tile_pad)
+                y1, x1 = min(h, y + tile + tile_pad), min(w, x + tile + tile_pad)
+                upc = oracle.esr_post(session(frame[y0:y1, x0:x1]))
+                yc0, xc0 = y - y0, x - x0
+                yc1, xc1 = yc0 + min(tile, h - y), xc0 + min(tile, w - x)
+                out[y:y + min(tile, h - y), x:x + min(tile, w - x)] = upc[yc0:yc1, xc0:xc1]
+        upscaled = out
+    else:
+        upscaled = oracle.esr_post(session(frame))
+    s = up.scale
+    upscaled = oracle.resize_cubic_u8(upscaled, frame.shape[0] * s, frame.shape[1] * s)
+    upscaled = oracle.resize_cubic_u8(upscaled, original.shape[0], original.shape[1])
+    if target_size:
+        upscaled = oracle.resize_cubic_u8(upscaled, target_size[1], target_size[0])
+    if blend_mode == "OFF":
+        return upscaled
+    alpha = {"LOW": 0.85, "MEDIUM": 0.5, "HIGH": 0.25}[blend_mode]
+    return oracle.add_weighted_u8(upscaled, alpha, original, 1 - alpha)
+
+
+@pytest.mark.parametrize("model,kw", [
+    ("RealESR_Animex4_fp16", dict(blend_mode="OFF", input_res_pct=100, target_size=None, tile=None, tile_pad=8)),
+    ("RealESR_Animex4_fp16", dict(blend_mode="LOW", input_res_pct=50, target_size=None, tile=None, tile_pad=8)),
+    ("RealESR_Animex4_fp16", dict(blend_mode="OFF", input_res_pct=75, target_size=(200, 120), tile=None, tile_pad=8)),
+    ("RealESR_Gx4_fp16", dict(blend_mode="HIGH", input_res_pct=100, target_size=None, tile=32, tile_pad=8)),
+    ("RealESRGAN_x4_fp16", dict(blend_mode="MEDIUM", input_res_pct=25, target_size=None, tile=None, tile_pad=8)),
+])
+def test_run_esrgan_end_to_end(R, oracle, model, kw):
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.upscale import Upscaler
+    torch.manual_seed(9)
+    # float32 network: the device prediction is deterministic for one input, so device glue and oracle glue see the same numbers
+    up = Upscaler(R, model, dtype=torch.float32)
+    frame, _ = synth.synth_frame(3, 72, 104)
+    got = up.run_esrgan(T(frame), **kw).cpu().numpy()
+    want = _run_esrgan_with_oracle_glue(up, oracle, frame, **kw)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), np.abs(got.astype(int) - want.astype(int)).max()
+
+
+def test_upscale_4x_output_and_fp16_default(R):
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.upscale import Upscaler
+    up = Upscaler(R, "RealESR_Gx4_fp16")
+    assert up.dtype == torch.float16                 # the reference's ONNX exports are fp16
+    frame, _ = synth.synth_frame(1, 54, 96)
+    out = up.upscale(T(frame))
+    assert tuple(out.shape) == (216, 384, 3) and out.dtype == torch.uint8
+
+
+def test_depth_frames_u8_with_inference_size(R, oracle):
+    """a24 with an explicit inference size (core/render_depth.py:1113-1116,1907-1917): prediction at the inference size -> uint8 ->
+    INTER_CUBIC back to the frame size."""
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import DepthPipe, depth_to_u8
+    pipe = DepthPipe("depth-anything-v2-small", device="cuda", renderer=R)
+    frame, _ = synth.synth_frame(2, 180, 320)
+    fr = T(frame)[None]
+    pred = pipe.infer_bgr_u8(fr, (224, 126), at_inference_size=True)
+    assert tuple(pred.shape) == (1, 126, 224)
+    pipe.infer_bgr_u8 = lambda *a, **k: pred        # the network is not run-to-run deterministic (atomics in the GEMMs): pin its output
+    got = pipe.depth_frames_u8(fr, inference_size=(224, 126), invert=True)
+    assert tuple(got.shape) == (1, 180, 320) and got.dtype == torch.uint8
+    small = depth_to_u8(pred, True)[0].cpu().numpy()
+    assert np.array_equal(got[0].cpu().numpy(), oracle.resize_cubic_u8(small, 180, 320))
+    # without an inference size nothing is resized
+    del pipe.infer_bgr_u8
+    full = pipe.depth_frames_u8(fr)
+    assert tuple(full.shape) == (1, 180, 320)

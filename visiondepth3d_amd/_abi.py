@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FMT_HALF_SBS, FMT_FULL_SBS, FMT_VR, FMT_ANAGLYPH, FMT_INTERLACED = range(5)
 FORMAT_IDS = {
@@ -14,7 +14,7 @@ FORMAT_IDS = {
     "Passive Interlaced": FMT_INTERLACED,
 }
 DEPTH_F32, DEPTH_BGR_U8, DEPTH_GRAY_U8 = range(3)
-DT_BF16, DT_F32 = range(2)   # vd3d_dtype
+DT_BF16, DT_F32, DT_F16 = range(3)   # vd3d_dtype (DT_F16: vd3d_esr_preprocess only)
 
 E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4
 

@@ -871,6 +871,61 @@ VD3D_EXPORT int vd3d_heal_missing_pixels(vd3d_ctx* c, const float* warped_chw, c
   return 0;
 }
 
+// cv2.resize(u8, (dw, dh), interpolation=cv2.INTER_CUBIC): a24 with an explicit inference size (core/render_depth.py:1917) and the
+// up-scale stage's size changes (core/merged_pipeline.py:260-264)
+VD3D_EXPORT int vd3d_resize_cubic_u8(vd3d_ctx* c, const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw) {
+  if (!c || !src || !dst || sh < 1 || sw < 1 || dh < 1 || dw < 1 || src == dst) return set_err(VD3D_E_INVALID, "bad argument");
+  if ((long long)sh * sw * cn >= (1ll << 31) || (long long)dh * dw * cn >= (1ll << 31)) return set_err(VD3D_E_INVALID, "image too large");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "resize_cubic");
+  if (!vd_launch_resize_cubic_u8(c->stream, src, sh, sw, cn, dst, dh, dw)) return set_err(VD3D_E_UNSUPPORTED, "resize_cubic_u8: %d channels (1 or 3)", cn);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_resize_area_u8(vd3d_ctx* c, const uint8_t* src_bgr, int sh, int sw, uint8_t* dst_bgr, int dh, int dw) {
+  if (!c || !src_bgr || !dst_bgr || sh < 1 || sw < 1 || dh < 1 || dw < 1 || src_bgr == dst_bgr) return set_err(VD3D_E_INVALID, "bad argument");
+  if ((long long)sh * sw * 3 >= (1ll << 31) || (long long)dh * dw * 3 >= (1ll << 31)) return set_err(VD3D_E_INVALID, "image too large");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "resize_area");
+  if (!vd_launch_resize_area_u8(c->stream, src_bgr, sh, sw, dst_bgr, dh, dw))
+    return set_err(VD3D_E_UNSUPPORTED, "resize_area_u8: %dx%d -> %dx%d exceeds the tap budget (ratio <= 10)", sw, sh, dw, dh);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// preprocess_esr / postprocess_esr / blend_images, core/merged_pipeline.py:219-236
+VD3D_EXPORT int vd3d_esr_preprocess(vd3d_ctx* c, int dtype, const uint8_t* frame_bgr, long long pitch_bytes, int h, int w, int channels_last,
+                                    void* out_rgb) {
+  if (!c || !frame_bgr || !out_rgb || h < 1 || w < 1 || pitch_bytes < 3ll * w) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "esr_pre");
+  if (!vd_launch_esr_pre(c->stream, dtype, frame_bgr, pitch_bytes, h, w, channels_last ? 1 : 0, out_rgb)) return set_err(VD3D_E_INVALID, "bad dtype %d", dtype);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_esr_postprocess(vd3d_ctx* c, const float* pred_rgb, int h, int w, int channels_last, int cy, int cx, int ch, int cw,
+                                     uint8_t* out_bgr, long long pitch_bytes) {
+  if (!c || !pred_rgb || !out_bgr || h < 1 || w < 1 || cy < 0 || cx < 0 || ch < 1 || cw < 1 || cy + ch > h || cx + cw > w || pitch_bytes < 3ll * cw)
+    return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "esr_post");
+  vd_launch_esr_post(c->stream, pred_rgb, h, w, channels_last ? 1 : 0, cy, cx, ch, cw, out_bgr, pitch_bytes);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_add_weighted_u8(vd3d_ctx* c, const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma, long long n,
+                                     uint8_t* out) {
+  if (!c || !a || !b || !out || n < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "add_weighted");
+  vd_launch_add_weighted_u8(c->stream, a, (float)alpha, b, (float)beta, (float)gamma, n, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // a24: depth-net prediction [B][ph][pw] float32 -> uint8 depth planes [B][H][W] (bicubic post-process + per-frame min-max)
 VD3D_EXPORT int vd3d_depth_handoff(vd3d_ctx* c, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint8_t* out_gray) {
   if (!c || !pred || !out_gray || B < 1 || ph < 1 || pw < 1 || H < 1 || W < 1) return set_err(VD3D_E_INVALID, "bad argument");

@@ -146,5 +146,12 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
                             int use_override, int bar_w, int bar_s, uint8_t* out);
 
+// ---- vd3d_upscale.hip
+bool vd_launch_resize_cubic_u8(hipStream_t s, const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw);
+bool vd_launch_resize_area_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
+bool vd_launch_esr_pre(hipStream_t s, int dtype, const uint8_t* src, long long pitch, int h, int w, int hwc, void* out);
+void vd_launch_esr_post(hipStream_t s, const float* pred, int h, int w, int hwc, int cy, int cx, int ch, int cw, uint8_t* dst, long long pitch);
+void vd_launch_add_weighted_u8(hipStream_t s, const uint8_t* a, float alpha, const uint8_t* b, float beta, float gamma, long long n, uint8_t* out);
+
 // ---- vd3d_heal.hip
 void vd_launch_heal(hipStream_t s, const float* warped, const float* orig, const float* edge_or_null, int H, int W, float hs, float* out);

@@ -457,36 +457,6 @@ struct vd_mux_geom {
   int frac;            // 1: non-integer (or mixed) INTER_AREA down-scale, generic area table path; 2: some dimension up-scales
   double sx, sy;       // OpenCV's scale = 1./((double)dsize/ssize)
 };
-// hal::resize linear coefficients in "area mode" (INTER_AREA with an up-scaling dimension), one destination index
-VD_DEV void vd_area_lin_coef(int ssize, int dsize, int d, int* idx, int* a0, int* a1) {
-  const double inv = (double)dsize / ssize, scale = 1.0 / inv;
-  int sx = (int)floor(d * scale);
-  float fx = (float)((d + 1) - (sx + 1) * inv);
-  fx = fx <= 0 ? 0.f : fx - floorf(fx);
-  if (sx < 0) { fx = 0.f; sx = 0; }
-  if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
-  *idx = sx;
-  *a0 = (int)rintf((1.f - fx) * 2048.f);
-  *a1 = (int)rintf(fx * 2048.f);
-}
-// computeResizeAreaTab (OpenCV resize.cpp) for ONE destination index: consecutive source indices s0..s0+n-1 with weights a[].
-#define VD_AREA_MAXT 12
-VD_DEV int vd_area_taps(int ssize, double scale, int d, int* s0, float* a) {
-  const double fsx1 = d * scale, fsx2 = fsx1 + scale;
-  const double cell = scale < (double)ssize - fsx1 ? scale : (double)ssize - fsx1;
-  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
-  sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
-  sx1 = sx1 < sx2 ? sx1 : sx2;
-  int n = 0;
-  *s0 = sx1;
-  if (sx1 - fsx1 > 1e-3) { *s0 = sx1 - 1; a[n++] = (float)((sx1 - fsx1) / cell); }
-  for (int sx = sx1; sx < sx2 && n < VD_AREA_MAXT; ++sx) a[n++] = (float)(1.0 / cell);
-  if (fsx2 - sx2 > 1e-3 && n < VD_AREA_MAXT) {
-    double t = fsx2 - sx2; t = t < 1.0 ? t : 1.0; t = t < cell ? t : cell;
-    a[n++] = (float)(t / cell);
-  }
-  return n;
-}
 __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, vd_mux_geom m,
                                                    float kn, float kc, uint8_t* __restrict__ out) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);

@@ -348,6 +348,22 @@ class DepthPipe:
         pred = F.interpolate(pred.float().unsqueeze(1), size=(oH, oW), mode="bicubic", align_corners=False).squeeze(1)
         return pred
 
+    @torch.no_grad()
+    def depth_frames_u8(self, frames_bgr: torch.Tensor, inference_size=None, invert: bool = False) -> torch.Tensor:
+        """The depth tab's per-frame product (core/render_depth.py:1907-1917) for uint8 [B,H,W,3] BGR frames: the prediction at the size
+        the pipeline saw (the frame, or ``inference_size`` = (W', H')) -> ``convert_depth_to_grayscale`` -> optional ``255 -`` ->
+        ``cv2.resize(..., (W, H), INTER_CUBIC)``.  Returns uint8 [B,H,W] on the device (what the reference writes to its depth video)."""
+        B, H, W, _ = frames_bgr.shape
+        u8 = depth_to_u8(self.infer_bgr_u8(frames_bgr, inference_size, at_inference_size=True), invert)
+        if tuple(u8.shape[-2:]) == (H, W):
+            return u8
+        if self.renderer is None:
+            raise RuntimeError("depth_frames_u8 with an inference size needs DepthPipe(renderer=...) for the uint8 INTER_CUBIC resize")
+        out = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
+        for b in range(B):
+            self.renderer.resize_cubic_u8(u8[b], H, W, out=out[b])
+        return out
+
     def __call__(self, images, inference_size=None):
         """Reference protocol: list of PIL images (or HxWx3 uint8 RGB arrays) -> list of dicts; ``predicted_depth`` has the size
         of the image the pipeline saw (the frame, or ``inference_size`` when given -- the caller then resizes the uint8 map back

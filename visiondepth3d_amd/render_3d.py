@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, DT_BF16, DT_F32, FrameScalars, RenderParams, ShiftParams, State
+from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, DT_BF16, DT_F16, DT_F32, FrameScalars, RenderParams, ShiftParams, State
 from .geometry import aspect_ratios  # noqa: F401  (re-exported like the reference module does)
 from .params import render_kwargs_to_params, shift_params_from_kwargs
 
@@ -288,6 +288,81 @@ class Renderer:
             out = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
         self._enter(p, out)
         _lib.check(self._L.vd3d_depth_handoff(self._ctx, _ptr(p), B, ph, pw, int(H), int(W), int(bool(invert)), _ptr(out)))
+        return out
+
+    # ---- uint8 glue shared by the depth hand-off (explicit inference size) and the up-scale stage ----
+    def resize_cubic_u8(self, src: torch.Tensor, dh: int, dw: int, out: torch.Tensor | None = None) -> torch.Tensor:
+        """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC) for uint8 [h,w] / [h,w,3] tensors (core/render_depth.py:1917,
+        core/merged_pipeline.py:260-264)."""
+        if src.dtype != torch.uint8 or src.dim() not in (2, 3) or (src.dim() == 3 and src.shape[2] != 3):
+            raise AssertionError("resize_cubic_u8 takes uint8 [h,w] or [h,w,3]")
+        s = src.to(self.device).contiguous()
+        cn = 1 if s.dim() == 2 else 3
+        if out is None:
+            out = torch.empty((int(dh), int(dw)) + ((3,) if cn == 3 else ()), dtype=torch.uint8, device=self.device)
+        self._enter(s, out)
+        _lib.check(self._L.vd3d_resize_cubic_u8(self._ctx, _ptr(s), int(s.shape[0]), int(s.shape[1]), cn, _ptr(out), int(dh), int(dw)))
+        return out
+
+    def resize_area_u8(self, src: torch.Tensor, dh: int, dw: int) -> torch.Tensor:
+        """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) for uint8 BGR [h,w,3] (core/merged_pipeline.py:246-248)."""
+        if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
+            raise AssertionError("resize_area_u8 takes uint8 [h,w,3]")
+        s = src.to(self.device).contiguous()
+        out = torch.empty((int(dh), int(dw), 3), dtype=torch.uint8, device=self.device)
+        self._enter(s, out)
+        _lib.check(self._L.vd3d_resize_area_u8(self._ctx, _ptr(s), int(s.shape[0]), int(s.shape[1]), _ptr(out), int(dh), int(dw)))
+        return out
+
+    def esr_preprocess(self, frame_bgr: torch.Tensor, y0=0, x0=0, h=None, w=None, dtype=torch.float32, channels_last=True):
+        """preprocess_esr (core/merged_pipeline.py:219-223) of the [y0:y0+h, x0:x0+w] crop of a uint8 BGR frame: a [1,3,h,w] RGB
+        tensor scaled by 1/255 (channels_last memory by default -- what the convolutions want)."""
+        f = frame_bgr.to(self.device).contiguous()
+        H, W = int(f.shape[0]), int(f.shape[1])
+        h = H - y0 if h is None else int(h)
+        w = W - x0 if w is None else int(w)
+        if f.dtype != torch.uint8 or f.dim() != 3 or f.shape[2] != 3 or y0 < 0 or x0 < 0 or y0 + h > H or x0 + w > W:
+            raise AssertionError("esr_preprocess takes a uint8 [H,W,3] frame and a crop inside it")
+        out = torch.empty((1, 3, h, w), dtype=dtype, device=self.device)
+        if channels_last:
+            out = out.contiguous(memory_format=torch.channels_last)
+        self._enter(f, out)
+        base = f.data_ptr() + (y0 * W + x0) * 3
+        _lib.check(self._L.vd3d_esr_preprocess(self._ctx, {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}[dtype], C.c_void_p(base), 3 * W, h, w,
+                                               int(bool(channels_last)), _ptr(out)))
+        return out
+
+    def esr_postprocess(self, pred: torch.Tensor, out: torch.Tensor | None = None, window=None, dst_yx=(0, 0)) -> torch.Tensor:
+        """postprocess_esr (core/merged_pipeline.py:225-229): [1,3,h,w] RGB float -> uint8 BGR.  ``window`` = (cy, cx, ch, cw) of the
+        prediction is written at ``dst_yx`` of ``out`` (the tile placement of _esrgan_tiled :266-284); default the whole prediction."""
+        p = pred.to(self.device, torch.float32)
+        if p.dim() != 4 or p.shape[0] != 1 or p.shape[1] != 3:
+            raise AssertionError("esr_postprocess takes a [1,3,h,w] prediction")
+        hwc = p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous()
+        if not hwc:
+            p = p.contiguous()
+        h, w = int(p.shape[2]), int(p.shape[3])
+        cy, cx, ch, cw = (0, 0, h, w) if window is None else [int(v) for v in window]
+        if out is None:
+            out = torch.empty((ch, cw, 3), dtype=torch.uint8, device=self.device)
+        dy, dx = int(dst_yx[0]), int(dst_yx[1])
+        OH, OW = int(out.shape[0]), int(out.shape[1])
+        if out.dtype != torch.uint8 or not out.is_contiguous() or dy < 0 or dx < 0 or dy + ch > OH or dx + cw > OW:
+            raise AssertionError("esr_postprocess: the window does not fit the output")
+        self._enter(p, out)
+        _lib.check(self._L.vd3d_esr_postprocess(self._ctx, _ptr(p), h, w, int(hwc), cy, cx, ch, cw,
+                                                C.c_void_p(out.data_ptr() + (dy * OW + dx) * 3), 3 * OW))
+        return out
+
+    def add_weighted_u8(self, a: torch.Tensor, alpha: float, b: torch.Tensor, beta: float, gamma: float = 0.0) -> torch.Tensor:
+        """cv2.addWeighted on uint8 tensors of one shape (blend_images, core/merged_pipeline.py:231-236)."""
+        a = a.to(self.device).contiguous()
+        b = b.to(self.device).contiguous()
+        if a.dtype != torch.uint8 or b.dtype != torch.uint8 or a.shape != b.shape:
+            raise AssertionError("add_weighted_u8 takes two uint8 tensors of one shape")
+        out = torch.empty_like(a)
+        self._enter(a, b, out)
+        _lib.check(self._L.vd3d_add_weighted_u8(self._ctx, _ptr(a), float(alpha), _ptr(b), float(beta), float(gamma), a.numel(), _ptr(out)))
         return out
 
     def heal_missing_pixels(self, warped_frame, original_frame, edge_mask=None, heal_strength=0.5) -> torch.Tensor:
