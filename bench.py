@@ -311,6 +311,89 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     return res
 
 
+def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
+    """BASELINE configs[4] on one GPU: 1080p frames -> DA-V2-Small (float32) -> DIBR Half-SBS 1920x1080 -> run_esrgan(input_res_pct=50,
+    target_size=(3840, 2160)) with the reference's default model (RealESR_Gx4_fp16, fp16 like its ONNX export).  A plain serial chain on
+    one stream (no cross-batch overlap): a sub-record, never the headline."""
+    torch = env.torch
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import DepthPipe
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    from visiondepth3d_amd.render_3d import Renderer
+    from visiondepth3d_amd.upscale import Upscaler
+    sh, sw = 1080, 1920
+    p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
+    r = Renderer(env.local_rank)
+    r.new_clip()
+    pipe = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.float32, renderer=r)
+    up = Upscaler(r, "RealESR_Gx4_fp16")
+    frames_np, _ = synth.synth_clip(B, sh, sw, start=0)
+    frames = torch.stack([torch.from_numpy(f) for f in frames_np]).cuda()
+    dbuf = torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda")
+    outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
+    ev = []
+    last = [None]
+
+    def step(timed):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        pred = pipe.infer_bgr_u8(frames, raw=True)
+        r.depth_handoff(pred, sh, sw, out=dbuf)
+        e[1].record()
+        for j in range(B):
+            r.render_frame(frames[j], dbuf[j], p, out=outs[j])
+        e[2].record()
+        for j in range(B):
+            last[0] = up.run_esrgan(outs[j], input_res_pct=50, target_size=(3840, 2160))
+        e[3].record()
+        if timed:
+            ev.append(e)
+
+    for _ in range(warmup):
+        step(False)
+    env.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    env.fence()
+    dt = time.perf_counter() - t0
+    ms = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) / B for i in range(3)]
+    # the network alone, for its MFMA figure
+    flops = [0.0]
+
+    def hook(mod, inp, out):
+        flops[0] += 2.0 * out.numel() * (mod.in_channels // mod.groups) * mod.kernel_size[0] * mod.kernel_size[1]
+
+    hs = [m.register_forward_hook(hook) for m in up.net.modules() if isinstance(m, torch.nn.Conv2d)]
+    x = r.esr_preprocess(r.resize_area_u8(outs[0], 540, 960), dtype=up.dtype)
+    with torch.no_grad():
+        up.net(x)
+    for h in hs:
+        h.remove()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    with torch.no_grad():
+        for _ in range(5):
+            up.net(x)
+    b.record()
+    torch.cuda.synchronize()
+    net_ms = a.elapsed_time(b) / 5
+    out_shape = list(last[0].shape)
+    del pipe, up
+    r.close()
+    torch.cuda.empty_cache()
+    return {"workload": "1080p-dav2s-dibr-esrgan4k",
+            "description": "BASELINE configs[4] on one GPU: 1080p, DA-V2-Small (float32) + DIBR Half-SBS + Real-ESRGAN x4 (RealESR_Gx4, fp16 like "
+                           "the reference's ONNX export) through run_esrgan(input_res_pct=50, target_size=(3840, 2160)); serial chain, one stream",
+            "value": round(steps * B / dt, 3), "unit": "stereo-pairs/s", "steps": steps, "warmup": warmup, "frames_timed": steps * B,
+            "ms_per_step": round(dt / steps * 1e3, 3), "dtype": "f32 depth net + f32 DIBR + fp16 up-scale net (the reference's precisions)",
+            "output": out_shape, "stage_ms_per_frame": {"depth_net+handoff": round(ms[0], 3), "dibr": round(ms[1], 3), "run_esrgan": round(ms[2], 3)},
+            "roofline_upscale_net": {"bound": "mfma", "kernel": "SRVGGNetCompact 64x32 on a 960x540 frame (MIOpen convolutions through PyTorch-ROCm, fp16)",
+                                     "achieved": round(flops[0] / (net_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                                     "frac": round(flops[0] / (net_ms * 1e-3) / 1e12 / 2500.0, 4), "flops_per_frame": flops[0],
+                                     "avg_forward_ms": round(net_ms, 3)}}
+
+
 def copy_yardstick(env):
     """measured streaming-copy rate: device-to-device copy of 1 GiB through the library's own copy kernel"""
     torch = env.torch
@@ -437,9 +520,13 @@ def main():
     ap.add_argument("--no-pixel-overlap", dest="pixel_overlap", action="store_false")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
+    ap.add_argument("--upscale-only", action="store_true", help="measure only the configs[4] sub-record (1080p depth + DIBR + Real-ESRGAN x4)")
     args = ap.parse_args()
 
     env = Env(args)
+    if args.upscale_only:
+        print(json.dumps(run_upscale_chain(env, args)), flush=True)
+        return
     single = args.workload is not None
     wl = args.workload or HEADLINE
     prof = not args.no_profile
@@ -453,6 +540,10 @@ def main():
         rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
         subs = {"4k-dibr": (r4, None), "1080p-dav2s-dibr": (r1e, None), "1080p-dibr": (r1d, None), "4k-dav2b-dibr-bf16": (rbf, None)}
         roof_src = r4
+        try:
+            up_rec = run_upscale_chain(env, args)
+        except Exception as e:   # a sub-record must never take the headline down
+            up_rec = {"workload": "1080p-dav2s-dibr-esrgan4k", "error": str(e)[:300]}
 
     if env.rank == 0:
         copy_gbs = copy_yardstick(env)
@@ -501,6 +592,7 @@ def main():
                     extra["note"] = ("same workload as the headline with the depth net in bfloat16: NOT like-for-like with the reference "
                                      "(float32); its uint8 depth-plane deviation is measured by tests/test_hip_depth_e2e.py")
                 sr[name] = sub_record(rs, extra)
+            sr[up_rec["workload"]] = up_rec
             res["sub_records"] = sr
         if env.world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(sh, sw, seconds_budget=12.0, max_frames=8 if sh > 1080 else 30)
