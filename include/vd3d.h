@@ -323,6 +323,12 @@ typedef enum vd3d_preview {
   VD3D_PREVIEW_RED_BLUE = 4      /* (right.B, right.G, left.R) */
 } vd3d_preview;
 int vd3d_preview_image(vd3d_ctx* ctx, int type, const uint8_t* left_bgr, const uint8_t* right_bgr, int h, int w, uint8_t* out_bgr);
+/* The colour-mapped types of the same function (core/preview_utils.py:42-66): type 0 "Shift Heatmap" (cv2.normalize NORM_MINMAX),
+ * 1 "Shift Heatmap (Abs)", 2 "Shift Heatmap (Clipped +-5px)", 3 "Feather Mask"; shift_map: float32 [h][w] (pixel_shift_cuda's third return),
+ * lut_bgr_dev: 256 x 3 uint8 BGR table in device memory -- OpenCV's COLORMAP_JET (types 0-2) / COLORMAP_BONE (3) as the caller obtained it
+ * (cv2.applyColorMap(np.arange(256, dtype=np.uint8), cmap)); the library holds no copy of those tables.  "Overlay Arrows" (OpenCV's line
+ * rasteriser) is not built. */
+int vd3d_preview_heatmap(vd3d_ctx* ctx, int type, const float* shift_map, int h, int w, const uint8_t* lut_bgr_dev, uint8_t* out_bgr);
 
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux

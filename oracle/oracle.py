@@ -394,3 +394,14 @@ def add_weighted_u8(a, alpha, b, beta, gamma=0.0):
     lib().vo_add_weighted_u8(a.ctypes.data_as(_u8p), C.c_double(alpha), b.ctypes.data_as(_u8p), C.c_double(beta), C.c_double(gamma),
                              C.c_longlong(a.size), out.ctypes.data_as(_u8p))
     return out
+
+
+def preview_heatmap(kind, shift, lut):
+    """The colour-mapped previews of generate_preview_image (core/preview_utils.py:42-66): kind 0 shift, 1 |shift|, 2 clipped, 3 feather
+    mask; ``lut``: uint8 [256,3] BGR."""
+    s, ps = _f(np.squeeze(shift))
+    lut = np.ascontiguousarray(lut, np.uint8).reshape(256, 3)
+    out = np.empty(s.shape + (3,), np.uint8)
+    rc = lib().vo_preview_heatmap(int(kind), ps, s.shape[0], s.shape[1], lut.ctypes.data_as(_u8p), out.ctypes.data_as(_u8p))
+    assert rc == 0
+    return out

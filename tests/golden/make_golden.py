@@ -388,6 +388,18 @@ def gen_previews():
         for pt in PREVIEW_TYPES:
             out[f"{tag}__{pt}"] = pu.generate_preview_image(pt, left, right, shift, w, h)
     save("previews.npz", **out)
+    # the colour-mapped types whose index arithmetic is plain numpy (:52-66); cv2.normalize (the two min-max heat-maps) is not stubbed.
+    # applyColorMap is ref_stubs' table look-up through a synthetic table, stored next to the outputs.
+    out = {"lut_JET": ref_stubs.test_colormap(ref_stubs.COLORMAP_JET), "lut_BONE": ref_stubs.test_colormap(ref_stubs.COLORMAP_BONE)}
+    rng = np.random.default_rng(77)
+    for tag, (h, w) in {"even": (54, 96), "odd": (37, 75)}.items():
+        shift = (rng.standard_normal((1, h, w)) * 3.5).astype(np.float32)
+        shift[0, 0, :8] = [-5.0, 5.0, 0.0, -0.0, 4.9999995, -7.5, 5.1, 0.02]
+        out[f"{tag}__shift"] = shift
+        left = synth.synth_frame(1, h, w)[0]
+        for pt in ("Shift Heatmap (Clipped \u00b15px)", "Feather Mask"):
+            out[f"{tag}__{pt}"] = pu.generate_preview_image(pt, left, left, torch.from_numpy(shift), w, h)
+    save("previews_heat.npz", **out)
 
 
 # ------------------------------------------------------------------------------------------

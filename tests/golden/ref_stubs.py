@@ -208,6 +208,20 @@ def merge(chs):
     return np.stack(chs, axis=2)
 
 
+COLORMAP_BONE, COLORMAP_JET = 1, 2
+
+
+def test_colormap(cmap):
+    """A synthetic 256 x 3 table per colour-map id: cv2's own tables are not available here, and what the fixtures pin is the INDEX
+    arithmetic of generate_preview_image -- applyColorMap itself is a table look-up."""
+    i = np.arange(256, dtype=np.int64)
+    return np.stack([(i * 3 + 17 * cmap) & 255, 255 - i, (i * i + cmap) & 255], axis=1).astype(np.uint8)
+
+
+def applyColorMap(src, cmap):
+    return test_colormap(cmap)[np.asarray(src, np.uint8)]
+
+
 def bitwise_and(a, b):
     return np.bitwise_and(a, b)
 
@@ -322,7 +336,7 @@ def install():
         "COLOR_BGR2RGB", "COLOR_RGB2BGR", "COLOR_BGR2GRAY", "COLOR_RGB2GRAY", "COLOR_GRAY2BGR",
         "INTER_NEAREST", "INTER_LINEAR", "INTER_CUBIC", "INTER_AREA",
         "CAP_PROP_POS_FRAMES", "CAP_PROP_FRAME_WIDTH", "CAP_PROP_FRAME_HEIGHT", "CAP_PROP_FPS",
-        "CAP_PROP_FRAME_COUNT", "cvtColor", "filter2D", "resize", "split", "merge", "absdiff", "bitwise_and",
+        "CAP_PROP_FRAME_COUNT", "cvtColor", "filter2D", "resize", "split", "merge", "absdiff", "bitwise_and", "COLORMAP_BONE", "COLORMAP_JET", "applyColorMap",
         "VideoWriter_fourcc", "VideoCapture", "VideoWriter")}
     _mod("cv2", _vd3d_stub=True, **cv2_attrs)
 

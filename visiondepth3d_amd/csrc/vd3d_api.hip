@@ -978,6 +978,17 @@ VD3D_EXPORT int vd3d_preview_image(vd3d_ctx* c, int type, const uint8_t* left_bg
   return 0;
 }
 
+// the colour-mapped previews of generate_preview_image (core/preview_utils.py:42-66); lut_bgr_dev: the caller's 256 x 3 BGR table in HBM
+VD3D_EXPORT int vd3d_preview_heatmap(vd3d_ctx* c, int type, const float* shift_map, int h, int w, const uint8_t* lut_bgr_dev, uint8_t* out_bgr) {
+  if (!c || !shift_map || !lut_bgr_dev || !out_bgr || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->mm_cap < 1) { HIPCHK(re_alloc(&c->mm, (size_t)3)); c->mm_cap = 1; }
+  if (!vd_launch_preview_heatmap(c->stream, type, shift_map, h, w, lut_bgr_dev, c->mm, out_bgr))
+    return set_err(VD3D_E_UNSUPPORTED, "heat-map type %d (0 shift, 1 |shift|, 2 clipped, 3 feather mask)", type);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
   if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

@@ -146,6 +146,8 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
                             int use_override, int bar_w, int bar_s, uint8_t* out);
 
+// ---- vd3d_heatmap.hip
+bool vd_launch_preview_heatmap(hipStream_t s, int type, const float* shift, int h, int w, const uint8_t* lut_dev, uint32_t* mm, uint8_t* out);
 // ---- vd3d_upscale.hip
 bool vd_launch_resize_cubic_u8(hipStream_t s, const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw);
 bool vd_launch_resize_area_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
