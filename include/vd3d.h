@@ -263,6 +263,17 @@ int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slo
 int vd3d_heal_missing_pixels(vd3d_ctx* ctx, const float* warped_chw, const float* original_chw, const float* edge_mask_or_null,
                              int H, int W, double heal_strength, float* out_chw);
 
+/* ---- optional NV12 wire format at the frame I/O boundary.  The reference moves bgr24 (cv2.VideoCapture.read() in,
+ * `ffmpeg -f rawvideo -pix_fmt bgr24` out, core/render_3d.py:987,1222,1143-1163,1422-1427) and leaves colour conversion to ffmpeg on
+ * the host; with a decoder that emits NV12 and `-pix_fmt nv12` on the encoder pipe the wire carries 1.5 bytes per pixel and the
+ * conversion runs on the frame already in HBM.  BT.601 limited range, 20-bit fixed point (OpenCV's cvtColor constants = swscale's
+ * default matrix); no reference counterpart to be bit-exact with.  h and w even; pitches in bytes; uv_plane holds h/2 rows of
+ * interleaved (U, V). */
+int vd3d_nv12_to_bgr(vd3d_ctx* ctx, const uint8_t* y_plane, long long y_pitch, const uint8_t* uv_plane, long long uv_pitch, int h, int w,
+                     uint8_t* out_bgr);
+int vd3d_bgr_to_nv12(vd3d_ctx* ctx, const uint8_t* bgr, int h, int w, uint8_t* y_plane, long long y_pitch, uint8_t* uv_plane,
+                     long long uv_pitch);
+
 /* ---- cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC) on uint8 images with cn = 1 or 3 interleaved channels: the resize of
  * the uint8 depth map back to the source size when the depth tab runs at an explicit inference size (a24,
  * core/render_depth.py:1914-1917) and the size changes of the up-scale stage (core/merged_pipeline.py:260-264).  OpenCV's

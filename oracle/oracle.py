@@ -405,3 +405,20 @@ def preview_heatmap(kind, shift, lut):
     rc = lib().vo_preview_heatmap(int(kind), ps, s.shape[0], s.shape[1], lut.ctypes.data_as(_u8p), out.ctypes.data_as(_u8p))
     assert rc == 0
     return out
+
+
+def nv12_to_bgr(nv12):
+    """uint8 [h*3/2, w] NV12 -> uint8 BGR [h,w,3] (BT.601 limited range, 20-bit fixed point; no reference counterpart)."""
+    t = np.ascontiguousarray(nv12, np.uint8)
+    h, w = t.shape[0] * 2 // 3, t.shape[1]
+    out = np.empty((h, w, 3), np.uint8)
+    lib().vo_nv12_to_bgr(t.ctypes.data_as(_u8p), h, w, out.ctypes.data_as(_u8p))
+    return out
+
+
+def bgr_to_nv12(bgr):
+    t = np.ascontiguousarray(bgr, np.uint8)
+    h, w = t.shape[:2]
+    out = np.empty((h * 3 // 2, w), np.uint8)
+    lib().vo_bgr_to_nv12(t.ctypes.data_as(_u8p), h, w, out.ctypes.data_as(_u8p))
+    return out

@@ -168,3 +168,25 @@ def test_depth_frames_u8_with_inference_size(R, oracle):
     del pipe.infer_bgr_u8
     full = pipe.depth_frames_u8(fr)
     assert tuple(full.shape) == (1, 180, 320)
+
+
+# ---- optional NV12 wire format --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w", [(2, 2), (54, 96), (270, 482), (1080, 1920), (2160, 3840)])
+def test_nv12_both_ways_bit_exact_and_round_trip(R, oracle, h, w):
+    from visiondepth3d_amd import synth
+    frame = synth.synth_frame(4, h, w)[0] if h >= 16 else np.random.default_rng(0).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    nv = R.bgr_to_nv12(T(frame)).cpu().numpy()
+    assert nv.shape == (h * 3 // 2, w)
+    assert np.array_equal(nv, oracle.bgr_to_nv12(frame))
+    rng = np.random.default_rng(h + w)
+    noise = rng.integers(0, 256, (h * 3 // 2, w), dtype=np.uint8)           # every code value, in and out of the legal range
+    for src in (nv, noise):
+        assert np.array_equal(R.nv12_to_bgr(T(src)).cpu().numpy(), oracle.nv12_to_bgr(src))
+    # luma survives a round trip within the 8-bit quantisation of two 20-bit fixed-point maps
+    back = R.nv12_to_bgr(T(nv)).cpu().numpy().astype(int)
+    y0 = (0.114 * frame[..., 0] + 0.587 * frame[..., 1] + 0.299 * frame[..., 2])
+    y1 = (0.114 * back[..., 0] + 0.587 * back[..., 1] + 0.299 * back[..., 2])
+    dy = np.abs(y0 - y1)            # saturated chroma at hard edges may clip: bound the bulk, not the worst pixel
+    assert dy.mean() <= 1.0 and np.percentile(dy, 99) <= 3.0
+    with pytest.raises(AssertionError):
+        R.bgr_to_nv12(T(np.zeros((5, 4, 3), np.uint8)))

@@ -190,6 +190,7 @@ def test_render_sbs_3d_shell_read_order_writer_and_window(monkeypatch):
 
 def test_render_sbs_3d_shell_cancel_blank_and_ffmpeg_pipe(monkeypatch):
     import sys
+    import numpy as np
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import ref_stubs
     from visiondepth3d_amd import video_io
@@ -250,6 +251,27 @@ def test_render_sbs_3d_shell_cancel_blank_and_ffmpeg_pipe(monkeypatch):
     assert len(procs[0].stdin.buf) == 7 * 54 * 96 * 3 and procs[0].stdin.closed and procs[0].waited
     assert video_io.ffmpeg_pipe_command(8, 4, 30.0, "hevc_nvenc", 21, "o.mp4")[-5:] == ["-cq", "21", "-b:v", "0", "o.mp4"]
     assert "-crf" not in video_io.ffmpeg_pipe_command(8, 4, 30.0, "h264_amf", 21, "o.mp4")
+
+    # opt-in NV12 wire format: the frame is converted where it lives and 1.5 bytes per pixel reach the pipe
+    from oracle import oracle as O
+
+    class Nv12Renderer(_FakeRenderer):
+        def bgr_to_nv12(self, t):
+            import torch
+            return torch.from_numpy(O.bgr_to_nv12(t.numpy()))
+    procs.clear()
+    monkeypatch.setattr(video_io, "PIPE_PIX_FMT", "nv12")
+    video_io.render_sbs_3d(**_shell_args(use_ffmpeg=True, selected_ffmpeg_codec="libx264"), renderer=Nv12Renderer())
+    cmd = procs[0].cmd
+    assert cmd[cmd.index("-pix_fmt") + 1] == "nv12" and cmd[cmd.index("-s") + 1] == "96x54"
+    assert len(procs[0].stdin.buf) == 7 * 54 * 96 * 3 // 2
+    first = np.frombuffer(bytes(procs[0].stdin.buf[:54 * 96 * 3 // 2]), np.uint8).reshape(81, 96)
+    assert np.array_equal(first, O.bgr_to_nv12(np.full((54, 96, 3), 1, np.uint8)))
+    # a format whose muxed frame is not the writer frame (interlaced: one canvas written, two opened) stays on bgr24
+    procs.clear()
+    video_io.render_sbs_3d(**_shell_args(use_ffmpeg=True, selected_ffmpeg_codec="libx264", output_format="Passive Interlaced"),
+                           renderer=Nv12Renderer())
+    assert procs[0].cmd[procs[0].cmd.index("-pix_fmt") + 1] == "bgr24"
 
 
 def test_dpt_front_end_matches_the_real_image_processor():

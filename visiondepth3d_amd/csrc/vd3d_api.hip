@@ -989,6 +989,28 @@ VD3D_EXPORT int vd3d_preview_heatmap(vd3d_ctx* c, int type, const float* shift_m
   return 0;
 }
 
+// optional NV12 wire format at the frame I/O boundary (vd3d_nv12.hip)
+VD3D_EXPORT int vd3d_nv12_to_bgr(vd3d_ctx* c, const uint8_t* y_plane, long long y_pitch, const uint8_t* uv_plane, long long uv_pitch, int h, int w,
+                                 uint8_t* out_bgr) {
+  if (!c || !y_plane || !uv_plane || !out_bgr || h < 2 || w < 2 || (h & 1) || (w & 1) || y_pitch < w || uv_pitch < w)
+    return set_err(VD3D_E_INVALID, "bad argument (NV12 needs even h and w)");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "nv12_in");
+  vd_launch_nv12_to_bgr(c->stream, y_plane, uv_plane, h, w, y_pitch, uv_pitch, out_bgr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+VD3D_EXPORT int vd3d_bgr_to_nv12(vd3d_ctx* c, const uint8_t* bgr, int h, int w, uint8_t* y_plane, long long y_pitch, uint8_t* uv_plane,
+                                 long long uv_pitch) {
+  if (!c || !y_plane || !uv_plane || !bgr || h < 2 || w < 2 || (h & 1) || (w & 1) || y_pitch < w || uv_pitch < w)
+    return set_err(VD3D_E_INVALID, "bad argument (NV12 needs even h and w)");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "nv12_out");
+  vd_launch_bgr_to_nv12(c->stream, bgr, h, w, y_plane, uv_plane, y_pitch, uv_pitch);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
   if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

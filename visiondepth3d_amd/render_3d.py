@@ -290,6 +290,34 @@ class Renderer:
         _lib.check(self._L.vd3d_depth_handoff(self._ctx, _ptr(p), B, ph, pw, int(H), int(W), int(bool(invert)), _ptr(out)))
         return out
 
+    # ---- optional NV12 wire format at the frame I/O boundary ----
+    def nv12_to_bgr(self, nv12: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """uint8 [h*3/2, w] NV12 frame (h rows of Y, then h/2 rows of interleaved UV: what ``-pix_fmt nv12`` rawvideo carries) ->
+        uint8 BGR [h,w,3]."""
+        t = nv12.to(self.device).contiguous()
+        if t.dtype != torch.uint8 or t.dim() != 2 or t.shape[0] % 3 or t.shape[1] % 2:
+            raise AssertionError("nv12_to_bgr takes a uint8 [h*3/2, w] frame with even h and w")
+        h, w = int(t.shape[0]) * 2 // 3, int(t.shape[1])
+        if h % 2:
+            raise AssertionError("nv12_to_bgr takes a uint8 [h*3/2, w] frame with even h and w")
+        if out is None:
+            out = torch.empty((h, w, 3), dtype=torch.uint8, device=self.device)
+        self._enter(t, out)
+        _lib.check(self._L.vd3d_nv12_to_bgr(self._ctx, _ptr(t), w, C.c_void_p(t.data_ptr() + h * w), w, h, w, _ptr(out)))
+        return out
+
+    def bgr_to_nv12(self, bgr: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """uint8 BGR [h,w,3] -> uint8 [h*3/2, w] NV12 (the frame ``ffmpeg -f rawvideo -pix_fmt nv12`` reads from stdin)."""
+        t = bgr.to(self.device).contiguous()
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3 or t.shape[0] % 2 or t.shape[1] % 2:
+            raise AssertionError("bgr_to_nv12 takes a uint8 [h,w,3] frame with even h and w")
+        h, w = int(t.shape[0]), int(t.shape[1])
+        if out is None:
+            out = torch.empty((h * 3 // 2, w), dtype=torch.uint8, device=self.device)
+        self._enter(t, out)
+        _lib.check(self._L.vd3d_bgr_to_nv12(self._ctx, _ptr(t), h, w, _ptr(out), w, C.c_void_p(out.data_ptr() + h * w), w))
+        return out
+
     # ---- uint8 glue shared by the depth hand-off (explicit inference size) and the up-scale stage ----
     def resize_cubic_u8(self, src: torch.Tensor, dh: int, dw: int, out: torch.Tensor | None = None) -> torch.Tensor:
         """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_CUBIC) for uint8 [h,w] / [h,w,3] tensors (core/render_depth.py:1917,

@@ -42,11 +42,16 @@ def _backend():
     return cv2
 
 
-def ffmpeg_pipe_command(out_w, out_h, fps, encoder, crf_value, output_path):
+# Wire format of the encoder pipe: "bgr24" is the reference's (:1146); "nv12" (opt-in) converts on the device and halves the bytes that
+# cross PCIe and the pipe -- ffmpeg then skips its own RGB -> YUV pass for the yuv420p output.
+PIPE_PIX_FMT = "bgr24"
+
+
+def ffmpeg_pipe_command(out_w, out_h, fps, encoder, crf_value, output_path, pix_fmt="bgr24"):
     """The rawvideo-over-stdin command line of :1143-1161 (bgr24 frames of the writer size in, yuv420p out)."""
     if not isinstance(encoder, str) or not encoder.strip() or encoder not in KNOWN_FFMPEG_ENCODERS:
         encoder = "libx264"
-    cmd = ["ffmpeg", "-y", "-f", "rawvideo", "-vcodec", "rawvideo", "-pix_fmt", "bgr24", "-s", f"{out_w}x{out_h}", "-r", str(fps),
+    cmd = ["ffmpeg", "-y", "-f", "rawvideo", "-vcodec", "rawvideo", "-pix_fmt", pix_fmt, "-s", f"{out_w}x{out_h}", "-r", str(fps),
            "-i", "-", "-an", "-c:v", encoder, "-preset", "slow", "-pix_fmt", "yuv420p"]
     if encoder.startswith("libx"):
         cmd += ["-crf", str(crf_value)]
@@ -69,19 +74,30 @@ def clip_window(total_frames, fps, start_s, end_s):
 class _Sink:
     """One of the reference's two writers behind one write()/close() pair."""
 
-    def __init__(self, cv, output_path, size, fps, use_ffmpeg, fourcc, encoder, crf_value):
+    def __init__(self, cv, output_path, size, fps, use_ffmpeg, fourcc, encoder, crf_value, pix_fmt="bgr24", renderer=None, frame_size=None):
         self.proc = self.writer = None
+        # NV12 only when the muxed frame IS the writer frame (not the interlaced / anaglyph mismatch of :851-858) and 4:2:0 divides it
+        self.nv12 = (bool(use_ffmpeg) and pix_fmt == "nv12" and size[0] % 2 == 0 and size[1] % 2 == 0
+                     and (frame_size is None or tuple(frame_size) == tuple(size)))
+        self.renderer = renderer
         if use_ffmpeg:
-            self.proc = popen(ffmpeg_pipe_command(size[0], size[1], fps, encoder, crf_value, output_path), stdin=subprocess.PIPE)
+            self.proc = popen(ffmpeg_pipe_command(size[0], size[1], fps, encoder, crf_value, output_path,
+                                                  "nv12" if self.nv12 else "bgr24"), stdin=subprocess.PIPE)
         else:
             self.writer = cv.VideoWriter(output_path, cv.VideoWriter_fourcc(*fourcc), fps, size)
             if not self.writer.isOpened():
                 self.writer = None
                 raise OSError("VideoWriter failed to open (codec / fourcc / path)")
 
-    def write(self, frame: np.ndarray) -> bool:
+    def write(self, frame) -> bool:
         if self.proc is not None:
             try:
+                if self.nv12:   # colour conversion on the frame that is still in HBM; 1.5 bytes per pixel come back
+                    import torch
+                    from .render_3d import default_renderer
+                    r = self.renderer or default_renderer()
+                    t = frame if torch.is_tensor(frame) else torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))
+                    frame = r.bgr_to_nv12(t).cpu().numpy()
                 self.proc.stdin.write(np.ascontiguousarray(frame, dtype=np.uint8).tobytes())
             except Exception as e:   # a dead encoder ends the render like in the reference (:1424-1426)
                 print(f"FFmpeg write error: {e}")
@@ -195,7 +211,8 @@ def render_sbs_3d(
                              original_video_width, original_video_height)
         try:
             sink = _Sink(cv, output_path, (geom["writer_w"], geom["writer_h"]), fps, use_ffmpeg, selected_codec,
-                         selected_ffmpeg_codec, crf_value)
+                         selected_ffmpeg_codec, crf_value, pix_fmt=PIPE_PIX_FMT, renderer=renderer,
+                         frame_size=(geom["out_w"], geom["out_h"]))
         except OSError as e:
             print(f"OpenCV VideoWriter failed to open. {e}")
             return
@@ -220,7 +237,7 @@ def render_sbs_3d(
                     return
                 yield f, d
 
-        clip = render_pairs(paired(), renderer=renderer,
+        clip = render_pairs(paired(), renderer=renderer, keep_on_device=sink.nv12,
                            target_ratio=target_ratio, blank_frames=blank, start_frame_idx=first_idx, skip_first=False,
                            output_height=output_height, fg_shift=fg_shift, mg_shift=mg_shift, bg_shift=bg_shift,
                            sharpness_factor=sharpness_factor, output_format=output_format, dof_strength=dof_strength,
