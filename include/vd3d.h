@@ -297,6 +297,16 @@ int vd3d_esr_postprocess(vd3d_ctx* ctx, const float* pred_rgb, int h, int w, int
 int vd3d_add_weighted_u8(vd3d_ctx* ctx, const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma, long long n,
                          uint8_t* out);
 
+/* One body layer of the up-scale network on the matrix cores: y = PReLU(conv3x3(x, stride 1, zero padding 1) + bias), 64 -> 64 channels,
+ * fp16 NHWC [H][W][64] in and out, float32 accumulate (v_mfma_f32_32x32x16_f16).  The reference runs these layers inside its ONNX
+ * session (core/merged_pipeline.py:250-252); realesr-general-x4v3 has 32 of them.
+ *   w_frag: the layer's weight Wt[oc][ic][kh][kw] pre-arranged in fragment order, fp16 [36 steps][2][64 lanes][8]:
+ *           step = (kh*3 + kw)*4 + kc, element [step][t][l][j] = Wt[32 t + (l & 31)][16 kc + 8 (l >> 5) + j][kh][kw]
+ *           (visiondepth3d_amd.upscale.conv_weight_fragments builds it)
+ *   bias, slope_or_null: float32 [64] (slope NULL = no activation).  All pointers 16-byte aligned; x != y. */
+int vd3d_conv3x3_c64_f16(vd3d_ctx* ctx, const void* x_nhwc, int H, int W, const void* w_frag, const float* bias, const float* slope_or_null,
+                         void* y_nhwc);
+
 /* ---- depth hand-off (a24): transformers' bicubic post-process to (H,W) + convert_depth_to_grayscale
  * (core/render_depth.py:585-611,1914-1916) for a batch of B predictions [B][ph][pw] float32 -> uint8 [B][H][W].
  * Replaces the reference's 8-bit depth video on disk while keeping its quantisation. */

@@ -190,3 +190,47 @@ def test_nv12_both_ways_bit_exact_and_round_trip(R, oracle, h, w):
     assert dy.mean() <= 1.0 and np.percentile(dy, 99) <= 3.0
     with pytest.raises(AssertionError):
         R.bgr_to_nv12(T(np.zeros((5, 4, 3), np.uint8)))
+
+
+# ---- body layers on the matrix cores (vd3d_conv3x3_c64_f16) ----------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W", [(16, 32), (17, 33), (5, 7), (1, 1), (64, 96), (135, 240)])
+@pytest.mark.parametrize("act", [True, False])
+def test_conv3x3_c64_f16_vs_float32_reference(R, H, W, act):
+    """fp16 operands, float32 accumulate on the MFMA units vs ATen's float32 convolution of the SAME fp16-rounded operands: the only
+    differences are the summation order (float32) and the final fp16 rounding of the output (2^-11 relative)."""
+    import torch.nn.functional as F
+    from visiondepth3d_amd.upscale import conv_weight_fragments
+    gen = torch.Generator().manual_seed(H * 1000 + W)
+    x = (torch.randn(1, 64, H, W, generator=gen) * 0.7).half()
+    w = (torch.randn(64, 64, 3, 3, generator=gen) * 0.06).half()          # asymmetric in every index
+    b = torch.randn(64, generator=gen) * 0.1
+    sl = torch.rand(64, generator=gen) * 0.5 if act else None
+    ref = F.conv2d(x.float().cuda(), w.float().cuda(), b.cuda(), padding=1)
+    if act:
+        ref = torch.where(ref >= 0, ref, ref * sl.cuda()[None, :, None, None])
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = R.conv3x3_c64(xd, conv_weight_fragments(w).cuda(), b.cuda(), sl.cuda() if act else None)
+    assert got.dtype == torch.float16 and got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.float() - ref).abs()
+    tol = 2e-3 * ref.abs() + 2e-3
+    assert bool((err <= tol).all()), (float(err.max()), float(ref.abs().max()))
+    # and much tighter on average than an fp16-accumulating kernel could be
+    assert float(err.mean()) < 2e-4 * max(1.0, float(ref.abs().mean()))
+
+
+def test_upscaler_hip_body_matches_the_library_convolutions(R):
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.upscale import Upscaler
+    torch.manual_seed(3)
+    a = Upscaler(R, "RealESR_Gx4_fp16", hip_body=True)
+    assert a._body is not None and len(a._body) == 32
+    b = Upscaler(R, "RealESR_Gx4_fp16", net=a.net, hip_body=False)
+    ref = Upscaler(R, "RealESR_Gx4_fp16", net=torch.nn.Module.float(__import__("copy").deepcopy(a.net)), dtype=torch.float32)
+    frame, _ = synth.synth_frame(5, 70, 100)
+    pa, pb, pr = a._infer(T(frame)), b._infer(T(frame)), ref._infer(T(frame))
+    # both fp16 paths sit within fp16 noise of the float32 network, and the hand-written body is not the worse of the two by much
+    ea, eb = float((pa - pr).abs().mean()), float((pb - pr).abs().mean())
+    assert ea < 5e-3 and ea <= 2.0 * eb + 1e-4, (ea, eb)
+    oa, ob = a.upscale(T(frame)), b.upscale(T(frame))
+    d = (oa.int() - ob.int()).abs()
+    assert int(d.max()) <= 3 and float((d > 1).float().mean()) < 0.01

@@ -989,6 +989,19 @@ VD3D_EXPORT int vd3d_preview_heatmap(vd3d_ctx* c, int type, const float* shift_m
   return 0;
 }
 
+// body layer of the up-scale network on the matrix cores (vd3d_conv.hip)
+VD3D_EXPORT int vd3d_conv3x3_c64_f16(vd3d_ctx* c, const void* x_nhwc, int H, int W, const void* w_frag, const float* bias, const float* slope_or_null,
+                                     void* y_nhwc) {
+  if (!c || !x_nhwc || !w_frag || !bias || !y_nhwc || H < 1 || W < 1 || x_nhwc == y_nhwc) return set_err(VD3D_E_INVALID, "bad argument");
+  if (((uintptr_t)x_nhwc | (uintptr_t)y_nhwc | (uintptr_t)w_frag | (uintptr_t)bias | (uintptr_t)slope_or_null) & 15)
+    return set_err(VD3D_E_INVALID, "conv3x3_c64_f16: pointers must be 16-byte aligned");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "conv3x3");
+  if (!vd_launch_conv3x3_c64_f16(c->stream, x_nhwc, H, W, w_frag, bias, slope_or_null, y_nhwc)) return set_err(VD3D_E_HIP, "conv3x3_c64_f16: LDS attribute");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // optional NV12 wire format at the frame I/O boundary (vd3d_nv12.hip)
 VD3D_EXPORT int vd3d_nv12_to_bgr(vd3d_ctx* c, const uint8_t* y_plane, long long y_pitch, const uint8_t* uv_plane, long long uv_pitch, int h, int w,
                                  uint8_t* out_bgr) {

@@ -1,0 +1,131 @@
+// vd3d_conv.hip -- the body layers of the up-scale network: 3x3 convolution, 64 -> 64 channels, stride 1, zero
+// padding 1, + bias + PReLU, fp16 in / fp16 out / float32 accumulate, on the gfx950 matrix cores.  realesr-general-x4v3 is 32 of these
+// layers back to back (animevideov3: 16) at input resolution; they hold > 95 % of the network's flops.
+//
+// Implicit GEMM per workgroup: D[oc][pixel] = sum over (tap, ic) of Wt[oc][tap, ic] * X[pixel + tap][ic]
+//   M = 64 output channels (2 MFMA tiles), N = 512 pixels = a 32 x 16 output tile (16 MFMA tiles), K = 9 taps x 64 channels = 36 steps of 16
+//   v_mfma_f32_32x32x16_f16: A = weights (lane&31 = output channel, lane>>5 = which 8 of the step's 16 input channels),
+//                            B = pixels  (lane&31 = pixel of a 32-pixel row, lane>>5 = the same 8-channel group),
+//                            C/D: col = lane&31 = pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = output channel of the tile
+//   4 waves, wave w owns tile rows 4w .. 4w+3 (4 pixel tiles x 2 channel tiles = 8 accumulators = 128 VGPRs)
+// LDS: the (32+2) x (16+2) x 64 fp16 input tile, CHUNK-major: 8 planes (one per 8-channel / 16-byte chunk) of 612 pixels x 16 B, so that
+//   the 32 lanes of a B-fragment read (consecutive pixels, one chunk) hit consecutive 16-byte slots -- conflict-free ds_read_b128 --
+//   and every element is reused by the 9 taps and both channel tiles from LDS.  78.3 KB -> 2 workgroups per CU (one loads while one
+//   multiplies).  Plane pitch padded to 10 016 B so the 8 chunks of one pixel land 2 slots apart on the write side.
+// Weights: pre-arranged on the host in fragment order [step 36][channel tile 2][lane 64][8 halves] (73.7 KB per layer, shared by every
+//   workgroup, L2-resident); each wave streams its two A fragments per step straight from global memory, one step ahead of use.
+// Epilogue: bias + PReLU in float32, convert, transpose through LDS (pixel-major, 144-byte pitch), 16-byte coalesced NHWC stores.
+// Bounds (960 x 540, one layer): 38.2 GFLOP -> 15 us at the 2.5 PFLOP/s dense fp16 peak; HBM 66 MB in (x 1.2 halo) + 66 MB out -> 18 us.
+#include "vd3d_dev.h"
+#include "vd3d_kernels.h"
+#include <hip/hip_fp16.h>
+
+typedef _Float16 cv_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cv_h4 __attribute__((ext_vector_type(4)));
+typedef float cv_f16 __attribute__((ext_vector_type(16)));
+
+#define CV_TW 32
+#define CV_TH 16
+#define CV_PW (CV_TW + 2)
+#define CV_PH (CV_TH + 2)
+#define CV_NPIX (CV_PW * CV_PH)          // 612
+#define CV_PLANE 10016                   // bytes per chunk plane: 612 * 16 = 9792, padded to == 32 (mod 256)
+#define CV_LDS (8 * CV_PLANE)            // 80 128 B
+#define CV_OP 144                        // epilogue: bytes per pixel (128 + 16 pad)
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_c64(const _Float16* __restrict__ x, int H, int W, const uint4* __restrict__ wfrag,
+                                                        const float* __restrict__ bias, const float* __restrict__ slope,
+                                                        _Float16* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t cv_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, g = lane >> 5;
+  const int x0 = blockIdx.x * CV_TW, y0 = blockIdx.y * CV_TH;
+
+  // A (weight) fragments of steps 0 and 1: independent of the tile, issued before the tile load.  Software pipeline of the main loop:
+  // weights two steps ahead (L2 latency), pixel fragments one step ahead (LDS latency); sched_barrier keeps the compiler from hoisting
+  // every load of the unrolled loop to the top (which spills).
+  const uint4* wp = wfrag + lane;
+  uint4 aw[3][2];
+  aw[0][0] = wp[0]; aw[0][1] = wp[64];
+  aw[1][0] = wp[128]; aw[1][1] = wp[192];
+
+  // input tile (+1 halo, zero outside the image) -> LDS; one task = one 16-byte chunk of one pixel
+  for (int t = tid; t < CV_NPIX * 8; t += 256) {
+    const int c = t & 7, pix = t >> 3;
+    const int py = pix / CV_PW, px = pix - py * CV_PW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const uint4*>(x + ((size_t)gy * W + gx) * 64 + c * 8);
+    *reinterpret_cast<uint4*>(cv_lds + c * CV_PLANE + pix * 16) = v;
+  }
+  __syncthreads();
+
+  cv_f16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  const uint8_t* bbase = cv_lds + g * CV_PLANE + ((wave * 4) * CV_PW + li) * 16;
+  cv_h8 bf[2][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) bf[0][m] = *reinterpret_cast<const cv_h8*>(bbase + m * CV_PW * 16);
+#pragma unroll
+  for (int s = 0; s < 36; ++s) {
+    if (s + 2 < 36) { aw[(s + 2) % 3][0] = wp[(s + 2) * 128]; aw[(s + 2) % 3][1] = wp[(s + 2) * 128 + 64]; }
+    if (s + 1 < 36) {
+      const int tap = (s + 1) >> 2, kc = (s + 1) & 3, dy = tap / 3, dx = tap - 3 * dy;
+      const uint8_t* bp = bbase + (2 * kc) * CV_PLANE + (dy * CV_PW + dx) * 16;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) bf[(s + 1) & 1][m] = *reinterpret_cast<const cv_h8*>(bp + m * CV_PW * 16);
+    }
+    const cv_h8 wa0 = __builtin_bit_cast(cv_h8, aw[s % 3][0]), wa1 = __builtin_bit_cast(cv_h8, aw[s % 3][1]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, bf[s & 1][m], acc[m][0], 0, 0, 0);
+      acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, bf[s & 1][m], acc[m][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();   // every wave is done with the input tile: LDS becomes the output staging buffer
+
+  // bias + PReLU (float32), fp16, pixel-major staging: lane = pixel li of row (wave*4 + m); regs 4q..4q+3 = channels 32t + 8q + 4g + (0..3)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = 32 * t + 8 * q + 4 * g;
+      const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+      float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (slope) sv = *reinterpret_cast<const float4*>(slope + ch);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float v0 = acc[m][t][4 * q] + bv.x, v1 = acc[m][t][4 * q + 1] + bv.y, v2 = acc[m][t][4 * q + 2] + bv.z, v3 = acc[m][t][4 * q + 3] + bv.w;
+        v0 = v0 >= 0.f ? v0 : v0 * sv.x; v1 = v1 >= 0.f ? v1 : v1 * sv.y; v2 = v2 >= 0.f ? v2 : v2 * sv.z; v3 = v3 >= 0.f ? v3 : v3 * sv.w;
+        const cv_h4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+        *reinterpret_cast<cv_h4*>(cv_lds + ((wave * 4 + m) * CV_TW + li) * CV_OP + ch * 2) = hv;
+      }
+    }
+  __syncthreads();
+  for (int t = tid; t < CV_TW * CV_TH * 8; t += 256) {
+    const int c = t & 7, pix = t >> 3;
+    const int py = pix / CV_TW, px = pix - py * CV_TW;
+    const int gy = y0 + py, gx = x0 + px;
+    if (gy < H && gx < W)
+      *reinterpret_cast<uint4*>(y + ((size_t)gy * W + gx) * 64 + c * 8) = *reinterpret_cast<const uint4*>(cv_lds + pix * CV_OP + c * 16);
+  }
+}
+
+bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const void* wfrag, const float* bias, const float* slope_or_null,
+                               void* y) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS) != hipSuccess)
+      return false;
+    attr_set = true;
+  }
+  dim3 grid((W + CV_TW - 1) / CV_TW, (H + CV_TH - 1) / CV_TH);
+  hipLaunchKernelGGL(k_conv3x3_c64, grid, dim3(256), CV_LDS, s, (const _Float16*)x, H, W, (const uint4*)wfrag, bias, slope_or_null, (_Float16*)y);
+  return true;
+}

@@ -382,6 +382,21 @@ class Renderer:
                                                 C.c_void_p(out.data_ptr() + (dy * OW + dx) * 3), 3 * OW))
         return out
 
+    def conv3x3_c64(self, x: torch.Tensor, w_frag: torch.Tensor, bias: torch.Tensor, slope: torch.Tensor | None,
+                    out: torch.Tensor | None = None) -> torch.Tensor:
+        """One body layer of the up-scale network on the matrix cores (``vd3d_conv3x3_c64_f16``): ``x`` is a [1,64,H,W] fp16 tensor in
+        channels_last memory; returns PReLU(conv3x3(x) + bias) in the same form.  ``w_frag``: ``upscale.conv_weight_fragments(weight)``."""
+        if (x.dtype != torch.float16 or x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 64
+                or not x.is_contiguous(memory_format=torch.channels_last)):
+            raise AssertionError("conv3x3_c64 takes a [1,64,H,W] fp16 tensor in channels_last memory")
+        H, W = int(x.shape[2]), int(x.shape[3])
+        if out is None:
+            out = torch.empty_like(x, memory_format=torch.channels_last)
+        self._enter(x, w_frag, bias, slope, out)
+        _lib.check(self._L.vd3d_conv3x3_c64_f16(self._ctx, _ptr(x), H, W, _ptr(w_frag), _ptr(bias), _ptr(slope) if slope is not None else None,
+                                                _ptr(out)))
+        return out
+
     def add_weighted_u8(self, a: torch.Tensor, alpha: float, b: torch.Tensor, beta: float, gamma: float = 0.0) -> torch.Tensor:
         """cv2.addWeighted on uint8 tensors of one shape (blend_images, core/merged_pipeline.py:231-236)."""
         a = a.to(self.device).contiguous()

@@ -111,6 +111,15 @@ class RRDBNet(nn.Module):
         return self.conv_last(F.leaky_relu(self.conv_hr(feat), 0.2))
 
 
+def conv_weight_fragments(weight: torch.Tensor) -> torch.Tensor:
+    """A [64,64,3,3] convolution weight in the fragment order ``vd3d_conv3x3_c64_f16`` streams (include/vd3d.h): fp16
+    [36 steps][2 channel tiles][64 lanes][8], element [(kh*3+kw)*4 + kc][t][l][j] = W[32t + (l & 31)][16kc + 8(l >> 5) + j][kh][kw]."""
+    if tuple(weight.shape) != (64, 64, 3, 3):
+        raise AssertionError("conv_weight_fragments takes a [64,64,3,3] weight")
+    w = weight.detach().to(torch.float16).permute(2, 3, 0, 1).reshape(9, 2, 32, 4, 2, 8)      # [tap][t][i][kc][g][j]
+    return w.permute(0, 3, 1, 4, 2, 5).reshape(36, 2, 64, 8).contiguous()                   # [tap][kc][t][g][i][j] -> [step][t][lane][j]
+
+
 def build_network(model_name: str = "RealESR_Gx4_fp16") -> nn.Module:
     arch, kw = MODEL_ZOO[model_name]
     return SRVGGNetCompact(**kw) if arch == "srvgg" else RRDBNet(**kw)
@@ -267,7 +276,10 @@ def _load_from_onnx(net: nn.Module, path: str) -> None:
 class Upscaler:
     """One Real-ESRGAN network + the HIP glue.  ``renderer`` is a ``visiondepth3d_amd.render_3d.Renderer`` (its context and stream)."""
 
-    def __init__(self, renderer, model_name: str = "RealESR_Gx4_fp16", net: nn.Module | None = None, dtype=torch.float16):
+    def __init__(self, renderer, model_name: str = "RealESR_Gx4_fp16", net: nn.Module | None = None, dtype=torch.float16,
+                 hip_body: bool = True):
+        """``hip_body``: run the 64 -> 64 body layers of the compact (SRVGG) networks through the hand-written matrix-core kernel
+        (``vd3d_conv3x3_c64_f16``: conv + bias + PReLU in one launch); the 3 -> 64 head and the 64 -> 48 tail stay on MIOpen."""
         self.renderer = renderer
         self.device = renderer.device
         self.model_name = model_name
@@ -275,6 +287,33 @@ class Upscaler:
         self.net = (net if net is not None else build_network(model_name)).to(self.device, dtype).eval()
         if self.device.type == "cuda":
             self.net = self.net.to(memory_format=torch.channels_last)
+        self._body = None
+        if (hip_body and self.device.type == "cuda" and dtype == torch.float16 and isinstance(self.net, SRVGGNetCompact)
+                and self.net.body[0].out_channels == 64):
+            self._body = self._prepare_body()
+
+    def _prepare_body(self):
+        """(weight fragments, bias, PReLU slope) per body layer, resident on the device."""
+        mods = list(self.net.body)
+        layers = []
+        for i in range(2, len(mods) - 1, 2):      # body[0..1] = head conv + PReLU, body[-1] = tail conv
+            conv, act = mods[i], mods[i + 1]
+            layers.append((conv_weight_fragments(conv.weight).to(self.device), conv.bias.detach().float().contiguous().to(self.device),
+                           act.weight.detach().float().contiguous().to(self.device)))
+        return layers
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._body is None:
+            return self.net(x)
+        R, net = self.renderer, self.net
+        h = net.body[1](net.body[0](x)).contiguous(memory_format=torch.channels_last)
+        spare = torch.empty_like(h, memory_format=torch.channels_last)
+        for wf, b, sl in self._body:
+            R.conv3x3_c64(h, wf, b, sl, out=spare)
+            h, spare = spare, h
+        R.ordered_after()
+        out = F.pixel_shuffle(net.body[-1](h), net.upscale)
+        return out + F.interpolate(x, scale_factor=net.upscale, mode="nearest")
 
     @classmethod
     def from_weights(cls, renderer, path: str, model_name: str = "RealESR_Gx4_fp16", dtype=torch.float16) -> "Upscaler":
@@ -301,7 +340,7 @@ class Upscaler:
         R = self.renderer
         x = R.esr_preprocess(frame, y0, x0, h, w, dtype=self.dtype, channels_last=True)
         R.ordered_after()
-        return self.net(x).float()
+        return self._forward(x).float()
 
     def _esrgan_tiled(self, img: torch.Tensor, tile: int, pad: int) -> torch.Tensor:
         """_esrgan_tiled :266-284, quirk included: the canvas has the INPUT size, so each tile contributes the top-left corner of the
