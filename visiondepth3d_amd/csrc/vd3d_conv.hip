@@ -16,6 +16,10 @@
 //   workgroup, L2-resident); each wave streams its two A fragments per step straight from global memory, one step ahead of use.
 // Epilogue: bias + PReLU in float32, convert, transpose through LDS (pixel-major, 144-byte pitch), 16-byte coalesced NHWC stores.
 // Bounds (960 x 540, one layer): 38.2 GFLOP -> 15 us at the 2.5 PFLOP/s dense fp16 peak; HBM 66 MB in (x 1.2 halo) + 66 MB out -> 18 us.
+// Measured (tools/probe_conv.py): 54 us = 705 TFLOP/s = 28 % of the fp16 peak, 3.3x MIOpen's convolution + PReLU pair.  The three phases
+// of a workgroup (tile load at ~11 B/clk/CU, 288 MFMAs, store tail at ~7 B/clk/CU) run back to back and the two workgroups of a CU move
+// in lock-step, so the time is their SUM; a 32 x 8 tile with 3 workgroups per CU (-DCV_TH=8) measures the same.  Next lever: a persistent
+// workgroup that issues the next tile's global loads before the MFMA loop (registers are there at CV_TH = 8), then two layers per launch.
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 #include <hip/hip_fp16.h>
@@ -25,15 +29,18 @@ typedef _Float16 cv_h4 __attribute__((ext_vector_type(4)));
 typedef float cv_f16 __attribute__((ext_vector_type(16)));
 
 #define CV_TW 32
+#ifndef CV_TH
 #define CV_TH 16
+#endif
+#define CV_RW (CV_TH / 4)             // tile rows per wave
 #define CV_PW (CV_TW + 2)
 #define CV_PH (CV_TH + 2)
 #define CV_NPIX (CV_PW * CV_PH)          // 612
-#define CV_PLANE 10016                   // bytes per chunk plane: 612 * 16 = 9792, padded to == 32 (mod 256)
+#define CV_PLANE ((CV_NPIX * 16 + 255) / 256 * 256 + 32)   // bytes per chunk plane, padded to == 32 (mod 256): 10 016 for 16 rows
 #define CV_LDS (8 * CV_PLANE)            // 80 128 B
 #define CV_OP 144                        // epilogue: bytes per pixel (128 + 16 pad)
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_c64(const _Float16* __restrict__ x, int H, int W, const uint4* __restrict__ wfrag,
+__global__ __launch_bounds__(256, CV_TH == 16 ? 2 : 3) void k_conv3x3_c64(const _Float16* __restrict__ x, int H, int W, const uint4* __restrict__ wfrag,
                                                         const float* __restrict__ bias, const float* __restrict__ slope,
                                                         _Float16* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_lds[];
@@ -48,29 +55,42 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c64(const _Float16* __restri
   aw[0][0] = wp[0]; aw[0][1] = wp[64];
   aw[1][0] = wp[128]; aw[1][1] = wp[192];
 
-  // input tile (+1 halo, zero outside the image) -> LDS; one task = one 16-byte chunk of one pixel
-  for (int t = tid; t < CV_NPIX * 8; t += 256) {
-    const int c = t & 7, pix = t >> 3;
-    const int py = pix / CV_PW, px = pix - py * CV_PW;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const uint4*>(x + ((size_t)gy * W + gx) * 64 + c * 8);
-    *reinterpret_cast<uint4*>(cv_lds + c * CV_PLANE + pix * 16) = v;
+  // input tile (+1 halo, zero outside the image) -> LDS; one task = one 16-byte chunk of one pixel.  Thread = (chunk tid&7, pixel
+  // (tid>>3) + 32k): ten loads in flight per thread before the first LDS write (two batches cover the 612 pixels).
+  {
+    const int c = tid & 7, p0 = tid >> 3;
+#pragma unroll
+    for (int h = 0; h < (CV_NPIX + 319) / 320; ++h) {
+      uint4 v[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const int pix = p0 + 32 * (10 * h + k);
+        const int py = pix / CV_PW, px = pix - py * CV_PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (pix < CV_NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) v[k] = *reinterpret_cast<const uint4*>(x + ((size_t)gy * W + gx) * 64 + c * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const int pix = p0 + 32 * (10 * h + k);
+        if (pix < CV_NPIX) *reinterpret_cast<uint4*>(cv_lds + c * CV_PLANE + pix * 16) = v[k];
+      }
+    }
   }
   __syncthreads();
 
-  cv_f16 acc[4][2];
+  cv_f16 acc[CV_RW][2];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < CV_RW; ++m)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
 
-  const uint8_t* bbase = cv_lds + g * CV_PLANE + ((wave * 4) * CV_PW + li) * 16;
-  cv_h8 bf[2][4];
+  const uint8_t* bbase = cv_lds + g * CV_PLANE + ((wave * CV_RW) * CV_PW + li) * 16;
+  cv_h8 bf[2][CV_RW];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) bf[0][m] = *reinterpret_cast<const cv_h8*>(bbase + m * CV_PW * 16);
+  for (int m = 0; m < CV_RW; ++m) bf[0][m] = *reinterpret_cast<const cv_h8*>(bbase + m * CV_PW * 16);
 #pragma unroll
   for (int s = 0; s < 36; ++s) {
     if (s + 2 < 36) { aw[(s + 2) % 3][0] = wp[(s + 2) * 128]; aw[(s + 2) % 3][1] = wp[(s + 2) * 128 + 64]; }
@@ -78,11 +98,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c64(const _Float16* __restri
       const int tap = (s + 1) >> 2, kc = (s + 1) & 3, dy = tap / 3, dx = tap - 3 * dy;
       const uint8_t* bp = bbase + (2 * kc) * CV_PLANE + (dy * CV_PW + dx) * 16;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) bf[(s + 1) & 1][m] = *reinterpret_cast<const cv_h8*>(bp + m * CV_PW * 16);
+      for (int m = 0; m < CV_RW; ++m) bf[(s + 1) & 1][m] = *reinterpret_cast<const cv_h8*>(bp + m * CV_PW * 16);
     }
     const cv_h8 wa0 = __builtin_bit_cast(cv_h8, aw[s % 3][0]), wa1 = __builtin_bit_cast(cv_h8, aw[s % 3][1]);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < CV_RW; ++m) {
       acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, bf[s & 1][m], acc[m][0], 0, 0, 0);
       acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, bf[s & 1][m], acc[m][1], 0, 0, 0);
     }
@@ -100,11 +120,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c64(const _Float16* __restri
       float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
       if (slope) sv = *reinterpret_cast<const float4*>(slope + ch);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < CV_RW; ++m) {
         float v0 = acc[m][t][4 * q] + bv.x, v1 = acc[m][t][4 * q + 1] + bv.y, v2 = acc[m][t][4 * q + 2] + bv.z, v3 = acc[m][t][4 * q + 3] + bv.w;
         v0 = v0 >= 0.f ? v0 : v0 * sv.x; v1 = v1 >= 0.f ? v1 : v1 * sv.y; v2 = v2 >= 0.f ? v2 : v2 * sv.z; v3 = v3 >= 0.f ? v3 : v3 * sv.w;
         const cv_h4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-        *reinterpret_cast<cv_h4*>(cv_lds + ((wave * 4 + m) * CV_TW + li) * CV_OP + ch * 2) = hv;
+        *reinterpret_cast<cv_h4*>(cv_lds + ((wave * CV_RW + m) * CV_TW + li) * CV_OP + ch * 2) = hv;
       }
     }
   __syncthreads();
