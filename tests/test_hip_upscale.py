@@ -82,12 +82,17 @@ def test_add_weighted_u8_bit_exact(R, oracle):
         assert np.array_equal(got, oracle.add_weighted_u8(a, alpha, b, 1 - alpha))
 
 
-def _run_esrgan_with_oracle_glue(up, oracle, frame, blend_mode, input_res_pct, target_size, tile, tile_pad):
-    """run_esrgan (core/merged_pipeline.py:237-284) with numpy / oracle glue; only ``net(x)`` runs on the device."""
-    def session(crop):
-        x = torch.from_numpy(oracle.esr_pre(crop))[None].to("cuda", up.dtype).contiguous(memory_format=torch.channels_last)
-        with torch.no_grad():
-            return up.net(x).float().cpu().numpy()[0]
+def _run_esrgan_with_oracle_glue(up, oracle, frame, preds, blend_mode, input_res_pct, target_size, tile, tile_pad):
+    """run_esrgan (core/merged_pipeline.py:237-284) with numpy / oracle glue.  ``preds``: the network outputs the device run produced, in
+    call order (the library convolutions are not run-to-run deterministic, so the session is replayed, not re-run); the INPUT each call
+    saw is re-derived here with the oracle and must have the recorded shape."""
+    it = iter(preds)
+
+    def session(crop, y0=0, x0=0):
+        p, (fy, fx, fh, fw) = next(it)
+        assert (fy, fx, fh, fw) == (y0, x0, crop.shape[0], crop.shape[1])      # the device run cut the same crop
+        assert p.shape == (3, crop.shape[0] * up.scale, crop.shape[1] * up.scale)
+        return p
 
     original = frame
     if input_res_pct != 100:
@@ -101,7 +106,7 @@ def _run_esrgan_with_oracle_glue(up, oracle, frame, blend_mode, input_res_pct, t
             for x in range(0, w, tile):
                 y0, x0 = max(0, y - tile_pad), max(0, x - tile_pad)
                 y1, x1 = min(h, y + tile + tile_pad), min(w, x + tile + tile_pad)
-                upc = oracle.esr_post(session(frame[y0:y1, x0:x1]))
+                upc = oracle.esr_post(session(frame[y0:y1, x0:x1], y0, x0))
                 yc0, xc0 = y - y0, x - x0
                 yc1, xc1 = yc0 + min(tile, h - y), xc0 + min(tile, w - x)
                 out[y:y + min(tile, h - y), x:x + min(tile, w - x)] = upc[yc0:yc1, xc0:xc1]
@@ -133,8 +138,15 @@ def test_run_esrgan_end_to_end(R, oracle, model, kw):
     # float32 network: the device prediction is deterministic for one input, so device glue and oracle glue see the same numbers
     up = Upscaler(R, model, dtype=torch.float32)
     frame, _ = synth.synth_frame(3, 72, 104)
+    preds, infer = [], up._infer
+
+    def recording(f, y0=0, x0=0, h=None, w=None):
+        p = infer(f, y0, x0, h, w)
+        preds.append((p.cpu().numpy()[0], (y0, x0, f.shape[0] - y0 if h is None else h, f.shape[1] - x0 if w is None else w)))
+        return p
+    up._infer = recording
     got = up.run_esrgan(T(frame), **kw).cpu().numpy()
-    want = _run_esrgan_with_oracle_glue(up, oracle, frame, **kw)
+    want = _run_esrgan_with_oracle_glue(up, oracle, frame, preds, **kw)
     assert got.shape == want.shape
     assert np.array_equal(got, want), np.abs(got.astype(int) - want.astype(int)).max()
 

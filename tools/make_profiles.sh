@@ -1,5 +1,6 @@
 # Collects the rocprofv3 evidence that profiles/ keeps (run on the GPU box through gpurun; outputs under gpurun_out/profiles_rXX/):
-#   1. kernel-trace --stats of the 4K DIBR-only roofline run (configs[2]) and of the headline (4K + DA-V2-Base float32)
+#   1. kernel-trace --stats of the 4K DIBR-only roofline run (configs[2]), of the headline (4K + DA-V2-Base float32) and of the
+#      configs[4] chain (1080p depth + DIBR + Real-ESRGAN x4)
 #   2. three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters) of the 4K DIBR-only run -- never combined with trace domains
 #      other than --kernel-trace (MI355X_MICROARCH.md HBM / rocprofv3 section)
 # usage: bash tools/make_profiles.sh r02
@@ -16,6 +17,7 @@ run_stats() {  # name, cmd
 }
 run_stats 4k_dibr "$DIBR"
 run_stats 4k_dav2b_f32 "$HEAD"
+run_stats 1080p_esrgan4k "python $R/bench.py --upscale-only"
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU"; do
   n=$(echo $c | cut -d" " -f1)
   rm -rf $O/p_$n; rocprofv3 --kernel-trace --pmc $c -d $O/p_$n -o p -- $DIBR > /dev/null 2>&1
