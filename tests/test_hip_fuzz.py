@@ -56,7 +56,7 @@ def test_render_loop_fuzz(R, oracle, seed):
     rng = np.random.default_rng(seed)
     sh, sw, kw = _random_render_kw(rng)
     try:
-        p = render_kwargs_to_params(sw, sh, **kw)
+        p = render_kwargs_to_params(sw, sh, dof_dense_conv=bool(seed & 1), **kw)   # odd seeds: the reference's dense DOF association
     except NotImplementedError:
         pytest.skip("feature outside the built scope")
     depth_as = ["bgr_u8", "gray_u8", "f32"][int(rng.integers(0, 3))]

@@ -417,8 +417,8 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
                       uint8_t* out, const vd_dev_work* wk = nullptr) {
   StageTimer t(c, "finish");
   if (!wk) wk = c->work;
-  const int dense = (p->dof_dense_conv && fc.nlev) ? 1 : 0;   // the reference's dense k x k conv order: unfused kernels only
-  if (c->use_fused && !dense && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out)) {
+  const int dense = (p->dof_dense_conv && fc.nlev) ? 1 : 0;   // the reference's dense k x k conv order
+  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out, dense)) {
     HIPCHK(hipGetLastError());
     return 0;
   }

@@ -90,6 +90,47 @@ VD_DEV void ff_level(ff_tile_t tile, const float* __restrict__ kern, bool active
   }
 }
 
+// The same level in the reference's DENSE association (vd3d_render_params::dof_dense_conv): one K x K window per
+// output, taps row-major, one FMA per tap from 0, weight = fl(k1[i] * k1[j]) -- what F.conv2d (oneDNN) computes on the CPU.  The strip's
+// 12-column window comes straight from the LDS tile (three ds_read_b128 per row and channel), the weight row is rebuilt per tile row
+// (K multiplies amortised over 12 K FMAs); four independent accumulation chains per channel.  No lane exchange: only the strips that
+// blend with this level run it.
+template <int OFF>
+VD_DEV void ff_level_dense(ff_tile_t tile, const float* __restrict__ kern, bool mine, int sy, int ss, int level, const int lo[4],
+                           vd_f4 vlo[3], vd_f4 vhi[3]) {
+  constexpr int K = 2 * (FF_R - OFF) + 1;
+  if (!mine) return;
+  float kw[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) kw[t] = kern[t];
+  vd_f4 acc[3];      // scalar FMAs on purpose: the v_pk_fma_f32 form (pairs of outputs) needs re-paired window registers, measured 16 % slower
+#pragma unroll
+  for (int c = 0; c < 3; ++c) acc[c] = (vd_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    float wr[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[j] = kw[i] * kw[j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* rp = &tile[c][sy + OFF + i][4 * ss - 4];
+      const vd_f4 w0 = *reinterpret_cast<const vd_f4*>(rp), w1 = *reinterpret_cast<const vd_f4*>(rp + 4), w2 = *reinterpret_cast<const vd_f4*>(rp + 8);
+      const float win[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[c][q] = vd_fma(win[q + OFF + j], wr[j], acc[c][q]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (level == lo[q]) vlo[c][q] = acc[c][q];
+      if (level == lo[q] + 1) vhi[c][q] = acc[c][q];
+    }
+}
+
 VD_DEV float ff_byte(uint32_t v, int sh) { return (float)((v >> sh) & 0xffu); }   // v_cvt_f32_ubyteN
 
 // 3x3 sharpen (:717-732) of 4 consecutive pixels of one row of the graded dword tile (interior: no reflection needed)
@@ -119,6 +160,7 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
 #ifndef FF_OCC_ATTR
 #define FF_OCC_ATTR   // A/B builds: -DFF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))' forces the 64-VGPR budget
 #endif
+template <bool DENSE>
 __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
                                                         const vd_dev_work* __restrict__ w, uint8_t* __restrict__ out) {
@@ -213,6 +255,15 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
     if (!(need_mask >> (l + 1) & 1)) continue;  // no pixel of this tile blends with this level (workgroup-uniform)
     const int off = FF_R - fc.ksz[l] / 2;
     const bool mine = (my_mask >> (l + 1)) & 1;
+    if (DENSE) {
+      switch (off) {
+        case 0: ff_level_dense<0>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        case 1: ff_level_dense<1>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        case 2: ff_level_dense<2>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        default: ff_level_dense<3>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      }
+      continue;
+    }
     switch (off) {  // compile-time tap count => all register indexing is static
       case 0: ff_level<0>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
       case 1: ff_level<1>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
@@ -357,7 +408,7 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
 // returns false when the fast path does not apply (caller runs the unfused kernels)
 bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
-                            int use_override, int bar_w, int bar_s, uint8_t* out) {
+                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense) {
   if (!(p.format == VD3D_FMT_HALF_SBS || p.format == VD3D_FMT_FULL_SBS || p.format == VD3D_FMT_INTERLACED)) return false;
   for (int l = 0; l < fc.nlev; ++l) if (fc.ksz[l] > 2 * FF_R + 1 || fc.ksz[l] < 3) return false;
   vd_ff_args a;
@@ -378,6 +429,7 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
   if (a.xo || a.yo || a.in_w != p.fit_w || a.in_h != p.fit_h)  // pad_to_aspect_ratio canvas (:124): black background
     (void)hipMemsetAsync(out, 0, (size_t)p.out_w * p.out_h * 3, s);
   dim3 g((p.warp_w + FF_TW - 1) / FF_TW, (p.warp_h + FF_TH - 1) / FF_TH, 2);
-  hipLaunchKernelGGL(k_finish_fused, g, dim3(FF_NT), 0, s, L, R, dn, fc, a, w, out);
+  if (dense) hipLaunchKernelGGL(k_finish_fused<true>, g, dim3(FF_NT), 0, s, L, R, dn, fc, a, w, out);
+  else hipLaunchKernelGGL(k_finish_fused<false>, g, dim3(FF_NT), 0, s, L, R, dn, fc, a, w, out);
   return true;
 }

@@ -144,7 +144,7 @@ void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, in
 // ---- vd3d_finish.hip
 bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
-                            int use_override, int bar_w, int bar_s, uint8_t* out);
+                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense);
 
 // ---- vd3d_conv.hip
 bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const void* wfrag, const float* bias, const float* slope_or_null, void* y);
