@@ -109,10 +109,11 @@ typedef struct vd3d_render_params {
   double target_ratio;           /* aspect_ratios[selected_aspect_ratio] (:1072); used when auto_crop_black_bars */
   /* Association of the DOF Gaussian levels (apply_dof_cuda -> torchvision gaussian_blur, core/render_3d.py:806).  The reference
    * blurs with a dense k x k depthwise convolution whose summation order belongs to the convolution library of the machine it
-   * runs on.  0 (default): separable columns-then-rows sums -- 4x less arithmetic, identical to <= 6e-7 in float, which the
-   * reference's own uint8 truncation turns into +-1 LSB on ~0.5 % of samples before the sharpen stage (gain ~4.5).
-   * 1: the dense convolution in the order PyTorch's CPU build (oneDNN) uses -- row-major taps, one fused multiply-add per tap --
-   * which reproduces the CPU reference's blur BIT FOR BIT (tests/test_oracle_vs_golden.py::test_b2_attribution*). */
+   * runs on.  1 (what vd3d_render_params_default sets): the dense convolution in the order PyTorch's CPU build (oneDNN) uses --
+   * row-major taps, one fused multiply-add per tap -- which reproduces the CPU reference's blur BIT FOR BIT
+   * (tests/test_oracle_vs_golden.py::test_b2_attribution*); fused into the finishing kernel.
+   * 0: separable columns-then-rows sums -- 4x less arithmetic, identical to <= 6e-7 in float, which the reference's own uint8
+   * truncation turns into +-1 LSB on ~0.5 % of samples before the sharpen stage (gain ~4.5): an opt-in fast mode. */
   int32_t dof_dense_conv;
   int32_t reserved0;
 } vd3d_render_params;

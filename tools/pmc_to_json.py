@@ -17,8 +17,9 @@ for p in paths:
         a[0] += value; a[1] += 1
 avg = lambda n, c: (acc[n][c][0] / acc[n][c][1]) if acc[n].get(c) and acc[n][c][1] else None
 out = {}
-for key, prefix in (("k_warp_fused", "void k_warp_fused<true, true>"), ("k_finish_fused", "k_finish_fused")):
-    n = next((k for k in acc if k.startswith(prefix)), None)
+for key, prefixes in (("k_warp_fused", ("void k_warp_fused<true, true>",)),
+                      ("k_finish_fused", ("void k_finish_fused<true>", "void k_finish_fused<false>", "k_finish_fused"))):
+    n = next((k for pre in prefixes for k in acc if k.startswith(pre)), None)
     if n is None:
         continue
     f, w, v = avg(n, "FETCH_SIZE"), avg(n, "WRITE_SIZE"), avg(n, "SQ_INSTS_VALU")

@@ -173,6 +173,7 @@ VD3D_EXPORT void vd3d_render_params_default(vd3d_render_params* p) {
   p->ipd_factor = 1.0; p->dof_strength = 0.0; p->sharpness_factor = 0.0;
   p->color_saturation = 1.0; p->color_contrast = 1.0; p->color_brightness = 0.0;
   p->format = VD3D_FMT_HALF_SBS;
+  p->dof_dense_conv = 1;   // the reference's convolution order (parity mode) is the default; 0 = separable levels
 }
 
 VD3D_EXPORT int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out) {
