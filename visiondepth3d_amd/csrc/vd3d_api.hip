@@ -994,6 +994,7 @@ VD3D_EXPORT int vd3d_preview_heatmap(vd3d_ctx* c, int type, const float* shift_m
 VD3D_EXPORT int vd3d_conv3x3_c64_f16(vd3d_ctx* c, const void* x_nhwc, int H, int W, const void* w_frag, const float* bias, const float* slope_or_null,
                                      void* y_nhwc) {
   if (!c || !x_nhwc || !w_frag || !bias || !y_nhwc || H < 1 || W < 1 || x_nhwc == y_nhwc) return set_err(VD3D_E_INVALID, "bad argument");
+  if ((long long)H * W * 128 >= (1ll << 32)) return set_err(VD3D_E_INVALID, "conv3x3_c64_f16: activation larger than 4 GB");
   if (((uintptr_t)x_nhwc | (uintptr_t)y_nhwc | (uintptr_t)w_frag | (uintptr_t)bias | (uintptr_t)slope_or_null) & 15)
     return set_err(VD3D_E_INVALID, "conv3x3_c64_f16: pointers must be 16-byte aligned");
   HIPCHK(hipSetDevice(c->device));

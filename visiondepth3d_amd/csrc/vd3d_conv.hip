@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256, CV_TH == 16 ? 2 : 3) void k_conv3x3_c64(const 
   }
 }
 
+
 bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const void* wfrag, const float* bias, const float* slope_or_null,
                                void* y) {
   static bool attr_set = false;
