@@ -297,6 +297,13 @@ int vd3d_esr_postprocess(vd3d_ctx* ctx, const float* pred_rgb, int h, int w, int
                          uint8_t* out_bgr, long long pitch_bytes);
 int vd3d_add_weighted_u8(vd3d_ctx* ctx, const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma, long long n,
                          uint8_t* out);
+/* run_rife's glue (core/merged_pipeline.py:195-218): concatenate_images + preprocess_rife -- two uint8 BGR frames / 255 stacked to six
+ * channels in the frames' own order, float32 / bf16 / fp16, planar [6][h][w] or channels-last; and the output side -- float32
+ * [3][h][w] (or channels-last) -> clip(0,1) * 255 truncated, channel order untouched.  The interpolation network between the two is
+ * the caller's (the reference's RIFE ONNX graph is not in /root/reference). */
+int vd3d_rife_preprocess(vd3d_ctx* ctx, int dtype, const uint8_t* frame1_bgr, const uint8_t* frame2_bgr, int h, int w, int channels_last,
+                         void* out6);
+int vd3d_rife_postprocess(vd3d_ctx* ctx, const float* pred3, int h, int w, int channels_last, uint8_t* out_bgr);
 
 /* One body layer of the up-scale network on the matrix cores: y = PReLU(conv3x3(x, stride 1, zero padding 1) + bias), 64 -> 64 channels,
  * fp16 NHWC [H][W][64] in and out, float32 accumulate (v_mfma_f32_32x32x16_f16).  The reference runs these layers inside its ONNX

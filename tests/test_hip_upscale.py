@@ -246,3 +246,30 @@ def test_upscaler_hip_body_matches_the_library_convolutions(R):
     oa, ob = a.upscale(T(frame)), b.upscale(T(frame))
     d = (oa.int() - ob.int()).abs()
     assert int(d.max()) <= 3 and float((d > 1).float().mean()) < 0.01
+
+
+def test_run_rife_glue(R):
+    """run_rife (core/merged_pipeline.py:195-218) around a stand-in session: the device glue must equal the reference's numpy lines."""
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.upscale import run_rife
+    f1, _ = synth.synth_frame(1, 46, 62)
+    f2, _ = synth.synth_frame(2, 46, 62)
+    seen = {}
+
+    def session(x):                                   # a "network" that mixes the two frames and overshoots [0, 1] in places
+        seen["x"] = x.clone()
+        return x[:, :3] * 0.75 + x[:, 3:] * 0.5 - 0.1
+    outs = run_rife(R, session, T(f1), T(f2), 3)
+    assert len(outs) == 2 and all(tuple(o.shape) == (46, 62, 3) and o.dtype == torch.uint8 for o in outs)
+    merged = np.concatenate((f1.astype(np.float32) / 255.0, f2.astype(np.float32) / 255.0), axis=2)          # concatenate_images :195-196
+    tensor = np.expand_dims(np.transpose(merged, (2, 0, 1)), 0).astype(np.float32)                             # preprocess_rife :198-201
+    batch = np.repeat(tensor, 2, axis=0)
+    assert np.array_equal(seen["x"].cpu().numpy(), batch)
+    out = session(torch.from_numpy(batch)).numpy()
+    out = np.transpose(np.clip(out, 0, 1), (0, 2, 3, 1))
+    want = [(fr * 255).astype(np.uint8) for fr in out]                                                        # :214-216
+    # the stand-in session runs in float32 on both sides; ATen's elementwise kernels agree bit for bit between CPU and GPU here
+    for o, wnt in zip(outs, want):
+        d = np.abs(o.cpu().numpy().astype(int) - wnt.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert run_rife(R, None, T(f1), T(f2), 2) == []

@@ -917,6 +917,23 @@ VD3D_EXPORT int vd3d_esr_postprocess(vd3d_ctx* c, const float* pred_rgb, int h, 
   return 0;
 }
 
+// run_rife's glue, core/merged_pipeline.py:195-218
+VD3D_EXPORT int vd3d_rife_preprocess(vd3d_ctx* c, int dtype, const uint8_t* frame1_bgr, const uint8_t* frame2_bgr, int h, int w, int channels_last,
+                                     void* out6) {
+  if (!c || !frame1_bgr || !frame2_bgr || !out6 || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!vd_launch_rife_pre(c->stream, dtype, frame1_bgr, frame2_bgr, h, w, channels_last ? 1 : 0, out6)) return set_err(VD3D_E_INVALID, "bad dtype %d", dtype);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+VD3D_EXPORT int vd3d_rife_postprocess(vd3d_ctx* c, const float* pred3, int h, int w, int channels_last, uint8_t* out_bgr) {
+  if (!c || !pred3 || !out_bgr || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  vd_launch_rife_post(c->stream, pred3, h, w, channels_last ? 1 : 0, out_bgr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_add_weighted_u8(vd3d_ctx* c, const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma, long long n,
                                      uint8_t* out) {
   if (!c || !a || !b || !out || n < 1) return set_err(VD3D_E_INVALID, "bad argument");

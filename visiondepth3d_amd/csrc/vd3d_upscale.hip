@@ -182,6 +182,42 @@ __global__ __launch_bounds__(256) void k_esr_post(const float* __restrict__ pred
   }
 }
 
+// run_rife's glue (core/merged_pipeline.py:195-218): concatenate_images + preprocess_rife = the two frames / 255 stacked to six
+// channels in the frames' own BGR order (no swap there), planar [6][h][w] or channels-last [h][w][6]; the output side is
+// clip(0,1) * 255 truncated with the channel order untouched.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rife_pre(const uint8_t* __restrict__ f1, const uint8_t* __restrict__ f2, int h, int w, int hwc,
+                                                  T* __restrict__ out) {
+  const long long n = (long long)h * w;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float v = (float)(c < 3 ? f1[3 * i + c] : f2[3 * i + c - 3]) / 255.f;
+      if (hwc) out[6 * i + c] = esr_cast<T>(v); else out[c * n + i] = esr_cast<T>(v);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_rife_post(const float* __restrict__ pred, int h, int w, int hwc, uint8_t* __restrict__ dst) {
+  const long long n = (long long)h * w;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[3 * i + c] = esr_u8(hwc ? pred[3 * i + c] : pred[c * n + i]);
+}
+bool vd_launch_rife_pre(hipStream_t s, int dtype, const uint8_t* f1, const uint8_t* f2, int h, int w, int hwc, void* out) {
+  const long long n = (long long)h * w;
+  const int g = (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256);
+  if (dtype == VD3D_DT_F32) hipLaunchKernelGGL(k_rife_pre<float>, dim3(g), dim3(256), 0, s, f1, f2, h, w, hwc, (float*)out);
+  else if (dtype == VD3D_DT_BF16) hipLaunchKernelGGL(k_rife_pre<__hip_bfloat16>, dim3(g), dim3(256), 0, s, f1, f2, h, w, hwc, (__hip_bfloat16*)out);
+  else if (dtype == VD3D_DT_F16) hipLaunchKernelGGL(k_rife_pre<__half>, dim3(g), dim3(256), 0, s, f1, f2, h, w, hwc, (__half*)out);
+  else return false;
+  return true;
+}
+void vd_launch_rife_post(hipStream_t s, const float* pred, int h, int w, int hwc, uint8_t* dst) {
+  const long long n = (long long)h * w;
+  const int g = (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_rife_post, dim3(g), dim3(256), 0, s, pred, h, w, hwc, dst);
+}
+
 bool vd_launch_esr_pre(hipStream_t s, int dtype, const uint8_t* src, long long pitch, int h, int w, int hwc, void* out) {
   const long long n = (long long)h * w;
   const int g = (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256);

@@ -273,6 +273,35 @@ def _load_from_onnx(net: nn.Module, path: str) -> None:
         raise ValueError(f"{path}: {ci} Conv / {pi} PRelu nodes, the architecture has {len(convs)} / {len(prelus)}")
 
 
+def run_rife(renderer, session, frame1, frame2, multiplier, dtype=torch.float32):
+    """run_rife (core/merged_pipeline.py:204-218) with the frames resident in HBM.  ``session``: the interpolation network as a callable
+    ``[N,6,H,W] -> [N,3,H,W]`` (the reference's RIFE ONNX graph is not in /root/reference, so none is built here; without one the
+    reference returns ``[]`` too, :205-206).  Returns ``multiplier - 1`` uint8 [H,W,3] tensors, like the reference's list of frames."""
+    if session is None:
+        return []
+    f1 = (frame1 if torch.is_tensor(frame1) else torch.from_numpy(np.ascontiguousarray(frame1))).to(renderer.device).contiguous()
+    f2 = (frame2 if torch.is_tensor(frame2) else torch.from_numpy(np.ascontiguousarray(frame2))).to(renderer.device).contiguous()
+    if f1.dtype != torch.uint8 or f1.shape != f2.shape or f1.dim() != 3 or f1.shape[2] != 3:
+        raise AssertionError("run_rife takes two uint8 [H,W,3] frames of one size")
+    from . import _lib
+    from ._abi import DT_BF16, DT_F16, DT_F32
+    h, w = int(f1.shape[0]), int(f1.shape[1])
+    x = torch.empty((1, 6, h, w), dtype=dtype, device=renderer.device)
+    renderer._enter(f1, f2, x)
+    _lib.check(renderer._L.vd3d_rife_preprocess(renderer._ctx, {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}[dtype],
+                                                f1.data_ptr(), f2.data_ptr(), h, w, 0, x.data_ptr()))
+    renderer.ordered_after()
+    with torch.no_grad():
+        pred = session(x.repeat(int(multiplier) - 1, 1, 1, 1)).float().contiguous()      # np.repeat(tensor, multiplier - 1, axis=0) :212
+    outs = []
+    for i in range(pred.shape[0]):
+        o = torch.empty((h, w, 3), dtype=torch.uint8, device=renderer.device)
+        renderer._enter(pred, o)
+        _lib.check(renderer._L.vd3d_rife_postprocess(renderer._ctx, pred[i].data_ptr(), h, w, 0, o.data_ptr()))
+        outs.append(o)
+    return outs
+
+
 class Upscaler:
     """One Real-ESRGAN network + the HIP glue.  ``renderer`` is a ``visiondepth3d_amd.render_3d.Renderer`` (its context and stream)."""
 
