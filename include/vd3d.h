@@ -355,9 +355,11 @@ int vd3d_preview_image(vd3d_ctx* ctx, int type, const uint8_t* left_bgr, const u
 /* The colour-mapped types of the same function (core/preview_utils.py:42-66): type 0 "Shift Heatmap" (cv2.normalize NORM_MINMAX),
  * 1 "Shift Heatmap (Abs)", 2 "Shift Heatmap (Clipped +-5px)", 3 "Feather Mask"; shift_map: float32 [h][w] (pixel_shift_cuda's third return),
  * lut_bgr_dev: 256 x 3 uint8 BGR table in device memory -- OpenCV's COLORMAP_JET (types 0-2) / COLORMAP_BONE (3) as the caller obtained it
- * (cv2.applyColorMap(np.arange(256, dtype=np.uint8), cmap)); the library holds no copy of those tables.  "Overlay Arrows" (OpenCV's line
- * rasteriser) is not built. */
+ * (cv2.applyColorMap(np.arange(256, dtype=np.uint8), cmap)); the library holds no copy of those tables. */
 int vd3d_preview_heatmap(vd3d_ctx* ctx, int type, const float* shift_map, int h, int w, const uint8_t* lut_bgr_dev, uint8_t* out_bgr);
+/* "Overlay Arrows" (core/preview_utils.py:74-82): the left eye with a green cv2.arrowedLine((x, y) -> (x + int(10 shift), y), tipLength 0.3)
+ * at every 20th pixel of every 20th row where |int(10 shift)| > 1.  left_bgr != out_bgr. */
+int vd3d_preview_arrows(vd3d_ctx* ctx, const uint8_t* left_bgr, const float* shift_map, int h, int w, uint8_t* out_bgr);
 
 /* ---- stage entry points (the pieces B2 is made of; exported for tests / profiling / sharded runner) */
 /* apply_dof_cuda + apply_color_grade + tensor_to_frame + side bars + apply_sharpening + fit + mux

@@ -422,3 +422,12 @@ def bgr_to_nv12(bgr):
     out = np.empty((h * 3 // 2, w), np.uint8)
     lib().vo_bgr_to_nv12(t.ctypes.data_as(_u8p), h, w, out.ctypes.data_as(_u8p))
     return out
+
+
+def preview_arrows(left, shift):
+    """ "Overlay Arrows" of generate_preview_image (core/preview_utils.py:74-82); unpinned (cv2.arrowedLine restated)."""
+    L, pl = _u(left)
+    s, ps = _f(np.squeeze(shift))
+    out = np.empty_like(L)
+    lib().vo_preview_arrows(pl, ps, L.shape[0], L.shape[1], out.ctypes.data_as(_u8p))
+    return out

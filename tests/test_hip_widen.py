@@ -195,9 +195,22 @@ def test_preview_visualisers_vs_oracle_and_golden(R, oracle):
             assert np.array_equal(got, oracle.preview_image(pt, left, right)), (tag, pt)
             if tag != "hd":
                 assert np.array_equal(got, g[f"{tag}__{pt}"]), (tag, pt)
-    with pytest.raises(NotImplementedError):
-        generate_preview_image("Overlay Arrows", left, right, None, w, h)
     assert generate_preview_image("no such preview", left, right, None, w, h) is None      # the reference returns None as well
+
+
+def test_preview_arrows_vs_oracle(R, oracle):
+    """"Overlay Arrows" (core/preview_utils.py:74-82): the closed-form HIP kernel against the oracle's LineIterator-style restatement, on
+    random shift maps (every arrow direction and length, arrows crossing each other and the image border)."""
+    from visiondepth3d_amd.preview_utils import generate_preview_image, preview_arrows
+    for seed, (h, w, amp) in enumerate([(54, 96, 1.5), (37, 75, 6.0), (1080, 1920, 3.0), (200, 300, 40.0)]):
+        rng = np.random.default_rng(seed)
+        left = synth.synth_frame(seed, h, w)[0]
+        shift = (rng.standard_normal((1, h, w)) * amp).astype(np.float32)
+        shift[0, 0, 0] = np.nan
+        got = preview_arrows(R, T(left), T(shift)).cpu().numpy()
+        assert np.array_equal(got, oracle.preview_arrows(left, shift)), (h, w)
+    out = generate_preview_image("Overlay Arrows", left, left, torch.from_numpy(shift), w, h)
+    assert np.array_equal(out, got)
 
 
 def test_preview_heatmaps_vs_oracle_and_golden(R, oracle):

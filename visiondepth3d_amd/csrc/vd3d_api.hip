@@ -1043,6 +1043,14 @@ VD3D_EXPORT int vd3d_bgr_to_nv12(vd3d_ctx* c, const uint8_t* bgr, int h, int w, 
   return 0;
 }
 
+VD3D_EXPORT int vd3d_preview_arrows(vd3d_ctx* c, const uint8_t* left_bgr, const float* shift_map, int h, int w, uint8_t* out_bgr) {
+  if (!c || !left_bgr || !shift_map || !out_bgr || h < 1 || w < 1 || left_bgr == out_bgr) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  vd_launch_preview_arrows(c->stream, left_bgr, shift_map, h, w, out_bgr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_detect_black_bars(vd3d_ctx* c, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host) {
   if (!c || !frame_bgr || !top_host || !bottom_host || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

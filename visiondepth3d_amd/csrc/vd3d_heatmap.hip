@@ -76,3 +76,35 @@ bool vd_launch_preview_heatmap(hipStream_t s, int type, const float* shift, int 
   hipLaunchKernelGGL(k_hm_map, dim3(g), dim3(256), 0, s, shift, n, type, mm, lut_dev, out);
   return true;
 }
+
+// "Overlay Arrows" (core/preview_utils.py:74-82): on a copy of the left eye, every 20th pixel of every 20th row gets
+// cv2.arrowedLine((x, y) -> (x + dx, y), green, thickness 1, tipLength 0.3) with dx = int(shift * 10) when |dx| > 1.
+// The arrows are horizontal, so OpenCV's rasteriser reduces to closed forms: the shaft is the pixel run between the end points; the two
+// tip strokes start at p = pt2 + round(0.3 |dx| (cos, sin)(angle +- pi/4)) with angle = atan2(0, -dx) in {0, pi}, i.e. at
+// (x2 -+ r, y -+ r) with r = round(0.3 |dx| / sqrt 2) -- checked for every |dx| <= 4000: both coordinates round to the same r, 7.6e-5
+// away from a tie -- and an exact 45-degree Bresenham line is its diagonal.  Lines are clipped to the image (cv::clipLine), which for
+// these slopes equals dropping the outside pixels.  All arrows have one colour, so overlapping writes need no order.
+// PARITY UNPINNED (cv2 is not in the build image); the closed forms follow drawing.cpp's arrowedLine / LineIterator.
+__global__ __launch_bounds__(256) void k_preview_arrows(const float* __restrict__ shift, int h, int w, int gw, int gn, uint8_t* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= gn) return;
+  const int gy = t / gw, gx = t - gy * gw;
+  const int y = 20 * gy, x = 20 * gx;
+  const float sv = shift[(size_t)y * w + x] * 10.f;
+  if (!(sv == sv) || fabsf(sv) >= 2.0e9f) return;       // int(nan) / int(inf) raise in the reference
+  const int dx = (int)sv;                                // Python int(): truncation toward zero
+  if (dx > -2 && dx < 2) return;
+  const int x2 = x + dx, adx = dx < 0 ? -dx : dx, sg = dx < 0 ? -1 : 1;
+  auto put = [&](int py, int px) {
+    if (py >= 0 && py < h && px >= 0 && px < w) { uint8_t* o = out + ((size_t)py * w + px) * 3; o[0] = 0; o[1] = 255; o[2] = 0; }
+  };
+  for (int i = 0; i <= adx; ++i) put(y, x + sg * i);
+  const int r = (int)rint((double)adx * 0.3 * 0.70710678118654757);
+  for (int i = 0; i <= r; ++i) { put(y - i, x2 - sg * i); put(y + i, x2 - sg * i); }
+}
+
+void vd_launch_preview_arrows(hipStream_t s, const uint8_t* left, const float* shift, int h, int w, uint8_t* out) {
+  (void)hipMemcpyAsync(out, left, (size_t)h * w * 3, hipMemcpyDeviceToDevice, s);
+  const int gw = (w + 19) / 20, gh = (h + 19) / 20, gn = gw * gh;
+  hipLaunchKernelGGL(k_preview_arrows, dim3((gn + 255) / 256), dim3(256), 0, s, shift, h, w, gw, gn, out);
+}

@@ -153,6 +153,7 @@ void vd_launch_nv12_to_bgr(hipStream_t s, const uint8_t* y, const uint8_t* uv, i
 void vd_launch_bgr_to_nv12(hipStream_t s, const uint8_t* bgr, int h, int w, uint8_t* y, uint8_t* uv, long long y_pitch, long long uv_pitch);
 // ---- vd3d_heatmap.hip
 bool vd_launch_preview_heatmap(hipStream_t s, int type, const float* shift, int h, int w, const uint8_t* lut_dev, uint32_t* mm, uint8_t* out);
+void vd_launch_preview_arrows(hipStream_t s, const uint8_t* left, const float* shift, int h, int w, uint8_t* out);
 // ---- vd3d_upscale.hip
 bool vd_launch_resize_cubic_u8(hipStream_t s, const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw);
 bool vd_launch_resize_area_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);

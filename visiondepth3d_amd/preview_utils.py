@@ -2,7 +2,7 @@
 library.  ``generate_preview_image`` keeps the reference's signature; the types whose definition is plain integer arithmetic
 run as one HIP launch (``vd3d_preview_image``); the colour-mapped heat-maps compute their index plane on device
 (``vd3d_preview_heatmap``) and look it up in OpenCV's own table, fetched from cv2 at first use or registered by the caller; the arrow
-overlay (OpenCV's line rasteriser) raises ``NotImplementedError`` -- never an approximation."""
+overlay (``vd3d_preview_arrows``) uses the closed forms OpenCV's rasteriser reduces to for horizontal arrows."""
 from __future__ import annotations
 
 import ctypes as C
@@ -17,7 +17,6 @@ PREVIEW_TYPES = {"Passive Interlaced": 0, "HSBS": 1, "Left-Right Diff": 2, "Feat
 # colour-mapped types: (vd3d_preview_heatmap type, OpenCV colour map)
 HEATMAP_TYPES = {"Shift Heatmap": (0, "JET"), "Shift Heatmap (Abs)": (1, "JET"), "Shift Heatmap (Clipped \u00b15px)": (2, "JET"),
                  "Feather Mask": (3, "BONE")}
-UNSUPPORTED = ("Overlay Arrows",)
 _COLORMAPS: dict = {}
 
 
@@ -58,10 +57,25 @@ def preview_heatmap(renderer: Renderer, preview_type: str, shift_map: torch.Tens
     return out
 
 
+def preview_arrows(renderer: Renderer, left: torch.Tensor, shift_map: torch.Tensor) -> torch.Tensor:
+    """ "Overlay Arrows" (core/preview_utils.py:74-82): uint8 BGR [h,w,3] left eye + float32 shift map -> the eye with green arrows."""
+    l_ = left.to(renderer.device, torch.uint8).contiguous()
+    s = shift_map.to(renderer.device, torch.float32)
+    if s.dim() == 3 and s.shape[0] == 1:
+        s = s[0]
+    s = s.contiguous()
+    if l_.dim() != 3 or l_.shape[2] != 3 or tuple(s.shape) != tuple(l_.shape[:2]):
+        raise AssertionError("left must be uint8 [h,w,3] and shift_map [h,w] / [1,h,w] of the same size")
+    out = torch.empty_like(l_)
+    renderer._enter(l_, s, out)
+    _lib.check(renderer._L.vd3d_preview_arrows(renderer._ctx, _ptr(l_), _ptr(s), int(l_.shape[0]), int(l_.shape[1]), _ptr(out)))
+    return out
+
+
 def preview_image(renderer: Renderer, preview_type: str, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
     """Device tensors in (uint8 BGR [h,w,3] eyes), device tensor out."""
     if preview_type not in PREVIEW_TYPES:
-        raise NotImplementedError(f"preview type {preview_type!r} is not an eye-only preview (heat-maps: preview_heatmap; arrows: not built)")
+        raise NotImplementedError(f"preview type {preview_type!r} is not an eye-only preview (heat-maps: preview_heatmap; arrows: preview_arrows)")
     l_ = left.to(renderer.device, torch.uint8).contiguous()
     r_ = right.to(renderer.device, torch.uint8).contiguous()
     if l_.shape != r_.shape or l_.dim() != 3 or l_.shape[2] != 3:
@@ -76,10 +90,11 @@ def preview_image(renderer: Renderer, preview_type: str, left: torch.Tensor, rig
 
 def generate_preview_image(preview_type, left, right, shift_map, w, h):
     """Reference signature (core/preview_utils.py:23): NumPy BGR eyes + the shift-map tensor in, NumPy BGR preview out (None for unknown
-    types).  "Overlay Arrows" needs OpenCV's line rasteriser and raises."""
-    if preview_type in UNSUPPORTED:
-        raise NotImplementedError(f"preview type {preview_type!r} needs OpenCV's line rasteriser (not built)")
+    types)."""
     r = default_renderer()
+    if preview_type == "Overlay Arrows":
+        return preview_arrows(r, torch.from_numpy(np.ascontiguousarray(left)),
+                              shift_map if torch.is_tensor(shift_map) else torch.from_numpy(np.asarray(shift_map))).cpu().numpy()
     if preview_type in HEATMAP_TYPES:
         return preview_heatmap(r, preview_type, shift_map if torch.is_tensor(shift_map) else torch.from_numpy(np.asarray(shift_map))).cpu().numpy()
     if preview_type not in PREVIEW_TYPES:
