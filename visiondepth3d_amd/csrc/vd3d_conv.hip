@@ -140,11 +140,13 @@ __global__ __launch_bounds__(256, CV_TH == 16 ? 2 : 3) void k_conv3x3_c64(const 
 
 bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const void* wfrag, const float* bias, const float* slope_or_null,
                                void* y) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};      // per device: the > 64 KB dynamic-LDS opt-in is a per-device function attribute
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS) != hipSuccess)
       return false;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   dim3 grid((W + CV_TW - 1) / CV_TW, (H + CV_TH - 1) / CV_TH);
   hipLaunchKernelGGL(k_conv3x3_c64, grid, dim3(256), CV_LDS, s, (const _Float16*)x, H, W, (const uint4*)wfrag, bias, slope_or_null, (_Float16*)y);
