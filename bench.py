@@ -616,7 +616,7 @@ def main():
                 except Exception as e:
                     res["cpu_depth_net"] = {"error": str(e)[:200]}
             try:   # same port on all host cores (bounded: a few frames per core)
-                res["cpu_baseline_allcores"] = cpu_baseline_allcores(1080, 1920, 4)
+                res["cpu_baseline_allcores"] = cpu_baseline_allcores(1080, 1920, 2)
             except Exception as e:   # the single-core figure above is the contract's baseline; this one is additional context
                 res["cpu_baseline_allcores"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
