@@ -11,6 +11,12 @@
 
 #define VD_DEV __device__ __forceinline__
 
+// XCD-aware tile order (MI355X: 8 XCDs, each with a private 4 MB L2; workgroup b is observed to run on XCD b % 8 -- a speed
+// assumption only, never a correctness one).  A 1-D grid of 8 * per workgroups walks the tiles so that every XCD owns one
+// contiguous band of `per` tiles in row-major order: neighbouring tiles' halo re-reads then hit the XCD's own L2 instead of being
+// fetched once per XCD through the fabric.  Returns the tile index (>= the tile count for the padding workgroups of the last band).
+VD_DEV int vd_xcd_tile(int b, int per, int on) { return on ? (b & 7) * per + (b >> 3) : b; }
+
 VD_DEV float vd_clamp(float x, float lo, float hi) {
   float t = x < lo ? lo : x;
   return t > hi ? hi : t;

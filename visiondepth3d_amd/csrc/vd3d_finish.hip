@@ -35,6 +35,7 @@ struct vd_ff_args {
   int fit_w, fit_h, in_w, in_h, xo, yo, fx, fy, out_w, format;
   int use_override, bar_w, bar_s;
   float focal;
+  int ntx, nty, ntiles, per, xcd;   // tile grid (both eyes: ntiles = 2 * ntx * nty), tiles per XCD band, band order on (vd_xcd_tile)
 };
 
 typedef float (*ff_tile_t)[FF_IH][FF_IW];
@@ -167,10 +168,13 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
   __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
   __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
   __shared__ int lvl_mask;                    // levels any pixel of this tile needs
-  const int eye = blockIdx.z;
+  const int tno = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
+  if (tno >= a.ntiles) return;                     // padding workgroup of the last band (workgroup-uniform, before any barrier)
+  const int eye = tno / (a.ntx * a.nty);
+  const int tin = tno - eye * (a.ntx * a.nty), tby = tin / a.ntx, tbx = tin - tby * a.ntx;
   const uint8_t* __restrict__ src = eye == 0 ? eyeL : eyeR;
   const int H = a.H, W = a.W;
-  const int x0 = blockIdx.x * FF_TW, y0 = blockIdx.y * FF_TH;
+  const int x0 = tbx * FF_TW, y0 = tby * FF_TH;
   const int gx0 = x0 - 4, gy0 = y0 - 1;            // graded region origin
   const int ix0 = gx0 - FF_R, iy0 = gy0 - FF_R;    // input tile origin
   const int tid = threadIdx.x;
@@ -428,7 +432,11 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
   a.use_override = use_override; a.bar_w = bar_w; a.bar_s = bar_s; a.focal = focal;
   if (a.xo || a.yo || a.in_w != p.fit_w || a.in_h != p.fit_h)  // pad_to_aspect_ratio canvas (:124): black background
     (void)hipMemsetAsync(out, 0, (size_t)p.out_w * p.out_h * 3, s);
-  dim3 g((p.warp_w + FF_TW - 1) / FF_TW, (p.warp_h + FF_TH - 1) / FF_TH, 2);
+  a.ntx = (p.warp_w + FF_TW - 1) / FF_TW; a.nty = (p.warp_h + FF_TH - 1) / FF_TH;
+  a.ntiles = 2 * a.ntx * a.nty;
+  a.xcd = vd_xcd_order_enabled() ? 1 : 0;
+  a.per = (a.ntiles + 7) / 8;
+  dim3 g(a.xcd ? 8 * a.per : a.ntiles);
   if (dense) hipLaunchKernelGGL(k_finish_fused<true>, g, dim3(FF_NT), 0, s, L, R, dn, fc, a, w, out);
   else hipLaunchKernelGGL(k_finish_fused<false>, g, dim3(FF_NT), 0, s, L, R, dn, fc, a, w, out);
   return true;

@@ -9,6 +9,15 @@ enum { VD_ST_A0 = 0, VD_ST_B0, VD_ST_A1, VD_ST_B1, VD_ST_A2, VD_ST_B2,
 #define PL_KMAX_HOST 33   // largest blur_ksize the pool kernel's LDS tile is sized for
 #define DF_RMAX_HOST 15   // largest Gaussian radius of the DOF kernel
 
+// XCD band order of the tiled pixel kernels (vd_xcd_tile, vd3d_dev.h).  VD3D_XCD_ORDER=0 restores the plain dispatch order: an A/B
+// switch for traffic measurements only (same tiles, same results).
+#include <stdlib.h>
+static inline bool vd_xcd_order_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("VD3D_XCD_ORDER"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+
 #define VD_ETAB 8
 struct vd_stage_args {
   int stage;

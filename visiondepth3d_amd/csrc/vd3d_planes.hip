@@ -97,8 +97,7 @@ struct vd_shift_consts {
 };
 __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int H, int W, const vd_dev_work* __restrict__ w,
                                                vd_shift_consts c, float* __restrict__ S) {
-  __shared__ float em[SH_TH + 4][SH_TW + 4];
-  __shared__ float hs[SH_TH + 4][SH_TW];
+  __shared__ __attribute__((aligned(16))) float em[SH_TH + 4][SH_TW + 4];
   const int x0 = blockIdx.x * SH_TW, y0 = blockIdx.y * SH_TH;
   if (c.edge) {
     for (int t = threadIdx.x; t < (SH_TH + 4) * (SH_TW + 4); t += 256) {
@@ -117,20 +116,30 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
       em[ty][tx] = e;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < (SH_TH + 4) * SH_TW; t += 256) {
-      const int ty = t / SH_TW, tx = t - ty * SH_TW;
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) s += em[ty][tx + j];
-      hs[ty][tx] = s;
-    }
-    __syncthreads();
   }
   const float fgf = w->fg, mgf = w->mg, bgf = w->bg;
-  for (int t = threadIdx.x; t < SH_TH * SH_TW; t += 256) {
-    const int ty = t / SH_TW, tx = t - ty * SH_TW;
-    const int y = y0 + ty, x = x0 + tx;
-    if (y >= H || x >= W) continue;
+  // one thread = 4 consecutive pixels of one row (SH_TH * SH_TW / 4 == 256 threads)
+  const int ty = threadIdx.x / (SH_TW / 4), tx = (threadIdx.x - ty * (SH_TW / 4)) * 4;
+  const int y = y0 + ty;
+  if (y >= H) return;
+  vd_f4 s5 = {0.f, 0.f, 0.f, 0.f};
+  if (c.edge) {
+    // avg_pool2d(5, 1, 2) in ATen's order (cpu_avg_pool2d): ONE float32 running sum over the window, row-major; the zero padding
+    // adds exact zeros.  Four outputs share the 8-column window of each tile row (two 16-byte LDS reads).
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const vd_f4 a = *reinterpret_cast<const vd_f4*>(&em[ty + i][tx]), b = *reinterpret_cast<const vd_f4*>(&em[ty + i][tx + 4]);
+      const float win[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s5[q] += win[q + j];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = x0 + tx + q;
+    if (x >= W) break;
     const float Dv = D[(size_t)y * W + x];
     const float fgw = vd_clamp(vd_pow15_cr(1.0f - Dv), 0.f, 1.f);
     const float mgw = vd_clamp(1.0f - fabsf(Dv - c.mid) * 3.0f, 0.f, 1.f);
@@ -141,10 +150,7 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
     sft = vd_clamp(sft, -w->msn, w->msn);
     if (w->have_conv) sft = sft - w->conv;
     if (c.edge) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) s += hs[ty + i][tx];
-      const float sm = s / 25.f;
+      const float sm = s5[q] / 25.f;
       sft = c.ma * sft + c.mb * (sft * sm);
     }
     S[(size_t)y * W + x] = sft;
@@ -198,7 +204,8 @@ void vd_launch_e2(hipStream_t s, const float* D, const float* S, int H, int W, f
 }
 
 // ------------------------------------------------------------------------------------------------
-// k x k zero-padded window average, separable (x ascending then y ascending), window start -(k/2)
+// k x k zero-padded window average in ATen's order (cpu_avg_pool2d: one float32 running sum over the window, row-major), window
+// start -(k/2).  Fallback kernel of the unfused path (blur sizes / frame sizes the fused warp kernel refuses).
 // ------------------------------------------------------------------------------------------------
 #define PL_TW 64
 #define PL_TH 16
@@ -209,7 +216,6 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ e2L, con
   const int r = k / 2;
   const int tw = PL_TW + k - 1, th = PL_TH + k - 1;
   float* tile = lds;                 // [th][tw]
-  float* hs = lds + (size_t)th * tw; // [th][PL_TW]
   const int x0 = blockIdx.x * PL_TW, y0 = blockIdx.y * PL_TH;
   const float div = (float)(k * k);
   for (int eye = 0; eye < 2; ++eye) {
@@ -221,19 +227,13 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ e2L, con
       tile[t] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < th * PL_TW; t += 256) {
-      const int ty = t / PL_TW, tx = t - ty * PL_TW;
-      float s = 0.f;
-      for (int j = 0; j < k; ++j) s += tile[ty * tw + tx + j];
-      hs[t] = s;
-    }
-    __syncthreads();
     for (int t = threadIdx.x; t < PL_TH * PL_TW; t += 256) {
       const int ty = t / PL_TW, tx = t - ty * PL_TW;
       const int y = y0 + ty, x = x0 + tx;
       if (y >= H || x >= W) continue;
       float s = 0.f;
-      for (int i = 0; i < k; ++i) s += hs[(ty + i) * PL_TW + tx];
+      for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) s += tile[(ty + i) * tw + tx + j];
       dst[(size_t)y * W + x] = s / div;
     }
     __syncthreads();
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ e2L, con
 }
 void vd_launch_pool(hipStream_t s, const float* e2L, const float* e2R, int H, int W, int k, float* bL, float* bR) {
   const int tw = PL_TW + k - 1, th = PL_TH + k - 1;
-  size_t lds = sizeof(float) * ((size_t)th * tw + (size_t)th * PL_TW);
+  size_t lds = sizeof(float) * ((size_t)th * tw);
   hipLaunchKernelGGL(k_pool, dim3((W + PL_TW - 1) / PL_TW, (H + PL_TH - 1) / PL_TH), dim3(256), lds, s, e2L, e2R, H, W, k, bL, bR);
 }
 

@@ -10,12 +10,14 @@
 //           column, so everything that depends on y (sample row, its weights, the south flag, all row base addresses) is
 //           scalar and everything that depends on x only (the linspace coordinate) is computed once per lane; the k leftover
 //           columns right of the first 64 are walked transposed (wave = column, lane = row).  ~35 VALU per position, was ~150.
-//   phase B e2 = clamp(|grad WD| * fs, 0, 1)            phase C horizontal k-sums (ascending x)
-//           (the eye-res RGB tile is prefetched into registers during B / C -- one wave = one tile row, scalar row addresses --
-//           and lands over the dead wd / e2 buffers)
-//   phase D vertical k-sums -> b (exact 3-operation division by k*k), RGB samples = nested bilinear (resize of :595 inside the
-//           grid_sample of :697) read from the LDS eye tile, one row per wave (row-uniform taps; exact skip of the south samples
-//           when the sample row is integral), blend, truncate, shuffle-packed 12-byte stores per 4 lanes.
+//   phase B e2 = clamp(|grad WD| * fs, 0, 1)
+//   phase C b = avg_pool2d(e2, k, 1, k/2) in ATen's order: ONE float32 running sum per output over the k x k window, row-major
+//           (cpu_avg_pool2d; any other association differs in the last bits of ~70 % of the outputs and shows as 1-LSB eye
+//           differences on noisy frames).  One thread = 4 consecutive pixels x both eyes: the (k+3)-column
+//           window of every e2 row comes from 16-byte LDS reads, 4 independent packed chains; exact 3-operation division by k*k.
+//   phase D RGB samples = nested bilinear (resize of :595 inside the grid_sample of :697) read from pre-interpolated rows in LDS,
+//           one row per wave (row-uniform taps; exact skip of the south samples when the sample row is integral), blend, truncate,
+//           shuffle-packed 12-byte stores per 4 lanes.
 // Arithmetic is identical to the unfused v0 kernels (same helpers, same association) => bit-exact vs the oracle.
 //
 // Algorithmic HBM bytes per stereo pair: read RGB 3N (eye-res f32 x3 at N/4) + D 4N + S 4N, write 6N.
@@ -33,11 +35,13 @@ struct vd_wf_args {
   int er_max;                           // eye-res rows one tile touches (exact maximum over the tile rows, host-computed)
   int nch;                              // warp-res columns of the pre-interpolated rows Hh: WF_TW + 2*bound + 2
   int tab_off;                          // float offset of the tables in LDS
+  int e2_off;                           // float offset of the e2 plane in LDS (multiple of 4)
   int fastdiv;                          // 1: x / (k*k) as q0 = x*rc, r = fma(-q0, kk, x), q = fma(r, rc, q0) -- verified exhaustively
   uint32_t m_ew;                        // ceil(2^32/d) reciprocal: q = umulhi(t, m) is exact for t, d < 2^16
   float fs, scale_h, scale_w;
   float step_x, step_y;                 // linspace steps (1-(-1))/(float)(W-1), .../(H-1): vd_lin11_step
   float kk, rc_kk;                      // (float)(k*k) and its correctly rounded reciprocal
+  int ntx, ntiles, per, xcd;            // tile grid: tiles per row, tile count, tiles per XCD band, band order on (vd_xcd_tile)
 };
 // LDS tables (built once per tile, so the per-pixel phases only do table look-ups):
 //   rowA[wh][4]   per halo row of phase A : yn, n, 1-n, south flag                      (grid_sample row part)
@@ -149,15 +153,19 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
                                                       uint8_t* __restrict__ R) {
   extern __shared__ float lds[];
   const int H = a.H, W = a.W, k = a.k, r = k / 2;
-  const int x0 = blockIdx.x * WF_TW, y0 = blockIdx.y * WF_TH;
+  const int tile = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
+  if (tile >= a.ntiles) return;                      // padding workgroup of the last band (workgroup-uniform, before any barrier)
+  const int tby = tile / a.ntx, tbx = tile - tby * a.ntx;
+  const int x0 = tbx * WF_TW, y0 = tby * WF_TH;
   const int ww = WF_TW + k, wh = WF_TH + k;          // wd region
   const int ew = WF_TW + k - 1, eh = WF_TH + k - 1;  // e2 region
-  // LDS aliasing (floats): wd2 [0, 2*wh*ww) is dead after phase B and becomes hs2 [0, 2*eh*TW); e2_2 follows wd2 and is dead after
-  // phase C; hs2 is consumed into registers (the blend weights b of the wave's four rows) before the pre-interpolated RGB rows
-  // Hh land over the whole region.  Live maximum at 4K / k = 9: max(wd2 + e2_2 = 45.9 KB, Hh = 47.3 KB) + 3.8 KB of tables = 51 KB
+  const int ewp = ew + (ew & 1);                     // e2 row pitch (even: 16-byte aligned rows of packed eye pairs)
+  // LDS aliasing (floats): wd2 [0, 2*wh*ww) is dead after phase B and becomes bb2 [0, 2*TH*TW) (the blend weights); e2_2 follows wd2
+  // and is dead after phase C; bb2 is consumed into registers (the weights of the wave's four rows) before the pre-interpolated RGB
+  // rows Hh land over the whole region.  Live maximum at 4K / k = 9: max(wd2 + e2_2 = 45.9 KB, Hh = 47.3 KB) + 3.8 KB of tables = 51 KB
   // => 3 workgroups per CU.
   vd_f2* wd = reinterpret_cast<vd_f2*>(lds);                       // [wh*ww]   (later hs [eh*WF_TW])
-  vd_f2* e2 = reinterpret_cast<vd_f2*>(lds + 2 * wh * ww);         // [eh*ew]
+  vd_f2* e2 = reinterpret_cast<vd_f2*>(lds + a.e2_off);            // [eh][ewp], 16 B aligned
   float* Hh = lds;                                                  // [3][er_max][nch]
   float* rowD = lds + a.tab_off;                                    // [WF_TH][WF_RD], 16 B aligned (host: after the aliased buffers)
   float* rowA = rowD + WF_TH * WF_RD;                               // [wh][4]        (phase A only)
@@ -273,18 +281,51 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
         const vd_f2 m = vd_f2{sqrtf(q.x), sqrtf(q.y)} * a.fs;
         e.x = vd_clamp_fin(m.x, 0.f, 1.f); e.y = vd_clamp_fin(m.y, 0.f, 1.f);
       }
-      e2[t] = e;
+      e2[ty * ewp + tx] = e;
       ty += bq; tx += br;
       if (tx >= ew) { tx -= ew; ++ty; }
     }
     __syncthreads();
-    // phase C: horizontal window sums (ascending x) into the dead wd buffer; wave = e2 row, lane = tile column
-    vd_f2* hs = wd;
-    for (int ty = wv; ty < eh; ty += WF_NW) {
-      const vd_f2* row = e2 + ty * ew + lane;
-      vd_f2 sacc = {0.f, 0.f};
-      for (int j = 0; j < k; ++j) sacc += row[j];
-      hs[ty * WF_TW + lane] = sacc;
+    // phase C: blend weights b (see the header) into the dead wd buffer; thread = (tile row, strip of 4 pixels), both eyes packed
+    {
+      vd_f2* bb = wd;   // [WF_TH][WF_TW]
+      const int ty = tid >> 4, tx0 = (tid & 15) * 4;
+      vd_f2 s0 = {0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+      if (k == 9) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const vd_f4* row = reinterpret_cast<const vd_f4*>(e2 + (ty + i) * ewp + tx0);
+          vd_f2 wn[12];
+#pragma unroll
+          for (int h = 0; h < 6; ++h) { const vd_f4 v = row[h]; wn[2 * h] = vd_f2{v.x, v.y}; wn[2 * h + 1] = vd_f2{v.z, v.w}; }
+#pragma unroll
+          for (int j = 0; j < 9; ++j) { s0 += wn[j]; s1 += wn[j + 1]; s2 += wn[j + 2]; s3 += wn[j + 3]; }
+        }
+      } else {
+        for (int i = 0; i < k; ++i) {
+          const vd_f2* row = e2 + (ty + i) * ewp + tx0;
+          vd_f2 w0 = row[0], w1 = row[1], w2 = row[2];
+          for (int j = 0; j < k; ++j) {
+            const vd_f2 w3 = row[j + 3];
+            s0 += w0; s1 += w1; s2 += w2; s3 += w3;
+            w0 = w1; w1 = w2; w2 = w3;
+          }
+        }
+      }
+      vd_f2 sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (a.fastdiv) {   // correctly rounded s / (k*k) in three packed operations (tools/verify_fastdiv.c: exhaustive)
+          const vd_f2 q0 = sv[q] * a.rc_kk;
+          const vd_f2 rr = vd_vfma(-q0, (vd_f2)(a.kk), sv[q]);
+          sv[q] = vd_vfma(rr, (vd_f2)(a.rc_kk), q0);
+        } else {
+          sv[q].x = sv[q].x / a.kk; sv[q].y = sv[q].y / a.kk;
+        }
+      }
+      vd_f4* dst = reinterpret_cast<vd_f4*>(bb + ty * WF_TW + tx0);
+      dst[0] = vd_f4{sv[0].x, sv[0].y, sv[1].x, sv[1].y};
+      dst[1] = vd_f4{sv[2].x, sv[2].y, sv[3].x, sv[3].y};
     }
   }
   // the shift values of this wave's phase-D rows: issued early so that their latency overlaps the Hh build
@@ -295,23 +336,12 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
     sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
   }
   __syncthreads();
-  // phase D0: the feather weights b of the wave's rows (vertical k-sums of hs2, / (k*k)) into registers -- hs2 dies here
+  // phase D0: the feather weights b of the wave's rows into registers -- bb2 dies here
   vd_f2 bD[WF_TH / WF_NW];
 #pragma unroll
   for (int j = 0; j < WF_TH / WF_NW; ++j) {
     vd_f2 b = {0.f, 0.f};
-    if (FEATHER) {
-      const vd_f2* col = wd + (wv + j * WF_NW) * WF_TW + lane;
-      vd_f2 sacc = {0.f, 0.f};
-      for (int i = 0; i < k; ++i) sacc += col[i * WF_TW];
-      if (a.fastdiv) {   // correctly rounded sacc / (k*k) in three packed operations (tools/verify_fastdiv.c: exhaustive)
-        const vd_f2 q0 = sacc * a.rc_kk;
-        const vd_f2 rr = vd_vfma(-q0, (vd_f2)(a.kk), sacc);
-        b = vd_vfma(rr, (vd_f2)(a.rc_kk), q0);
-      } else {
-        b.x = sacc.x / a.kk; b.y = sacc.y / a.kk;
-      }
-    }
+    if (FEATHER) b = wd[(wv + j * WF_NW) * WF_TW + lane];
     bD[j] = b;
   }
   if (RESIZE) {
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
       const vd_tap t = wf_tap(a.iw, W, a.scale_w, min(cb + j, W - 1));
       colT[2 * j] = __int_as_float(t.i0); colT[2 * j + 1] = t.w1;
     }
-    __syncthreads();   // hs2 fully consumed, colT complete
+    __syncthreads();   // bb2 fully consumed, colT complete
     // phase D1: Hh[c][r][X] = the HORIZONTAL half of the resize of :595 for warp-res column cb + X and eye-res row er0 + r:
     //   fma(p[i0], 1 - w1, w1 * p[i0 + 1])  -- exactly the first two operations of ATen's bilinear (rows, then columns), computed
     // once and shared by every sample that needs it (~4.4 per element) instead of inside each of them.  One wave = one 64-column
@@ -487,7 +517,7 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   const bool resize = !(ih == H && iw == W);
   const int k = a.k;
   a.kk = (float)(k * k); a.rc_kk = 1.0f / a.kk; a.fastdiv = wf_fastdiv_ok(k) ? 1 : 0;
-  a.er_max = 0; a.nch = 0;
+  a.er_max = 0; a.nch = 0; a.e2_off = 0;
   size_t sz_hh = 0;
   if (resize) {
     // exact number of eye-res rows a tile touches: the same float32 tap arithmetic as the kernel (wf_tap), over every tile row
@@ -511,7 +541,9 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   // aliased layout (see the kernel): max(wd2 + e2_2, Hh) when feathering, else Hh alone
   size_t fl = sz_hh;
   if (a.feather) {
-    const size_t sz_wd = (size_t)2 * (WF_TH + k) * (WF_TW + k), sz_e2 = (size_t)2 * (WF_TH + k - 1) * (WF_TW + k - 1);
+    const int ew = WF_TW + k - 1, ewp = ew + (ew & 1);
+    const size_t sz_wd = ((size_t)2 * (WF_TH + k) * (WF_TW + k) + 3) & ~(size_t)3, sz_e2 = (size_t)2 * (WF_TH + k - 1) * ewp;
+    a.e2_off = (int)sz_wd;
     fl = sz_wd + sz_e2 > sz_hh ? sz_wd + sz_e2 : sz_hh;
   }
   fl = (fl + 3) & ~(size_t)3;            // tables start 16 B aligned (ds_read_b128)
@@ -526,7 +558,11 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   if (H >= (1 << 24) || W >= (1 << 24) || (unsigned long long)H * W * 3ull >= (1ull << 32) || (unsigned long long)ih * iw * 3ull >= (1ull << 32)) return false;  // 32-bit offsets
   const size_t bytes = fl * sizeof(float);
   if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 51 KB)
-  dim3 g((W + WF_TW - 1) / WF_TW, (H + WF_TH - 1) / WF_TH);
+  a.ntx = (W + WF_TW - 1) / WF_TW;
+  a.ntiles = a.ntx * ((H + WF_TH - 1) / WF_TH);
+  a.xcd = vd_xcd_order_enabled() ? 1 : 0;
+  a.per = (a.ntiles + 7) / 8;
+  dim3 g(a.xcd ? 8 * a.per : a.ntiles);
   static bool attr[64] = {false};   // per device: the attribute belongs to the device's copy of the code object
   int dev = 0;
   (void)hipGetDevice(&dev);
