@@ -28,6 +28,32 @@ def u8_diff_stats(a, b):
     return int(d.max()), float(np.count_nonzero(d)) / d.size, float(np.count_nonzero(d > 1)) / d.size
 
 
+# Measured ceilings of |HIP / oracle - reference| per committed loop fixture (max LSB, fraction of samples that differ, fraction that
+# differ by more than 1 LSB), with a small margin: a regression cannot hide under them.  What is left after the
+# avg_pool2d order was matched to ATen (round 3) has ONE named cause: torch-CPU's SLEEF pow is a 1-ULP routine, the oracle's is
+# correctly rounded -> the shaped depth differs by 1 ULP on ~0.6 % of its samples -> the warped-depth gradient mask, averaged over
+# k x k windows, differs in the last bits almost everywhere -> the feather blend flips a uint8 truncation on ~1e-4 of the eye samples
+# (<= 1 LSB each, B1 bar).  Formats whose eyes are the frame itself (Full-SBS with preserve, Interlaced, Anaglyph: identity resize,
+# full sensor noise) show it; Half-SBS eyes are 2x up-scaled (smooth) and stay exact.  The sharpen (gain ~4.5) and the Dubois rows
+# (x1.43) turn some of those 1-LSB eye differences into 2-7 LSB in the muxed frame.  The finishing stage itself is EXACT on the
+# reference's own eyes for every format (test_b2_attribution_*).
+PARITY_BARS = {
+    # small fixtures (tests/golden/render_loop.npz, widen.npz, blank.npz)
+    "half_sbs_cli": (0, 0.0, 0.0), "half_sbs_gui_nodof": (0, 0.0, 0.0), "half_sbs_cli_second": (0, 0.0, 0.0),
+    "full_sbs_preserve": (5, 4e-4, 1e-4), "interlaced": (6, 6e-4, 2e-4), "anaglyph_43crop": (7, 2e-3, 8e-4),
+    "autocrop_letterbox": (0, 0.0, 0.0), "vr_1080": (0, 0.0, 0.0),
+    "blank_half_sbs": (2, 1.5e-4, 8e-5), "blank_interlaced_up": (5, 1.5e-4, 5e-5), "blank_anaglyph_43": (6, 2e-3, 8e-4),
+    # real size (tests/golden/real1080.npz, real1080_formats.npz): bands + 8x decimation of 1920x1080 renders
+    "real_half_sbs": (2, 3e-5, 1.5e-5), "real_full_sbs_preserve": (6, 9e-4, 2.5e-4), "real_interlaced": (6, 9e-4, 2.5e-4),
+    "real_anaglyph": (8, 1.2e-3, 4e-4),
+}
+
+
+def assert_parity(name, mx, frac, frac_gt1):
+    bmx, bfr, bf1 = PARITY_BARS[name]
+    assert mx <= bmx and frac <= bfr and frac_gt1 <= bf1, (name, "measured", (mx, frac, frac_gt1), "bar", PARITY_BARS[name])
+
+
 def b2_max_bound(kw):
     """Largest end-to-end difference (in LSB) a <= 1-LSB difference at the warp output (the B1 bar: SLEEF 1-ULP pow / exp in torch vs
     correctly rounded here) can grow to in the muxed frame.  The colour grade scales a channel by up to max(1,sat)*max(1,con) and

@@ -464,6 +464,8 @@ ATTRIB_CASES = {
                                          use_subject_tracking=True, use_floating_window=True, color_saturation=1.2,
                                          color_contrast=1.05, color_brightness=0.02)),
     "full_sbs_preserve": LOOP_CASES["full_sbs_preserve"],
+    "interlaced": LOOP_CASES["interlaced"],
+    "anaglyph_43crop": LOOP_CASES["anaglyph_43crop"],
 }
 
 
@@ -555,6 +557,37 @@ def gen_real1080():
     save("real1080.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 11. the other output formats at REAL size: Full-SBS with preserve_original_aspect (eye = the 1920x1080 frame
+#     itself, identity resize: the most noise-sensitive case), Passive Interlaced, Red-Cyan Anaglyph.  Same storage as real1080.npz.
+# ------------------------------------------------------------------------------------------
+_REAL_COMMON = dict(output_height=1080, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
+                    feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+REAL_FORMAT_CASES = {
+    "full_sbs_preserve": dict(_REAL_COMMON, output_format="Full-SBS", preserve_original_aspect=True, original_video_width=1920,
+                              original_video_height=1080),
+    "interlaced": dict(_REAL_COMMON, output_format="Passive Interlaced"),
+    "anaglyph": dict(_REAL_COMMON, output_format="Red-Cyan Anaglyph"),
+}
+
+
+def gen_real1080_formats():
+    sh, sw, n = 1080, 1920, 3
+    out = {"cases_json": np.frombuffer(json.dumps(REAL_FORMAT_CASES).encode(), dtype=np.uint8),
+           "bands_json": np.frombuffer(json.dumps(REAL_BANDS).encode(), dtype=np.uint8)}
+    for name, kw in REAL_FORMAT_CASES.items():
+        written, _ = run_loop_capturing(sh, sw, n, kw)
+        out[f"{name}__shape"] = np.array(written[0].shape, dtype=np.int64)
+        for i, fr in enumerate(written):
+            out[f"{name}__bands_{i}"] = np.concatenate([fr[a:b] for a, b in REAL_BANDS])
+            out[f"{name}__rowsum_{i}"] = fr.astype(np.int64).sum(axis=1)
+            out[f"{name}__colsum_{i}"] = fr.astype(np.int64).sum(axis=0)
+            out[f"{name}__dec8_{i}"] = fr[::8, ::8].copy()
+            out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+        print(f"  real1080 {name}: {len(written)} frames of {written[0].shape}")
+    save("real1080_formats.npz", **out)
+
+
 def gen_heal():
     """a23 heal_missing_pixels (core/render_3d.py:431-459), pure torch: pinned directly."""
     out = {"cases": np.frombuffer(json.dumps(HEAL_CASES).encode(), dtype=np.uint8)}
@@ -568,11 +601,13 @@ def gen_heal():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats"]
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:
         gen_real1080()
+    if "real1080_formats" in which:
+        gen_real1080_formats()
     if "heal" in which:
         gen_heal()
     if "blank" in which:

@@ -4,7 +4,7 @@ HIP (through the C ABI) vs the CPU oracle: bit-exact; vs the reference goldens (
 import numpy as np
 import pytest
 
-from conftest import golden_json, load_golden, u8_diff_stats
+from conftest import assert_parity, golden_json, load_golden, u8_diff_stats
 from visiondepth3d_amd import synth
 from visiondepth3d_amd._lib import Vd3dError
 from visiondepth3d_amd.params import render_kwargs_to_params
@@ -68,8 +68,7 @@ def test_autocrop_loop_bit_exact(R, oracle):
     p = render_kwargs_to_params(sw, sh, **kw)
     got, exp = _loop(R, oracle, frames, depth_bgr, p)
     assert np.array_equal(got, exp), u8_diff_stats(got, exp)
-    mx, frac, frac_gt1 = u8_diff_stats(got, g["autocrop_letterbox__frames"])
-    assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2
+    assert_parity("autocrop_letterbox", *u8_diff_stats(got, g["autocrop_letterbox__frames"]))
     # a later clip WITHOUT auto crop on the same context reports (0, 0) again and uses the static crop
     kw2 = dict(kw); kw2["auto_crop_black_bars"] = False
     p2 = render_kwargs_to_params(sw, sh, **kw2)
@@ -117,8 +116,7 @@ def test_vr_loop_bit_exact_and_golden(R, oracle):
     assert got.shape == (2, 1600, 2880, 3)
     assert np.array_equal(got, exp), u8_diff_stats(got, exp)
     for (a, b) in bands:
-        mx, frac, frac_gt1 = u8_diff_stats(got[:, a:b], g[f"vr_1080__rows_{a}_{b}"])
-        assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2, (a, b, mx, frac, frac_gt1)
+        assert_parity("vr_1080", *u8_diff_stats(got[:, a:b], g[f"vr_1080__rows_{a}_{b}"]))
 
 
 def test_full_sbs_720_like_upscale_loop(R, oracle):
@@ -272,8 +270,7 @@ def test_blank_frame_loops(R, oracle):
             if b:
                 assert np.array_equal(got, ref), (name, idx)
             else:
-                mx, frac, frac_gt1 = u8_diff_stats(got, ref)
-                assert mx <= 8 and frac_gt1 < 5e-3 and frac < 1.5e-2, (name, idx, mx, frac, frac_gt1)
+                assert_parity(name, *u8_diff_stats(got, ref))
         assert R.export_state().as_dict() == ro.state.as_dict(), name
 
 
