@@ -157,7 +157,7 @@ class Env:
 
 
 def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_dtype: str = "f32", profile: bool = True,
-                 isolated_pass: bool = True):
+                 isolated_pass: bool = True, host_io=None):
     """Time `steps` steps of one workload after `warmup` untimed steps.  Returns a dict with the timing, the HIP-event stage
     averages taken inside the timed region, and the parameters needed to price them."""
     torch, dist = env.torch, env.dist
@@ -167,6 +167,7 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     from visiondepth3d_amd.render_3d import Renderer
 
     sh, sw, model_name, desc = WORKLOADS[workload]
+    host_io = bool(args.host_io) if host_io is None else bool(host_io)
     p = render_kwargs_to_params(sw, sh, output_height=sh, dof_dense_conv=not workload.endswith("-sepdof"), **RENDER_KW)
     overlap = (not args.no_overlap) and model_name is not None
     r = Renderer(local_rank, private_stream=overlap, auto_order=False)   # bench orders its streams by hand; DIBR chain on its own stream when a depth net shares the GPU
@@ -181,13 +182,13 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     depths = torch.stack([torch.from_numpy(d) for d in depths_np]).cuda()          # [C,h,w] f32
     outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
     ring = h_clip = None
-    if args.host_io:   # the clip lives in pinned host memory, results return to pinned host memory
+    if host_io:   # the clip lives in pinned host memory, results return to pinned host memory
         from visiondepth3d_amd.frame_io import PinnedRing
         h_clip = frames.cpu().pin_memory()
         ring = PinnedRing(B, (sh, sw, 3), (p.out_h, p.out_w, 3), torch.device("cuda", local_rank), depth=3)
 
     # host-io: measured slower with the overlapped passes (the copy engines then compete with two compute streams)
-    pix_ov = (not args.host_io) if args.pixel_overlap is None else bool(args.pixel_overlap)
+    pix_ov = (not host_io) if args.pixel_overlap is None else bool(args.pixel_overlap)
     shr2 = None
     if world > 1 or args.sharded or pix_ov:
         from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
@@ -304,7 +305,8 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     res = dict(workload=workload, desc=desc, sh=sh, sw=sw, model=model_name, B=B, steps=steps, warmup=warmup, dt=dt,
                frames_total=world * steps * B, stage_ms=stage_ms, iso_ms=iso_ms, net_ms=net_ms, flops_per_frame=flops,
                N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), depth_dtype=depth_dtype if model_name else None,
-               host_io=bool(args.host_io))
+               host_io=host_io, clip=args.clip,
+               shard_bytes=(shr2[0].bytes_per_step() if (shr2 and hasattr(shr2[0], "bytes_per_step")) else None))
     del pipe
     r.close()
     if rh is not r:
@@ -369,17 +371,23 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     hs = [m.register_forward_hook(hook) for m in up.net.modules() if isinstance(m, torch.nn.Conv2d)]
     x = r.esr_preprocess(r.resize_area_u8(outs[0], 540, 960), dtype=up.dtype)
     with torch.no_grad():
-        up.net(x)
+        up.net(x)          # flop count only (the module graph has the same convolutions as the product path)
     for h in hs:
         h.remove()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    with torch.no_grad():
-        for _ in range(5):
-            up.net(x)
-    b.record()
-    torch.cuda.synchronize()
-    net_ms = a.elapsed_time(b) / 5
+
+    def timed(fn, n=5):
+        with torch.no_grad():
+            fn(x)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        with torch.no_grad():
+            for _ in range(n):
+                fn(x)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+    net_ms = timed(up._forward)        # the PRODUCT path: 32 body layers on vd3d_conv3x3_c64_f16, head / tail through MIOpen
+    lib_ms = timed(up.net)             # the same network through the library convolutions only (context, not the product)
     out_shape = list(last[0].shape)
     del pipe, up
     r.close()
@@ -390,10 +398,11 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
             "value": round(steps * B / dt, 3), "unit": "stereo-pairs/s", "steps": steps, "warmup": warmup, "frames_timed": steps * B,
             "ms_per_step": round(dt / steps * 1e3, 3), "dtype": "f32 depth net + f32 DIBR + fp16 up-scale net (the reference's precisions)",
             "output": out_shape, "stage_ms_per_frame": {"depth_net+handoff": round(ms[0], 3), "dibr": round(ms[1], 3), "run_esrgan": round(ms[2], 3)},
-            "roofline_upscale_net": {"bound": "mfma", "kernel": "SRVGGNetCompact 64x32 on a 960x540 frame (MIOpen convolutions through PyTorch-ROCm, fp16)",
+            "roofline_upscale_net": {"bound": "mfma", "kernel": "SRVGGNetCompact 64x32 on a 960x540 frame, Upscaler._forward = the product path: 32 body "
+                                     "layers on the hand-written k_conv3x3_c64 (MFMA, fp16), head 3->64 and tail 64->48 + pixel-shuffle through MIOpen",
                                      "achieved": round(flops[0] / (net_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                      "frac": round(flops[0] / (net_ms * 1e-3) / 1e12 / 2500.0, 4), "flops_per_frame": flops[0],
-                                     "avg_forward_ms": round(net_ms, 3)}}
+                                     "avg_forward_ms": round(net_ms, 3), "library_only_forward_ms": round(lib_ms, 3)}}
 
 
 def copy_yardstick(env):
@@ -437,6 +446,7 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
         rf = {"bound": "valu" if lane else "hbm", "kernel": "k_warp_fused (W1: feather mask + pool + warp + blend, one launch)",
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
               "traffic": w1.get("corrected_bytes_per_launch"), "traffic_source": w1.get("source"),
+              "traffic_taken_at_commit": (_pmc("commit") or None),
               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": w1_ms,
               "isolated_avg_launch_ms": iso.get("w1"),
               "isolated_frac": round(alg / (iso["w1"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso.get("w1", 0) > 0 else None,
@@ -509,7 +519,8 @@ def main():
     ap.add_argument("--depth-dtype", default="f32", choices=("f32", "bf16"), help="depth-net precision of the measured workload "
                     "(f32 = the reference's; bf16 is labelled reduced precision)")
     ap.add_argument("--batch", type=int, default=16, help="frames per step")
-    ap.add_argument("--clip", type=int, default=16, help="distinct synthetic frames resident in HBM (cycled)")
+    ap.add_argument("--clip", type=int, default=32, help="distinct synthetic frames resident in HBM (cycled); default 2 x batch so that "
+                    "consecutive steps render different frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="headline only")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
@@ -541,8 +552,12 @@ def main():
         r1d = run_workload(env, args, "1080p-dibr", 10, 3, profile=prof)
         rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
         rdn = run_workload(env, args, "4k-dibr-sepdof", 4, 2, profile=prof, isolated_pass=False)
+        rhi = run_workload(env, args, "4k-dibr", 6, 2, profile=False, isolated_pass=False, host_io=True)   # host-I/O-included figure
+        rhi["workload"] = "4k-dibr-hostio"
+        rhi["desc"] = ("4K DIBR only with the frames starting in pinned host memory and the muxed frames copied back to pinned host memory "
+                       "(frame_io.PinnedRing, three slots: H2D, render and D2H of consecutive steps overlap): the PCIe-inclusive rate, never `value`")
         subs = {"4k-dibr": (r4, None), "1080p-dav2s-dibr": (r1e, None), "1080p-dibr": (r1d, None), "4k-dav2b-dibr-bf16": (rbf, None),
-                "4k-dibr-sepdof": (rdn, None)}
+                "4k-dibr-sepdof": (rdn, None), "4k-dibr-hostio": (rhi, None)}
         roof_src = r4
         try:
             up_rec = run_upscale_chain(env, args)
@@ -569,6 +584,9 @@ def main():
                        "pixel_overlap": head["pix_ov"],
                        "sharding": "contiguous frame chunks per rank; scalar records all-gathered and trackers replayed on every rank "
                                    "(bit-identical to 1 GPU)" if env.world > 1 else None,
+                       "rccl_ranks": env.world if env.world > 1 else None,
+                       "comm_per_step_per_rank": head.get("shard_bytes") if env.world > 1 else None,
+                       "distinct_frames_per_rank": head.get("clip"),
                        "params": "render_cli.py defaults + dof_strength 2.0; DOF levels in the reference's dense convolution order (parity mode)"},
         }
         hr = rooflines(head, copy_gbs)
@@ -595,6 +613,11 @@ def main():
                 if name == "4k-dibr-sepdof":
                     extra["note"] = ("opt-in fast mode of the finishing stage (DESIGN.md section 2); every other record, the headline included, "
                                      "runs the dense association that matches the reference's CPU result exactly")
+                if name == "4k-dibr-hostio":
+                    bpf = rs["sh"] * rs["sw"] * 3 * 2   # one source frame up, one muxed Half-SBS frame (same size) down; the float32 depth planes stay in HBM
+                    extra["pcie_bytes_per_frame"] = bpf
+                    extra["pcie_GBs_each_way"] = round(bpf / 2 * rs["frames_total"] / rs["dt"] / 1e9, 2)
+                    extra["note"] = "host-I/O-inclusive (PCIe Gen5 x16, 63 GB/s spec each way); depth planes precomputed and resident, like `4k-dibr`"
                 if name == "4k-dav2b-dibr-bf16":
                     extra["note"] = ("same workload as the headline with the depth net in bfloat16: NOT like-for-like with the reference "
                                      "(float32); its uint8 depth-plane deviation is measured by tests/test_hip_depth_e2e.py")
@@ -615,8 +638,10 @@ def main():
                     res["cpu_depth_net"] = cpu_depth_net(model_name, sh, sw) if model_name else None
                 except Exception as e:
                     res["cpu_depth_net"] = {"error": str(e)[:200]}
-            try:   # same port on all host cores (bounded: a few frames per core)
+            try:   # same port on all host cores (bounded: a few frames per core), at 1080p (configs[1]) and 4K (configs[3])
                 res["cpu_baseline_allcores"] = cpu_baseline_allcores(1080, 1920, 2)
+                if subs:
+                    res["cpu_baseline_allcores_4k"] = cpu_baseline_allcores(2160, 3840, 1, timeout_s=120.0)
             except Exception as e:   # the single-core figure above is the contract's baseline; this one is additional context
                 res["cpu_baseline_allcores"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)

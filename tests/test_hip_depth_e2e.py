@@ -157,3 +157,41 @@ def test_configs3_slice_dav2_base_4k_one_frame(R, oracle):
     assert not np.array_equal(left, right)                      # a real stereo pair
     d = np.abs(left.astype(np.int16) - right.astype(np.int16))
     assert float((d <= 48).mean()) > 0.9                        # ... of the same scene: parallax moves edges, not the picture
+
+
+def test_configs4_chain_1080p_depth_dibr_esrgan_to_4k(R, oracle):
+    """BASELINE configs[4] as ONE chain on the HIP path: a 1920x1080 synthetic frame -> Depth-Anything-V2-Small
+    (float32) -> 8-bit hand-off -> vd3d_render_frame (Half-SBS 1920x1080, bit-exact vs the oracle on the same uint8 plane) ->
+    ``Upscaler.run_esrgan(input_res_pct=50, target_size=(3840, 2160))`` with the hand-written matrix-core body (hip_body=True, fp16
+    like the reference's ONNX export, core/merged_pipeline.py:237-264).  The network's own prediction is replayed into the oracle's
+    glue (INTER_AREA down, esr post-process, three INTER_CUBIC resizes): the 2160x3840 output must equal it exactly."""
+    from visiondepth3d_amd.upscale import Upscaler
+    st, outs, _ = _e2e_vs_oracle(R, oracle, "depth-anything-v2-small", 1080, 1920, 2)
+    assert st["exact"] >= 0.995 and st["max"] <= 1, st
+    sbs = outs[1]                                            # the second rendered frame (trackers warmed by the first)
+    assert sbs.shape == (1080, 1920, 3)
+    up = Upscaler(R, "RealESR_Gx4_fp16", hip_body=True)
+    assert up._body is not None and up.dtype == torch.float16   # the product path: MFMA conv3x3 body, not the library convolutions
+    preds, infer = [], up._infer
+
+    def recording(f, y0=0, x0=0, h=None, w=None):
+        p = infer(f, y0, x0, h, w)
+        preds.append(p.cpu().numpy()[0])
+        return p
+    up._infer = recording
+    R.set_profiling(True)
+    got = up.run_esrgan(torch.from_numpy(sbs).cuda(), input_res_pct=50, target_size=(3840, 2160))
+    R.sync()
+    assert R.stage_calls("conv3x3") >= 32                       # every body layer went through vd3d_conv3x3_c64_f16
+    R.set_profiling(False)
+    got = got.cpu().numpy()
+    assert got.shape == (2160, 3840, 3) and got.dtype == np.uint8
+    assert len(preds) == 1 and preds[0].shape == (3, 4 * 540, 4 * 960)
+    small = oracle.resize_area(sbs, 960, 540)                                      # :246-248 (50 %)
+    upscaled = oracle.esr_post(preds[0])                                           # :225-229 on the device prediction
+    upscaled = oracle.resize_cubic_u8(upscaled, small.shape[0] * 4, small.shape[1] * 4)   # :259-260
+    upscaled = oracle.resize_cubic_u8(upscaled, 1080, 1920)                        # :261
+    want = oracle.resize_cubic_u8(upscaled, 2160, 3840)                            # :262-263 target_size
+    assert np.array_equal(got, want), int(np.abs(got.astype(int) - want.astype(int)).max())
+    # a real picture, not a constant canvas: the up-scaled pair still carries the stereo pair's structure
+    assert got.std() > 5.0 and not np.array_equal(got[:, :1920], got[:, 1920:])

@@ -484,3 +484,30 @@ def test_real_size_other_formats_hip_vs_reference_fixture_and_oracle(R, oracle):
         ro.new_clip()
         exp = ro.render(f, d, 1)
         assert np.array_equal(out, exp), (name, u8_diff_stats(out, exp))
+
+
+def test_render_clip_with_a_private_stream_renderer(oracle):
+    """render_pairs / render_clip with Renderer(private_stream=True) must order its device-to-host copies behind the
+    renderer's own stream (the copy runs on torch's current stream).  A long clip at 1080p keeps the private stream busy while the
+    host races ahead; every frame must still equal the oracle's."""
+    from visiondepth3d_amd.render_3d import Renderer, render_clip
+    sh, sw, n = 540, 960, 6
+    frames, depths = synth.synth_clip(n, sh, sw)
+    kw = dict(output_format="Half-SBS", output_height=sh, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+              dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+    r = Renderer(0, private_stream=True)
+    try:
+        got = list(render_clip(frames, depths, renderer=r, **kw))
+        r.reset_state()    # the second render starts from fresh trackers too (they persist across renders like the reference's singletons)
+        dev = list(render_clip([T(f) for f in frames], [T(d) for d in depths], renderer=r, keep_on_device=True, **kw))
+    finally:
+        torch.cuda.synchronize()
+        r.close()
+    p = render_kwargs_to_params(sw, sh, **kw)
+    ro = oracle.RenderOracle(p)
+    ro.new_clip()
+    exp = [ro.render(f, d, 0) for f, d in list(zip(frames, depths))[1:]]
+    assert len(got) == len(exp) == n - 1
+    for i, (a, b, e) in enumerate(zip(got, dev, exp)):
+        assert np.array_equal(a, e), (i, u8_diff_stats(a, e))
+        assert np.array_equal(b.cpu().numpy(), e), i

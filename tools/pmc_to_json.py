@@ -28,5 +28,6 @@ for key, prefixes in (("k_warp_fused", ("void k_warp_fused<true, true>",)),
                 "valu_wave_instr_per_launch": v, "valu_lane_instr_per_launch": v * 64 if v is not None else None,
                 "lds_wave_instr_per_launch": avg(n, "SQ_INSTS_LDS"), "lds_bank_conflict_cycles": avg(n, "SQ_LDS_BANK_CONFLICT"),
                 "source": f"profiles/{tag}_pmc_4k_dibr.md"}
-print(json.dumps({"4k-dibr": out, "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in three separate passes over "
+import os
+print(json.dumps({"4k-dibr": out, "commit": os.environ.get("VD3D_COMMIT", "unknown"), "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in three separate passes over "
                   "`bench.py --workload 4k-dibr`; read side x2 (gfx950 FETCH_SIZE counts 64 B per 128-B request; calibrated on k_stream_copy)"}, indent=1))

@@ -144,6 +144,40 @@ __global__ __launch_bounds__(256) void k_read(const uint32_t* __restrict__ src, 
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// streaming-copy variants (the yardstick kernel of bench.py): which access pattern reaches the guide's 6.29 TB/s float4 copy?
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+template <int NT>   // A: grid-stride, four loads in flight a whole grid apart (the round-2 kernel)
+__global__ __launch_bounds__(256) void k_copy_a(const u4* __restrict__ src, u4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    u4 a, b, c, d;
+    if (NT) { a = __builtin_nontemporal_load(src + i); b = __builtin_nontemporal_load(src + i + stride); c = __builtin_nontemporal_load(src + i + 2 * stride); d = __builtin_nontemporal_load(src + i + 3 * stride); }
+    else { a = src[i]; b = src[i + stride]; c = src[i + 2 * stride]; d = src[i + 3 * stride]; }
+    if (NT) { __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride); __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride); }
+    else { dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d; }
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+template <int NT>   // B: every workgroup owns one contiguous chunk; four loads in flight 4 KB apart
+__global__ __launch_bounds__(256) void k_copy_b(const u4* __restrict__ src, u4* __restrict__ dst, size_t n16) {
+  const size_t chunk = (n16 + gridDim.x - 1) / gridDim.x;
+  const size_t beg = (size_t)blockIdx.x * chunk, end = beg + chunk < n16 ? beg + chunk : n16;
+  size_t i = beg + threadIdx.x;
+  for (; i + 768 < end; i += 1024) {
+    u4 a, b, c, d;
+    if (NT) { a = __builtin_nontemporal_load(src + i); b = __builtin_nontemporal_load(src + i + 256); c = __builtin_nontemporal_load(src + i + 512); d = __builtin_nontemporal_load(src + i + 768); }
+    else { a = src[i]; b = src[i + 256]; c = src[i + 512]; d = src[i + 768]; }
+    if (NT) { __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + 256); __builtin_nontemporal_store(c, dst + i + 512); __builtin_nontemporal_store(d, dst + i + 768); }
+    else { dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d; }
+  }
+  for (; i < end; i += 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_copy_c(const u4* __restrict__ src, u4* __restrict__ dst, size_t n16) {   // C: one element per thread
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <typename F>
@@ -216,6 +250,35 @@ int main() {
     CK(hipDeviceSynchronize());
     printf("k_read<1|3|4>: %zu bytes per launch (compare with FETCH_SIZE under --pmc)\n", nb);
     CK(hipFree(src));
+  }
+  {
+    const size_t nb = (size_t)1 << 30, n16 = nb / 16;
+    u4 *a, *b;
+    CK(hipMalloc(&a, nb)); CK(hipMalloc(&b, nb));
+    CK(hipMemset(a, 1, nb));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#define TIMEIT(NM, LAUNCH)                                                                        \
+    do {                                                                                          \
+      for (int r_ = 0; r_ < 2; ++r_) { LAUNCH; }                                                  \
+      (void)hipEventRecord(e0, 0);                                                                \
+      for (int r_ = 0; r_ < 5; ++r_) { LAUNCH; }                                                  \
+      (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);                                 \
+      float ms_ = 0; (void)hipEventElapsedTime(&ms_, e0, e1);                                     \
+      printf("copy %-44s %8.1f GB/s (read + write)\n", NM, 2.0 * nb * 5 / (ms_ * 1e-3) / 1e9);   \
+      fflush(stdout);                                                                             \
+    } while (0)
+    const int grids[4] = {1024, 2048, 4096, 8192};
+    for (int gi = 0; gi < 4; ++gi) {
+      const int g = grids[gi];
+      char nm[64];
+      snprintf(nm, sizeof nm, "A grid-stride nt, %d blocks", g); TIMEIT(nm, hipLaunchKernelGGL(k_copy_a<1>, dim3(g), dim3(256), 0, 0, a, b, n16));
+      snprintf(nm, sizeof nm, "A grid-stride plain, %d blocks", g); TIMEIT(nm, hipLaunchKernelGGL(k_copy_a<0>, dim3(g), dim3(256), 0, 0, a, b, n16));
+      snprintf(nm, sizeof nm, "B chunk nt, %d blocks", g); TIMEIT(nm, hipLaunchKernelGGL(k_copy_b<1>, dim3(g), dim3(256), 0, 0, a, b, n16));
+      snprintf(nm, sizeof nm, "B chunk plain, %d blocks", g); TIMEIT(nm, hipLaunchKernelGGL(k_copy_b<0>, dim3(g), dim3(256), 0, 0, a, b, n16));
+    }
+    TIMEIT("C one element per thread", hipLaunchKernelGGL(k_copy_c, dim3((unsigned)(n16 / 256)), dim3(256), 0, 0, a, b, n16));
+    TIMEIT("hipMemcpyAsync D2D", (void)hipMemcpyAsync(b, a, nb, hipMemcpyDeviceToDevice, 0));
+    CK(hipFree(a)); CK(hipFree(b));
   }
   for (int k : {2, 4}) {
     const int blocks = 256 * k;

@@ -67,6 +67,8 @@ struct vd3d_ctx {
   hipStream_t pix_stream = nullptr; bool pix_overlap = false; bool pix_pending = false;
   hipEvent_t ev_chain = nullptr, ev_pix_last = nullptr;
   std::vector<hipEvent_t> slot_done; std::vector<char> slot_busy;
+  // dense DOF weight table of the fused finishing kernel (vd_finish_consts::w2) in device memory + the host copy it was uploaded from
+  float* d_w2 = nullptr; float w2_host[4][81]; bool w2_valid = false;
   // profiling
   bool profiling = false;
   bool use_fused = true;   // VD3D_UNFUSED=1 selects the one-stage-per-kernel v0 path (A/B and debugging)
@@ -202,7 +204,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->d_w2};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
     for (float* q : *v) (void)hipFree(q);
@@ -377,6 +379,9 @@ static int make_finish_consts(const vd3d_render_params* p, vd_finish_consts* fc)
         sum += fc->kern[l - 1][i];
       }
       for (int i = 0; i < k; ++i) fc->kern[l - 1][i] = fc->kern[l - 1][i] / sum;
+      if (k <= 9)   // dense association: weight of tap (i, j) = the float32 product of the two 1-D weights (what torchvision's outer product holds)
+        for (int i = 0; i < k; ++i)
+          for (int j = 0; j < k; ++j) fc->w2[l - 1][i * k + j] = fc->kern[l - 1][i] * fc->kern[l - 1][j];
     }
   }
   fc->fw = (float)(0.35 + 1e-6);
@@ -419,7 +424,16 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
   StageTimer t(c, "finish");
   if (!wk) wk = c->work;
   const int dense = (p->dof_dense_conv && fc.nlev) ? 1 : 0;   // the reference's dense k x k conv order
-  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out, dense)) {
+  if (dense && c->use_fused && (!c->w2_valid || memcmp(c->w2_host, fc.w2, sizeof fc.w2) != 0)) {
+    // first frame or a new dof_strength: the table changes (rare) -> drain whatever may still read the old one, then replace it
+    if (!c->d_w2) HIPCHK(hipMalloc((void**)&c->d_w2, sizeof fc.w2));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
+    memcpy(c->w2_host, fc.w2, sizeof fc.w2);
+    HIPCHK(hipMemcpy(c->d_w2, c->w2_host, sizeof fc.w2, hipMemcpyHostToDevice));
+    c->w2_valid = true;
+  }
+  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out, dense, c->d_w2)) {
     HIPCHK(hipGetLastError());
     return 0;
   }

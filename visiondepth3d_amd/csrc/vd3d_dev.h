@@ -16,6 +16,17 @@
 // contiguous band of `per` tiles in row-major order: neighbouring tiles' halo re-reads then hit the XCD's own L2 instead of being
 // fetched once per XCD through the fabric.  Returns the tile index (>= the tile count for the padding workgroups of the last band).
 VD_DEV int vd_xcd_tile(int b, int per, int on) { return on ? (b & 7) * per + (b >> 3) : b; }
+// The same idea for kernels whose cost per tile follows the image content (E1: the DOF levels a tile needs): contiguous bands would
+// give every XCD one region of the picture and unbalance them (measured: +18 % kernel time), so the tile rows are dealt out in groups
+// of G rows, group g to XCD g % 8; inside a group the walk is row-major, so the horizontal halo and the halo between the group's rows
+// stay in one L2.  Returns row = -1 ... the caller checks row < rows.  Grid: 8 * ceil(ceil(rows / G) / 8) * G * ntx workgroups.
+VD_DEV void vd_xcd_tile_rows(int b, int ntx, int G, int on, int* row, int* col) {
+  if (!on) { *row = b / ntx; *col = b - *row * ntx; return; }
+  const int x = b & 7, k = b >> 3, pg = G * ntx;
+  const int gl = k / pg, within = k - gl * pg, wr = within / ntx;
+  *row = (gl * 8 + x) * G + wr;
+  *col = within - wr * ntx;
+}
 
 VD_DEV float vd_clamp(float x, float lo, float hi) {
   float t = x < lo ? lo : x;

@@ -2,43 +2,57 @@
 // apply_side_mask + apply_sharpening + INTER_AREA fit + SBS / interlaced mux in ONE launch for both eyes
 // (core/render_3d.py:1340-1419).  Replaces k_dof_grade x2 + k_sharp_mux and their two graded planes (-12N B of HBM).
 //
-// Per 64x16 tile of sharpened pixels (384 threads = 6 waves, blockIdx.z = eye).  The kernel is latency-bound (its time
-// scales 1/occupancy), so the design minimises LDS (30.5 KB -> 5 workgroups per CU) and barriers (3 in total):
-//   load    (16+2+8) x (64+8+8) reflect-padded u8 tile -> v/255 (exact 3-op form) -> planar float tile in LDS
-//   thread  = (graded row 0..17, 4-pixel strip 0..19); one wave owns 3 whole rows (60 lanes), so a strip's horizontal
-//           neighbours are the adjacent LANES: no second LDS buffer, no barrier between the passes
-//   level l V-pass: k x ds_read_b128 down the tile, symmetric-pair FMA tap sums on float4 (v_pk_add/fma_f32);
-//           H-pass: the left / right strips arrive through DPP wave shifts, 12-value register window, 4 outputs
-//   blend the two levels each pixel needs, grade, truncate, side bars -> packed BGR0 dwords in LDS (one b128 per strip)
+// Two geometries of one kernel template (<DENSE, WIDE>; <true, false> = dense levels in the 64x16 geometry serves fit factor 4):
+//   <true, true>  DENSE (default, the reference's dense k x k convolution order): 64x30 tile of sharpened pixels, 576 threads
+//           = 9 waves.  Waves 0-7: thread = (graded row, 4-pixel strip) of the 64 x 32 block of graded pixels the tile's own columns need
+//           (4 rows x 16 strips per wave, every lane busy).  Wave 8: thread = ONE pixel of the two halo columns x0 - 1 / x0 + 64 that only the
+//           3x3 sharpen of the edge columns reads (32 rows x 2 sides) -- a quarter of a strip's work, in its own wave so that it costs a
+//           quarter.  8.3 wave-executions of strip code per 1 920 pixels (round 2: 64x16 tile, 20 strips x 3 rows per wave with 4 idle lanes
+//           and two full halo strips: 6 per 1 024; -26 %).
+//   <false, false> separable levels (opt-in): 64x16 tile, 384 threads = 6 waves x 3 rows x 20 strips; a strip's horizontal neighbours are the
+//           adjacent LANES (DPP wave shifts), so the halo strips stay in the row.
+// Common to both:
+//   load    reflect-padded u8 tile -> v/255 (exact 3-op form) -> planar float tile in LDS (interior tiles: 12-byte groups, ds_write_b128)
+//   blur weight per strip: the 2:1 depth resize of Half-SBS shares its taps between the four pixels (8 loads, 24 operations); the division by
+//           the focus width is the verified 3-operation form (tools/verify_fastdiv_fw.c)
+//   level l dense: K x K window per output, taps row-major, one FMA per tap from 0, weight fl(k1[i] * k1[j]); the strip's 12-column window
+//           comes from three ds_read_b128 per row and channel; only the strips that blend with a level run it
+//           separable: V-pass on float4, H-pass through DPP
+//   blend the two levels each pixel needs, grade, truncate, side bars -> packed BGR0 dwords in LDS
 //   epilogue: 3x3 sharpen on float4 (4 pixels per lane), integer-ratio box average, 12-byte packed stores;
 //           interior tiles with fit (1,1) / (2,1) take the vector path, everything else the generic per-pixel one.
-// Arithmetic identical to k_dof_grade / k_sharp_mux and the oracle (vertical pass first, then horizontal; explicit FMAs
-// only in the Gaussian tap sums, vd_gauss_sym).
+// Arithmetic identical to k_dof_grade / k_sharp_mux and the oracle.
 // Fast path conditions (else the unfused kernels run): Gaussian taps <= 9 (dof_strength <= 2), fit factors in {1,2,4},
 // format in {Half-SBS, Full-SBS, Passive Interlaced}.
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 
 #define FF_TW 64
-#define FF_TH 16
 #define FF_R 4                      // max Gaussian radius of the fast path == strip width
 #define FF_GW (FF_TW + 8)           // graded region width  (4-pixel halo each side: aligned strips; 1 is needed)
-#define FF_GH (FF_TH + 2)           // graded region height (1-pixel halo)
 #define FF_IW (FF_GW + 2 * FF_R)    // input tile width  = 80
-#define FF_IH (FF_GH + 2 * FF_R)    // input tile height = 26
-#define FF_IS (FF_IW / 4)           // strips per tile row = 20 (strip 0 and 19 are halo)
+#define FF_IS (FF_IW / 4)           // strips per tile row = 20 (strip 0 and 19 are input halo, 1 and 18 the graded halo columns)
 #define FF_GP 76                    // pitch of the graded dword tile (multiple of 4: b128 rows)
-#define FF_NT 384                   // 6 waves x 3 rows x 20 strips (4 idle lanes per wave)
+#define FF_XG 2                     // tile rows per XCD group (vd_xcd_tile_rows)
+#define FF_HS 368                   // halo-window plane of one side: 40 rows x 9 floats = 360, padded to 16 mod 32 banks
+#define FF_HC (2 * FF_HS)           // ... of one channel (both sides)
+// geometry per instantiation (DENSE / separable): tile height, graded rows (1-pixel halo), input rows, threads
+template <bool WIDE> struct ff_geo {
+  static constexpr int TH = WIDE ? 30 : 16;
+  static constexpr int GH = TH + 2;
+  static constexpr int IH = GH + 2 * FF_R;
+  static constexpr int NT = WIDE ? 576 : 384;   // 8 strip waves + 1 halo-pixel wave | 6 waves x 3 rows x 20 strips (4 idle lanes)
+};
+#define FF_FW_STD 0.350001007f      // (float)(0.35 + 1e-6): focus_width of the render loop (core/render_3d.py:1357-1360) + :794's 1e-6
 
 struct vd_ff_args {
   int H, W, eh, ew;
   int fit_w, fit_h, in_w, in_h, xo, yo, fx, fy, out_w, format;
   int use_override, bar_w, bar_s;
   float focal;
-  int ntx, nty, ntiles, per, xcd;   // tile grid (both eyes: ntiles = 2 * ntx * nty), tiles per XCD band, band order on (vd_xcd_tile)
+  int ntx, nty, xcd;                // tile grid per eye; XCD row-group order on (vd_xcd_tile_rows)
 };
 
-typedef float (*ff_tile_t)[FF_IH][FF_IW];
 
 // neighbour lanes through DPP (gfx9 wave shifts): value of lane-1 / lane+1 (own value at the wave edge, never used there)
 VD_DEV float ff_from_left(float v) {
@@ -50,8 +64,8 @@ VD_DEV float ff_from_right(float v) {
 
 // one Gaussian level: K = 9 - 2*OFF taps, vertical then horizontal.  Executed by every lane of the wave (the DPP exchange
 // needs the neighbours' vertical sums); `mine` = this strip blends with this level.
-template <int OFF>
-VD_DEV void ff_level(ff_tile_t tile, const float* __restrict__ kern, bool active, bool mine, int sy, int ss, int level,
+template <int OFF, int IH>
+VD_DEV void ff_level(const float (*tile)[IH][FF_IW], const float* __restrict__ kern, bool active, bool mine, int sy, int ss, int level,
                      const int lo[4], vd_f4 vlo[3], vd_f4 vhi[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
   float kw[K];
@@ -96,31 +110,27 @@ VD_DEV void ff_level(ff_tile_t tile, const float* __restrict__ kern, bool active
 // 12-column window comes straight from the LDS tile (three ds_read_b128 per row and channel), the weight row is rebuilt per tile row
 // (K multiplies amortised over 12 K FMAs); four independent accumulation chains per channel.  No lane exchange: only the strips that
 // blend with this level run it.
-template <int OFF>
-VD_DEV void ff_level_dense(ff_tile_t tile, const float* __restrict__ kern, bool mine, int sy, int ss, int level, const int lo[4],
+template <int OFF, int IH>
+VD_DEV void ff_level_dense(const float (*tile)[IH][FF_IW], const float* __restrict__ w2, bool mine, int sy, int ss, int level, const int lo[4],
                            vd_f4 vlo[3], vd_f4 vhi[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
   if (!mine) return;
-  float kw[K];
-#pragma unroll
-  for (int t = 0; t < K; ++t) kw[t] = kern[t];
-  vd_f4 acc[3];      // scalar FMAs on purpose: the v_pk_fma_f32 form (pairs of outputs) needs re-paired window registers, measured 16 % slower
+  vd_f4 acc[3];      // scalar FMAs on purpose: v_pk_fma_f32 issues at half the rate of v_fma_f32 on gfx950 (tools/ubench_valu.hip: +9 % at best)
 #pragma unroll
   for (int c = 0; c < 3; ++c) acc[c] = (vd_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    float wr[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) wr[j] = kw[i] * kw[j];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float* rp = &tile[c][sy + OFF + i][4 * ss - 4];
-      const vd_f4 w0 = *reinterpret_cast<const vd_f4*>(rp), w1 = *reinterpret_cast<const vd_f4*>(rp + 4), w2 = *reinterpret_cast<const vd_f4*>(rp + 8);
-      const float win[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+      const vd_f4 w0 = *reinterpret_cast<const vd_f4*>(rp), w1 = *reinterpret_cast<const vd_f4*>(rp + 4), w2v = *reinterpret_cast<const vd_f4*>(rp + 8);
+      const float win[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
 #pragma unroll
-      for (int j = 0; j < K; ++j)
+      for (int j = 0; j < K; ++j) {
+        const float wt = w2[i * K + j];   // fl(k1[i] * k1[j]) from the host: a scalar operand of the FMAs
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[c][q] = vd_fma(win[q + OFF + j], wr[j], acc[c][q]);
+        for (int q = 0; q < 4; ++q) acc[c][q] = vd_fma(win[q + OFF + j], wt, acc[c][q]);
+      }
     }
   }
 #pragma unroll
@@ -130,6 +140,31 @@ VD_DEV void ff_level_dense(ff_tile_t tile, const float* __restrict__ kern, bool 
       if (level == lo[q]) vlo[c][q] = acc[c][q];
       if (level == lo[q] + 1) vhi[c][q] = acc[c][q];
     }
+}
+
+// One pixel of a halo column (graded row sy, side 0 = column x0 - 1 / 1 = column x0 + 64) in the same dense association, from the
+// 9-column halo windows `hal` (see the kernel): single-dword LDS reads, one accumulation chain per channel.  Result in element 0 of vlo / vhi.
+template <int OFF>
+VD_DEV void ff_level_dense_px(const float* __restrict__ hal, const float* __restrict__ w2, bool mine, int sy, int side, int level, int lo0,
+                              vd_f4 vlo[3], vd_f4 vhi[3]) {
+  constexpr int K = 2 * (FF_R - OFF) + 1;
+  if (!mine) return;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* rp = hal + c * FF_HC + side * FF_HS + (sy + OFF + i) * 9 + OFF;
+#pragma unroll
+      for (int j = 0; j < K; ++j) acc[c] = vd_fma(rp[j], w2[i * K + j], acc[c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep one window row of loads in flight: the kernel is register-limited (2 workgroups per CU)
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (level == lo0) vlo[c][0] = acc[c];
+    if (level == lo0 + 1) vhi[c][0] = acc[c];
+  }
 }
 
 VD_DEV float ff_byte(uint32_t v, int sh) { return (float)((v >> sh) & 0xffu); }   // v_cvt_f32_ubyteN
@@ -161,17 +196,24 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
 #ifndef FF_OCC_ATTR
 #define FF_OCC_ATTR   // A/B builds: -DFF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))' forces the 64-VGPR budget
 #endif
-template <bool DENSE>
-__global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
+template <bool DENSE, bool WIDE>
+__global__ __launch_bounds__(ff_geo<WIDE>::NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
-                                                        const vd_dev_work* __restrict__ w, uint8_t* __restrict__ out) {
+                                                        const vd_dev_work* __restrict__ w, const float* __restrict__ w2g,
+                                                        uint8_t* __restrict__ out) {
+  static_assert(DENSE || !WIDE, "the separable levels exchange vertical sums between adjacent lanes: 64x16 geometry only");
+  constexpr int FF_TH = ff_geo<WIDE>::TH, FF_GH = ff_geo<WIDE>::GH, FF_IH = ff_geo<WIDE>::IH, FF_NT = ff_geo<WIDE>::NT;
   __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
   __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
+  // WIDE: the 9-column windows of the two halo columns, copied out of the tile with a 9-float pitch: the halo-pixel wave reads single
+  // dwords, and in the tile itself its 32 lanes of a half-wave would share 4 banks (one column, pitch 16 mod 32).  Here lane (row, side)
+  // reads bank (9 row + 16 side + j) mod 32: all different.
+  __shared__ float hal[WIDE ? 3 * FF_HC : 1];
   __shared__ int lvl_mask;                    // levels any pixel of this tile needs
-  const int tno = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
-  if (tno >= a.ntiles) return;                     // padding workgroup of the last band (workgroup-uniform, before any barrier)
-  const int eye = tno / (a.ntx * a.nty);
-  const int tin = tno - eye * (a.ntx * a.nty), tby = tin / a.ntx, tbx = tin - tby * a.ntx;
+  int trow, tbx;                                   // tile row over both eyes (0 .. 2 nty - 1) and tile column
+  vd_xcd_tile_rows(blockIdx.x, a.ntx, FF_XG, a.xcd, &trow, &tbx);
+  if (trow >= 2 * a.nty) return;                   // padding workgroup of the last group (workgroup-uniform, before any barrier)
+  const int eye = trow >= a.nty ? 1 : 0, tby = trow - eye * a.nty;
   const uint8_t* __restrict__ src = eye == 0 ? eyeL : eyeR;
   const int H = a.H, W = a.W;
   const int x0 = tbx * FF_TW, y0 = tby * FF_TH;
@@ -208,42 +250,97 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
       tile[2][ty][tx] = vd_u8_unit((float)px[0]);
     }
   }
-  // thread = (graded row sy, tile strip ss); wave v owns rows 3v..3v+2; strips 1..18 are the graded region
   const int lane = tid & 63, wv = tid >> 6;
-  const bool active = lane < 3 * FF_IS;
-  const int sy = active ? 3 * wv + lane / FF_IS : 0, ss = active ? lane % FF_IS : 0;
-  const bool strip = active && ss >= 1 && ss <= FF_IS - 2;
+  bool active, strip, halo_px = false;
+  int sy, ss, hq = 0;                             // hq: the live pixel of a halo-column strip (WIDE: 3 = left column x0 - 1, 0 = right column x0 + 64)
+  if (WIDE) {
+    // waves 0-7: thread = (graded row 4 wv + lane % 4, strip 2 + lane / 4) -- the 64 x 32 graded pixels of the tile's own columns.  Row
+    // fastest: with the 80-float tile pitch (16 banks mod 64) every 16-lane group of a ds_read_b128 then covers the 64 banks exactly
+    // (row-major lanes measured 18x the bank-conflict cycles: two rows of a group alias 32 banks);
+    // wave 8: thread = one pixel of the halo columns (graded row lane / 2; even lanes the left column, odd lanes the right one)
+    active = true; strip = true;
+    if (wv < 8) { sy = 4 * wv + (lane & 3); ss = 2 + (lane >> 2); }
+    else { sy = lane >> 1; halo_px = true; ss = (lane & 1) ? FF_IS - 2 : 1; hq = (lane & 1) ? 0 : 3; }
+  } else {
+    // thread = (graded row sy, tile strip ss); wave v owns rows 3v..3v+2; strips 1..18 are the graded region
+    active = lane < 3 * FF_IS;
+    sy = active ? 3 * wv + lane / FF_IS : 0; ss = active ? lane % FF_IS : 0;
+    strip = active && ss >= 1 && ss <= FF_IS - 2;
+  }
   const int gy = gy0 + sy, gxs = ix0 + 4 * ss;    // image coordinates of the strip's first pixel
   int lo[4] = {0, 0, 0, 0};
   vd_f4 alpha = {0.f, 0.f, 0.f, 0.f};
   int lmin = 9, lmax = -1;
   __syncthreads();   // lvl_mask = 0 visible before the atomicOr below; tile complete
+  if (WIDE && DENSE) {   // halo-column windows (consumed after the next barrier)
+    for (int t = tid; t < 3 * 2 * FF_IH; t += FF_NT) {
+      const int c = t / (2 * FF_IH), rem = t - c * (2 * FF_IH), side = rem / FF_IH, row = rem - side * FF_IH;
+      const float* srcp = &tile[c][row][side ? (4 * (FF_IS - 2)) - FF_R : (4 + 3) - FF_R];   // window of tile column 72 / 7
+      float* dstp = &hal[c * FF_HC + side * FF_HS + row * 9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) dstp[j] = srcp[j];
+    }
+  }
   int my_mask = 0;
   if (strip && fc.nlev) {
     const float focal = a.use_override ? a.focal : w->focal;
+    float dd[4];
+    const int yc = min(max(gy, 0), H - 1);   // halo pixels outside the image are never used
+    if (2 * a.eh == H && 2 * a.ew == W && gxs >= 4 && gxs + 6 <= W) {
+      // exact 2:1 (Half-SBS), strip away from the left / right border: the four pixels x = 4m .. 4m+3 share the eye columns
+      // 2m-1 .. 2m+2 and their taps are a parity rule (vd_tap21: even x -> (i0, w1) = (x/2 - 1, 0.75), odd x -> ((x-1)/2, 0.25)),
+      // so the strip costs 8 loads and 24 operations instead of 4 independent bilinear samples.  Same association as vd_bilerp:
+      // a = fma(p[i0], w0, w1 * p[i1]) per row, then fma(a, wy0, wy1 * b).
+      const vd_tap ay = vd_tap21(a.eh, yc);
+      const int c0 = (gxs >> 1) - 1;
+      const float* r0 = dn + (size_t)ay.i0 * a.ew + c0;
+      const float* r1 = dn + (size_t)ay.i1 * a.ew + c0;
+      const float p0[4] = {r0[0], r0[1], r0[2], r0[3]}, p1[4] = {r1[0], r1[1], r1[2], r1[3]};
+      const float a0 = vd_fma(p0[0], 0.25f, 0.75f * p0[1]), b0 = vd_fma(p1[0], 0.25f, 0.75f * p1[1]);
+      const float a1 = vd_fma(p0[1], 0.75f, 0.25f * p0[2]), b1 = vd_fma(p1[1], 0.75f, 0.25f * p1[2]);
+      const float a2 = vd_fma(p0[1], 0.25f, 0.75f * p0[2]), b2 = vd_fma(p1[1], 0.25f, 0.75f * p1[2]);
+      const float a3 = vd_fma(p0[2], 0.75f, 0.25f * p0[3]), b3 = vd_fma(p1[2], 0.75f, 0.25f * p1[3]);
+      dd[0] = vd_fma(a0, ay.w0, ay.w1 * b0); dd[1] = vd_fma(a1, ay.w0, ay.w1 * b1);
+      dd[2] = vd_fma(a2, ay.w0, ay.w1 * b2); dd[3] = vd_fma(a3, ay.w0, ay.w1 * b3);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = min(max(gxs + q, 0), W - 1);
+        if (a.eh == H && a.ew == W) dd[q] = dn[(size_t)yc * W + x];
+        else if (2 * a.eh == H && 2 * a.ew == W) {   // exact 2:1 at the frame border
+          const vd_tap ay = vd_tap21(a.eh, yc), ax = vd_tap21(a.ew, x);
+          const float* r0 = dn + (size_t)ay.i0 * a.ew;
+          const float* r1 = dn + (size_t)ay.i1 * a.ew;
+          dd[q] = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
+        } else {
+          const vd_tap ay = vd_interp_tap(a.eh, H, yc), ax = vd_interp_tap(a.ew, W, x);
+          const float* r0 = dn + (size_t)ay.i0 * a.ew;
+          const float* r1 = dn + (size_t)ay.i1 * a.ew;
+          dd[q] = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
+        }
+      }
+    }
+    // blur weight |d - focal| / fw: for the loop's focus width (fw == FF_FW_STD) the division is the verified 3-operation form
+    // (tools/verify_fastdiv_fw.c: every float in [1e-30, 1] equals the IEEE quotient; 0 maps to 0; the 4.3 M floats below 2.2e-32,
+    // where the residual underflows, take the IEEE division)
+    const bool fastfw = fc.fw == FF_FW_STD;
+    const float rcfw = 1.0f / FF_FW_STD;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int y = min(max(gy, 0), H - 1), x = min(max(gxs + q, 0), W - 1);  // halo pixels outside the image are never used
-      float dd;
-      if (a.eh == H && a.ew == W) dd = dn[(size_t)y * W + x];
-      else if (2 * a.eh == H && 2 * a.ew == W) {   // exact 2:1 (Half-SBS): src = 0.5*o - 0.25 is exact, the tap is a parity rule
-        const vd_tap ay = vd_tap21(a.eh, y), ax = vd_tap21(a.ew, x);
-        const float* r0 = dn + (size_t)ay.i0 * a.ew;
-        const float* r1 = dn + (size_t)ay.i1 * a.ew;
-        dd = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
-      } else {
-        const vd_tap ay = vd_interp_tap(a.eh, H, y), ax = vd_interp_tap(a.ew, W, x);
-        const float* r0 = dn + (size_t)ay.i0 * a.ew;
-        const float* r1 = dn + (size_t)ay.i1 * a.ew;
-        dd = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
-      }
-      const float bw = vd_clamp_fin(fabsf(dd - focal) / fc.fw, 0.f, 1.f);
+      const float ad = fabsf(dd[q] - focal);
+      float qv;
+      if (fastfw && (ad >= 1e-30f || ad == 0.f)) {
+        const float q0 = ad * rcfw;
+        qv = vd_fma(vd_fma(-q0, FF_FW_STD, ad), rcfw, q0);
+      } else qv = ad / fc.fw;
+      const float bw = vd_clamp_fin(qv, 0.f, 1.f);
       const float bi = vd_clamp_fin(bw * (float)fc.nlev, 0.f, fc.imax);
       int l = (int)floorf(bi);
       l = l > fc.nlev - 1 ? fc.nlev - 1 : (l < 0 ? 0 : l);
       lo[q] = l; alpha[q] = bi - (float)l;
-      lmin = min(lmin, l); lmax = max(lmax, l + 1);
+      if (!WIDE || !halo_px || q == hq) { lmin = min(lmin, l); lmax = max(lmax, l + 1); }
     }
+    if (WIDE && halo_px && hq == 3) { lo[0] = lo[3]; alpha[0] = alpha[3]; }   // a halo-column thread keeps its one pixel in element 0
     for (int l = max(lmin, 1); l <= lmax; ++l) my_mask |= 1 << l;
     if (my_mask) atomicOr(&lvl_mask, my_mask);
   }
@@ -251,6 +348,7 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     vlo[c] = *reinterpret_cast<const vd_f4*>(&tile[c][sy + FF_R][4 * ss]);
+    if (WIDE && halo_px && hq == 3) vlo[c][0] = vlo[c][3];
     vhi[c] = vlo[c];
   }
   __syncthreads();
@@ -260,19 +358,29 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
     const int off = FF_R - fc.ksz[l] / 2;
     const bool mine = (my_mask >> (l + 1)) & 1;
     if (DENSE) {
+      if (WIDE && wv == 8) {   // wave-uniform: the halo-pixel wave
+        const int side = lane & 1;
+        switch (off) {
+          case 0: ff_level_dense_px<0>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          case 1: ff_level_dense_px<1>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          case 2: ff_level_dense_px<2>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          default: ff_level_dense_px<3>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+        }
+        continue;
+      }
       switch (off) {
-        case 0: ff_level_dense<0>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
-        case 1: ff_level_dense<1>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
-        case 2: ff_level_dense<2>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
-        default: ff_level_dense<3>(tile, fc.kern[l], mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        case 0: ff_level_dense<0, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        case 1: ff_level_dense<1, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        case 2: ff_level_dense<2, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        default: ff_level_dense<3, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
       }
       continue;
     }
     switch (off) {  // compile-time tap count => all register indexing is static
-      case 0: ff_level<0>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-      case 1: ff_level<1>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-      case 2: ff_level<2>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-      default: ff_level<3>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      case 0: ff_level<0, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      case 1: ff_level<1, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      case 2: ff_level<2, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      default: ff_level<3, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
     }
   }
   if (strip) {  // blend, grade (:750-767), truncate, side bars (:885-892); float4 = the strip's 4 pixels
@@ -303,11 +411,12 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int x = gxs + q;
+      const int x = gxs + ((WIDE && halo_px) ? hq : q);   // a halo-column thread: element 0 is pixel hq of its strip
       const bool masked = bar_w > 0 && ((bar_s == 2 && x < bar_w) || (bar_s == 1 && x >= W - bar_w));
       if (masked) pk[q] = 0u;
     }
-    *reinterpret_cast<uint4*>(&gb[sy][4 * (ss - 1)]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    if (WIDE && halo_px) gb[sy][4 * (ss - 1) + hq] = pk[0];
+    else *reinterpret_cast<uint4*>(&gb[sy][4 * (ss - 1)]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
   __syncthreads();
   // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux
@@ -412,7 +521,7 @@ __global__ __launch_bounds__(FF_NT) FF_OCC_ATTR void k_finish_fused(const uint8_
 // returns false when the fast path does not apply (caller runs the unfused kernels)
 bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
-                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense) {
+                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense, const float* w2_dev) {
   if (!(p.format == VD3D_FMT_HALF_SBS || p.format == VD3D_FMT_FULL_SBS || p.format == VD3D_FMT_INTERLACED)) return false;
   for (int l = 0; l < fc.nlev; ++l) if (fc.ksz[l] > 2 * FF_R + 1 || fc.ksz[l] < 3) return false;
   vd_ff_args a;
@@ -432,12 +541,15 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
   a.use_override = use_override; a.bar_w = bar_w; a.bar_s = bar_s; a.focal = focal;
   if (a.xo || a.yo || a.in_w != p.fit_w || a.in_h != p.fit_h)  // pad_to_aspect_ratio canvas (:124): black background
     (void)hipMemsetAsync(out, 0, (size_t)p.out_w * p.out_h * 3, s);
-  a.ntx = (p.warp_w + FF_TW - 1) / FF_TW; a.nty = (p.warp_h + FF_TH - 1) / FF_TH;
-  a.ntiles = 2 * a.ntx * a.nty;
+  const bool wide = dense && (ff_geo<true>::TH % a.fy) == 0;   // 64x30 tiles; fit factor 4 keeps the 64x16 geometry
+  const int th = wide ? ff_geo<true>::TH : ff_geo<false>::TH;
+  a.ntx = (p.warp_w + FF_TW - 1) / FF_TW; a.nty = (p.warp_h + th - 1) / th;
   a.xcd = vd_xcd_order_enabled() ? 1 : 0;
-  a.per = (a.ntiles + 7) / 8;
-  dim3 g(a.xcd ? 8 * a.per : a.ntiles);
-  if (dense) hipLaunchKernelGGL(k_finish_fused<true>, g, dim3(FF_NT), 0, s, L, R, dn, fc, a, w, out);
-  else hipLaunchKernelGGL(k_finish_fused<false>, g, dim3(FF_NT), 0, s, L, R, dn, fc, a, w, out);
+  const int ngrp = (2 * a.nty + FF_XG - 1) / FF_XG;
+  dim3 g(a.xcd ? 8 * ((ngrp + 7) / 8) * FF_XG * a.ntx : 2 * a.ntx * a.nty);
+  if (dense && !w2_dev) return false;
+  if (wide) hipLaunchKernelGGL((k_finish_fused<true, true>), g, dim3(ff_geo<true>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
+  else if (dense) hipLaunchKernelGGL((k_finish_fused<true, false>), g, dim3(ff_geo<false>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
+  else hipLaunchKernelGGL((k_finish_fused<false, false>), g, dim3(ff_geo<false>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   return true;
 }

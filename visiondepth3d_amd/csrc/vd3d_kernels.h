@@ -115,6 +115,9 @@ struct vd_finish_consts {
   int nlev;                 // number of blurred levels (4 when dof on, 0 when off)
   int ksz[4];               // kernel sizes
   float kern[4][32];        // 1-D Gaussian weights per level (torchvision _get_gaussian_kernel1d)
+  float w2[4][81];          // levels of <= 9 taps: the dense K x K weights fl(k1[i] * k1[j]), row-major with pitch K.  The host keeps a copy
+                            // of this table in device memory (vd3d_ctx::d_w2); E1 reads it through scalar loads, so the FMAs take the
+                            // weight as a scalar operand: no weight registers, no per-row weight products in the kernel
   float fw, imax;           // focus_width + 1e-6, (N-1) - 1e-6
   float sat, con, bri;
   float sharp_kn, sharp_kc; // normalised sharpen taps
@@ -153,7 +156,7 @@ void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, in
 // ---- vd3d_finish.hip
 bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
-                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense);
+                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense, const float* w2_dev);
 
 // ---- vd3d_conv.hip
 bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const void* wfrag, const float* bias, const float* slope_or_null, void* y);

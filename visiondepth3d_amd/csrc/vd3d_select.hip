@@ -778,107 +778,134 @@ struct FWorkSrc {
     const float curv = 1.f - (xx * xx + yy * yy);
     return vd_clamp(d + curv * (float)0.08, 0.f, 1.f);
   }
+  // at(y, x .. x + 3) for the exact 2:1 resize of a plain plane (norm == 0), x a multiple of 4 with 4 <= x and x + 6 <= W: the four
+  // pixels share the eye columns x/2 - 1 .. x/2 + 2 and their taps are a parity rule (vd_tap21: even x -> (i0, w1) = (x/2 - 1, 0.75),
+  // odd x -> ((x - 1)/2, 0.25)): 8 loads and 24 operations instead of 16 taps.  Same association as vd_bilerp, same values as at().
+  VD_DEV vd_f4 at4_21(int y, int x) const {
+    const vd_tap ty = vd_tap21(ih, y);
+    const float* r0 = src + (size_t)ty.i0 * iw + ((x >> 1) - 1);
+    const float* r1 = src + (size_t)ty.i1 * iw + ((x >> 1) - 1);
+    const float p0[4] = {r0[0], r0[1], r0[2], r0[3]}, p1[4] = {r1[0], r1[1], r1[2], r1[3]};
+    const float a0 = vd_fma(p0[0], 0.25f, 0.75f * p0[1]), b0 = vd_fma(p1[0], 0.25f, 0.75f * p1[1]);
+    const float a1 = vd_fma(p0[1], 0.75f, 0.25f * p0[2]), b1 = vd_fma(p1[1], 0.75f, 0.25f * p1[2]);
+    const float a2 = vd_fma(p0[1], 0.25f, 0.75f * p0[2]), b2 = vd_fma(p1[1], 0.25f, 0.75f * p1[2]);
+    const float a3 = vd_fma(p0[2], 0.75f, 0.25f * p0[3]), b3 = vd_fma(p1[2], 0.75f, 0.25f * p1[3]);
+    const float d[4] = {vd_fma(a0, ty.w0, ty.w1 * b0), vd_fma(a1, ty.w0, ty.w1 * b1), vd_fma(a2, ty.w0, ty.w1 * b2),
+                        vd_fma(a3, ty.w0, ty.w1 * b3)};
+    const float yy = vd_lin11_step(step_y, H, y), yy2 = yy * yy;
+    vd_f4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xx = vd_lin11_step(step_x, W, x + q);
+      const float curv = 1.f - (xx * xx + yy2);
+      v[q] = vd_clamp(d[q] + curv * (float)0.08, 0.f, 1.f);
+    }
+    return v;
+  }
 };
 
-// K3: [eye workgroups] normalise + centre-crop sums + MAD + pass A of J1   |   [work workgroups] pass A of J2 + J3
-//     last workgroup: scan A1.   n_eye_wg = 0 for the bare pixel_shift_cuda entry point.
-__global__ __launch_bounds__(1024) void k_chain_stage1(const float* __restrict__ tdf, float* __restrict__ dn_cur,
-                                                       const float* __restrict__ dn_prev, int eh, int ew, int n_eye_wg,
-                                                       FWorkSrc f, float* __restrict__ dc, vd_dev_work* w, uint32_t* histA,
-                                                       const uint32_t* histB, vd_stage_args a) {
-  __shared__ uint32_t h0[NBL];
+// K3a (eye resolution; skipped by the bare pixel_shift_cuda entry point): normalise the filtered plane -> dn_cur, the exact centre-crop sums,
+//     the MAD against the previous plane, pass A of J1.  No ticket: its scan runs with K3b's.
+__global__ __launch_bounds__(1024) void k_chain_norm(const float* __restrict__ tdf, float* __restrict__ dn_cur,
+                                                     const float* __restrict__ dn_prev, int eh, int ew, vd_dev_work* w, uint32_t* histA,
+                                                     vd_stage_args a) {
   __shared__ uint32_t h1[NBL];
-  __shared__ uint32_t sm[128];
   __shared__ long long part[3][16];
   // normalisation scalars: stage B0's (device) or, in the measure/replay sharding, this frame's row of the replayed table;
   // there dn_prev is the PREVIOUS FILTERED plane and is normalised on the fly with the previous frame's row
   const bool m3 = a.shard == 3;
   const float* e_cur = m3 ? a.etab + VD_ETAB * (a.shard_idx + 1) : nullptr;
   const float* e_prv = m3 ? a.etab + VD_ETAB * a.shard_idx : nullptr;
-  const float n_lo = m3 ? e_cur[0] : w->ema_lo, n_den = m3 ? e_cur[1] : w->ema_den;
-  const int n_col = m3 ? (int)e_cur[2] : w->collapse;
-  if (f.norm) { f.lo = n_lo; f.den = n_den; f.collapse = n_col; }
-  for (int b = threadIdx.x; b < NBL; b += 1024) { h0[b] = 0; h1[b] = 0; }
+  const float lo = m3 ? e_cur[0] : w->ema_lo, den = m3 ? e_cur[1] : w->ema_den;
+  const int collapse = m3 ? (int)e_cur[2] : w->collapse;
+  for (int b = threadIdx.x; b < NBL; b += 1024) h1[b] = 0;
   __syncthreads();
-  if ((int)blockIdx.x < n_eye_wg) {
-    const long long n = (long long)eh * ew;
-    const float lo = n_lo, den = n_den;
-    const int collapse = n_col, have_prev = m3 ? (int)e_prv[3] : w->st.prev_depth_valid;
-    const float p_lo = m3 ? e_prv[0] : 0.f, p_den = m3 ? e_prv[1] : 1.f;
-    const int p_col = m3 ? (int)e_prv[2] : 0;
-    long long s1 = 0, s2 = 0, sd = 0;
-    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)n_eye_wg * 1024) {
-      const long long i = base + threadIdx.x;
-      float v = 0.f; bool in_crop = false;
-      if (i < n) {
-        const float d = vd_clamp(tdf[i], 0.f, 1.f);
-        v = collapse ? d : vd_clamp((d - lo) / den, 0.f, 1.f);
-        dn_cur[i] = v;
-        const int y = (int)((unsigned)i / (unsigned)ew), x = (int)((unsigned)i - (unsigned)y * (unsigned)ew);
-        if (y >= eh / 4 && y < eh * 3 / 4 && x >= ew / 4 && x < ew * 3 / 4) {
-          const double dv = (double)v;
-          s1 += vd_fx40(dv); s2 += vd_fx40(dv * dv);
-        }
-        if (have_prev) {
-          float vp = dn_prev[i];
-          if (m3) { const float dp = vd_clamp(vp, 0.f, 1.f); vp = p_col ? dp : vd_clamp((dp - p_lo) / p_den, 0.f, 1.f); }
-          sd += vd_fx40((double)fabsf(v - vp));
-        }
-        in_crop = vd_in_subject_crop(y, x, eh, ew, v);
+  const long long n = (long long)eh * ew;
+  const int have_prev = m3 ? (int)e_prv[3] : w->st.prev_depth_valid;
+  const float p_lo = m3 ? e_prv[0] : 0.f, p_den = m3 ? e_prv[1] : 1.f;
+  const int p_col = m3 ? (int)e_prv[2] : 0;
+  long long s1 = 0, s2 = 0, sd = 0;
+  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+    const long long i = base + threadIdx.x;
+    float v = 0.f; bool in_crop = false;
+    if (i < n) {
+      const float d = vd_clamp(tdf[i], 0.f, 1.f);
+      v = collapse ? d : vd_clamp((d - lo) / den, 0.f, 1.f);
+      dn_cur[i] = v;
+      const int y = (int)((unsigned)i / (unsigned)ew), x = (int)((unsigned)i - (unsigned)y * (unsigned)ew);
+      if (y >= eh / 4 && y < eh * 3 / 4 && x >= ew / 4 && x < ew * 3 / 4) {
+        const double dv = (double)v;
+        s1 += vd_fx40(dv); s2 += vd_fx40(dv * dv);
       }
-      vd_lds_hist_add(h1, key_a(v), in_crop);
+      if (have_prev) {
+        float vp = dn_prev[i];
+        if (m3) { const float dp = vd_clamp(vp, 0.f, 1.f); vp = p_col ? dp : vd_clamp((dp - p_lo) / p_den, 0.f, 1.f); }
+        sd += vd_fx40((double)fabsf(v - vp));
+      }
+      in_crop = vd_in_subject_crop(y, x, eh, ew, v);
     }
-    s1 = vd_wave_sum_ll(s1); s2 = vd_wave_sum_ll(s2); sd = vd_wave_sum_ll(sd);
-    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s1; part[1][threadIdx.x >> 6] = s2; part[2][threadIdx.x >> 6] = sd; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-      long long v = 0;
-      for (int i = 0; i < 16; ++i) v += part[threadIdx.x][i];
-      long long* dst = threadIdx.x == 0 ? &w->sum1 : (threadIdx.x == 1 ? &w->sum2 : &w->sum_mad);
-      if (v) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
-    }
-    lds_hist_flush(h1, histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A);
-  } else {
-    const long long n = (long long)f.H * f.W;
-    const int nwg = (int)gridDim.x - n_eye_wg, wg = (int)blockIdx.x - n_eye_wg;
-    if ((f.W & 3) == 0 && (reinterpret_cast<uintptr_t>(dc) & 15) == 0) {
-      const long long n4 = n >> 2;
-      for (long long b4 = (long long)wg * 1024; b4 < n4; b4 += (long long)nwg * 1024) {
-        const long long i4 = b4 + threadIdx.x;
-        const bool ok = i4 < n4;
-        vd_f4 v = {0.f, 0.f, 0.f, 0.f};
-        int y = 0, x = 0;
-        if (ok) {
-          const unsigned i = (unsigned)i4 * 4u;
-          y = (int)(i / (unsigned)f.W); x = (int)(i - (unsigned)y * (unsigned)f.W);
-          v.x = f.at(y, x); v.y = f.at(y, x + 1); v.z = f.at(y, x + 2); v.w = f.at(y, x + 3);
-          reinterpret_cast<vd_f4*>(dc)[i4] = v;   // curved depth plane: pass B and the shape kernel stream it
-        }
+    vd_lds_hist_add(h1, key_a(v), in_crop);
+  }
+  s1 = vd_wave_sum_ll(s1); s2 = vd_wave_sum_ll(s2); sd = vd_wave_sum_ll(sd);
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s1; part[1][threadIdx.x >> 6] = s2; part[2][threadIdx.x >> 6] = sd; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    long long v = 0;
+    for (int i = 0; i < 16; ++i) v += part[threadIdx.x][i];
+    long long* dst = threadIdx.x == 0 ? &w->sum1 : (threadIdx.x == 1 ? &w->sum2 : &w->sum_mad);
+    if (v) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
+  }
+  lds_hist_flush(h1, histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A);
+}
+
+// K3b (warp resolution): curved depth of the NORMALISED plane -> dc, pass A of J2 (all pixels) + J3 (subject crop); last workgroup: scan A1.
+// One LDS histogram serves both jobs: the low half-word counts every pixel of the bin, the high half-word the pixels inside the subject
+// crop (a workgroup sees at most VD_K3_MAX_PX < 65536 pixels: the host sizes the grid), so a pixel costs ONE ds_add and the kernel needs
+// 65 KB of LDS instead of 130 KB -- two workgroups per CU.  With the exact 2:1 resize of Half-SBS four pixels share their taps (at4_21).
+#define VD_K3_MAX_PX 61440
+__global__ __launch_bounds__(1024) void k_chain_stage1(FWorkSrc f, float* __restrict__ dc, vd_dev_work* w, uint32_t* histA,
+                                                       const uint32_t* histB, vd_stage_args a) {
+  __shared__ uint32_t hp[NBL];
+  __shared__ uint32_t sm[128];
+  for (int b = threadIdx.x; b < NBL; b += 1024) hp[b] = 0;
+  __syncthreads();
+  const long long n = (long long)f.H * f.W;
+  const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+  if ((f.W & 3) == 0 && (reinterpret_cast<uintptr_t>(dc) & 15) == 0) {
+    const bool two = !f.norm && 2 * f.ih == f.H && 2 * f.iw == f.W;
+    const long long n4 = n >> 2;
+    for (long long b4 = (long long)wg * 1024; b4 < n4; b4 += (long long)nwg * 1024) {
+      const long long i4 = b4 + threadIdx.x;
+      const bool ok = i4 < n4;
+      vd_f4 v = {0.f, 0.f, 0.f, 0.f};
+      int y = 0, x = 0;
+      if (ok) {
+        const unsigned i = (unsigned)i4 * 4u;
+        y = (int)(i / (unsigned)f.W); x = (int)(i - (unsigned)y * (unsigned)f.W);
+        if (two && x >= 4 && x + 6 <= f.W) v = f.at4_21(y, x);
+        else { v.x = f.at(y, x); v.y = f.at(y, x + 1); v.z = f.at(y, x + 2); v.w = f.at(y, x + 3); }
+        reinterpret_cast<vd_f4*>(dc)[i4] = v;   // curved depth plane: pass B and the shape kernel stream it
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned key = key_a(v[q]);
-          vd_lds_hist_add(h0, key, ok);
-          vd_lds_hist_add(h1, key, ok && vd_in_subject_crop(y, x + q, f.H, f.W, v[q]));
-        }
-      }
-    } else {
+      for (int q = 0; q < 4; ++q)
+        if (ok) atomicAdd(&hp[key_a(v[q])], vd_in_subject_crop(y, x + q, f.H, f.W, v[q]) ? 0x10001u : 1u);
+    }
+  } else {
     for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
       const long long i = base + threadIdx.x;
-      float v = 0.f; bool in_crop = false;
       if (i < n) {
         const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W);
-        v = f.at(y, x);
+        const float v = f.at(y, x);
         dc[i] = v;   // curved depth plane: pass B and the shape kernel stream it instead of re-deriving it from 4 taps
-        in_crop = vd_in_subject_crop(y, x, f.H, f.W, v);
+        atomicAdd(&hp[key_a(v)], vd_in_subject_crop(y, x, f.H, f.W, v) ? 0x10001u : 1u);
       }
-      const unsigned key = key_a(v);
-      vd_lds_hist_add(h0, key, i < n);
-      vd_lds_hist_add(h1, key, in_crop);
     }
-    }
-    __syncthreads();
-    lds_hist_flush(h0, histA + (size_t)VD_J_WORK_Q * VD_NB_A);
-    lds_hist_flush(h1, histA + (size_t)VD_J_WORK_S0 * VD_NB_A);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < NBL; b += 1024) {
+    const uint32_t c = hp[b];
+    if (c & 0xffffu) atomicAdd(&histA[(size_t)VD_J_WORK_Q * VD_NB_A + b], c & 0xffffu);
+    if (c >> 16) atomicAdd(&histA[(size_t)VD_J_WORK_S0 * VD_NB_A + b], c >> 16);
   }
   if (last_workgroup(&w->ticket[2], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A1; run_scalar_stage(w, histA, histB, a, sm); }
 }
@@ -1011,14 +1038,16 @@ void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* 
   f.scale_h = (float)ih / (float)H; f.scale_w = (float)iw / (float)W;
   f.step_x = W > 1 ? (1.f - (-1.f)) / (float)(W - 1) : 0.f; f.step_y = H > 1 ? (1.f - (-1.f)) / (float)(H - 1) : 0.f;
   const long long ne = (long long)ih * iw, n = (long long)H * W;
-  const int eye_wg = have_eye ? chain_grid(ne, 4096, 128) : 0;
-  const int work_wg = chain_grid(n, 8192, 256);     // K3: 130 KB of LDS histograms -> one resident workgroup per CU
-  const int eye_wg_b = eye_wg;
+  const int eye_wg = have_eye ? chain_grid(ne, 4096, 256) : 0;
+  // K3b: 65 KB of LDS -> two workgroups per CU; every workgroup walks <= VD_K3_MAX_PX pixels (its packed histogram counts in 16 bits)
+  int work_wg = chain_grid(n, 16384, 512);
+  { const long long need = (n + VD_K3_MAX_PX - 4096 - 1) / (VD_K3_MAX_PX - 4096); if (work_wg < need) work_wg = (int)need; }
+  const int eye_wg_b = have_eye ? chain_grid(ne, 4096, 128) : 0;
   const int work_wg_b = chain_grid(n, 4096, 512);   // K4: streams the stored curved-depth plane (one release fence per workgroup)
-  // K3's warp-res workgroups must not read the dn plane its eye-res workgroups are writing: they read the filtered plane
-  // and apply the (device-scalar) normalisation per tap; K4/K5 read the stored plane, complete by then.
-  hipLaunchKernelGGL(k_chain_stage1, dim3(eye_wg + work_wg), dim3(1024), 0, s, src, dn_cur, dn_prev, ih, iw, eye_wg, f, dc, w, histA, histB, a);
+  // K3a normalises the eye-res plane (its own launch: K3b then samples plain values -- no per-tap division, taps shared by four pixels)
+  if (have_eye) hipLaunchKernelGGL(k_chain_norm, dim3(eye_wg), dim3(1024), 0, s, src, dn_cur, dn_prev, ih, iw, w, histA, a);
   f.src = have_eye ? dn_cur : src; f.norm = 0;
+  hipLaunchKernelGGL(k_chain_stage1, dim3(work_wg), dim3(1024), 0, s, f, dc, w, histA, histB, a);
   hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b), dim3(1024), 0, s, dn_cur, ih, iw, eye_wg_b, f, dc, w, histA, histB, a);
   hipLaunchKernelGGL(k_chain_shape, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, f, dc, w, mid, gamma, D, histA, histB, a);
   hipLaunchKernelGGL(k_chain_b2, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, D, H, W, w, histA, histB, a);

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* _
   const int x0 = tbx * WF_TW, y0 = tby * WF_TH;
   const int ww = WF_TW + k, wh = WF_TH + k;          // wd region
   const int ew = WF_TW + k - 1, eh = WF_TH + k - 1;  // e2 region
-  const int ewp = ew + (ew & 1);                     // e2 row pitch (even: 16-byte aligned rows of packed eye pairs)
+  const int ewp = ew + ((2 - ew) & 3);               // e2 row pitch in eye pairs, = 2 mod 4: rows stay 16-byte aligned and consecutive rows
+                                                     // are 4 banks (mod 8) apart, which makes the 16-byte window reads of phase C conflict-free
   // LDS aliasing (floats): wd2 [0, 2*wh*ww) is dead after phase B and becomes bb2 [0, 2*TH*TW) (the blend weights); e2_2 follows wd2
   // and is dead after phase C; bb2 is consumed into registers (the weights of the wave's four rows) before the pre-interpolated RGB
   // rows Hh land over the whole region.  Live maximum at 4K / k = 9: max(wd2 + e2_2 = 45.9 KB, Hh = 47.3 KB) + 3.8 KB of tables = 51 KB
@@ -541,7 +542,7 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   // aliased layout (see the kernel): max(wd2 + e2_2, Hh) when feathering, else Hh alone
   size_t fl = sz_hh;
   if (a.feather) {
-    const int ew = WF_TW + k - 1, ewp = ew + (ew & 1);
+    const int ew = WF_TW + k - 1, ewp = ew + ((2 - ew) & 3);
     const size_t sz_wd = ((size_t)2 * (WF_TH + k) * (WF_TW + k) + 3) & ~(size_t)3, sz_e2 = (size_t)2 * (WF_TH + k - 1) * ewp;
     a.e2_off = (int)sz_wd;
     fl = sz_wd + sz_e2 > sz_hh ? sz_wd + sz_e2 : sz_hh;

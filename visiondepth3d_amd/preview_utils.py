@@ -93,8 +93,15 @@ def generate_preview_image(preview_type, left, right, shift_map, w, h):
     types)."""
     r = default_renderer()
     if preview_type == "Overlay Arrows":
-        return preview_arrows(r, torch.from_numpy(np.ascontiguousarray(left)),
-                              shift_map if torch.is_tensor(shift_map) else torch.from_numpy(np.asarray(shift_map))).cpu().numpy()
+        sm = shift_map if torch.is_tensor(shift_map) else torch.from_numpy(np.asarray(shift_map))
+        H, W = int(left.shape[0]), int(left.shape[1])
+        if int(h) > H or int(w) > W:   # the reference indexes shift_np[y, x] over range(0, h) x range(0, w) (:77-79)
+            raise IndexError("Overlay Arrows: (w, h) exceeds the frame")
+        if (int(h), int(w)) != (H, W):   # arrows start only inside the (w, h) grid: a zero shift draws nothing (|dx| <= 1)
+            sm = sm.clone()
+            sm[..., int(h):, :] = 0
+            sm[..., :, int(w):] = 0
+        return preview_arrows(r, torch.from_numpy(np.ascontiguousarray(left)), sm).cpu().numpy()
     if preview_type in HEATMAP_TYPES:
         return preview_heatmap(r, preview_type, shift_map if torch.is_tensor(shift_map) else torch.from_numpy(np.asarray(shift_map))).cpu().numpy()
     if preview_type not in PREVIEW_TYPES:

@@ -71,6 +71,13 @@ class Renderer:
                 if t is not None and torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(st)
 
+    def to_host(self, t: torch.Tensor) -> torch.Tensor:
+        """``t.cpu()`` for a tensor this renderer produced: with a private stream the copy (which runs on torch's current stream)
+        is first ordered behind the renderer's stream, so it cannot read an unfinished frame."""
+        if self._private:
+            self.ordered_after()
+        return t.cpu()
+
     def ordered_after(self, stream=None):
         """Make ``stream`` (default: torch's current stream) wait for everything this renderer has enqueued so far."""
         st = self.stream
@@ -273,6 +280,10 @@ class Renderer:
             f = blank_frame.to(self.device, torch.uint8).contiguous()
             self._enter(out, f)
             _lib.check(self._L.vd3d_shard_pixels_blank(self._ctx, int(slot), _ptr(f), C.byref(params), _ptr(out)))
+            ps = self.pixel_stream
+            if ps is not None:   # the overlapped pass reads `f` on a stream torch does not know: keep its memory until that stream is done
+                f.record_stream(ps)
+                out.record_stream(ps)
             return out
         self._enter(out)
         _lib.check(self._L.vd3d_shard_pixels(self._ctx, int(slot), C.byref(params), _ptr(out)))
@@ -547,8 +558,8 @@ def pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg_shift, mg_shi
     r = default_renderer()
     res = r.pixel_shift(frame_tensor, depth_tensor, width, height, p, want_shift=bool(return_shift_map))
     if return_shift_map:
-        return res[0].cpu().numpy(), res[1].cpu().numpy(), res[2].cpu()
-    return res[0].cpu().numpy(), res[1].cpu().numpy()
+        return r.to_host(res[0]).numpy(), r.to_host(res[1]).numpy(), r.to_host(res[2])
+    return r.to_host(res[0]).numpy(), r.to_host(res[1]).numpy()
 
 
 def heal_missing_pixels(warped_frame, warped_depth, original_frame, edge_mask, heal_strength=0.5):
@@ -586,6 +597,8 @@ def render_pairs(pairs, *, renderer: Renderer | None = None, target_ratio=16 / 9
         dt = d if torch.is_tensor(d) else torch.from_numpy(np.ascontiguousarray(d))
         out = r.render_frame(ft.to(r.device, non_blocking=True), dt.to(r.device, non_blocking=True), params,
                              blank=(start_frame_idx + idx) in blank)
+        if getattr(r, "_private", False):   # the consumer (a D2H copy below, or the caller's own kernels on torch's stream) runs behind the renderer's stream
+            r.ordered_after()
         yield out if keep_on_device else out.cpu().numpy()
 
 

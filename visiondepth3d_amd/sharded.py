@@ -105,6 +105,17 @@ class ChunkSharder:
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
+    def bytes_per_step(self) -> dict:
+        """Communication of ONE step per rank, for the benchmark record (so a scaling run can be checked against the protocol):
+        one eye-size float32 plane sent and one received per chunk boundary (none at world 1), two all-gathers of the per-frame
+        records (q: 2 x float32, m: 4 x int64 per frame of the step)."""
+        n = self.world * self.B
+        ph, pw = self.b.plane_shape()
+        return {"ranks": self.world, "frames_per_step": n, "p2p_plane_bytes_sent": 0 if self.world == 1 else int(ph) * int(pw) * 4,
+                "p2p_plane_bytes_received": 0 if self.world == 1 else int(ph) * int(pw) * 4,
+                "allgather_bytes_received": 0 if self.world == 1 else n * (2 * 4 + 4 * 8),
+                "collectives_per_step": 0 if self.world == 1 else 2, "backend": "nccl (RCCL over xGMI)" if self.world > 1 else None}
+
     def _send(self, t, dst):
         dist.send(t.contiguous(), dst, group=self.group)
 

@@ -400,7 +400,7 @@ class Upscaler:
             upscaled = self._esrgan_tiled(frame, int(tile), int(tile_pad))
         else:
             upscaled = R.esr_postprocess(self._infer(frame))
-        scale = self.scale
+        scale = 2 if "x2" in str(model_name or self.model_name).lower() else 4    # :259: from the CALL's model name, like the reference
         fh, fw = int(frame.shape[0]), int(frame.shape[1])
         upscaled = R.resize_cubic_u8(upscaled, fh * scale, fw * scale)
         upscaled = R.resize_cubic_u8(upscaled, int(original.shape[0]), int(original.shape[1]))

@@ -97,7 +97,8 @@ class _Sink:
                     from .render_3d import default_renderer
                     r = self.renderer or default_renderer()
                     t = frame if torch.is_tensor(frame) else torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))
-                    frame = r.bgr_to_nv12(t).cpu().numpy()
+                    nv = r.bgr_to_nv12(t)
+                    frame = (r.to_host(nv) if hasattr(r, "to_host") else nv.cpu()).numpy()   # to_host: ordered behind a private stream
                 self.proc.stdin.write(np.ascontiguousarray(frame, dtype=np.uint8).tobytes())
             except Exception as e:   # a dead encoder ends the render like in the reference (:1424-1426)
                 print(f"FFmpeg write error: {e}")
@@ -207,6 +208,13 @@ def render_sbs_3d(
         label = selected_aspect_ratio.get() if hasattr(selected_aspect_ratio, "get") else selected_aspect_ratio
         target_ratio = aspect_ratios.get(label, 16 / 9)
         src_h, src_w = int(probe.shape[0]), int(probe.shape[1])
+        if preserve_original_aspect and auto_crop_black_bars and (original_video_width is None or original_video_height is None):
+            # the reference's fallback size is the first frame AFTER crop_black_bars_torch (core/render_3d.py:1066-1089)
+            import torch
+            from .render_3d import default_renderer
+            top, bottom = (renderer or default_renderer()).detect_black_bars(torch.from_numpy(np.ascontiguousarray(probe)))
+            original_video_width = src_w
+            original_video_height = src_h - top - bottom if top + bottom < src_h else src_h   # :326 guard: an all-bar frame stays uncropped
         geom = plan_geometry(src_w, src_h, output_height, output_format, target_ratio, preserve_original_aspect,
                              original_video_width, original_video_height)
         try:
