@@ -175,3 +175,32 @@ def test_pth_checkpoint_round_trip(tmp_path):
     for (k, a), (_, b) in zip(src.state_dict().items(), up.net.state_dict().items()):
         assert torch.equal(a, b), k
     assert up.scale == 4
+
+
+def test_rife_network_on_cpu_shapes_padding_and_determinism():
+    """The interpolation network behind run_rife (visiondepth3d_amd/rife.py, IFNet HDv3 with synthetic weights) on the CPU: the
+    [N,6,H,W] -> [N,3,H,W] session contract of core/merged_pipeline.py:204-218, sizes that are not multiples of 32, determinism, the
+    state-dict key names of the published checkpoints, and an output that is neither of the inputs nor their plain average."""
+    import numpy as np
+    import torch
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.rife import RifeNet, RifeSession
+    s = RifeSession(device="cpu")
+    keys = set(s.net.state_dict())
+    for k in ("block0.conv0.0.0.weight", "block0.conv0.0.1.weight", "block1.convblock3.1.0.bias", "block2.conv1.0.weight", "block2.conv1.1.weight",
+              "block2.conv2.2.weight"):
+        assert k in keys, k
+    assert s.net.state_dict()["block0.conv0.0.0.weight"].shape == (45, 11, 3, 3)      # 3 + 3 + 1 image channels + 4 flow channels -> c / 2
+    assert s.net.state_dict()["block2.conv1.2.weight"].shape == (45, 4, 4, 4)         # transposed convolution to the 4 flow channels
+    f1, _ = synth.synth_frame(1, 70, 100)
+    f2, _ = synth.synth_frame(2, 70, 100)
+    x = torch.from_numpy(np.concatenate((f1.astype(np.float32) / 255.0, f2.astype(np.float32) / 255.0), axis=2)).permute(2, 0, 1)[None]
+    y = s(x.repeat(2, 1, 1, 1))
+    assert tuple(y.shape) == (2, 3, 70, 100) and torch.allclose(y[0], y[1], atol=1e-5, rtol=0)   # (oneDNN blocks differently per batch size)
+    assert torch.allclose(y[0], RifeSession(device="cpu")(x)[0], atol=1e-5, rtol=0)     # same weights, same result
+    assert 0.0 < float(y.min()) and float(y.max()) < 1.0
+    mid = (x[:, :3] + x[:, 3:]) / 2
+    assert 1e-3 < float((y[:1] - mid).abs().mean()) < 0.05                              # a warp + blend, not a plain average ...
+    assert float((y[:1] - x[:, :3]).abs().mean()) > float((y[:1] - mid).abs().mean())  # ... and closer to the mid-point than to a frame
+    n = RifeNet()
+    n.load_state_dict(s.net.state_dict())                                               # round trip like a checkpoint

@@ -36,7 +36,7 @@ struct vd_prof_rec { std::string name; hipEvent_t a, b; };
 struct vd3d_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  bool own_stream = false;
+  bool own_stream = false, own_stream_escaped = false;
   vd_dev_work* work = nullptr;
   uint32_t* histA = nullptr;  // [VD_NJOBS][VD_NB_A] followed by histB [VD_NJOBS][VD_MAX_T][VD_NB_B]
   uint32_t* histB = nullptr;
@@ -64,7 +64,7 @@ struct vd3d_ctx {
   vd_dev_work* slot_work = nullptr;
   // overlapped pixel passes (vd3d_set_pixel_overlap): vd3d_shard_pixels runs on pix_stream behind the measurement chain of the
   // NEXT step, which stays on `stream`; slot_done[slot] guards the slot's planes against being overwritten too early
-  hipStream_t pix_stream = nullptr; bool pix_overlap = false; bool pix_pending = false;
+  hipStream_t pix_stream = nullptr; bool pix_overlap = false; bool pix_pending = false; bool pix_stream_escaped = false;
   hipEvent_t ev_chain = nullptr, ev_pix_last = nullptr;
   std::vector<hipEvent_t> slot_done; std::vector<char> slot_busy;
   // dense DOF weight table of the fused finishing kernel (vd_finish_consts::w2) in device memory + the host copy it was uploaded from
@@ -209,11 +209,11 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
     for (float* q : *v) (void)hipFree(q);
   if (c->slot_work) (void)hipFree(c->slot_work);
-  if (c->pix_stream) { (void)hipStreamSynchronize(c->pix_stream); (void)hipStreamDestroy(c->pix_stream); }
+  if (c->pix_stream) { (void)hipStreamSynchronize(c->pix_stream); if (!c->pix_stream_escaped) (void)hipStreamDestroy(c->pix_stream); }
   for (auto e : c->slot_done) (void)hipEventDestroy(e);
   if (c->ev_chain) (void)hipEventDestroy(c->ev_chain);
   if (c->ev_pix_last) (void)hipEventDestroy(c->ev_pix_last);
-  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream && !c->own_stream_escaped) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
@@ -223,7 +223,10 @@ VD3D_EXPORT int vd3d_sync(vd3d_ctx* c) {
   prof_collect(c);
   return 0;
 }
-VD3D_EXPORT void* vd3d_ctx_stream(vd3d_ctx* c) { return (void*)c->stream; }
+VD3D_EXPORT void* vd3d_ctx_stream(vd3d_ctx* c) {
+  if (c && c->own_stream) c->own_stream_escaped = true;   // see vd3d_ctx_pixel_stream
+  return c ? (void*)c->stream : nullptr;
+}
 // Re-target a context that enqueues on a caller-owned stream (e.g. whatever stream is current in PyTorch at call time).  Work already
 // enqueued stays on the old stream; the new stream is ordered behind it with an event, so the context's planes are never raced.
 VD3D_EXPORT int vd3d_ctx_set_stream(vd3d_ctx* c, void* stream) {
@@ -241,7 +244,13 @@ VD3D_EXPORT int vd3d_ctx_set_stream(vd3d_ctx* c, void* stream) {
   c->stream = (hipStream_t)stream;
   return 0;
 }
-VD3D_EXPORT void* vd3d_ctx_pixel_stream(vd3d_ctx* c) { return c ? (void*)c->pix_stream : nullptr; }
+// The handle escapes to the caller (PyTorch wraps it and may record events on it when tensors marked with record_stream() are freed, possibly
+// after the context is gone): from then on the stream is never destroyed (vd3d_ctx_destroy leaves it to the process).
+VD3D_EXPORT void* vd3d_ctx_pixel_stream(vd3d_ctx* c) {
+  if (!c) return nullptr;
+  if (c->pix_stream) c->pix_stream_escaped = true;
+  return (void*)c->pix_stream;
+}
 
 // ---- state ------------------------------------------------------------------------------------
 VD3D_EXPORT int vd3d_state_export(vd3d_ctx* c, vd3d_state* out) {

@@ -118,12 +118,21 @@ VD_DEV void ff_level_dense(const float (*tile)[IH][FF_IW], const float* __restri
   vd_f4 acc[3];      // scalar FMAs on purpose: v_pk_fma_f32 issues at half the rate of v_fma_f32 on gfx950 (tools/ubench_valu.hip: +9 % at best)
 #pragma unroll
   for (int c = 0; c < 3; ++c) acc[c] = (vd_f4){0.f, 0.f, 0.f, 0.f};
+  // window groups (tap row i, channel c), software-pipelined: the three 16-byte reads of the next group are issued before the 4 K FMAs of
+  // the current one, so a wave meets one exposed LDS latency per level instead of 3 K (+4 registers; folding the two level values into one
+  // running blend value to pay for more was tried: hipcc then spills -- 168 VGPRs + scratch -- so lo / hi stay separate)
+  const float* rp0 = &tile[0][sy + OFF][4 * ss - 4];
+  vd_f4 n0 = *reinterpret_cast<const vd_f4*>(rp0), n1 = *reinterpret_cast<const vd_f4*>(rp0 + 4), n2 = *reinterpret_cast<const vd_f4*>(rp0 + 8);
 #pragma unroll
   for (int i = 0; i < K; ++i) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float* rp = &tile[c][sy + OFF + i][4 * ss - 4];
-      const vd_f4 w0 = *reinterpret_cast<const vd_f4*>(rp), w1 = *reinterpret_cast<const vd_f4*>(rp + 4), w2v = *reinterpret_cast<const vd_f4*>(rp + 8);
+      const vd_f4 w0 = n0, w1 = n1, w2v = n2;
+      if (i + 1 < K || c + 1 < 3) {
+        const float* rp = &tile[c + 1 < 3 ? c + 1 : 0][sy + OFF + (c + 1 < 3 ? i : i + 1)][4 * ss - 4];
+        n0 = *reinterpret_cast<const vd_f4*>(rp); n1 = *reinterpret_cast<const vd_f4*>(rp + 4); n2 = *reinterpret_cast<const vd_f4*>(rp + 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the prefetch stays in front of this group's arithmetic
       const float win[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
 #pragma unroll
       for (int j = 0; j < K; ++j) {
@@ -131,6 +140,7 @@ VD_DEV void ff_level_dense(const float (*tile)[IH][FF_IW], const float* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[c][q] = vd_fma(win[q + OFF + j], wt, acc[c][q]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll

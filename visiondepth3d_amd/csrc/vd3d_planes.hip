@@ -561,24 +561,22 @@ void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// streaming copy: the measured-peak yardstick for roofline.frac (16 B / lane, grid-stride)
+// streaming copy: the measured-peak yardstick for roofline.frac.  ONE 16-byte element per thread, no loop: of the access patterns tried
+// on MI355X (tools/ubench_valu.hip, 1 GiB: grid-stride with four loads in flight 4.4-5.2 TB/s, contiguous chunk per workgroup 5.6-5.9,
+// hipMemcpyAsync 5.5) this is the one that reaches the guide's 6.2-6.3 TB/s.
 // ------------------------------------------------------------------------------------------------
-// four independent 16-byte loads in flight per lane, then four stores; non-temporal both ways (a streaming copy must not churn L2)
 typedef unsigned int vd_u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_stream_copy(const vd_u4* __restrict__ src, vd_u4* __restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const vd_u4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const vd_u4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-    __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-    __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
-  }
-  for (; i < n16; i += stride) dst[i] = src[i];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
 }
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes) {
-  size_t n16 = bytes / 16;
-  hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, s, (const vd_u4*)src, (vd_u4*)dst, n16);
+  const size_t n16 = bytes / 16;
+  const size_t per = (size_t)1 << 31;   // elements per launch (the grid dimension is 32-bit)
+  for (size_t off = 0; off < n16; off += per) {
+    const size_t n = n16 - off < per ? n16 - off : per;
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const vd_u4*)src + off, (vd_u4*)dst + off, n);
+  }
   if (bytes % 16) (void)hipMemcpyAsync((char*)dst + n16 * 16, (const char*)src + n16 * 16, bytes % 16, hipMemcpyDeviceToDevice, s);
 }
 

@@ -46,8 +46,12 @@ class Renderer:
         self._L = L
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
-            # default: enqueue on torch's current stream so tensor ops and vd3d kernels stay ordered
-            stream = C.c_void_p(-1) if private_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            # default: enqueue on torch's current stream so tensor ops and vd3d kernels stay ordered.  A private stream is taken from
+            # PyTorch's stream pool and handed to the context as a caller-owned stream: tensors marked with record_stream() may outlive the
+            # renderer, and the caching allocator records an event on that stream when they are freed -- a stream the context had created
+            # and destroyed itself would be a dangling handle by then (segfault in hipEventRecord).
+            self._own_stream = torch.cuda.Stream(device=self.device) if private_stream else None
+            stream = C.c_void_p(self._own_stream.cuda_stream if private_stream else torch.cuda.current_stream(self.device).cuda_stream)
             _lib.check(L.vd3d_ctx_create(self.device.index, stream, C.byref(self._ctx)))
             self._private, self._auto_order = bool(private_stream), bool(auto_order)
             self._bound = None if private_stream else int(torch.cuda.current_stream(self.device).cuda_stream)
@@ -90,6 +94,8 @@ class Renderer:
     @property
     def stream(self) -> "torch.cuda.Stream":
         """The HIP stream this renderer enqueues on, as a torch stream object (for events / record_stream)."""
+        if self._private:
+            return self._own_stream
         ptr = self._L.vd3d_ctx_stream(self._ctx)
         if not ptr:
             return torch.cuda.default_stream(self.device)

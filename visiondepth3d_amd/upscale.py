@@ -275,8 +275,9 @@ def _load_from_onnx(net: nn.Module, path: str) -> None:
 
 def run_rife(renderer, session, frame1, frame2, multiplier, dtype=torch.float32):
     """run_rife (core/merged_pipeline.py:204-218) with the frames resident in HBM.  ``session``: the interpolation network as a callable
-    ``[N,6,H,W] -> [N,3,H,W]`` (the reference's RIFE ONNX graph is not in /root/reference, so none is built here; without one the
-    reference returns ``[]`` too, :205-206).  Returns ``multiplier - 1`` uint8 [H,W,3] tensors, like the reference's list of frames."""
+    ``[N,6,H,W] -> [N,3,H,W]`` -- ``visiondepth3d_amd.rife.RifeSession`` (IFNet HDv3 on PyTorch-ROCm; the reference's ``RIFE_fp32.onnx`` is not
+    in /root/reference) or any other; ``None`` returns ``[]`` like the reference without a loaded model (:205-206).  Returns
+    ``multiplier - 1`` uint8 [H,W,3] tensors, like the reference's list of frames (all equal: the reference repeats ONE mid-point input)."""
     if session is None:
         return []
     f1 = (frame1 if torch.is_tensor(frame1) else torch.from_numpy(np.ascontiguousarray(frame1))).to(renderer.device).contiguous()
