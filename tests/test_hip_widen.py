@@ -78,7 +78,7 @@ def test_autocrop_loop_bit_exact(R, oracle):
 
 
 @pytest.mark.parametrize("fmt", ["Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph"])
-def test_autocrop_other_formats_and_unfused(R, oracle, fmt, monkeypatch):
+def test_autocrop_other_formats(R, oracle, fmt):
     frames, depth_bgr = synth.letterbox_clip(3, 96, 160, 7, 9)
     p = render_kwargs_to_params(160, 96, output_format=fmt, output_height=90, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
                                 sharpness_factor=0.2, dof_strength=1.0, auto_crop_black_bars=True, preserve_original_aspect=True,

@@ -17,8 +17,8 @@ for p in paths:
         a[0] += value; a[1] += 1
 avg = lambda n, c: (acc[n][c][0] / acc[n][c][1]) if acc[n].get(c) and acc[n][c][1] else None
 out = {}
-for key, prefixes in (("k_warp_fused", ("void k_warp_fused<true, true>",)),
-                      ("k_finish_fused", ("void k_finish_fused<true>", "void k_finish_fused<false>", "k_finish_fused"))):
+for key, prefixes in (("k_warp_fused", ("void k_warp_fused<true, true",)),
+                      ("k_finish_fused", ("void k_finish_fused<true, 30", "void k_finish_fused<true", "void k_finish_fused<false", "k_finish_fused"))):
     n = next((k for pre in prefixes for k in acc if k.startswith(pre)), None)
     if n is None:
         continue

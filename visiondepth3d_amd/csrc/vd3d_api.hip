@@ -71,7 +71,6 @@ struct vd3d_ctx {
   float* d_w2 = nullptr; float w2_host[4][81]; bool w2_valid = false;
   // profiling
   bool profiling = false;
-  bool use_fused = true;   // VD3D_UNFUSED=1 selects the one-stage-per-kernel v0 path (A/B and debugging)
   std::vector<vd_prof_rec> recs;
   std::vector<hipEvent_t> ev_pool;
   std::map<std::string, std::pair<double, long>> acc;
@@ -186,7 +185,6 @@ VD3D_EXPORT int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out) {
   HIPCHK(hipSetDevice(device));
   vd3d_ctx* c = new vd3d_ctx();
   c->device = device;
-  { const char* e = getenv("VD3D_UNFUSED"); c->use_fused = !(e && e[0] == '1'); }
   if (stream == VD3D_STREAM_PRIVATE) { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
   else c->stream = (hipStream_t)stream;  // NULL = the default stream
   HIPCHK(hipMalloc((void**)&c->work, sizeof(vd_dev_work)));
@@ -297,37 +295,17 @@ static int check_shift_params(const vd3d_shift_params* p, int H, int W) {
 static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_plane, int ih, int iw, int W, int H,
                               const vd3d_shift_params& sp, vd_stage_args a, bool skip_pixels = false) {
   hipStream_t s = c->stream;
-  if (c->use_fused) {
-    StageTimer t(c, "select_dc");   // fused chain: stage1 (A1), b1 (B1), shape (+A2), b2 (B2)
+  {
+    StageTimer t(c, "select_dc");   // fused chain: norm + stage1 (A1), b1 (B1), shape (+A2), b2 (B2)
     vd_launch_chain_work(s, a.have_eye, a.have_eye ? c->tdf : depth_plane, a.have_eye ? const_cast<float*>(depth_plane) : nullptr,
                          a.have_eye ? c->dn[c->dn_cur ^ 1] : nullptr, ih, iw, H, W, c->work, (float)sp.depth_pop_mid,
                          (float)sp.depth_pop_gamma, c->dc, c->D, c->histA, c->histB, a);
-  } else {
-  { StageTimer t(c, "select_dc");
-    vd_launch_hist_work_dc(s, false, depth_plane, ih, iw, H, W, c->work, c->histA, c->histB);
-    if (a.have_eye) vd_launch_hist_eye_subj(s, false, depth_plane, ih, iw, c->work, c->histA, c->histB);
-    a.stage = VD_ST_A1; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
-    vd_launch_hist_work_dc(s, true, depth_plane, ih, iw, H, W, c->work, c->histA, c->histB);
-    if (a.have_eye) vd_launch_hist_eye_subj(s, true, depth_plane, ih, iw, c->work, c->histA, c->histB);
-    a.stage = VD_ST_B1; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
-  }
-  { StageTimer t(c, "shape");
-    vd_launch_shape(s, depth_plane, ih, iw, H, W, c->work, (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, c->D);
-  }
-  { StageTimer t(c, "select_s1");
-    vd_launch_hist_work_s1(s, false, c->D, H, W, c->work, c->histA, c->histB);
-    a.stage = VD_ST_A2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
-    vd_launch_hist_work_s1(s, true, c->D, H, W, c->work, c->histA, c->histB);
-    a.stage = VD_ST_B2; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
-  }
   }
   if (!skip_pixels) { StageTimer t(c, "warp");
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
     bool fused = false;
-    if (c->use_fused) { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R); }
-    if (fused) {
-      // fused path taken
-    } else {
+    { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R); }
+    if (!fused) {   // blur sizes / frame sizes the fused kernel refuses (its LDS tile would not fit): one stage per kernel
     if (sp.enable_feathering) {
       vd_launch_e2(s, c->D, c->S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
       vd_launch_pool(s, c->e2L, c->e2R, H, W, sp.blur_ksize, c->bL, c->bR);
@@ -433,7 +411,7 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
   StageTimer t(c, "finish");
   if (!wk) wk = c->work;
   const int dense = (p->dof_dense_conv && fc.nlev) ? 1 : 0;   // the reference's dense k x k conv order
-  if (dense && c->use_fused && (!c->w2_valid || memcmp(c->w2_host, fc.w2, sizeof fc.w2) != 0)) {
+  if (dense && (!c->w2_valid || memcmp(c->w2_host, fc.w2, sizeof fc.w2) != 0)) {
     // first frame or a new dof_strength: the table changes (rare) -> drain whatever may still read the old one, then replace it
     if (!c->d_w2) HIPCHK(hipMalloc((void**)&c->d_w2, sizeof fc.w2));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -442,7 +420,7 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
     HIPCHK(hipMemcpy(c->d_w2, c->w2_host, sizeof fc.w2, hipMemcpyHostToDevice));
     c->w2_valid = true;
   }
-  if (c->use_fused && vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out, dense, c->d_w2)) {
+  if (vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out, dense, c->d_w2)) {
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -509,7 +487,6 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a.ipd_factor = p->ipd_factor; a.shift = sp;
   float* dn_cur = c->dn[c->dn_cur];
-  float* dn_prev = c->dn[c->dn_cur ^ 1];
   if (p->auto_crop_black_bars) {   // :1230-1248 decided on device, no host round trip
     if (p->src_h > c->rowflag_cap) { HIPCHK(re_alloc(&c->rowflag, (size_t)p->src_h)); c->rowflag_cap = p->src_h; }
     vd_launch_autocrop(s, frame_bgr, p->src_h, p->src_w, p->target_ratio, c->rowflag, c->work);
@@ -518,22 +495,10 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
     HIPCHK(hipMemsetAsync(&c->work->fs.crop_top, 0, 2 * sizeof(int32_t), s));
     c->crop_scalars_dirty = false;
   }
-  if (c->use_fused) {
+  {
     StageTimer t(c, "select_eye");   // fused chain: ingest (+A0), b0 (B0); eye stats ride on the next launch
     HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
     vd_launch_chain_eye(s, frame_bgr, depth, depth_fmt, *p, c->work, c->rgb_eye, c->tdf, c->histA, c->histB, a);
-  } else {
-  { StageTimer t(c, "ingest");
-    HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
-    vd_launch_ingest(s, frame_bgr, depth, depth_fmt, *p, c->work, c->rgb_eye, c->tdf);
-  }
-  { StageTimer t(c, "select_eye");
-    vd_launch_hist_eye_d(s, false, c->tdf, ne, c->work, c->histA, c->histB);
-    a.stage = VD_ST_A0; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
-    vd_launch_hist_eye_d(s, true, c->tdf, ne, c->work, c->histA, c->histB);
-    a.stage = VD_ST_B0; vd_launch_scalar_stage(s, c->work, c->histA, c->histB, a);
-    vd_launch_eye_stats(s, c->tdf, dn_cur, dn_prev, p->eye_h, p->eye_w, c->work);
-  }
   }
   // a blank frame still runs the whole select chain (its eye-res half carries the filters and the bars; the work-res half only
   // computes unused pop-shaping constants -- blank frames are rare and this keeps one code path), but no shift map and no warp
@@ -570,7 +535,6 @@ VD3D_EXPORT int vd3d_render_frame_blank(vd3d_ctx* c, const uint8_t* frame_bgr, c
 // ---- frame sharding, three-phase protocol (visiondepth3d_amd/sharded.py) ----------------------------------
 VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n_slots) {
   if (!c || !p || n_slots < 1 || n_slots > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
-  if (!c->use_fused) return set_err(VD3D_E_UNSUPPORTED, "frame sharding needs the fused chain (unset VD3D_UNFUSED)");
   HIPCHK(hipSetDevice(c->device));
   int rc;
   if ((rc = ensure_eye(c, p->eye_h, p->eye_w))) return rc;
@@ -735,7 +699,6 @@ VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
   if (p->auto_crop_black_bars && !c->crop_tab_set)
     return set_err(VD3D_E_INVALID, "auto_crop_black_bars in a sharded step: call vd3d_shard2_p0 on the own frames and vd3d_shard2_set_crops first");
-  if (!c->use_fused) return set_err(VD3D_E_UNSUPPORTED, "frame sharding needs the fused chain (unset VD3D_UNFUSED)");
   HIPCHK(hipSetDevice(c->device));
   { int rcw = wait_slot(c, slot); if (rcw) return rcw; }
   hipStream_t s = c->stream;

@@ -34,14 +34,19 @@
 #define FF_IS (FF_IW / 4)           // strips per tile row = 20 (strip 0 and 19 are input halo, 1 and 18 the graded halo columns)
 #define FF_GP 76                    // pitch of the graded dword tile (multiple of 4: b128 rows)
 #define FF_XG 2                     // tile rows per XCD group (vd_xcd_tile_rows)
-#define FF_HS 368                   // halo-window plane of one side: 40 rows x 9 floats = 360, padded to 16 mod 32 banks
-#define FF_HC (2 * FF_HS)           // ... of one channel (both sides)
 // geometry per instantiation (DENSE / separable): tile height, graded rows (1-pixel halo), input rows, threads
-template <bool WIDE> struct ff_geo {
-  static constexpr int TH = WIDE ? 30 : 16;
+// TH = 16: the round-2 geometry (6 waves x 3 rows x 20 strips, 4 idle lanes).  TH = 30 ("wide" thread mapping): (TH + 2) / 4 = 8 strip waves
+// of 4 rows x 16 strips + 1 halo-pixel wave.
+template <int TH_> struct ff_geo {
+  static constexpr int TH = TH_;
+  static constexpr bool WIDE = TH_ != 16;
   static constexpr int GH = TH + 2;
   static constexpr int IH = GH + 2 * FF_R;
-  static constexpr int NT = WIDE ? 576 : 384;   // 8 strip waves + 1 halo-pixel wave | 6 waves x 3 rows x 20 strips (4 idle lanes)
+  static constexpr int NSW = GH / 4;                               // strip waves (wide mapping)
+  static constexpr int NT = WIDE ? 64 * (NSW + 1) : 384;
+  static constexpr int HS = IH * 9 + ((16 - (IH * 9) % 32 + 32) % 32);   // halo-window plane of one side: IH rows x 9 floats, padded to 16 mod 32 banks
+  static constexpr int HC = 2 * HS;                                // ... of one channel (both sides)
+  static_assert(!WIDE || (GH % 4 == 0 && 2 * GH <= 64), "wide mapping: whole strip waves and one halo wave");
 };
 #define FF_FW_STD 0.350001007f      // (float)(0.35 + 1e-6): focus_width of the render loop (core/render_3d.py:1357-1360) + :794's 1e-6
 
@@ -154,7 +159,7 @@ VD_DEV void ff_level_dense(const float (*tile)[IH][FF_IW], const float* __restri
 
 // One pixel of a halo column (graded row sy, side 0 = column x0 - 1 / 1 = column x0 + 64) in the same dense association, from the
 // 9-column halo windows `hal` (see the kernel): single-dword LDS reads, one accumulation chain per channel.  Result in element 0 of vlo / vhi.
-template <int OFF>
+template <int OFF, int FF_HS>
 VD_DEV void ff_level_dense_px(const float* __restrict__ hal, const float* __restrict__ w2, bool mine, int sy, int side, int level, int lo0,
                               vd_f4 vlo[3], vd_f4 vhi[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
@@ -164,7 +169,7 @@ VD_DEV void ff_level_dense_px(const float* __restrict__ hal, const float* __rest
   for (int i = 0; i < K; ++i) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float* rp = hal + c * FF_HC + side * FF_HS + (sy + OFF + i) * 9 + OFF;
+      const float* rp = hal + c * (2 * FF_HS) + side * FF_HS + (sy + OFF + i) * 9 + OFF;
 #pragma unroll
       for (int j = 0; j < K; ++j) acc[c] = vd_fma(rp[j], w2[i * K + j], acc[c]);
     }
@@ -206,13 +211,15 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
 #ifndef FF_OCC_ATTR
 #define FF_OCC_ATTR   // A/B builds: -DFF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))' forces the 64-VGPR budget
 #endif
-template <bool DENSE, bool WIDE>
-__global__ __launch_bounds__(ff_geo<WIDE>::NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
+template <bool DENSE, int TH_>
+__global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
                                                         const vd_dev_work* __restrict__ w, const float* __restrict__ w2g,
                                                         uint8_t* __restrict__ out) {
+  constexpr bool WIDE = ff_geo<TH_>::WIDE;
   static_assert(DENSE || !WIDE, "the separable levels exchange vertical sums between adjacent lanes: 64x16 geometry only");
-  constexpr int FF_TH = ff_geo<WIDE>::TH, FF_GH = ff_geo<WIDE>::GH, FF_IH = ff_geo<WIDE>::IH, FF_NT = ff_geo<WIDE>::NT;
+  constexpr int FF_TH = ff_geo<TH_>::TH, FF_GH = ff_geo<TH_>::GH, FF_IH = ff_geo<TH_>::IH, FF_NT = ff_geo<TH_>::NT;
+  constexpr int FF_HS = ff_geo<TH_>::HS, FF_HC = ff_geo<TH_>::HC, FF_NSW = ff_geo<TH_>::NSW;
   __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
   __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
   // WIDE: the 9-column windows of the two halo columns, copied out of the tile with a 9-float pitch: the halo-pixel wave reads single
@@ -269,8 +276,11 @@ __global__ __launch_bounds__(ff_geo<WIDE>::NT) FF_OCC_ATTR void k_finish_fused(c
     // (row-major lanes measured 18x the bank-conflict cycles: two rows of a group alias 32 banks);
     // wave 8: thread = one pixel of the halo columns (graded row lane / 2; even lanes the left column, odd lanes the right one)
     active = true; strip = true;
-    if (wv < 8) { sy = 4 * wv + (lane & 3); ss = 2 + (lane >> 2); }
-    else { sy = lane >> 1; halo_px = true; ss = (lane & 1) ? FF_IS - 2 : 1; hq = (lane & 1) ? 0 : 3; }
+    if (wv < FF_NSW) { sy = 4 * wv + (lane & 3); ss = 2 + (lane >> 2); }
+    else {
+      sy = min(lane >> 1, FF_GH - 1); halo_px = true; ss = (lane & 1) ? FF_IS - 2 : 1; hq = (lane & 1) ? 0 : 3;
+      strip = (lane >> 1) < FF_GH;                 // 2 GH halo pixels; the rest of the wave idles (TH = 14)
+    }
   } else {
     // thread = (graded row sy, tile strip ss); wave v owns rows 3v..3v+2; strips 1..18 are the graded region
     active = lane < 3 * FF_IS;
@@ -368,13 +378,13 @@ __global__ __launch_bounds__(ff_geo<WIDE>::NT) FF_OCC_ATTR void k_finish_fused(c
     const int off = FF_R - fc.ksz[l] / 2;
     const bool mine = (my_mask >> (l + 1)) & 1;
     if (DENSE) {
-      if (WIDE && wv == 8) {   // wave-uniform: the halo-pixel wave
+      if (WIDE && wv == FF_NSW) {   // wave-uniform: the halo-pixel wave
         const int side = lane & 1;
         switch (off) {
-          case 0: ff_level_dense_px<0>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
-          case 1: ff_level_dense_px<1>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
-          case 2: ff_level_dense_px<2>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
-          default: ff_level_dense_px<3>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          case 0: ff_level_dense_px<0, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          case 1: ff_level_dense_px<1, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          case 2: ff_level_dense_px<2, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          default: ff_level_dense_px<3, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
         }
         continue;
       }
@@ -551,15 +561,17 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
   a.use_override = use_override; a.bar_w = bar_w; a.bar_s = bar_s; a.focal = focal;
   if (a.xo || a.yo || a.in_w != p.fit_w || a.in_h != p.fit_h)  // pad_to_aspect_ratio canvas (:124): black background
     (void)hipMemsetAsync(out, 0, (size_t)p.out_w * p.out_h * 3, s);
-  const bool wide = dense && (ff_geo<true>::TH % a.fy) == 0;   // 64x30 tiles; fit factor 4 keeps the 64x16 geometry
-  const int th = wide ? ff_geo<true>::TH : ff_geo<false>::TH;
+  // wide geometry: 64x30 tiles.  (64x14 tiles -- 5 waves, 4 workgroups per CU -- measured 414 vs 426 us at 4K with 14 % more instructions
+  // and a 2.1x instead of 1.7x input halo: not kept.)  Fit factor 4 keeps the 64x16 geometry.
+  const bool wide = dense && (30 % a.fy) == 0;
+  const int th = wide ? 30 : 16;
   a.ntx = (p.warp_w + FF_TW - 1) / FF_TW; a.nty = (p.warp_h + th - 1) / th;
-  a.xcd = vd_xcd_order_enabled() ? 1 : 0;
+  a.xcd = 1;
   const int ngrp = (2 * a.nty + FF_XG - 1) / FF_XG;
   dim3 g(a.xcd ? 8 * ((ngrp + 7) / 8) * FF_XG * a.ntx : 2 * a.ntx * a.nty);
   if (dense && !w2_dev) return false;
-  if (wide) hipLaunchKernelGGL((k_finish_fused<true, true>), g, dim3(ff_geo<true>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
-  else if (dense) hipLaunchKernelGGL((k_finish_fused<true, false>), g, dim3(ff_geo<false>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
-  else hipLaunchKernelGGL((k_finish_fused<false, false>), g, dim3(ff_geo<false>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
+  if (wide) hipLaunchKernelGGL((k_finish_fused<true, 30>), g, dim3(ff_geo<30>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
+  else if (dense) hipLaunchKernelGGL((k_finish_fused<true, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
+  else hipLaunchKernelGGL((k_finish_fused<false, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   return true;
 }

@@ -9,15 +9,6 @@ enum { VD_ST_A0 = 0, VD_ST_B0, VD_ST_A1, VD_ST_B1, VD_ST_A2, VD_ST_B2,
 #define PL_KMAX_HOST 33   // largest blur_ksize the pool kernel's LDS tile is sized for
 #define DF_RMAX_HOST 15   // largest Gaussian radius of the DOF kernel
 
-// XCD band order of the tiled pixel kernels (vd_xcd_tile, vd3d_dev.h).  VD3D_XCD_ORDER=0 restores the plain dispatch order: an A/B
-// switch for traffic measurements only (same tiles, same results).
-#include <stdlib.h>
-static inline bool vd_xcd_order_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("VD3D_XCD_ORDER"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on != 0;
-}
-
 #define VD_ETAB 8
 struct vd_stage_args {
   int stage;
@@ -105,8 +96,6 @@ void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* 
 
 // ---- vd3d_select.hip
 void vd_launch_hist_eye_d(hipStream_t s, bool passB, const float* tdf, long long n, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
-void vd_launch_hist_eye_subj(hipStream_t s, bool passB, const float* dn, int eh, int ew, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
-void vd_launch_hist_work_dc(hipStream_t s, bool passB, const float* dn, int ih, int iw, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
 void vd_launch_hist_work_s1(hipStream_t s, bool passB, const float* D, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB);
 void vd_launch_scalar_stage(hipStream_t s, vd_dev_work* w, const uint32_t* histA, const uint32_t* histB, const vd_stage_args& a);
 
@@ -122,10 +111,6 @@ struct vd_finish_consts {
   float sat, con, bri;
   float sharp_kn, sharp_kc; // normalised sharpen taps
 };
-void vd_launch_ingest(hipStream_t s, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params& p,
-                      const vd_dev_work* w, float* rgb_eye, float* tdf_prev);
-void vd_launch_eye_stats(hipStream_t s, const float* tdf, float* dn_cur, const float* dn_prev, int eh, int ew, vd_dev_work* w);
-void vd_launch_shape(hipStream_t s, const float* dn, int ih, int iw, int H, int W, const vd_dev_work* w, float mid, float gamma, float* D);
 void vd_launch_shift(hipStream_t s, const float* D, int H, int W, const vd_dev_work* w, const vd3d_shift_params& p, float* S);
 void vd_launch_e2(hipStream_t s, const float* D, const float* S, int H, int W, float fs, float* e2L, float* e2R);
 void vd_launch_pool(hipStream_t s, const float* e2L, const float* e2R, int H, int W, int k, float* bL, float* bR);

@@ -10,83 +10,6 @@
 #include "vd3d_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-// ingest: uint8 frame + depth -> eye-res float planes, temporal filter in place
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt,
-                                                vd3d_render_params p, const vd_dev_work* __restrict__ w,
-                                                float* __restrict__ rgb_eye, float* __restrict__ tdf) {
-  const int ex = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int ey = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (ex >= p.eye_w || ey >= p.eye_h) return;
-  if (p.auto_crop_black_bars) { p.crop_x = w->acrop[0]; p.crop_y = w->acrop[1]; p.crop_w = w->acrop[2]; p.crop_h = w->acrop[3]; }
-  vd_ingest_pixel(frame, depth, fmt, p, w->st.tdf_valid, rgb_eye, tdf, ey, ex);
-}
-
-void vd_launch_ingest(hipStream_t s, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params& p,
-                      const vd_dev_work* w, float* rgb_eye, float* tdf_prev) {
-  dim3 g((p.eye_w + 31) / 32, (p.eye_h + 7) / 8);
-  hipLaunchKernelGGL(k_ingest, g, dim3(256), 0, s, frame_bgr, depth, depth_fmt, p, w, rgb_eye, tdf_prev);
-}
-
-// ------------------------------------------------------------------------------------------------
-// eye stats: normalise, centre-crop fixed-point sums, motion MAD
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_eye_stats(const float* __restrict__ tdf, float* __restrict__ dn_cur,
-                                                   const float* __restrict__ dn_prev, int eh, int ew, vd_dev_work* w) {
-  const long long n = (long long)eh * ew;
-  const float lo = w->ema_lo, den = w->ema_den;
-  const int collapse = w->collapse, have_prev = w->st.prev_depth_valid;
-  long long s1 = 0, s2 = 0, sm = 0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float d = vd_clamp(tdf[i], 0.f, 1.f);
-    const float v = collapse ? d : vd_clamp((d - lo) / den, 0.f, 1.f);
-    dn_cur[i] = v;
-    const int y = (int)((unsigned)i / (unsigned)ew), x = (int)((unsigned)i - (unsigned)y * (unsigned)ew);
-    if (y >= eh / 4 && y < eh * 3 / 4 && x >= ew / 4 && x < ew * 3 / 4) {
-      const double dv = (double)v;
-      s1 += vd_fx40(dv);
-      s2 += vd_fx40(dv * dv);
-    }
-    if (have_prev) sm += vd_fx40((double)fabsf(v - dn_prev[i]));
-  }
-  __shared__ long long part[3][4];
-  s1 = vd_wave_sum_ll(s1); s2 = vd_wave_sum_ll(s2); sm = vd_wave_sum_ll(sm);
-  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s1; part[1][threadIdx.x >> 6] = s2; part[2][threadIdx.x >> 6] = sm; }
-  __syncthreads();
-  if (threadIdx.x < 3) {  // one atomic per sum per workgroup (integer: order-independent)
-    const long long v = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
-    long long* dst = threadIdx.x == 0 ? &w->sum1 : (threadIdx.x == 1 ? &w->sum2 : &w->sum_mad);
-    if (v) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
-  }
-}
-void vd_launch_eye_stats(hipStream_t s, const float* tdf, float* dn_cur, const float* dn_prev, int eh, int ew, vd_dev_work* w) {
-  long long n = (long long)eh * ew;
-  int g = (int)((n + 256 * 8 - 1) / (256 * 8));
-  g = g > 1024 ? 1024 : (g < 1 ? 1 : g);
-  hipLaunchKernelGGL(k_eye_stats, dim3(g), dim3(256), 0, s, tdf, dn_cur, dn_prev, eh, ew, w);
-}
-
-// ------------------------------------------------------------------------------------------------
-// shape_depth_for_pop -> D plane
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_shape(const float* __restrict__ dn, int ih, int iw, int H, int W,
-                                               const vd_dev_work* __restrict__ w, float mid, float gamma, float* __restrict__ D) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
-  const float d = vd_curved_depth(dn, ih, iw, H, W, y, x);
-  const float ds = w->shp_stretch ? vd_clamp((d - w->shp_lo) / w->shp_den, 0.f, 1.f) : d;
-  const float centered = (ds - w->shp_subj_s) + mid;
-  const float t = centered - mid;
-  const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
-  const float shaped = sgn * vd_pow_cr(fabsf(t), gamma) + mid;
-  D[(size_t)y * W + x] = vd_clamp(shaped, 0.f, 1.f);
-}
-void vd_launch_shape(hipStream_t s, const float* dn, int ih, int iw, int H, int W, const vd_dev_work* w, float mid, float gamma, float* D) {
-  hipLaunchKernelGGL(k_shape, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, dn, ih, iw, H, W, w, mid, gamma, D);
-}
-
-// ------------------------------------------------------------------------------------------------
 // shift plane: layer weights, zero-parallax, clamp, convergence, edge-mask suppression
 // ------------------------------------------------------------------------------------------------
 #define SH_TW 64

@@ -130,18 +130,6 @@ void vd_launch_hist_eye_d(hipStream_t s, bool passB, const float* tdf, long long
   if (!passB) hipLaunchKernelGGL((k_hist_a<FEyeD, VD_J_EYE_Q, -1>), dim3(hist_grid(n, 4096, 512)), dim3(1024), 0, s, f, histA);
   else hipLaunchKernelGGL((k_hist_b<FEyeD, VD_J_EYE_Q, -1>), dim3(hist_grid(n, 1024, 2048)), dim3(256), 0, s, f, w, histB);
 }
-void vd_launch_hist_eye_subj(hipStream_t s, bool passB, const float* dn, int eh, int ew, vd_dev_work* w, uint32_t* histA, uint32_t* histB) {
-  FPlaneSubj f{dn, eh, ew};
-  long long n = (long long)eh * ew;
-  if (!passB) hipLaunchKernelGGL((k_hist_a<FPlaneSubj, -1, VD_J_EYE_SUBJ>), dim3(hist_grid(n, 4096, 512)), dim3(1024), 0, s, f, histA);
-  else hipLaunchKernelGGL((k_hist_b<FPlaneSubj, -1, VD_J_EYE_SUBJ>), dim3(hist_grid(n, 1024, 2048)), dim3(256), 0, s, f, w, histB);
-}
-void vd_launch_hist_work_dc(hipStream_t s, bool passB, const float* dn, int ih, int iw, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB) {
-  FWorkDc f{dn, ih, iw, H, W};
-  long long n = (long long)H * W;
-  if (!passB) hipLaunchKernelGGL((k_hist_a<FWorkDc, VD_J_WORK_Q, VD_J_WORK_S0>), dim3(hist_grid(n, 8192, 256)), dim3(1024), 0, s, f, histA);
-  else hipLaunchKernelGGL((k_hist_b<FWorkDc, VD_J_WORK_Q, VD_J_WORK_S0>), dim3(hist_grid(n, 1024, 2048)), dim3(256), 0, s, f, w, histB);
-}
 void vd_launch_hist_work_s1(hipStream_t s, bool passB, const float* D, int H, int W, vd_dev_work* w, uint32_t* histA, uint32_t* histB) {
   FPlaneSubj f{D, H, W};
   long long n = (long long)H * W;

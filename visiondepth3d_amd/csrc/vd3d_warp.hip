@@ -25,9 +25,8 @@
 #include "vd3d_kernels.h"
 
 #define WF_TW 64
-#define WF_TH 32
-#define WF_NT 512
-#define WF_NW (WF_NT / 64)
+// tile height WF_TH is a template parameter of the kernel; threads = 16 per tile row.  64x32 tiles (512 threads, 3 workgroups per CU); 64x16
+// tiles (256 threads, 5 per CU) measured 170 vs 155 us at 4K: the mask phases' halo grows from 1.46x to 1.78x.
 #define WF_AB 3   // halo rows of phase A a wave walks together (loads of all of them in flight)
 
 struct vd_wf_args {
@@ -147,10 +146,11 @@ VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
 #define WF_OCC_ATTR   // A/B builds: -DWF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))'
 #endif
 #define WF_HB 6   // Hh rows a wave builds together (2 * WF_HB loads in flight)
-template <bool RESIZE, bool FEATHER>
-__global__ __launch_bounds__(WF_NT) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
+template <bool RESIZE, bool FEATHER, int WF_TH>
+__global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
                                                       uint8_t* __restrict__ R) {
+  constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
   extern __shared__ float lds[];
   const int H = a.H, W = a.W, k = a.k, r = k / 2;
   const int tile = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
@@ -507,6 +507,7 @@ static bool wf_fastdiv_ok(int k) {   // every float in [0, k*k] checked; inexact
 // returns false when the fused kernel cannot be used (tiles would not fit the 160 KB LDS): caller falls back to v0
 bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
                           const vd3d_shift_params& p, uint8_t* L, uint8_t* R) {
+  constexpr int WF_TH = 32, WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
   vd_wf_args a;
   a.ih = ih; a.iw = iw; a.H = H; a.W = W; a.k = p.enable_feathering ? p.blur_ksize : 1; a.feather = p.enable_feathering ? 1 : 0;
   a.fs = (float)p.feather_strength;
@@ -561,22 +562,26 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 51 KB)
   a.ntx = (W + WF_TW - 1) / WF_TW;
   a.ntiles = a.ntx * ((H + WF_TH - 1) / WF_TH);
-  a.xcd = vd_xcd_order_enabled() ? 1 : 0;
+  a.xcd = 1;
   a.per = (a.ntiles + 7) / 8;
   dim3 g(a.xcd ? 8 * a.per : a.ntiles);
   static bool attr[64] = {false};   // per device: the attribute belongs to the device's copy of the code object
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr[dev]) {
-    (void)hipFuncSetAttribute((const void*)k_warp_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_warp_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_warp_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_warp_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define WF_ATTR(R_, F_, T_) (void)hipFuncSetAttribute((const void*)k_warp_fused<R_, F_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    WF_ATTR(true, true, 32); WF_ATTR(true, false, 32); WF_ATTR(false, true, 32); WF_ATTR(false, false, 32);
+#undef WF_ATTR
     attr[dev] = true;
   }
-  if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
-  else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
-  else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
-  else hipLaunchKernelGGL((k_warp_fused<false, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);
+#define WF_LAUNCH(T_)                                                                                                              \
+  do {                                                                                                                             \
+    if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);       \
+    else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);              \
+    else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);           \
+    else hipLaunchKernelGGL((k_warp_fused<false, false, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);                         \
+  } while (0)
+  WF_LAUNCH(32);
+#undef WF_LAUNCH
   return true;
 }
