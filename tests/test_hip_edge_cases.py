@@ -48,7 +48,8 @@ def test_pixel_shift_odd_sizes_and_ratios(R, oracle, sizes):
 
 
 @pytest.mark.parametrize("kw", [dict(blur_ksize=2), dict(blur_ksize=4, feather_strength=3.0), dict(blur_ksize=15, feather_strength=20.0),
-                                dict(blur_ksize=33), dict(blur_ksize=1, feather_strength=0.0),
+                                dict(blur_ksize=33), dict(blur_ksize=35), dict(blur_ksize=64, feather_strength=4.0), dict(blur_ksize=129),
+                                dict(blur_ksize=1, feather_strength=0.0),
                                 dict(max_pixel_shift_percent=0.3),                       # bound too large for the fused LDS tiles -> fallback
                                 dict(max_pixel_shift_percent=0.12, blur_ksize=21),
                                 dict(convergence_strength=5.0), dict(convergence_strength=-3.0, enable_dynamic_convergence=False),
@@ -64,7 +65,7 @@ def test_blur_ksize_limits(R):
     with pytest.raises(Vd3dError):
         R.pixel_shift(f, d, 16, 16, ShiftParams.defaults(1, 1, 1, blur_ksize=0))      # avg_pool2d raises in the reference
     with pytest.raises(Vd3dError) as e:
-        R.pixel_shift(f, d, 16, 16, ShiftParams.defaults(1, 1, 1, blur_ksize=35))     # valid in the reference, not built: loud
+        R.pixel_shift(f, d, 16, 16, ShiftParams.defaults(1, 1, 1, blur_ksize=131))    # valid in the reference, beyond the 160 KB LDS tile: loud
     assert e.value.code == -4
 
 

@@ -1,0 +1,11 @@
+# A/B builds of libvd3d_hip.so with one compile-time difference (same ABI; select with VD3D_LIB_PATH).  usage: bash tools/build_ab.sh NAME -DFLAG...
+set -e
+NAME=$1; shift
+R=$(cd "$(dirname "$0")/.." && pwd)
+B=$R/gpurun_out/ab_build_$NAME; mkdir -p $B $R/visiondepth3d_amd/ab
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function"
+cd $R/visiondepth3d_amd/csrc
+for f in *.hip; do /opt/rocm/bin/hipcc $FLAGS "$@" -c $f -o $B/${f%.hip}.o & done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/visiondepth3d_amd/ab/libvd3d_hip_$NAME.so $B/*.o
+rm -rf $B
+ls -la $R/visiondepth3d_amd/ab/libvd3d_hip_$NAME.so

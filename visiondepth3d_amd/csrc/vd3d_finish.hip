@@ -34,6 +34,9 @@
 #define FF_IS (FF_IW / 4)           // strips per tile row = 20 (strip 0 and 19 are input halo, 1 and 18 the graded halo columns)
 #define FF_GP 76                    // pitch of the graded dword tile (multiple of 4: b128 rows)
 #define FF_XG 2                     // tile rows per XCD group (vd_xcd_tile_rows)
+#ifndef FF_WIDE_TH
+#define FF_WIDE_TH 30               // tile height of the wide geometry (A/B builds: -DFF_WIDE_TH=14, tools/build_ab.sh)
+#endif
 // geometry per instantiation (DENSE / separable): tile height, graded rows (1-pixel halo), input rows, threads
 // TH = 16: the round-2 geometry (6 waves x 3 rows x 20 strips, 4 idle lanes).  TH = 30 ("wide" thread mapping): (TH + 2) / 4 = 8 strip waves
 // of 4 rows x 16 strips + 1 halo-pixel wave.
@@ -563,14 +566,18 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
     (void)hipMemsetAsync(out, 0, (size_t)p.out_w * p.out_h * 3, s);
   // wide geometry: 64x30 tiles.  (64x14 tiles -- 5 waves, 4 workgroups per CU -- measured 414 vs 426 us at 4K with 14 % more instructions
   // and a 2.1x instead of 1.7x input halo: not kept.)  Fit factor 4 keeps the 64x16 geometry.
-  const bool wide = dense && (30 % a.fy) == 0;
-  const int th = wide ? 30 : 16;
+#ifdef FF_AB_GEO16   // A/B build (tools/build_ab.sh): dense levels in the 64x16 geometry everywhere
+  const bool wide = false;
+#else
+  const bool wide = dense && (FF_WIDE_TH % a.fy) == 0;
+#endif
+  const int th = wide ? FF_WIDE_TH : 16;
   a.ntx = (p.warp_w + FF_TW - 1) / FF_TW; a.nty = (p.warp_h + th - 1) / th;
   a.xcd = 1;
   const int ngrp = (2 * a.nty + FF_XG - 1) / FF_XG;
   dim3 g(a.xcd ? 8 * ((ngrp + 7) / 8) * FF_XG * a.ntx : 2 * a.ntx * a.nty);
   if (dense && !w2_dev) return false;
-  if (wide) hipLaunchKernelGGL((k_finish_fused<true, 30>), g, dim3(ff_geo<30>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
+  if (wide) hipLaunchKernelGGL((k_finish_fused<true, FF_WIDE_TH>), g, dim3(ff_geo<FF_WIDE_TH>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   else if (dense) hipLaunchKernelGGL((k_finish_fused<true, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   else hipLaunchKernelGGL((k_finish_fused<false, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   return true;

@@ -6,7 +6,8 @@
 
 enum { VD_ST_A0 = 0, VD_ST_B0, VD_ST_A1, VD_ST_B1, VD_ST_A2, VD_ST_B2,
        VD_ST_AQ, VD_ST_BQ, VD_ST_BS };  // AQ/BQ: generic quantile pair, BS: bare subject depth (test entry points)
-#define PL_KMAX_HOST 33   // largest blur_ksize the pool kernel's LDS tile is sized for
+#define PL_KMAX_HOST 129  // largest blur_ksize of the fallback pool kernel (LDS tile (16 + k - 1) x (64 + k - 1) floats = 108 KB at 129; the fused
+                          // warp kernel takes k <= ~17 at 4K, larger windows run e2 / pool / warp as separate launches)
 #define DF_RMAX_HOST 15   // largest Gaussian radius of the DOF kernel
 
 #define VD_ETAB 8

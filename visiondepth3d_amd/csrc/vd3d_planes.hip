@@ -132,7 +132,6 @@ void vd_launch_e2(hipStream_t s, const float* D, const float* S, int H, int W, f
 // ------------------------------------------------------------------------------------------------
 #define PL_TW 64
 #define PL_TH 16
-#define PL_KMAX 33
 __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ e2L, const float* __restrict__ e2R, int H, int W, int k,
                                               float* __restrict__ bL, float* __restrict__ bR) {
   extern __shared__ float lds[];
@@ -165,6 +164,15 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ e2L, con
 void vd_launch_pool(hipStream_t s, const float* e2L, const float* e2R, int H, int W, int k, float* bL, float* bR) {
   const int tw = PL_TW + k - 1, th = PL_TH + k - 1;
   size_t lds = sizeof(float) * ((size_t)th * tw);
+  if (lds > 64 * 1024) {   // large blur_ksize: the tile needs the opt-in LDS range
+    static bool attr[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
+      (void)hipFuncSetAttribute((const void*)k_pool, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr[dev] = true;
+    }
+  }
   hipLaunchKernelGGL(k_pool, dim3((W + PL_TW - 1) / PL_TW, (H + PL_TH - 1) / PL_TH), dim3(256), lds, s, e2L, e2R, H, W, k, bL, bR);
 }
 
