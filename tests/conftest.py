@@ -51,6 +51,10 @@ PARITY_BARS = {
 
 def assert_parity(name, mx, frac, frac_gt1):
     bmx, bfr, bf1 = PARITY_BARS[name]
+    rep = os.environ.get("VD3D_PARITY_REPORT")          # append the measured numbers to a file (how the bars above were taken)
+    if rep:
+        with open(rep, "a") as f:
+            f.write("%s max=%d frac=%.3e frac_gt1=%.3e\n" % (name, mx, frac, frac_gt1))
     assert mx <= bmx and frac <= bfr and frac_gt1 <= bf1, (name, "measured", (mx, frac, frac_gt1), "bar", PARITY_BARS[name])
 
 
