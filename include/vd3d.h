@@ -377,6 +377,12 @@ int vd3d_subject_depth(vd3d_ctx* ctx, const float* plane, int H, int W, float* o
 int vd3d_detect_black_bars(vd3d_ctx* ctx, const uint8_t* frame_bgr, int h, int w, int* top_host, int* bottom_host);
 /* device-to-device streaming copy used as the measured-peak yardstick for roofline.frac */
 int vd3d_stream_copy(vd3d_ctx* ctx, const void* src, void* dst, size_t bytes);
+/* The three transcendental operators of the path, elementwise on a device float32 array, with the VALUES torch's CPU kernels give
+ * (which is what the reference computes with): op 0 = torch.pow(x, param) for x >= 0 (_signed_pow core/render_3d.py:517, the layer
+ * weight :620; SLEEF Sleef_powf_u10 and ATen's special exponents), op 1 = torch.sigmoid(x) (:209; 1 / (1 + Sleef_expf_u10(0 - x))),
+ * op 2 = torch.sqrt(x) (:206, :349, :440; MKL VML vsSqrt -- one ULP low on 0.6 % of the inputs).  The kernels of the chain call the
+ * same device functions; this entry exists so that they can be compared against the oracle / torch on arbitrary inputs. */
+int vd3d_torch_math(vd3d_ctx* ctx, int op, const float* x, float param, float* out, long long n);
 /* HIP-event profiling of the stages on the ctx stream ("frame", "ingest", "select_eye", "select_dc", "shape",
  * "select_s1", "warp" (= "shift" + "w1", the fused warp kernel alone), "finish", "handoff", "advance", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
  * profiling was enabled (-1 if never seen); both getters synchronise. */

@@ -110,6 +110,16 @@ def interp_bilinear(t, oh, ow):
     return out
 
 
+def torch_math(op, x, param=0.0):
+    """torch.pow(x, param) / torch.sigmoid(x) / torch.sqrt(x) as torch's CPU kernels evaluate them (pow_torch / sigmoid_torch /
+    sqrt_torch of vd3d_oracle.c), elementwise."""
+    x, px = _f(x)
+    out = np.empty_like(x)
+    lib().vo_torch_math(C.c_int({"pow": 0, "sigmoid": 1, "sqrt": 2}[op]), px, C.c_float(np.float32(param)), out.ctypes.data_as(_f32p),
+                        C.c_longlong(x.size))
+    return out
+
+
 def quantile(v, q):
     v, pv = _f(np.ravel(v))
     return float(lib().vo_quantile(pv, v.size, C.c_float(np.float32(q))))

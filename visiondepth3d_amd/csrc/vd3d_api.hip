@@ -1058,6 +1058,15 @@ VD3D_EXPORT int vd3d_stream_copy(vd3d_ctx* c, const void* src, void* dst, size_t
   return 0;
 }
 
+VD3D_EXPORT int vd3d_torch_math(vd3d_ctx* c, int op, const float* x, float param, float* out, long long n) {
+  if (!c) return set_err(VD3D_E_INVALID, "NULL context");
+  if (op < 0 || op > 2 || n < 0 || (n > 0 && (!x || !out))) return set_err(VD3D_E_INVALID, "vd3d_torch_math: op 0..2, n >= 0, device pointers");
+  HIPCHK(hipSetDevice(c->device));
+  if (n) vd_launch_torch_math(c->stream, op, x, param, out, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_set_profiling(vd3d_ctx* c, int enable) {
   vd3d_sync(c);
   c->profiling = enable != 0;

@@ -52,56 +52,132 @@ VD_DEV float vd_lin11_step(float step, int steps, int i) {
   if (i < steps / 2) return vd_fma(step, (float)i, -1.f);
   return vd_fma(-step, (float)(steps - 1 - i), 1.f);
 }
-// correctly-rounded float32 pow / exp through float64 (device libm is < 1 ULP in float64)
-VD_DEV float vd_pow_cr(float x, float e) { return (float)pow((double)x, (double)e); }
+// correctly-rounded float32 exp through float64 (device libm is < 1 ULP in float64): torch.exp on the k-tap Gaussian window
 VD_DEV float vd_exp_cr(float x) { return (float)exp((double)x); }
-// Table-driven float64 pow for x in (0, 1]: log2 by a 128-entry table + degree-7 polynomial, 2^f by a 64-entry table + degree-6
-// polynomial, ~30 float64 operations instead of libm's ~200.  Relative error < 2^-45; whenever the float64 result lies within
-// 2^-39 of a float32 rounding boundary (3e-5 of the inputs) the function reports "ambiguous" and the caller uses vd_pow_cr, so the
-// value is ALWAYS the float32 rounding of the libm result.  tools/verify_fastpow.c restates these exact operations on the CPU and
-// checks every float in (0, 1] for g = 0.85 (the only exponent render_sbs_3d passes), 0.3, 0.5, 0.999, 1, 1.5, 2.2: 0 mismatches.
-// tab: [0,128) 1/c_i, [128,256) log2 c_i, [256,320) 2^(j/64)  (vd3d_pow_tables.h; the kernels stage it in LDS).
-VD_DEV bool vd_pow_fast(float x, double g, const double* __restrict__ tab, float* out) {
-  const uint32_t b = __float_as_uint(x);
-  if (b < 0x00800000u || b > 0x3f800000u) return false;          // zero, subnormal, > 1: exact path
-  const int e = (int)(b >> 23) - 127;
-  const int i = (int)((b >> 16) & 0x7fu);
-  const double m = (double)__uint_as_float((b & 0x007fffffu) | 0x3f800000u);
-  const double r = __builtin_fma(m, tab[i], -1.0);               // |r| <= 2^-8
-  const double C1 = 1.4426950408889634074, C2 = -0.72134752044448170368, C3 = 0.48089834696298780245, C4 = -0.36067376022224085184,
-               C5 = 0.28853900817779268147, C6 = -0.24044917348149390123, C7 = 0.20609929155556620106;
-  double p = __builtin_fma(r, C7, C6); p = __builtin_fma(r, p, C5); p = __builtin_fma(r, p, C4); p = __builtin_fma(r, p, C3);
-  p = __builtin_fma(r, p, C2); p = __builtin_fma(r, p, C1);
-  const double L = ((double)e + tab[128 + i]) + r * p;
-  const double y = g * L;
-  if (!(y > -120.0)) return false;
-  const double k = __builtin_rint(y * 64.0);
-  const double f = __builtin_fma(k, -1.0 / 64.0, y);             // |f| <= 2^-7
-  const long long ki = (long long)k;
-  const int j = (int)(ki & 63);
-  const int n = (int)((ki - j) / 64);
-  const double t = f * 0.69314718055994530942;
-  double q = __builtin_fma(t, 1.0 / 6.0, 1.0); q = __builtin_fma(t * (1.0 / 5.0), q, 1.0); q = __builtin_fma(t * (1.0 / 4.0), q, 1.0);
-  q = __builtin_fma(t * (1.0 / 3.0), q, 1.0); q = __builtin_fma(t * 0.5, q, 1.0); q = __builtin_fma(t, q, 1.0);
-  const double res = ldexp(tab[256 + j] * q, n);
-  const uint32_t low = (uint32_t)((unsigned long long)__double_as_longlong(res) & 0x1fffffffull);   // mantissa bits below float32 precision
-  const uint32_t half = 0x10000000u;
-  const uint32_t dist = low > half ? low - half : half - low;
-  if (dist < (1u << 13)) return false;                           // within 2^-39 of a rounding boundary
-  *out = (float)res;
-  return true;
-}
-VD_DEV float vd_pow_cr_fast(float x, float e, const double* __restrict__ tab) {   // == vd_pow_cr(x, e) for every x
-  float v;
-  if (vd_pow_fast(x, (double)e, tab, &v)) return v;
-  return vd_pow_cr(x, e);
-}
 
-// x^1.5 == x*sqrt(x): float64 sqrt is correctly rounded, product error < 1 ULP(float64) => same float32 as pow
-VD_DEV float vd_pow15_cr(float x) {
-  double d = (double)x;
-  return (float)(d * sqrt(d));
+// ---- torch-CPU transcendental numerics, reproduced bit for bit ----------------------------------------------------------------
+// The reference runs on ATen's CPU kernels: torch.pow(tensor, float) = SLEEF Sleef_powf_u10, torch.sigmoid = 1 / (1 + Sleef_expf_u10(0 - x)),
+// torch.sqrt = MKL VML vsSqrt (one fused correction step on the AVX-512 VRSQRT14 estimate -- NOT the correctly rounded root).  These
+// are float32-only algorithms (double-float arithmetic on FMAs), so they run at full VALU rate here; every operation below is one
+// IEEE float32 rounding (the library is built with -ffp-contract=off; 1.0f / x and the fmas are exact-rounded on gfx950, float32
+// denormals are on).  oracle/vd3d_oracle.c holds the independent C restatement that is pinned against torch itself; the parity tests
+// compare the two bit for bit.  Published algorithm: SLEEF 3.6 sleefsimdsp.c (xpowf -> logkf / expkf, xexpf) and df.h.
+struct vd_df { float x, y; };
+VD_DEV vd_df df_norm(vd_df t) { vd_df s; s.x = t.x + t.y; s.y = t.x - s.x + t.y; return s; }
+VD_DEV vd_df df_add2_ff(float x, float y) { vd_df s; s.x = x + y; const float v = s.x - x; s.y = (x - (s.x - v)) + (y - v); return s; }
+VD_DEV vd_df df_add_22(vd_df x, vd_df y) { vd_df s; s.x = x.x + y.x; s.y = x.x - s.x + y.x + x.y + y.y; return s; }
+VD_DEV vd_df df_add2_2f(vd_df x, float y) { vd_df s; s.x = x.x + y; const float v = s.x - x.x; s.y = (x.x - (s.x - v)) + (y - v); s.y = s.y + x.y; return s; }
+VD_DEV vd_df df_add2_22(vd_df x, vd_df y) { vd_df s; s.x = x.x + y.x; const float v = s.x - x.x; s.y = (x.x - (s.x - v)) + (y.x - v); s.y = s.y + (x.y + y.y); return s; }
+VD_DEV vd_df df_add_f2(float x, vd_df y) { vd_df s; s.x = x + y.x; s.y = x - s.x + y.x + y.y; return s; }
+VD_DEV vd_df df_mul_22(vd_df x, vd_df y) { vd_df r; r.x = x.x * y.x; r.y = vd_fma(x.x, y.y, vd_fma(x.y, y.x, vd_fma(x.x, y.x, -r.x))); return r; }
+VD_DEV vd_df df_mul_2f(vd_df x, float y) { vd_df r; r.x = x.x * y; r.y = vd_fma(x.y, y, vd_fma(x.x, y, -r.x)); return r; }
+VD_DEV vd_df df_squ(vd_df x) { vd_df r; r.x = x.x * x.x; r.y = vd_fma(x.x + x.x, x.y, vd_fma(x.x, x.x, -r.x)); return r; }
+VD_DEV vd_df df_div(vd_df n, vd_df d) {
+  const float t = 1.0f / d.x, s = n.x * t;
+  const float u = vd_fma(t, n.x, -s);
+  const float v = vd_fma(-d.y, t, vd_fma(-d.x, t, 1.0f));
+  vd_df r; r.x = s; r.y = vd_fma(s, v, vd_fma(n.y, t, u)); return r;
 }
+VD_DEV vd_df vd_sleef_logkf(float d) {   // d > 0
+  const int e = __builtin_amdgcn_frexp_expf(d * (1.0f / 0.75f)) - 1;                     // vgetexp(d / 0.75)
+  const float m = __builtin_amdgcn_ldexpf(d, -e);                                         // vgetmant: [0.75, 1.5)
+  const vd_df x = df_div(df_add2_ff(-1.0f, m), df_add2_ff(1.0f, m));
+  const vd_df x2 = df_squ(x);
+  float t = 0.240320354700088500976562f;
+  t = vd_fma(t, x2.x, 0.285112679004669189453125f);
+  t = vd_fma(t, x2.x, 0.400007992982864379882812f);
+  const vd_df c = {0.66666662693023681640625f, 3.69183861259614332084311e-09f};
+  const vd_df l2 = {0.69314718246459960938f, -1.904654323148236017e-09f};
+  vd_df s = df_mul_2f(l2, (float)e);
+  const vd_df x_2 = {x.x * 2.0f, x.y * 2.0f};
+  s = df_add_22(s, x_2);
+  s = df_add_22(s, df_mul_22(df_mul_22(x2, x), df_add2_22(df_mul_2f(x2, t), c)));
+  return s;
+}
+VD_DEV float vd_sleef_expkf(vd_df d) {
+  float u = (d.x + d.y) * 1.442695040888963407359924681001892137426645954152985934135449406931f;
+  const float qf = __builtin_rintf(u);
+  vd_df s = df_add2_2f(d, qf * -0.693145751953125f);
+  s = df_add2_2f(s, qf * -1.428606765330187045e-06f);
+  s = df_norm(s);
+  u = 0.00136324646882712841033936f;
+  u = vd_fma(u, s.x, 0.00836596917361021041870117f);
+  u = vd_fma(u, s.x, 0.0416710823774337768554688f);
+  u = vd_fma(u, s.x, 0.166665524244308471679688f);
+  u = vd_fma(u, s.x, 0.499999850988388061523438f);
+  vd_df t = df_add2_22(s, df_mul_2f(df_squ(s), u));
+  t = df_add_f2(1.0f, t);
+  u = __builtin_amdgcn_ldexpf(t.x + t.y, (int)qf);
+  return d.x < -104.0f ? 0.0f : u;
+}
+// 64 (intercept, slope) pairs of AVX-512 VRSQRT14 (index = exponent parity * 32 + top 5 mantissa bits), see vd_rsqrt14
+static __constant__ const int2 c_vd_rs14[64] = {
+{67102976,2002}, {65052928,1910}, {63096064,1830}, {61223424,1754}, {59428352,1682}, {57706240,1614}, {56052992,1550}, {54464768,1494},
+{52935168,1438}, {51462400,1386}, {50042624,1338}, {48673792,1294}, {47350272,1250}, {46070272,1206}, {44834560,1170}, {43637504,1134},
+{42477312,1098}, {41353984,1066}, {40263424,1034}, {39204864,1002}, {38178048,974}, {37180160,946}, {36210688,922}, {35267328,898},
+{34348800,874}, {33454848,850}, {32585216,830}, {31735296,806}, {30908160,786}, {30103040,770}, {29314816,750}, {28547584,734},
+{27792640,1414}, {26343680,1350}, {24960000,1294}, {23634944,1238}, {22367232,1190}, {21149440,1142}, {19980544,1098}, {18856192,1054},
+{17775872,1018}, {16734976,982}, {15729920,946}, {14761216,914}, {13825280,882}, {12921344,854}, {12046592,826}, {11201280,802},
+{10381056,778}, {9585408,754}, {8814336,730}, {8067328,710}, {7340800,690}, {6635008,670}, {5948416,650}, {5281792,634},
+{4633088,618}, {4001024,602}, {3385088,586}, {2784768,570}, {2200832,558}, {1629440,542}, {1073152,530}, {529920,518}
+};
+VD_DEV float vd_rsqrt14(float x, const int2* __restrict__ tab) {   // x normal and > 0: the instruction's result, bit for bit
+  const uint32_t b = __float_as_uint(x);
+  const int e = (int)(b >> 23) - 127, odd = e & 1, half = (e - odd) / 2;
+  const uint32_t m = b & 0x7fffffu;
+  const int2 ab = tab[odd * 32 + (int)(m >> 18)];
+  uint32_t r = 0x3f000000u + ((uint32_t)((ab.x - ab.y * (int)((m >> 8) & 0x3ffu)) >> 10) << 7);
+  if (m == 0 && !odd) r = 0x3f800000u;                           // exact powers of 4 come back exactly
+  return __uint_as_float(r - ((uint32_t)half << 23));
+}
+// torch.sqrt (MKL VML vsSqrt, high accuracy, AVX-512 path): y = VRSQRT14(x); s = x y; h = y / 2; fma(fma(-s, s, x), h, s).
+// tab: c_vd_rs14 or a copy of it in LDS (vd_stage_rs14).
+VD_DEV float vd_sqrt_torch(float x, const int2* __restrict__ tab) {
+  if (!(x >= 0x1p-100f) || x == __builtin_inff()) return sqrtf(x);  // 0 (every flat pixel), < 2^-100 (not reproduced, see the oracle), inf, nan
+  const float y = vd_rsqrt14(x, tab), s = x * y, h = 0.5f * y;
+  return vd_fma(vd_fma(-s, s, x), h, s);
+}
+VD_DEV void vd_stage_rs14(int2* lds, int tid, int nthreads) {      // caller synchronises
+  for (int i = tid; i < 64; i += nthreads) lds[i] = c_vd_rs14[i];
+}
+// torch.pow(x, e) for x >= 0, e a Python float: ATen's special exponents first (0 -> 1, 1 -> x, 0.5 -> sqrt, 2 -> x*x, 3 -> x*x*x,
+// -0.5 / -1 / -2 the reciprocals), else SLEEF.  e is uniform over a launch, so the branches are.
+VD_DEV float vd_pow_torch(float x, float e, const int2* __restrict__ rs14) {
+  if (e == 0.0f) return 1.0f;
+  if (e == 1.0f) return x;
+  if (e == 0.5f) return vd_sqrt_torch(x, rs14);
+  if (e == 2.0f) return x * x;
+  if (e == 3.0f) return (x * x) * x;
+  if (e == -0.5f) return 1.0f / sqrtf(x);
+  if (e == -1.0f) return 1.0f / x;
+  if (e == -2.0f) return 1.0f / (x * x);
+  if (x == 0.0f) return e < 0.0f ? __builtin_inff() : 0.0f;
+  if (x == 1.0f) return 1.0f;
+  return vd_sleef_expkf(df_mul_2f(vd_sleef_logkf(x), e));
+}
+VD_DEV float vd_pow15_torch(float x) {                             // torch.pow(x, 1.5), x >= 0
+  if (x == 0.0f) return 0.0f;
+  if (x == 1.0f) return 1.0f;
+  return vd_sleef_expkf(df_mul_2f(vd_sleef_logkf(x), 1.5f));
+}
+VD_DEV float vd_sleef_expf(float d) {
+  const float qf = __builtin_rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+  const int q = (int)qf;
+  float s = vd_fma(qf, -0.693145751953125f, d);
+  s = vd_fma(qf, -1.428606765330187045e-06f, s);
+  float u = 0.000198527617612853646278381f;
+  u = vd_fma(u, s, 0.00139304355252534151077271f);
+  u = vd_fma(u, s, 0.00833336077630519866943359f);
+  u = vd_fma(u, s, 0.0416664853692054748535156f);
+  u = vd_fma(u, s, 0.166666671633720397949219f);
+  u = vd_fma(u, s, 0.5f);
+  u = 1.0f + vd_fma(s * s, u, s);
+  u = __builtin_amdgcn_ldexpf(__builtin_amdgcn_ldexpf(u, q >> 1), q - (q >> 1));
+  if (d < -104.0f) u = 0.0f;
+  if (d > 100.0f) u = __builtin_inff();
+  return u;
+}
+VD_DEV float vd_sigmoid_torch(float x) { return 1.0f / (1.0f + vd_sleef_expf(0.0f - x)); }
 
 // packed-f32 vector types: hipcc lowers arithmetic on these to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (2 lanes-worth of
 // IEEE float32 work per VALU issue slot on gfx950); each element is rounded exactly like the scalar operator.

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_heal(const float* __restrict__ warped, 
       const float c = gray[ty + 1][tx + 1];
       const float gx = x > 0 ? c - gray[ty + 1][tx] : 0.f;
       const float gy = y > 0 ? c - gray[ty][tx + 1] : 0.f;
-      f = sqrtf(gx * gx + gy * gy) > (float)0.05 ? 1.f : 0.f;
+      f = vd_sqrt_torch(gx * gx + gy * gy, c_vd_rs14) > (float)0.05 ? 1.f : 0.f;
     }
     flag[ty][tx] = f;
   }

@@ -125,6 +125,7 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
                          const vd_finish_consts& fc, uint8_t* out);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
+void vd_launch_torch_math(hipStream_t s, int op, const float* x, float p, float* out, long long n);
 void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const vd_dev_work* wk, uint8_t* dst);
 
 bool vd_launch_preview(hipStream_t s, int type, const uint8_t* L, const uint8_t* R, int h, int w, uint8_t* out);

@@ -21,8 +21,11 @@ struct vd_shift_consts {
 __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int H, int W, const vd_dev_work* __restrict__ w,
                                                vd_shift_consts c, float* __restrict__ S) {
   __shared__ __attribute__((aligned(16))) float em[SH_TH + 4][SH_TW + 4];
+  __shared__ int2 rs14[64];
   const int x0 = blockIdx.x * SH_TW, y0 = blockIdx.y * SH_TH;
   if (c.edge) {
+    vd_stage_rs14(rs14, threadIdx.x, 256);
+    __syncthreads();
     for (int t = threadIdx.x; t < (SH_TH + 4) * (SH_TW + 4); t += 256) {
       const int ty = t / (SH_TW + 4), tx = t - ty * (SH_TW + 4);
       const int y = y0 - 2 + ty, x = x0 - 2 + tx;
@@ -31,10 +34,9 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
         const float cc = D[(size_t)y * W + x];
         const float dx = x > 0 ? fabsf(cc - D[(size_t)y * W + x - 1]) : 0.f;
         const float dy = y > 0 ? fabsf(cc - D[(size_t)(y - 1) * W + x]) : 0.f;
-        const float g = sqrtf(dx * dx + dy * dy);
+        const float g = vd_sqrt_torch(dx * dx + dy * dy, rs14);      // torch.sqrt / torch.sigmoid: the CPU libraries' values
         const float z = ((g - (float)0.02) * c.fs) * 5.f;
-        const float sg = 1.f / (1.f + vd_exp_cr(-z));
-        e = 1.f - sg;
+        e = 1.f - vd_sigmoid_torch(z);
       }
       em[ty][tx] = e;
     }
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
     const int x = x0 + tx + q;
     if (x >= W) break;
     const float Dv = D[(size_t)y * W + x];
-    const float fgw = vd_clamp(vd_pow15_cr(1.0f - Dv), 0.f, 1.f);
+    const float fgw = vd_clamp(vd_pow15_torch(1.0f - Dv), 0.f, 1.f);
     const float mgw = vd_clamp(1.0f - fabsf(Dv - c.mid) * 3.0f, 0.f, 1.f);
     const float bgw = vd_clamp(Dv, 0.f, 1.f);
     const float raw = ((fgw * fgf) * c.fgm + mgw * mgf) + (bgw * bgf) * c.bgm;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void k_e2(const float* __restrict__ D, const f
     const float c = warped_depth(D, S, H, W, y, x, sign);
     const float gx = x > 0 ? c - warped_depth(D, S, H, W, y, x - 1, sign) : 0.f;
     const float gy = y > 0 ? c - warped_depth(D, S, H, W, y - 1, x, sign) : 0.f;
-    const float g = sqrtf(gx * gx + gy * gy);
+    const float g = vd_sqrt_torch(gx * gx + gy * gy, c_vd_rs14);
     (eye == 0 ? e2L : e2R)[(size_t)y * W + x] = vd_clamp(g * fs, 0.f, 1.f);
   }
 }
@@ -496,6 +498,21 @@ void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const 
 // on MI355X (tools/ubench_valu.hip, 1 GiB: grid-stride with four loads in flight 4.4-5.2 TB/s, contiguous chunk per workgroup 5.6-5.9,
 // hipMemcpyAsync 5.5) this is the one that reaches the guide's 6.2-6.3 TB/s.
 // ------------------------------------------------------------------------------------------------
+// elementwise torch-CPU math exactly as the chain's kernels evaluate it (vd3d_torch_math; test / diagnostic entry)
+__global__ __launch_bounds__(256) void k_torch_math(int op, const float* __restrict__ x, float p, float* __restrict__ out, long long n) {
+  __shared__ int2 rs14[64];
+  vd_stage_rs14(rs14, threadIdx.x, 256);
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    out[i] = op == 0 ? vd_pow_torch(v, p, rs14) : op == 1 ? vd_sigmoid_torch(v) : vd_sqrt_torch(v, rs14);
+  }
+}
+void vd_launch_torch_math(hipStream_t s, int op, const float* x, float p, float* out, long long n) {
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_torch_math, dim3((unsigned)(nb < 16384 ? (nb > 0 ? nb : 1) : 16384)), dim3(256), 0, s, op, x, p, out, n);
+}
+
 typedef unsigned int vd_u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_stream_copy(const vd_u4* __restrict__ src, vd_u4* __restrict__ dst, size_t n16) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -17,7 +17,6 @@
 // the two frame-sharding protocols.
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
-#include "vd3d_pow_tables.h"
 
 #define NBL 16272  // LDS bins per job (>= 0x3F80 + 1)
 
@@ -933,19 +932,13 @@ __global__ __launch_bounds__(1024) void k_chain_b1(const float* __restrict__ dn_
   if (last_workgroup(&w->ticket[3], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B1; run_scalar_stage(w, histA, histB, a, sm); }
 }
 
-#define VD_X_NONE(v)
-#define VD_X_VAL(v) v,
-__constant__ double c_pow_tab[320] = {VD_POW_TABLES(VD_X_VAL, VD_X_NONE, VD_X_NONE) VD_POW_TABLES(VD_X_NONE, VD_X_VAL, VD_X_NONE)
-                                      VD_POW_TABLES(VD_X_NONE, VD_X_NONE, VD_X_VAL)};
 // K5: shape_depth_for_pop -> D plane + pass A of J4 ; last workgroup: scan A2
 __global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* __restrict__ dc, vd_dev_work* w, float mid, float gamma,
                                                       float* __restrict__ D,
                                                       uint32_t* histA, const uint32_t* histB, vd_stage_args a) {
   __shared__ uint32_t h1[NBL];
   __shared__ uint32_t sm[128];
-  __shared__ double ptab[320];   // vd_pow_fast tables
   for (int b = threadIdx.x; b < NBL; b += 1024) h1[b] = 0;
-  if (threadIdx.x < 320) ptab[threadIdx.x] = c_pow_tab[threadIdx.x];
   __syncthreads();
   const long long n = (long long)f.H * f.W;
   const int stretch = w->shp_stretch;
@@ -955,7 +948,7 @@ __global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* _
     const float centered = (ds - subj_s) + mid;
     const float t = centered - mid;
     const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
-    return vd_clamp(sgn * vd_pow_cr_fast(fabsf(t), gamma, ptab) + mid, 0.f, 1.f);
+    return vd_clamp(sgn * vd_pow_torch(fabsf(t), gamma, c_vd_rs14) + mid, 0.f, 1.f);   // torch.pow: SLEEF's value
   };
   if ((f.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(dc) | reinterpret_cast<uintptr_t>(D)) & 15) == 0) {
     const long long n4 = n >> 2;   // 4 pixels per thread: one 16-byte load / store, one integer division, 4 independent pow chains

@@ -21,6 +21,7 @@
 // Arithmetic is identical to the unfused v0 kernels (same helpers, same association) => bit-exact vs the oracle.
 //
 // Algorithmic HBM bytes per stereo pair: read RGB 3N (eye-res f32 x3 at N/4) + D 4N + S 4N, write 6N.
+#include <cstdio>
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 
@@ -146,12 +147,21 @@ VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
 #define WF_OCC_ATTR   // A/B builds: -DWF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))'
 #endif
 #define WF_HB 6   // Hh rows a wave builds together (2 * WF_HB loads in flight)
+// torch.sqrt of a finite x >= 0 (vd_sqrt_torch): zero -- every flat pixel -- and the never-reached x < 2^-100 take the rounded root
+VD_DEV float wf_sqrt_torch(float x, const int2* __restrict__ tab) {
+  const float xs = fmaxf(x, 0x1p-100f);
+  const float y = vd_rsqrt14(xs, tab), s = xs * y, h = 0.5f * y;
+  float r = vd_fma(vd_fma(-s, s, xs), h, s);
+  if (x < 0x1p-100f) r = sqrtf(x);
+  return r;
+}
 template <bool RESIZE, bool FEATHER, int WF_TH>
 __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
                                                       uint8_t* __restrict__ R) {
   constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
   extern __shared__ float lds[];
+  __shared__ int2 rs14[64];                          // VRSQRT14 table of vd_sqrt_torch (phase B)
   const int H = a.H, W = a.W, k = a.k, r = k / 2;
   const int tile = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
   if (tile >= a.ntiles) return;                      // padding workgroup of the last band (workgroup-uniform, before any barrier)
@@ -199,6 +209,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     t[8] = __int_as_float((t1.i0 - er0) * rp); t[9] = __int_as_float((t1.i1 - er0) * rp); t[10] = t1.w0; t[11] = t1.w1;
     t[12] = n; t[13] = sr; t[14] = __int_as_float((s_ok && n != 0.f) ? 1 : 0); t[15] = __int_as_float(yn);
   }
+  if (FEATHER && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
   __syncthreads();
   if (FEATHER) {
     // phase A, main block: wave = halo row (scalar row part), lane = the first 64 halo columns (gx once per lane).  The phase is
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
         const vd_f2 gx = x > 0 ? c - wvp[-1] : z;
         const vd_f2 gy = y > 0 ? c - wvp[-ww] : z;
         const vd_f2 q = gx * gx + gy * gy;
-        const vd_f2 m = vd_f2{sqrtf(q.x), sqrtf(q.y)} * a.fs;
+        const vd_f2 m = vd_f2{wf_sqrt_torch(q.x, rs14), wf_sqrt_torch(q.y, rs14)} * a.fs;   // torch.sqrt = MKL vsSqrt, not the rounded root
         e.x = vd_clamp_fin(m.x, 0.f, 1.f); e.y = vd_clamp_fin(m.y, 0.f, 1.f);
       }
       e2[ty * ewp + tx] = e;
@@ -569,7 +580,20 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr[dev]) {
-#define WF_ATTR(R_, F_, T_) (void)hipFuncSetAttribute((const void*)k_warp_fused<R_, F_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    // dynamic LDS limit = the CU's 160 KB minus the kernel's static LDS (the VRSQRT14 table); a failed call would otherwise surface as a
+    // sticky "invalid argument" at the next hipGetLastError
+#define WF_ATTR(R_, F_, T_)                                                                                                        \
+  do {                                                                                                                             \
+    hipFuncAttributes fa_;                                                                                                         \
+    size_t st_ = 0;                                                                                                                \
+    if (hipFuncGetAttributes(&fa_, (const void*)k_warp_fused<R_, F_, T_>) == hipSuccess) st_ = fa_.sharedSizeBytes;                \
+    if (hipFuncSetAttribute((const void*)k_warp_fused<R_, F_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize,                     \
+                            (int)(160 * 1024 - st_)) != hipSuccess) {                                                              \
+      (void)hipGetLastError();                                                                                                     \
+      fprintf(stderr, "vd3d: hipFuncSetAttribute(k_warp_fused, max dynamic LDS) failed; using the unfused warp kernels\n");        \
+      return false;                                                                                                                \
+    }                                                                                                                              \
+  } while (0)
     WF_ATTR(true, true, 32); WF_ATTR(true, false, 32); WF_ATTR(false, true, 32); WF_ATTR(false, false, 32);
 #undef WF_ATTR
     attr[dev] = true;

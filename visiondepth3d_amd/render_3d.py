@@ -454,6 +454,15 @@ class Renderer:
         return out
 
     # ---- exact reductions (test / diagnostic entry points) ----
+    def torch_math(self, op: str, x: torch.Tensor, param: float = 0.0) -> torch.Tensor:
+        """torch.pow(x, param) / torch.sigmoid(x) / torch.sqrt(x) with the values torch's CPU kernels give (SLEEF / MKL VML), as the
+        chain's kernels evaluate them (core/render_3d.py:517, 620, 209, 206)."""
+        t = x.to(self.device, torch.float32).contiguous()
+        o = torch.empty_like(t)
+        self._enter(t, o)
+        _lib.check(self._L.vd3d_torch_math(self._ctx, {"pow": 0, "sigmoid": 1, "sqrt": 2}[op], _ptr(t), float(param), _ptr(o), t.numel()))
+        return o
+
     def quantiles(self, plane: torch.Tensor, qs):
         p = plane.to(self.device, torch.float32).contiguous()
         q = (C.c_float * len(qs))(*[float(np.float32(v)) for v in qs])
