@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_valu(float* out, long long* cyc, float 
   for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 0.001f + i; p[i] = f2{a[i], a[i] + 1.f}; }
   const float b = s, c = 0.5f;
   const f2 pb = {s, s}, pc = {0.5f, 0.25f};
-  const long long t0 = clock64();
+  const long long t0 = clock64(), w0 = wall_clock64();
   for (int it = 0; it < ITER; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -44,6 +44,25 @@ __global__ __launch_bounds__(256) void k_valu(float* out, long long* cyc, float 
   for (int i = 0; i < 8; ++i) r += a[i] + p[i].x + p[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { cyc[256 * 8 * 8] = t1 - t0; cyc[256 * 8 * 8 + 1] = wall_clock64() - w0; }   // shader cycles, 100 MHz ticks
+}
+
+// dependent-chain test: NCH independent v_fma_f32 accumulators per wave, each instruction depends on the one NCH places earlier
+// (E1's dense DOF loop has 4: the four pixels of a strip; does the VALU pipeline need more to issue back to back?)
+template <int NCH>
+__global__ __launch_bounds__(256) void k_chain(float* out, float s) {
+  float a[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) a[i] = threadIdx.x * 0.001f + i;
+  const float b = s, c = 0.5f;
+  for (int it = 0; it < ITER * 8 / NCH; ++it) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) r += a[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
 // MFMA f32 waves and VALU waves in one workgroup: waves [0, nm) run MFMA chains, the rest run v_fma / v_pk_fma chains.
@@ -210,14 +229,30 @@ static int run(const char* name, F launch, int blocks, int threads, double inst_
 int main() {
   float* out; long long* cyc;
   CK(hipMalloc(&out, 256 * 8 * 512 * sizeof(float)));
-  CK(hipMalloc(&cyc, 256 * 8 * 8 * sizeof(long long)));
+  CK(hipMalloc(&cyc, (256 * 8 * 8 + 2) * sizeof(long long)));
   const double n = (double)ITER * 8;
   for (int k : {1, 2, 4, 8}) {
     const int blocks = 256 * k;
+    {   // the shader clock under this load: s_memtime (cycles) against s_memrealtime (100 MHz) inside one wave of a long v_fma launch
+      for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL(k_valu<0>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0001f);
+      CK(hipDeviceSynchronize());
+      long long h[2];
+      CK(hipMemcpy(h, cyc + 256 * 8 * 8, sizeof h, hipMemcpyDeviceToHost));
+      printf("shader clock under v_fma_f32 at %d waves/SIMD: %lld cycles in %.2f us = %.0f MHz; %.2f cycles per wave-instruction of one wave\n", k, h[0], h[1] / 100.0,
+             h[0] / (h[1] / 100.0), (double)h[0] / (ITER * 8.0));
+    }
     run("v_fma_f32", [&] { hipLaunchKernelGGL(k_valu<0>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0001f); }, blocks, 256, n, n * 64 * 2, out, cyc);
     run("v_pk_fma_f32", [&] { hipLaunchKernelGGL(k_valu<1>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0001f); }, blocks, 256, n, n * 64 * 4, out, cyc);
     run("v_pk_mul_f32 / v_pk_add_f32", [&] { hipLaunchKernelGGL(k_valu<2>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0001f); }, blocks, 256, n, n * 64 * 2, out, cyc);
     run("v_fma_f32 : v_pk_fma_f32 1:1", [&] { hipLaunchKernelGGL(k_valu<3>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0001f); }, blocks, 256, n, n * 64 * 3, out, cyc);
+  }
+  for (int k : {1, 2, 4, 5, 8}) {
+    const int blocks = 256 * k;
+    char nm[64];
+#define CHAIN(N) snprintf(nm, sizeof nm, "v_fma_f32, %d independent chains", N); \
+    run(nm, [&] { hipLaunchKernelGGL(k_chain<N>, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); }, blocks, 256, n, n * 64 * 2, out, cyc);
+    CHAIN(1) CHAIN(2) CHAIN(4) CHAIN(8) CHAIN(16)
+#undef CHAIN
   }
   // MFMA next to VALU: 512-thread workgroups, 1 per CU (2 waves per SIMD) and 2 per CU (4 waves per SIMD)
   const double nmf32 = (double)(ITER / 16) * 4, nmf16 = (double)(ITER / 16) * 8;

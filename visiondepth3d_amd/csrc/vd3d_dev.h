@@ -55,6 +55,24 @@ VD_DEV float vd_lin11_step(float step, int steps, int i) {
 // correctly-rounded float32 exp through float64 (device libm is < 1 ULP in float64): torch.exp on the k-tap Gaussian window
 VD_DEV float vd_exp_cr(float x) { return (float)exp((double)x); }
 
+// Development aid (compiled out unless -DVD_PHASE_STAMPS: bash tools/build_ab.sh stamps -DVD_PHASE_STAMPS): thread 0 of every 67th workgroup (64 slots)
+// records s_memtime (shader cycles) at phase boundaries and s_memrealtime (100 MHz) at stamp 0 and at the last stamp, so that a probe can
+// print cycles per phase and the shader clock the kernel actually ran at (tools/probe_phases.py).  One table per translation unit.
+#ifdef VD_PHASE_STAMPS
+#define VD_STAMP_DECL(name) static __device__ unsigned long long name[64][16]
+#define VD_STAMP(name, k, last)                                                                                            \
+  do {                                                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x % 67 == 7 && blockIdx.x / 67 < 64) {                                              \
+      name[blockIdx.x / 67][k] = __builtin_amdgcn_s_memtime();                                                            \
+      if ((k) == 0) name[blockIdx.x / 67][14] = __builtin_amdgcn_s_memrealtime();                                          \
+      if (last) name[blockIdx.x / 67][15] = __builtin_amdgcn_s_memrealtime();                                              \
+    }                                                                                                                      \
+  } while (0)
+#else
+#define VD_STAMP_DECL(name)
+#define VD_STAMP(name, k, last) do { } while (0)
+#endif
+
 // ---- torch-CPU transcendental numerics, reproduced bit for bit ----------------------------------------------------------------
 // The reference runs on ATen's CPU kernels: torch.pow(tensor, float) = SLEEF Sleef_powf_u10, torch.sigmoid = 1 / (1 + Sleef_expf_u10(0 - x)),
 // torch.sqrt = MKL VML vsSqrt (one fused correction step on the AVX-512 VRSQRT14 estimate -- NOT the correctly rounded root).  These

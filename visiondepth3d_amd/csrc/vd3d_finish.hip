@@ -35,11 +35,14 @@
 #define FF_GP 76                    // pitch of the graded dword tile (multiple of 4: b128 rows)
 #define FF_XG 2                     // tile rows per XCD group (vd_xcd_tile_rows)
 #ifndef FF_WIDE_TH
-#define FF_WIDE_TH 30               // tile height of the wide geometry (A/B builds: -DFF_WIDE_TH=14, tools/build_ab.sh)
+#define FF_WIDE_TH 26               // tile height of the wide geometry (A/B builds: -DFF_WIDE_TH=30 / 22 / 14, tools/build_ab.sh)
 #endif
 // geometry per instantiation (DENSE / separable): tile height, graded rows (1-pixel halo), input rows, threads
-// TH = 16: the round-2 geometry (6 waves x 3 rows x 20 strips, 4 idle lanes).  TH = 30 ("wide" thread mapping): (TH + 2) / 4 = 8 strip waves
-// of 4 rows x 16 strips + 1 halo-pixel wave.
+// TH = 16: the round-2 geometry (6 waves x 3 rows x 20 strips, 4 idle lanes).  "Wide" thread mapping: (TH + 2) / 4 strip waves of 4 rows x
+// 16 strips + 1 halo-pixel wave.  TH = 26 -> 7 + 1 = 8 waves, two per SIMD: with the kernel's 88 VGPRs (5 waves per SIMD) TWO workgroups are
+// resident per CU.  TH = 30 (9 waves, the first wide geometry) has the fewest instructions per pixel but one SIMD carries 3 waves of a
+// workgroup, a second workgroup would need 6 there, and the residency probe (tools/probe_phases.py: HW_ID + s_memrealtime per workgroup)
+// showed exactly ONE workgroup per CU at any time: 425 us per 4K frame against 341 us for TH = 26 (TH = 22: 396 us).
 template <int TH_> struct ff_geo {
   static constexpr int TH = TH_;
   static constexpr bool WIDE = TH_ != 16;
@@ -214,6 +217,18 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
 #ifndef FF_OCC_ATTR
 #define FF_OCC_ATTR   // A/B builds: -DFF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))' forces the 64-VGPR budget
 #endif
+VD_STAMP_DECL(ff_stamps);
+#ifdef VD_PHASE_STAMPS
+extern "C" __attribute__((visibility("default"))) int vd3d_debug_stamps_e1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_stamps), sizeof(ff_stamps)); }
+// residency probe: every workgroup records where (HW_ID, XCC_ID) and when (s_memrealtime at entry / exit of thread 0) it ran
+static __device__ unsigned long long ff_occ[16384][4];
+extern "C" __attribute__((visibility("default"))) int vd3d_debug_occ_e1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_occ), sizeof(ff_occ)); }
+#define FF_OCC_IN() do { if (threadIdx.x == 0 && blockIdx.x < 16384) { ff_occ[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); ff_occ[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); ff_occ[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define FF_OCC_OUT() do { if (threadIdx.x == 0 && blockIdx.x < 16384) ff_occ[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FF_OCC_IN() do { } while (0)
+#define FF_OCC_OUT() do { } while (0)
+#endif
 template <bool DENSE, int TH_>
 __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
@@ -240,7 +255,45 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   const int gx0 = x0 - 4, gy0 = y0 - 1;            // graded region origin
   const int ix0 = gx0 - FF_R, iy0 = gy0 - FF_R;    // input tile origin
   const int tid = threadIdx.x;
+  VD_STAMP(ff_stamps, 0, false);
+  FF_OCC_IN();
 
+  const int lane = tid & 63, wv = tid >> 6;
+  bool active, strip, halo_px = false;
+  int sy, ss, hq = 0;                             // hq: the live pixel of a halo-column strip (WIDE: 3 = left column x0 - 1, 0 = right column x0 + 64)
+  if (WIDE) {
+    // waves 0-7: thread = (graded row 4 wv + lane % 4, strip 2 + lane / 4) -- the 64 x 32 graded pixels of the tile's own columns.  Row
+    // fastest: with the 80-float tile pitch (16 banks mod 64) every 16-lane group of a ds_read_b128 then covers the 64 banks exactly
+    // (row-major lanes measured 18x the bank-conflict cycles: two rows of a group alias 32 banks);
+    // wave 8: thread = one pixel of the halo columns (graded row lane / 2; even lanes the left column, odd lanes the right one)
+    active = true; strip = true;
+    if (wv < FF_NSW) { sy = 4 * wv + (lane & 3); ss = 2 + (lane >> 2); }
+    else {
+      sy = min(lane >> 1, FF_GH - 1); halo_px = true; ss = (lane & 1) ? FF_IS - 2 : 1; hq = (lane & 1) ? 0 : 3;
+      strip = (lane >> 1) < FF_GH;                 // 2 GH halo pixels; the rest of the wave idles (TH = 14)
+    }
+  } else {
+    // thread = (graded row sy, tile strip ss); wave v owns rows 3v..3v+2; strips 1..18 are the graded region
+    active = lane < 3 * FF_IS;
+    sy = active ? 3 * wv + lane / FF_IS : 0; ss = active ? lane % FF_IS : 0;
+    strip = active && ss >= 1 && ss <= FF_IS - 2;
+  }
+  const int gy = gy0 + sy, gxs = ix0 + 4 * ss;    // image coordinates of the strip's first pixel
+  // The depth samples of the blur weight (exact 2:1 interior strips: 8 loads) are requested NOW, before the tile load, and consumed after
+  // the first barrier: at two resident workgroups per CU their round trip was the longest exposed wait of the kernel (s_memtime stamps:
+  // 42 % of a workgroup's life sat in the phase that used to issue them).
+  const int yc = min(max(gy, 0), H - 1);   // halo pixels outside the image are never used
+  const bool fast21 = strip && fc.nlev && 2 * a.eh == H && 2 * a.ew == W && gxs >= 4 && gxs + 6 <= W;
+  vd_tap ay21 = {0, 0, 0.f, 0.f};
+  float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fast21) {
+    ay21 = vd_tap21(a.eh, yc);
+    const int c0 = (gxs >> 1) - 1;
+    const float* r0 = dn + (size_t)ay21.i0 * a.ew + c0;
+    const float* r1 = dn + (size_t)ay21.i1 * a.ew + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p0[j] = r0[j]; p1[j] = r1[j]; }
+  }
   if (tid == 0) lvl_mask = 0;
   const bool in_interior = ix0 >= 0 && ix0 + FF_IW <= W && iy0 >= 0 && iy0 + FF_IH <= H && (W & 3) == 0 &&
                            (reinterpret_cast<uintptr_t>(src) & 3) == 0;
@@ -270,31 +323,11 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       tile[2][ty][tx] = vd_u8_unit((float)px[0]);
     }
   }
-  const int lane = tid & 63, wv = tid >> 6;
-  bool active, strip, halo_px = false;
-  int sy, ss, hq = 0;                             // hq: the live pixel of a halo-column strip (WIDE: 3 = left column x0 - 1, 0 = right column x0 + 64)
-  if (WIDE) {
-    // waves 0-7: thread = (graded row 4 wv + lane % 4, strip 2 + lane / 4) -- the 64 x 32 graded pixels of the tile's own columns.  Row
-    // fastest: with the 80-float tile pitch (16 banks mod 64) every 16-lane group of a ds_read_b128 then covers the 64 banks exactly
-    // (row-major lanes measured 18x the bank-conflict cycles: two rows of a group alias 32 banks);
-    // wave 8: thread = one pixel of the halo columns (graded row lane / 2; even lanes the left column, odd lanes the right one)
-    active = true; strip = true;
-    if (wv < FF_NSW) { sy = 4 * wv + (lane & 3); ss = 2 + (lane >> 2); }
-    else {
-      sy = min(lane >> 1, FF_GH - 1); halo_px = true; ss = (lane & 1) ? FF_IS - 2 : 1; hq = (lane & 1) ? 0 : 3;
-      strip = (lane >> 1) < FF_GH;                 // 2 GH halo pixels; the rest of the wave idles (TH = 14)
-    }
-  } else {
-    // thread = (graded row sy, tile strip ss); wave v owns rows 3v..3v+2; strips 1..18 are the graded region
-    active = lane < 3 * FF_IS;
-    sy = active ? 3 * wv + lane / FF_IS : 0; ss = active ? lane % FF_IS : 0;
-    strip = active && ss >= 1 && ss <= FF_IS - 2;
-  }
-  const int gy = gy0 + sy, gxs = ix0 + 4 * ss;    // image coordinates of the strip's first pixel
   int lo[4] = {0, 0, 0, 0};
   vd_f4 alpha = {0.f, 0.f, 0.f, 0.f};
   int lmin = 9, lmax = -1;
   __syncthreads();   // lvl_mask = 0 visible before the atomicOr below; tile complete
+  VD_STAMP(ff_stamps, 1, false);
   if (WIDE && DENSE) {   // halo-column windows (consumed after the next barrier)
     for (int t = tid; t < 3 * 2 * FF_IH; t += FF_NT) {
       const int c = t / (2 * FF_IH), rem = t - c * (2 * FF_IH), side = rem / FF_IH, row = rem - side * FF_IH;
@@ -308,17 +341,12 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   if (strip && fc.nlev) {
     const float focal = a.use_override ? a.focal : w->focal;
     float dd[4];
-    const int yc = min(max(gy, 0), H - 1);   // halo pixels outside the image are never used
-    if (2 * a.eh == H && 2 * a.ew == W && gxs >= 4 && gxs + 6 <= W) {
+    if (fast21) {
       // exact 2:1 (Half-SBS), strip away from the left / right border: the four pixels x = 4m .. 4m+3 share the eye columns
       // 2m-1 .. 2m+2 and their taps are a parity rule (vd_tap21: even x -> (i0, w1) = (x/2 - 1, 0.75), odd x -> ((x-1)/2, 0.25)),
-      // so the strip costs 8 loads and 24 operations instead of 4 independent bilinear samples.  Same association as vd_bilerp:
-      // a = fma(p[i0], w0, w1 * p[i1]) per row, then fma(a, wy0, wy1 * b).
-      const vd_tap ay = vd_tap21(a.eh, yc);
-      const int c0 = (gxs >> 1) - 1;
-      const float* r0 = dn + (size_t)ay.i0 * a.ew + c0;
-      const float* r1 = dn + (size_t)ay.i1 * a.ew + c0;
-      const float p0[4] = {r0[0], r0[1], r0[2], r0[3]}, p1[4] = {r1[0], r1[1], r1[2], r1[3]};
+      // so the strip costs 8 loads (issued at the top of the kernel) and 24 operations instead of 4 independent bilinear samples.
+      // Same association as vd_bilerp: a = fma(p[i0], w0, w1 * p[i1]) per row, then fma(a, wy0, wy1 * b).
+      const vd_tap ay = ay21;
       const float a0 = vd_fma(p0[0], 0.25f, 0.75f * p0[1]), b0 = vd_fma(p1[0], 0.25f, 0.75f * p1[1]);
       const float a1 = vd_fma(p0[1], 0.75f, 0.25f * p0[2]), b1 = vd_fma(p1[1], 0.75f, 0.25f * p1[2]);
       const float a2 = vd_fma(p0[1], 0.25f, 0.75f * p0[2]), b2 = vd_fma(p1[1], 0.25f, 0.75f * p1[2]);
@@ -375,6 +403,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
     vhi[c] = vlo[c];
   }
   __syncthreads();
+  VD_STAMP(ff_stamps, 2, false);
   const int need_mask = lvl_mask;
   for (int l = 0; l < fc.nlev; ++l) {  // level l+1 of the reference's stack
     if (!(need_mask >> (l + 1) & 1)) continue;  // no pixel of this tile blends with this level (workgroup-uniform)
@@ -406,6 +435,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       default: ff_level<3, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
     }
   }
+  VD_STAMP(ff_stamps, 3, false);
   if (strip) {  // blend, grade (:750-767), truncate, side bars (:885-892); float4 = the strip's 4 pixels
     const int bar_w = a.use_override ? a.bar_w : w->bar_width, bar_s = a.use_override ? a.bar_s : w->bar_side;
     vd_f4 rgbv[3];
@@ -442,6 +472,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
     else *reinterpret_cast<uint4*>(&gb[sy][4 * (ss - 1)]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
   __syncthreads();
+  VD_STAMP(ff_stamps, 4, false);
   // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux
   const int ow = FF_TW / a.fx, oh = FF_TH / a.fy;      // output pixels produced by this tile
   const int ox0 = x0 / a.fx, oy0 = y0 / a.fy;
@@ -486,6 +517,8 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
         for (int bi = 0; bi < 12; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
       }
     }
+    VD_STAMP(ff_stamps, 5, true);
+    FF_OCC_OUT();
     return;
   }
   const float scale = 1.f / (float)(a.fx * a.fy);
@@ -539,6 +572,8 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       for (int bi = 0; bi < 3 * nvalid; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
     }
   }
+  VD_STAMP(ff_stamps, 5, true);
+  FF_OCC_OUT();
 }
 
 // returns false when the fast path does not apply (caller runs the unfused kernels)

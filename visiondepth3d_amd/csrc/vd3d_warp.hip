@@ -147,6 +147,10 @@ VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
 #define WF_OCC_ATTR   // A/B builds: -DWF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))'
 #endif
 #define WF_HB 6   // Hh rows a wave builds together (2 * WF_HB loads in flight)
+VD_STAMP_DECL(wf_stamps);
+#ifdef VD_PHASE_STAMPS
+extern "C" __attribute__((visibility("default"))) int vd3d_debug_stamps_w1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_stamps), sizeof(wf_stamps)); }
+#endif
 // torch.sqrt of a finite x >= 0 (vd_sqrt_torch): zero -- every flat pixel -- and the never-reached x < 2^-100 take the rounded root
 VD_DEV float wf_sqrt_torch(float x, const int2* __restrict__ tab) {
   const float xs = fmaxf(x, 0x1p-100f);
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   float* rowA = rowD + WF_TH * WF_RD;                               // [wh][4]        (phase A only)
   float* colT = rowA;                                               // [nch][2]       (built after phase C: rowA is dead by then)
   const int tid = threadIdx.x;
+  VD_STAMP(wf_stamps, 0, false);
   const int lane = tid & 63, wv = wf_uni(tid >> 6);
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
   const int cb = max(x0 - a.bound, 0);                              // first warp-res column of Hh / colT
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   }
   if (FEATHER && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
   __syncthreads();
+  VD_STAMP(wf_stamps, 1, false);
   if (FEATHER) {
     // phase A, main block: wave = halo row (scalar row part), lane = the first 64 halo columns (gx once per lane).  The phase is
     // LATENCY-bound (two dependent global round trips per position: S, then the D gathers), so WF_AB rows are walked together: all
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     }
   }
   __syncthreads();
+  VD_STAMP(wf_stamps, 2, false);
   if (FEATHER) {
     // phase B: e2 = clamp(|grad WD| * fs, 0, 1) (:347-352), zero outside the image (avg_pool2d zero padding)
     const int bq = WF_NT / ew, br = WF_NT - bq * ew;
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       if (tx >= ew) { tx -= ew; ++ty; }
     }
     __syncthreads();
+    VD_STAMP(wf_stamps, 3, false);
     // phase C: blend weights b (see the header) into the dead wd buffer; thread = (tile row, strip of 4 pixels), both eyes packed
     {
       vd_f2* bb = wd;   // [WF_TH][WF_TW]
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
   }
   __syncthreads();
+  VD_STAMP(wf_stamps, 4, false);
   // phase D0: the feather weights b of the wave's rows into registers -- bb2 dies here
   vd_f2 bD[WF_TH / WF_NW];
 #pragma unroll
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       colT[2 * j] = __int_as_float(t.i0); colT[2 * j + 1] = t.w1;
     }
     __syncthreads();   // bb2 fully consumed, colT complete
+    VD_STAMP(wf_stamps, 5, false);
     // phase D1: Hh[c][r][X] = the HORIZONTAL half of the resize of :595 for warp-res column cb + X and eye-res row er0 + r:
     //   fma(p[i0], 1 - w1, w1 * p[i0 + 1])  -- exactly the first two operations of ATen's bilinear (rows, then columns), computed
     // once and shared by every sample that needs it (~4.4 per element) instead of inside each of them.  One wave = one 64-column
@@ -398,6 +408,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     }
   }
   __syncthreads();
+  VD_STAMP(wf_stamps, 6, false);
   // phase D2: one wave = 64 consecutive pixels of ONE row per iteration, so everything that depends on y only (sample rows yn / yn+1,
   // their resize taps, the vertical weights) is wave-uniform and comes from rowD.  ~70 % of rows have an exactly integral sample row
   // (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 -> skipped (bit-exact: fma(v, 0, acc) == acc).
@@ -505,6 +516,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       orr[0] = (uint8_t)pR; orr[1] = (uint8_t)(pR >> 8); orr[2] = (uint8_t)(pR >> 16);
     }
   }
+  VD_STAMP(wf_stamps, 7, true);
 }
 
 // blur_ksize values whose k*k passed tools/verify_fastdiv.c (all floats in [0, k*k], 3-operation division == IEEE division)
