@@ -36,24 +36,25 @@ for name, fn, labels in (("W1 k_warp_fused", "vd3d_debug_stamps_w1", ["tables", 
     for k, lb in enumerate(labels):
         print(f"  {lb:28s} {d[:, k].mean():9.0f} cycles  {100 * d[:, k].mean() / tot.mean():5.1f} %   (min {d[:, k].min():.0f}, max {d[:, k].max():.0f})")
 
-# residency of E1: which workgroups overlapped in time on the same CU (HW_ID bits: gfx9 layout -- wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13)
-buf = (C.c_ulonglong * (16384 * 4))()
-L.vd3d_debug_occ_e1.argtypes = [C.c_void_p]
-assert L.vd3d_debug_occ_e1(buf) == 0
-o = np.array(buf, dtype=np.uint64).reshape(16384, 4).astype(np.int64)
-o = o[o[:, 2] > 0]
-hw, xcc = o[:, 0], o[:, 1] & 0xF
-cu = (xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
-t0 = o[:, 2].min()
-print(f"E1 residency: {len(o)} workgroups on {len(np.unique(cu))} distinct CUs, launch span {(o[:, 3].max() - t0) / 100.0:.1f} us, mean workgroup life {np.mean(o[:, 3] - o[:, 2]) / 100.0:.2f} us")
-conc = []
-for c in np.unique(cu):
-    sel = o[cu == c]
-    ev = sorted([(a, 1) for a in sel[:, 2]] + [(b, -1) for b in sel[:, 3]])
-    cur = mx = 0; area = 0; last = ev[0][0]
-    for tm, dlt in ev:
-        area += cur * (tm - last); last = tm
-        cur += dlt; mx = max(mx, cur)
-    conc.append((mx, area / max(1, ev[-1][0] - ev[0][0]), len(sel)))
-conc = np.array(conc, dtype=np.float64)
-print(f"  per CU: max concurrent workgroups {conc[:, 0].min():.0f} .. {conc[:, 0].max():.0f} (mean {conc[:, 0].mean():.2f}), time-averaged concurrency {conc[:, 1].mean():.2f}, workgroups per CU {conc[:, 2].min():.0f} .. {conc[:, 2].max():.0f}")
+# residency: which workgroups overlapped in time on the same CU (HW_ID bits, gfx9 layout: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13)
+for name, fn in (("W1", "vd3d_debug_occ_w1"), ("E1", "vd3d_debug_occ_e1")):
+    buf = (C.c_ulonglong * (16384 * 4))()
+    f = getattr(L, fn); f.argtypes = [C.c_void_p]
+    assert f(buf) == 0
+    o = np.array(buf, dtype=np.uint64).reshape(16384, 4).astype(np.int64)
+    o = o[(o[:, 2] > 0) & (o[:, 3] > 0)]
+    hw, xcc = o[:, 0], o[:, 1] & 0xF
+    cu = (xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+    t0 = o[:, 2].min()
+    print(f"{name} residency: {len(o)} workgroups on {len(np.unique(cu))} distinct CUs, launch span {(o[:, 3].max() - t0) / 100.0:.1f} us, mean workgroup life {np.mean(o[:, 3] - o[:, 2]) / 100.0:.2f} us")
+    conc = []
+    for c in np.unique(cu):
+        sel = o[cu == c]
+        ev = sorted([(a, 1) for a in sel[:, 2]] + [(b, -1) for b in sel[:, 3]])
+        cur = mx = 0; area = 0; last = ev[0][0]
+        for tm, dlt in ev:
+            area += cur * (tm - last); last = tm
+            cur += dlt; mx = max(mx, cur)
+        conc.append((mx, area / max(1, ev[-1][0] - ev[0][0]), len(sel)))
+    conc = np.array(conc, dtype=np.float64)
+    print(f"  per CU: max concurrent workgroups {conc[:, 0].min():.0f} .. {conc[:, 0].max():.0f} (mean {conc[:, 0].mean():.2f}), time-averaged concurrency {conc[:, 1].mean():.2f}, workgroups per CU {conc[:, 2].min():.0f} .. {conc[:, 2].max():.0f}")

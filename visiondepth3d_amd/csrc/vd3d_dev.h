@@ -68,9 +68,25 @@ VD_DEV float vd_exp_cr(float x) { return (float)exp((double)x); }
       if (last) name[blockIdx.x / 67][15] = __builtin_amdgcn_s_memrealtime();                                              \
     }                                                                                                                      \
   } while (0)
+// residency probe: EVERY workgroup records where (HW_ID, XCC_ID) and when (s_memrealtime at entry / exit of thread 0) it ran
+#define VD_OCC_DECL(name, getter)                                                                                          \
+  static __device__ unsigned long long name[16384][4];                                                                     \
+  extern "C" __attribute__((visibility("default"))) int getter(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(name), sizeof(name)); }
+#define VD_OCC_IN(name)                                                                                                    \
+  do {                                                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                                          \
+      name[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                                     \
+      name[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                                    \
+      name[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();                                                              \
+    }                                                                                                                      \
+  } while (0)
+#define VD_OCC_OUT(name) do { if (threadIdx.x == 0 && blockIdx.x < 16384) name[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define VD_STAMP_DECL(name)
 #define VD_STAMP(name, k, last) do { } while (0)
+#define VD_OCC_DECL(name, getter)
+#define VD_OCC_IN(name) do { } while (0)
+#define VD_OCC_OUT(name) do { } while (0)
 #endif
 
 // ---- torch-CPU transcendental numerics, reproduced bit for bit ----------------------------------------------------------------

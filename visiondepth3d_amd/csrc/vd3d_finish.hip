@@ -220,15 +220,9 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
 VD_STAMP_DECL(ff_stamps);
 #ifdef VD_PHASE_STAMPS
 extern "C" __attribute__((visibility("default"))) int vd3d_debug_stamps_e1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_stamps), sizeof(ff_stamps)); }
-// residency probe: every workgroup records where (HW_ID, XCC_ID) and when (s_memrealtime at entry / exit of thread 0) it ran
-static __device__ unsigned long long ff_occ[16384][4];
-extern "C" __attribute__((visibility("default"))) int vd3d_debug_occ_e1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_occ), sizeof(ff_occ)); }
-#define FF_OCC_IN() do { if (threadIdx.x == 0 && blockIdx.x < 16384) { ff_occ[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); ff_occ[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); ff_occ[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#define FF_OCC_OUT() do { if (threadIdx.x == 0 && blockIdx.x < 16384) ff_occ[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define FF_OCC_IN() do { } while (0)
-#define FF_OCC_OUT() do { } while (0)
 #endif
+VD_OCC_DECL(ff_occ, vd3d_debug_occ_e1)
+
 template <bool DENSE, int TH_>
 __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                         const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
@@ -256,7 +250,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   const int ix0 = gx0 - FF_R, iy0 = gy0 - FF_R;    // input tile origin
   const int tid = threadIdx.x;
   VD_STAMP(ff_stamps, 0, false);
-  FF_OCC_IN();
+  VD_OCC_IN(ff_occ);
 
   const int lane = tid & 63, wv = tid >> 6;
   bool active, strip, halo_px = false;
@@ -518,7 +512,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       }
     }
     VD_STAMP(ff_stamps, 5, true);
-    FF_OCC_OUT();
+    VD_OCC_OUT(ff_occ);
     return;
   }
   const float scale = 1.f / (float)(a.fx * a.fy);
@@ -573,7 +567,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
     }
   }
   VD_STAMP(ff_stamps, 5, true);
-  FF_OCC_OUT();
+  VD_OCC_OUT(ff_occ);
 }
 
 // returns false when the fast path does not apply (caller runs the unfused kernels)

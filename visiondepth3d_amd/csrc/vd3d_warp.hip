@@ -151,6 +151,7 @@ VD_STAMP_DECL(wf_stamps);
 #ifdef VD_PHASE_STAMPS
 extern "C" __attribute__((visibility("default"))) int vd3d_debug_stamps_w1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_stamps), sizeof(wf_stamps)); }
 #endif
+VD_OCC_DECL(wf_occ, vd3d_debug_occ_w1)
 // torch.sqrt of a finite x >= 0 (vd_sqrt_torch): zero -- every flat pixel -- and the never-reached x < 2^-100 take the rounded root
 VD_DEV float wf_sqrt_torch(float x, const int2* __restrict__ tab) {
   const float xs = fmaxf(x, 0x1p-100f);
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   float* colT = rowA;                                               // [nch][2]       (built after phase C: rowA is dead by then)
   const int tid = threadIdx.x;
   VD_STAMP(wf_stamps, 0, false);
+  VD_OCC_IN(wf_occ);
   const int lane = tid & 63, wv = wf_uni(tid >> 6);
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
   const int cb = max(x0 - a.bound, 0);                              // first warp-res column of Hh / colT
@@ -517,6 +519,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     }
   }
   VD_STAMP(wf_stamps, 7, true);
+  VD_OCC_OUT(wf_occ);
 }
 
 // blur_ksize values whose k*k passed tools/verify_fastdiv.c (all floats in [0, k*k], 3-operation division == IEEE division)
