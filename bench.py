@@ -386,7 +386,7 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
         b.record()
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
-    net_ms = timed(up._forward)        # the PRODUCT path: 32 body layers on vd3d_conv3x3_c64_f16, head / tail through MIOpen
+    net_ms = timed(up._forward)        # the PRODUCT path: every layer hand-written (head, 32 body layers + tail convolution on the MFMA kernel, pixel-shuffle + add)
     lib_ms = timed(up.net)             # the same network through the library convolutions only (context, not the product)
     out_shape = list(last[0].shape)
     del pipe, up
@@ -399,7 +399,7 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
             "ms_per_step": round(dt / steps * 1e3, 3), "dtype": "f32 depth net + f32 DIBR + fp16 up-scale net (the reference's precisions)",
             "output": out_shape, "stage_ms_per_frame": {"depth_net+handoff": round(ms[0], 3), "dibr": round(ms[1], 3), "run_esrgan": round(ms[2], 3)},
             "roofline_upscale_net": {"bound": "mfma", "kernel": "SRVGGNetCompact 64x32 on a 960x540 frame, Upscaler._forward = the product path: 32 body "
-                                     "layers on the hand-written k_conv3x3_c64 (MFMA, fp16), head 3->64 and tail 64->48 + pixel-shuffle through MIOpen",
+                                     "layers and the 64->48 tail convolution on the hand-written k_conv3x3_c64 (MFMA, fp16), head 3->64 (k_conv3x3_head) and pixel-shuffle + nearest add (k_esr_tail) in HIP: no library call",
                                      "achieved": round(flops[0] / (net_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                      "frac": round(flops[0] / (net_ms * 1e-3) / 1e12 / 2500.0, 4), "flops_per_frame": flops[0],
                                      "avg_forward_ms": round(net_ms, 3), "library_only_forward_ms": round(lib_ms, 3)}}

@@ -314,6 +314,16 @@ int vd3d_rife_postprocess(vd3d_ctx* ctx, const float* pred3, int h, int w, int c
  *   bias, slope_or_null: float32 [64] (slope NULL = no activation).  All pointers 16-byte aligned; x != y. */
 int vd3d_conv3x3_c64_f16(vd3d_ctx* ctx, const void* x_nhwc, int H, int W, const void* w_frag, const float* bias, const float* slope_or_null,
                          void* y_nhwc);
+/* The other two layers of the compact (SRVGG) networks the reference's model list holds (VisionDepth3D.py:1094-1098), also inside its ONNX
+ * session (core/merged_pipeline.py:250-252):
+ *   head: y = PReLU(conv3x3(x) + bias), 3 -> 64 channels, x fp16 NHWC [H][W][3] (vd3d_esr_preprocess, channels_last), y fp16 NHWC [H][W][64];
+ *         w27x64: float32 [27][64], row (kh*3 + kw)*3 + ic, column oc = Wt[oc][ic][kh][kw]; float32 accumulate in that row order.
+ *   tail: the 64 -> 3 r^2 convolution is vd3d_conv3x3_c64_f16 with weight fragments and bias zero-padded to 64 output channels and no activation;
+ *         vd3d_esr_tail_f32 then applies pixel_shuffle(r) and adds the nearest-neighbour up-sampled input (the fp16 addition of the network)
+ *         and writes the float32 planar prediction [3][r H][r W] that vd3d_esr_postprocess takes.  r = 2 or 4. */
+int vd3d_conv3x3_head_f16(vd3d_ctx* ctx, const void* x_nhwc3, int H, int W, const float* w27x64, const float* bias, const float* slope_or_null,
+                          void* y_nhwc64);
+int vd3d_esr_tail_f32(vd3d_ctx* ctx, const void* t_nhwc64, const void* x_nhwc3, int H, int W, int r, float* out_planar);
 
 /* ---- depth hand-off (a24): transformers' bicubic post-process to (H,W) + convert_depth_to_grayscale
  * (core/render_depth.py:585-611,1914-1916) for a batch of B predictions [B][ph][pw] float32 -> uint8 [B][H][W].

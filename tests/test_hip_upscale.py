@@ -230,6 +230,41 @@ def test_conv3x3_c64_f16_vs_float32_reference(R, H, W, act):
     assert float(err.mean()) < 2e-4 * max(1.0, float(ref.abs().mean()))
 
 
+@pytest.mark.parametrize("H,W", [(5, 7), (1, 1), (64, 66), (135, 240), (540, 960)])
+@pytest.mark.parametrize("act", [True, False])
+def test_conv3x3_head_vs_float32_reference(R, H, W, act):
+    """3 -> 64 head layer (vd3d_conv3x3_head_f16): fp16 operands, float32 accumulate vs ATen's float32 convolution of the same fp16-rounded
+    operands: summation order and the final fp16 rounding only."""
+    import torch.nn.functional as F
+    from visiondepth3d_amd.upscale import head_weight_matrix
+    gen = torch.Generator().manual_seed(7 * H + W)
+    x = torch.rand(1, 3, H, W, generator=gen).half()
+    w = (torch.randn(64, 3, 3, 3, generator=gen) * 0.2).half()
+    b = torch.randn(64, generator=gen) * 0.1
+    sl = torch.rand(64, generator=gen) * 0.5 if act else None
+    ref = F.conv2d(x.float().cuda(), w.float().cuda(), b.cuda(), padding=1)
+    if act:
+        ref = torch.where(ref >= 0, ref, ref * sl.cuda()[None, :, None, None])
+    got = R.conv3x3_head(x.cuda().contiguous(memory_format=torch.channels_last), head_weight_matrix(w).cuda(), b.cuda(), sl.cuda() if act else None)
+    assert got.dtype == torch.float16 and tuple(got.shape) == (1, 64, H, W) and got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.float() - ref).abs()
+    assert bool((err <= 1e-3 * ref.abs() + 1e-3).all()), float(err.max())
+
+
+@pytest.mark.parametrize("r", [4, 2])
+@pytest.mark.parametrize("H,W", [(3, 5), (64, 64), (70, 100), (135, 241)])
+def test_esr_tail_equals_pixel_shuffle_plus_nearest_add(R, H, W, r):
+    """vd3d_esr_tail_f32 == float(pixel_shuffle(t[:, :3 r^2], r) + interpolate(x, nearest)) bit for bit (fp16 addition like the network's)."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(H * 31 + W + r)
+    t = (torch.randn(1, 64, H, W, generator=gen) * 0.3).half().cuda().contiguous(memory_format=torch.channels_last)
+    x = torch.rand(1, 3, H, W, generator=gen).half().cuda().contiguous(memory_format=torch.channels_last)
+    exp = (F.pixel_shuffle(t[:, :3 * r * r], r) + F.interpolate(x, scale_factor=r, mode="nearest")).float()
+    got = R.esr_tail(t, x, r)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (1, 3, H * r, W * r)
+    assert torch.equal(got, exp.contiguous())
+
+
 def test_upscaler_hip_body_matches_the_library_convolutions(R):
     from visiondepth3d_amd import synth
     from visiondepth3d_amd.upscale import Upscaler

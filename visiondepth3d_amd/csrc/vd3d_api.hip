@@ -1007,6 +1007,28 @@ VD3D_EXPORT int vd3d_conv3x3_c64_f16(vd3d_ctx* c, const void* x_nhwc, int H, int
   return 0;
 }
 
+VD3D_EXPORT int vd3d_conv3x3_head_f16(vd3d_ctx* c, const void* x_nhwc3, int H, int W, const float* w27x64, const float* bias, const float* slope_or_null,
+                                      void* y_nhwc64) {
+  if (!c || !x_nhwc3 || !w27x64 || !bias || !y_nhwc64 || H < 1 || W < 1) return set_err(VD3D_E_INVALID, "conv3x3_head_f16: bad argument");
+  if ((long long)H * W * 128 >= (1ll << 32)) return set_err(VD3D_E_INVALID, "conv3x3_head_f16: activation larger than 4 GB");
+  if ((reinterpret_cast<uintptr_t>(y_nhwc64) | reinterpret_cast<uintptr_t>(w27x64)) & 15) return set_err(VD3D_E_INVALID, "conv3x3_head_f16: y and w must be 16-byte aligned");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "conv_head");
+  vd_launch_conv3x3_head_f16(c->stream, x_nhwc3, H, W, w27x64, bias, slope_or_null, y_nhwc64);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_esr_tail_f32(vd3d_ctx* c, const void* t_nhwc64, const void* x_nhwc3, int H, int W, int r, float* out_planar) {
+  if (!c || !t_nhwc64 || !x_nhwc3 || !out_planar || H < 1 || W < 1 || (r != 2 && r != 4)) return set_err(VD3D_E_INVALID, "esr_tail_f32: bad argument (r = 2 or 4)");
+  if (reinterpret_cast<uintptr_t>(t_nhwc64) & 15) return set_err(VD3D_E_INVALID, "esr_tail_f32: t must be 16-byte aligned");
+  HIPCHK(hipSetDevice(c->device));
+  StageTimer t(c, "esr_tail");
+  vd_launch_esr_tail_f32(c->stream, t_nhwc64, x_nhwc3, H, W, r, out_planar);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // optional NV12 wire format at the frame I/O boundary (vd3d_nv12.hip)
 VD3D_EXPORT int vd3d_nv12_to_bgr(vd3d_ctx* c, const uint8_t* y_plane, long long y_pitch, const uint8_t* uv_plane, long long uv_pitch, int h, int w,
                                  uint8_t* out_bgr) {

@@ -152,3 +152,102 @@ bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const
   hipLaunchKernelGGL(k_conv3x3_c64, grid, dim3(256), CV_LDS, s, (const _Float16*)x, H, W, (const uint4*)wfrag, bias, slope_or_null, (_Float16*)y);
   return true;
 }
+
+// ------------------------------------------------------------------------------------------------
+// head and tail of the compact (SRVGG) up-scale networks (round 3): until now the only layers left on MIOpen.
+//
+// k_conv3x3_head: 3 -> 64 convolution + bias + PReLU, fp16 NHWC [H][W][3] in, fp16 NHWC [H][W][64] out, float32 accumulate in the order
+//   (kh, kw, ic).  1.8 GFLOP at 960 x 540: far too little for the matrix cores to matter -- the layer is the 66 MB it writes.  A workgroup
+//   = a 64 x 2 pixel tile; thread = (strip of 4 pixels, group of 8 output channels): 32 accumulators, the 27 x 64 float32 weights and the
+//   (2 + 2) x 66 x 3 input patch in LDS; the 8 threads of a pixel store its 128 bytes as consecutive 16-byte pieces.
+// k_esr_tail: the tail after its 64 -> 48 (x4) / 64 -> 12 (x2) convolution -- which IS the MFMA kernel above, with the weight fragments and
+//   the bias zero-padded to 64 output channels and no activation -- pixel_shuffle(r) + the nearest-neighbour up-sampled input + conversion
+//   to the float32 planar prediction the reference's post-processing takes (core/merged_pipeline.py:225-229):
+//   out[c][h r + i][w r + j] = float(half(float(t[h][w][c r^2 + i r + j]) + float(x[h][w][c])))   (the fp16 addition torch performs).
+//   One workgroup = 64 pixels of one input row, staged through LDS so that the loads are 16-byte and the stores whole float32 rows.
+// ------------------------------------------------------------------------------------------------
+#define CH_TW 64
+#define CH_TH 2
+__global__ __launch_bounds__(256) void k_conv3x3_head(const _Float16* __restrict__ x, int H, int W, const float* __restrict__ w27, const float* __restrict__ bias,
+                                                      const float* __restrict__ slope, _Float16* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float lw[27][64];
+  __shared__ float lp[CH_TH + 2][CH_TW + 2][3];
+  const int tid = threadIdx.x, g = tid & 7, strip = tid >> 3;       // strip 0..31: row strip >> 4, columns 4 (strip & 15) ..
+  const int x0 = blockIdx.x * CH_TW, y0 = blockIdx.y * CH_TH;
+  for (int i = tid; i < 27 * 64; i += 256) (&lw[0][0])[i] = w27[i];
+  for (int i = tid; i < (CH_TH + 2) * (CH_TW + 2) * 3; i += 256) {
+    const int c = i % 3, px = (i / 3) % (CH_TW + 2), py = i / (3 * (CH_TW + 2));
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    (&lp[0][0][0])[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (float)x[((size_t)gy * W + gx) * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  const int ty = strip >> 4, tx = (strip & 15) * 4;
+  float acc[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[q][o] = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    float row[6][3];                     // the 6 x 3 input values of this tap row that the strip's 4 pixels x 3 tap columns touch
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) row[p][c] = lp[ty + kh][tx + p][c];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int t = (kh * 3 + kw) * 3 + c;
+        const vd_f4 wa = *reinterpret_cast<const vd_f4*>(&lw[t][8 * g]), wb = *reinterpret_cast<const vd_f4*>(&lw[t][8 * g + 4]);
+        const float wv[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc[q][o] = vd_fma(row[q + kw][c], wv[o], acc[q][o]);
+      }
+  }
+  const int gy = y0 + ty;
+  if (gy >= H) return;
+  float bv[8], sv[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) { bv[o] = bias[8 * g + o]; sv[o] = slope ? slope[8 * g + o] : 1.f; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int gx = x0 + tx + q;
+    if (gx >= W) break;
+    cv_h8 hv;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { float v = acc[q][o] + bv[o]; v = v >= 0.f ? v : v * sv[o]; hv[o] = (_Float16)v; }
+    *reinterpret_cast<cv_h8*>(y + ((size_t)gy * W + gx) * 64 + 8 * g) = hv;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_esr_tail(const _Float16* __restrict__ t, const _Float16* __restrict__ x, int H, int W, int r, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) _Float16 lt[64][72];     // 64 pixels x 64 channels (+8 pad: 144-byte pitch)
+  __shared__ _Float16 lx[64][4];
+  const int tid = threadIdx.x, h = blockIdx.y, x0 = blockIdx.x * 64;
+  const int npx = min(64, W - x0);
+  for (int i = tid; i < 64 * 8; i += 256) {            // 16-byte pieces: pixel i >> 3, channels 8 (i & 7) ..
+    const int p = i >> 3, cg = i & 7;
+    if (p < npx) *reinterpret_cast<uint4*>(&lt[p][8 * cg]) = *reinterpret_cast<const uint4*>(t + ((size_t)h * W + x0 + p) * 64 + 8 * cg);
+  }
+  if (tid < 64 * 3) { const int p = tid / 3, c = tid - 3 * p; if (p < npx) lx[p][c] = x[((size_t)h * W + x0 + p) * 3 + c]; }
+  __syncthreads();
+  const size_t OW = (size_t)W * r, plane = (size_t)H * r * OW;
+  const int p = tid / r, j = tid - p * r;               // output column x0 r + tid of this segment = input pixel p, sub-column j
+  if (tid >= 64 * r || p >= npx) return;
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < r; ++i) {
+      const _Float16 s = (_Float16)((float)lt[p][c * r * r + i * r + j] + (float)lx[p][c]);    // the fp16 add of `out + interpolate(x)`
+      out[c * plane + ((size_t)h * r + i) * OW + (size_t)x0 * r + tid] = (float)s;
+    }
+}
+
+void vd_launch_conv3x3_head_f16(hipStream_t s, const void* x, int H, int W, const float* w27, const float* bias, const float* slope_or_null, void* y) {
+  hipLaunchKernelGGL(k_conv3x3_head, dim3((W + CH_TW - 1) / CH_TW, (H + CH_TH - 1) / CH_TH), dim3(256), 0, s, (const _Float16*)x, H, W, w27, bias, slope_or_null,
+                     (_Float16*)y);
+}
+void vd_launch_esr_tail_f32(hipStream_t s, const void* t, const void* x, int H, int W, int r, float* out) {
+  hipLaunchKernelGGL(k_esr_tail, dim3((W + 63) / 64, H), dim3(256), 0, s, (const _Float16*)t, (const _Float16*)x, H, W, r, out);
+}

@@ -147,6 +147,8 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
 
 // ---- vd3d_conv.hip
 bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const void* wfrag, const float* bias, const float* slope_or_null, void* y);
+void vd_launch_conv3x3_head_f16(hipStream_t s, const void* x, int H, int W, const float* w27, const float* bias, const float* slope_or_null, void* y);
+void vd_launch_esr_tail_f32(hipStream_t s, const void* t, const void* x, int H, int W, int r, float* out);
 // ---- vd3d_nv12.hip
 void vd_launch_nv12_to_bgr(hipStream_t s, const uint8_t* y, const uint8_t* uv, int h, int w, long long y_pitch, long long uv_pitch, uint8_t* out);
 void vd_launch_bgr_to_nv12(hipStream_t s, const uint8_t* bgr, int h, int w, uint8_t* y, uint8_t* uv, long long y_pitch, long long uv_pitch);

@@ -414,6 +414,29 @@ class Renderer:
                                                 _ptr(out)))
         return out
 
+    def conv3x3_head(self, x: torch.Tensor, w27: torch.Tensor, bias: torch.Tensor, slope: torch.Tensor | None) -> torch.Tensor:
+        """Head layer of the compact up-scale networks (``vd3d_conv3x3_head_f16``): ``x`` [1,3,H,W] fp16 channels_last ->
+        PReLU(conv3x3(x) + bias) as [1,64,H,W] fp16 channels_last.  ``w27``: ``upscale.head_weight_matrix(weight)`` (float32 [27,64])."""
+        if (x.dtype != torch.float16 or x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3
+                or not x.is_contiguous(memory_format=torch.channels_last)):
+            raise AssertionError("conv3x3_head takes a [1,3,H,W] fp16 tensor in channels_last memory")
+        H, W = int(x.shape[2]), int(x.shape[3])
+        out = torch.empty((1, 64, H, W), dtype=torch.float16, device=self.device).contiguous(memory_format=torch.channels_last)
+        self._enter(x, w27, bias, slope, out)
+        _lib.check(self._L.vd3d_conv3x3_head_f16(self._ctx, _ptr(x), H, W, _ptr(w27), _ptr(bias), _ptr(slope) if slope is not None else None, _ptr(out)))
+        return out
+
+    def esr_tail(self, t: torch.Tensor, x: torch.Tensor, r: int) -> torch.Tensor:
+        """pixel_shuffle(r) of the tail convolution's output ``t`` ([1,64,H,W] fp16 channels_last, channels >= 3 r^2 zero) + the nearest-neighbour
+        up-sampled network input ``x`` ([1,3,H,W] fp16 channels_last) -> the float32 planar prediction [1,3,rH,rW] (``vd3d_esr_tail_f32``)."""
+        H, W = int(x.shape[2]), int(x.shape[3])
+        if t.dtype != torch.float16 or tuple(t.shape) != (1, 64, H, W) or not t.is_contiguous(memory_format=torch.channels_last):
+            raise AssertionError("esr_tail takes the [1,64,H,W] fp16 channels_last output of the tail convolution")
+        out = torch.empty((1, 3, H * r, W * r), dtype=torch.float32, device=self.device)
+        self._enter(t, x, out)
+        _lib.check(self._L.vd3d_esr_tail_f32(self._ctx, _ptr(t), _ptr(x), H, W, int(r), _ptr(out)))
+        return out
+
     def add_weighted_u8(self, a: torch.Tensor, alpha: float, b: torch.Tensor, beta: float, gamma: float = 0.0) -> torch.Tensor:
         """cv2.addWeighted on uint8 tensors of one shape (blend_images, core/merged_pipeline.py:231-236)."""
         a = a.to(self.device).contiguous()

@@ -120,6 +120,14 @@ def conv_weight_fragments(weight: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 3, 1, 4, 2, 5).reshape(36, 2, 64, 8).contiguous()                   # [tap][kc][t][g][i][j] -> [step][t][lane][j]
 
 
+def head_weight_matrix(weight: torch.Tensor) -> torch.Tensor:
+    """A [64,3,3,3] head convolution weight as the float32 [27,64] matrix ``vd3d_conv3x3_head_f16`` takes: row (kh*3 + kw)*3 + ic, column oc
+    (the fp16 values of the checkpoint, widened)."""
+    if tuple(weight.shape) != (64, 3, 3, 3):
+        raise AssertionError("head_weight_matrix takes a [64,3,3,3] weight")
+    return weight.detach().to(torch.float16).float().permute(2, 3, 1, 0).reshape(27, 64).contiguous()
+
+
 def build_network(model_name: str = "RealESR_Gx4_fp16") -> nn.Module:
     arch, kw = MODEL_ZOO[model_name]
     return SRVGGNetCompact(**kw) if arch == "srvgg" else RRDBNet(**kw)
@@ -309,7 +317,8 @@ class Upscaler:
     def __init__(self, renderer, model_name: str = "RealESR_Gx4_fp16", net: nn.Module | None = None, dtype=torch.float16,
                  hip_body: bool = True):
         """``hip_body``: run the 64 -> 64 body layers of the compact (SRVGG) networks through the hand-written matrix-core kernel
-        (``vd3d_conv3x3_c64_f16``: conv + bias + PReLU in one launch); the 3 -> 64 head and the 64 -> 48 tail stay on MIOpen."""
+        (``vd3d_conv3x3_c64_f16``: conv + bias + PReLU in one launch), and -- since round 3 -- the 3 -> 64 head, the 64 -> 3 r^2 tail convolution
+        (same kernel, zero-padded) and pixel-shuffle + nearest add through HIP as well: no library call is left in the compact networks."""
         self.renderer = renderer
         self.device = renderer.device
         self.model_name = model_name
@@ -323,27 +332,42 @@ class Upscaler:
             self._body = self._prepare_body()
 
     def _prepare_body(self):
-        """(weight fragments, bias, PReLU slope) per body layer, resident on the device."""
+        """Device-resident operands of every layer: head (weight matrix, bias, slope), body [(weight fragments, bias, PReLU slope)], tail (weight
+        fragments and bias zero-padded from 3 r^2 to 64 output channels: the tail convolution runs on the body's matrix-core kernel)."""
         mods = list(self.net.body)
+        dev = self.device
+        self._head = (head_weight_matrix(mods[0].weight).to(dev), mods[0].bias.detach().float().contiguous().to(dev),
+                      mods[1].weight.detach().float().contiguous().to(dev))
         layers = []
         for i in range(2, len(mods) - 1, 2):      # body[0..1] = head conv + PReLU, body[-1] = tail conv
             conv, act = mods[i], mods[i + 1]
-            layers.append((conv_weight_fragments(conv.weight).to(self.device), conv.bias.detach().float().contiguous().to(self.device),
-                           act.weight.detach().float().contiguous().to(self.device)))
+            layers.append((conv_weight_fragments(conv.weight).to(dev), conv.bias.detach().float().contiguous().to(dev),
+                           act.weight.detach().float().contiguous().to(dev)))
+        tail = mods[-1]
+        oc = tail.out_channels                    # 3 r^2: 48 (x4) or 12 (x2)
+        wt = torch.zeros((64, 64, 3, 3), dtype=tail.weight.dtype)
+        wt[:oc] = tail.weight.detach().cpu()
+        bt = torch.zeros(64, dtype=torch.float32)
+        bt[:oc] = tail.bias.detach().float().cpu()
+        self._tail = (conv_weight_fragments(wt).to(dev), bt.to(dev))
         return layers
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        """The network on ``x`` ([1,3,H,W], channels_last).  Library path: the module's own dtype; HIP path (compact networks, fp16): every
+        layer hand-written -- head (``vd3d_conv3x3_head_f16``), body and tail convolution (``vd3d_conv3x3_c64_f16``, matrix cores), pixel-shuffle
+        + nearest add (``vd3d_esr_tail_f32``) -- and the result is already the float32 prediction."""
         if self._body is None:
             return self.net(x)
         R, net = self.renderer, self.net
-        h = net.body[1](net.body[0](x)).contiguous(memory_format=torch.channels_last)
+        h = R.conv3x3_head(x, *self._head)
         spare = torch.empty_like(h, memory_format=torch.channels_last)
         for wf, b, sl in self._body:
             R.conv3x3_c64(h, wf, b, sl, out=spare)
             h, spare = spare, h
+        R.conv3x3_c64(h, self._tail[0], self._tail[1], None, out=spare)
+        out = R.esr_tail(spare, x, net.upscale)
         R.ordered_after()
-        out = F.pixel_shuffle(net.body[-1](h), net.upscale)
-        return out + F.interpolate(x, scale_factor=net.upscale, mode="nearest")
+        return out
 
     @classmethod
     def from_weights(cls, renderer, path: str, model_name: str = "RealESR_Gx4_fp16", dtype=torch.float16) -> "Upscaler":
