@@ -205,7 +205,7 @@ def test_nv12_both_ways_bit_exact_and_round_trip(R, oracle, h, w):
 
 
 # ---- body layers on the matrix cores (vd3d_conv3x3_c64_f16) ----------------------------------------------------------------------------
-@pytest.mark.parametrize("H,W", [(16, 32), (17, 33), (5, 7), (1, 1), (64, 96), (135, 240), (300, 500), (540, 960), (1080, 1920)])   # > 256 tiles: the persistent kernel
+@pytest.mark.parametrize("H,W", [(16, 32), (17, 33), (5, 7), (1, 1), (64, 96), (135, 240), (300, 500), (540, 960), (1080, 1920)])   # up to 4 080 workgroups: several per CU
 @pytest.mark.parametrize("act", [True, False])
 def test_conv3x3_c64_f16_vs_float32_reference(R, H, W, act):
     """fp16 operands, float32 accumulate on the MFMA units vs ATen's float32 convolution of the SAME fp16-rounded operands: the only
