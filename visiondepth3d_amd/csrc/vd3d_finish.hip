@@ -273,6 +273,9 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
     strip = active && ss >= 1 && ss <= FF_IS - 2;
   }
   const int gy = gy0 + sy, gxs = ix0 + 4 * ss;    // image coordinates of the strip's first pixel
+  // the frame scalars of the device-resident trackers: requested at the top (scalar loads), consumed two and three barriers later
+  const float w_focal = a.use_override ? a.focal : w->focal;
+  const int w_bar_w = a.use_override ? a.bar_w : w->bar_width, w_bar_s = a.use_override ? a.bar_s : w->bar_side;
   // The depth samples of the blur weight (exact 2:1 interior strips: 8 loads) are requested NOW, before the tile load, and consumed after
   // the first barrier: at two resident workgroups per CU their round trip was the longest exposed wait of the kernel (s_memtime stamps:
   // 42 % of a workgroup's life sat in the phase that used to issue them).
@@ -292,20 +295,35 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   const bool in_interior = ix0 >= 0 && ix0 + FF_IW <= W && iy0 >= 0 && iy0 + FF_IH <= H && (W & 3) == 0 &&
                            (reinterpret_cast<uintptr_t>(src) & 3) == 0;
   if (in_interior) {
-    // one task = 4 pixels of one row: 3 dword loads (12 B = 4 BGR pixels), three ds_write_b128
-    for (int t = tid; t < FF_IH * FF_IS; t += FF_NT) {
-      const int ty = t / FF_IS, g = t - ty * FF_IS;
-      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(src + ((size_t)(iy0 + ty) * W + ix0 + 4 * g) * 3);
-      const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2];
-      // byte k of the 12-byte group: pixel k/3, channel BGR[k%3]
+    // one task = 4 pixels of one row: 3 dword loads (12 B = 4 BGR pixels), three ds_write_b128.  A thread owns tasks tid and tid + NT
+    // (IH * IS <= 2 NT): both tasks' loads are requested before either is converted, so the phase waits for ONE global round trip, not two.
+    static_assert(FF_IH * FF_IS <= 2 * FF_NT, "two tile-load tasks per thread");
+    uint32_t ld[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int t = tid + k * FF_NT;
+      if (t < FF_IH * FF_IS) {
+        const int ty = t / FF_IS, g = t - ty * FF_IS;
+        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(src + ((size_t)(iy0 + ty) * W + ix0 + 4 * g) * 3);
+        ld[k][0] = p0[0]; ld[k][1] = p0[1]; ld[k][2] = p0[2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int t = tid + k * FF_NT;
+      if (t < FF_IH * FF_IS) {
+        const int ty = t / FF_IS, g = t - ty * FF_IS;
+        const uint32_t a0 = ld[k][0], a1 = ld[k][1], a2 = ld[k][2];
+        // byte k of the 12-byte group: pixel k/3, channel BGR[k%3]
 #define FF_B(k) ff_byte((k) < 4 ? a0 : ((k) < 8 ? a1 : a2), 8 * ((k) & 3))
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {   // plane 0 = R (byte 2), 1 = G (byte 1), 2 = B (byte 0)
-        const int bo = 2 - c;
-        const vd_f4 v4 = {vd_u8_unit(FF_B(0 + bo)), vd_u8_unit(FF_B(3 + bo)), vd_u8_unit(FF_B(6 + bo)), vd_u8_unit(FF_B(9 + bo))};
-        *reinterpret_cast<vd_f4*>(&tile[c][ty][4 * g]) = v4;
-      }
+        for (int c = 0; c < 3; ++c) {   // plane 0 = R (byte 2), 1 = G (byte 1), 2 = B (byte 0)
+          const int bo = 2 - c;
+          const vd_f4 v4 = {vd_u8_unit(FF_B(0 + bo)), vd_u8_unit(FF_B(3 + bo)), vd_u8_unit(FF_B(6 + bo)), vd_u8_unit(FF_B(9 + bo))};
+          *reinterpret_cast<vd_f4*>(&tile[c][ty][4 * g]) = v4;
+        }
 #undef FF_B
+      }
     }
   } else {
     for (int t = tid; t < FF_IH * FF_IW; t += FF_NT) {
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   }
   int my_mask = 0;
   if (strip && fc.nlev) {
-    const float focal = a.use_override ? a.focal : w->focal;
+    const float focal = w_focal;
     float dd[4];
     if (fast21) {
       // exact 2:1 (Half-SBS), strip away from the left / right border: the four pixels x = 4m .. 4m+3 share the eye columns
@@ -387,7 +405,15 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
     }
     if (WIDE && halo_px && hq == 3) { lo[0] = lo[3]; alpha[0] = alpha[3]; }   // a halo-column thread keeps its one pixel in element 0
     for (int l = max(lmin, 1); l <= lmax; ++l) my_mask |= 1 << l;
-    if (my_mask) atomicOr(&lvl_mask, my_mask);
+  }
+  {
+    // The tile's level set: OR of the lanes' masks.  One same-address LDS atomic per LANE serialises 512 ways; reduce inside the wave first
+    // (one ballot per level bit, the result is wave-uniform) and let one lane per wave publish it: 8 atomics per workgroup.
+    int wmask = 0;
+#pragma unroll
+    for (int l = 1; l <= 4; ++l)
+      if (__ballot((my_mask >> l) & 1)) wmask |= 1 << l;
+    if ((tid & 63) == 0 && wmask) atomicOr(&lvl_mask, wmask);
   }
   vd_f4 vlo[3], vhi[3];
 #pragma unroll
@@ -431,7 +457,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   }
   VD_STAMP(ff_stamps, 3, false);
   if (strip) {  // blend, grade (:750-767), truncate, side bars (:885-892); float4 = the strip's 4 pixels
-    const int bar_w = a.use_override ? a.bar_w : w->bar_width, bar_s = a.use_override ? a.bar_s : w->bar_side;
+    const int bar_w = w_bar_w, bar_s = w_bar_s;
     vd_f4 rgbv[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
