@@ -48,7 +48,10 @@ RENDER_KW = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shif
                  feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)  # render_cli.py:24-33
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense f32-input MFMA (= vector rate) / dense bf16
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9           # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz (one wave64 VALU issue = 4 clk)
+VALU_PEAK_LANE_OPS = 50.2e12   # MEASURED v_fma_f32 issue rate of the chip (tools/ubench_valu.hip, 8 waves / SIMD: 100.3 TFLOP/s = 50.2 T lane-FMAs/s;
+                               # a wave64 VALU instruction issues every ~2.3 cycles per SIMD at the 1.77 GHz the chip sustains under that load --
+                               # the data sheet's 157 TFLOP/s assumes 2.4 GHz).  Until round 3 this was 256 x 4 x 16 x 2.4e9 = 39.3 T, which the
+                               # micro-benchmark itself exceeds.
 
 
 def cpu_baseline(sh, sw, seconds_budget=20.0, max_frames=30):
@@ -453,7 +456,7 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
               "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
               "note": "frac prices SURVEY 8(d)'s 13 N algorithmic bytes against the 8 TB/s HBM spec (north_star's yardstick); the kernel is "
                       "VALU-issue-bound, not HBM-bound (the reference's nested-bilinear arithmetic is kept bit-exact): `valu` prices the "
-                      "PMC-counted VALU lane-instructions of one launch against the chip's VALU issue peak. avg_launch_ms = HIP events "
+                      "PMC-counted VALU lane-instructions of one launch against the chip's MEASURED v_fma_f32 issue rate (50.2 T lane-ops/s). avg_launch_ms = HIP events "
                       "inside the timed region (the kernel shares the CUs with the overlapped streams); isolated_* = the same kernel in a "
                       "sequential DIBR-only pass after the timed region"}
         if lane:
