@@ -204,3 +204,39 @@ def test_rife_network_on_cpu_shapes_padding_and_determinism():
     assert float((y[:1] - x[:, :3]).abs().mean()) > float((y[:1] - mid).abs().mean())  # ... and closer to the mid-point than to a frame
     n = RifeNet()
     n.load_state_dict(s.net.state_dict())                                               # round trip like a checkpoint
+
+
+def test_head_weight_matrix_and_tail_padding_layouts():
+    """The operand layouts the hand-written head / tail layers take (include/vd3d.h), pinned on the CPU against ATen: the head's [27,64]
+    matrix is the convolution weight in (kh, kw, ic) x oc order; the tail convolution zero-padded to 64 output channels followed by the
+    kernel's pixel-shuffle index rule (channel c r^2 + i r + j of pixel (h, w) -> out[c][h r + i][w r + j]) and the nearest-neighbour add is the
+    network's own tail."""
+    from visiondepth3d_amd.upscale import SRVGGNetCompact, conv_weight_fragments, head_weight_matrix
+    torch.manual_seed(5)
+    x = torch.rand(1, 3, 9, 11)
+    w = torch.randn(64, 3, 3, 3) * 0.2
+    m = head_weight_matrix(w)                                   # float32 [27, 64] of the fp16-rounded weights
+    assert m.dtype == torch.float32 and tuple(m.shape) == (27, 64)
+    cols = F.unfold(x, 3, padding=1)                            # [1, ic*kh*kw, L] in (ic, kh, kw) order
+    cols = cols.view(1, 3, 3, 3, -1).permute(0, 2, 3, 1, 4).reshape(1, 27, -1)   # -> (kh, kw, ic)
+    got = torch.einsum("tl,to->ol", cols[0], m).view(1, 64, 9, 11)
+    assert torch.allclose(got, F.conv2d(x, w.half().float(), padding=1), atol=1e-5)
+    for r in (4, 2):
+        net = SRVGGNetCompact(num_conv=1, upscale=r).eval()
+        tail = net.body[-1]
+        oc = tail.out_channels
+        assert oc == 3 * r * r
+        wt = torch.zeros(64, 64, 3, 3)
+        wt[:oc] = tail.weight.detach()
+        assert tuple(conv_weight_fragments(wt).shape) == (36, 2, 64, 8)
+        feat = torch.randn(1, 64, 6, 7)
+        t = F.conv2d(feat, wt, torch.cat([tail.bias.detach(), torch.zeros(64 - oc)]), padding=1)      # what the padded MFMA layer computes
+        assert float(t[:, oc:].abs().max()) == 0.0
+        out = torch.empty(1, 3, 6 * r, 7 * r)
+        xin = torch.rand(1, 3, 6, 7)
+        for c in range(3):
+            for i in range(r):
+                for j in range(r):
+                    out[0, c, i::r, j::r] = t[0, c * r * r + i * r + j] + xin[0, c]
+        exp = F.pixel_shuffle(tail(feat), r) + F.interpolate(xin, scale_factor=r, mode="nearest")
+        assert torch.allclose(out, exp, atol=1e-6)
