@@ -120,6 +120,33 @@ def torch_math(op, x, param=0.0):
     return out
 
 
+def avg_pool2d(plane, k):
+    """F.avg_pool2d(plane[None], k, stride=1, padding=k // 2) on one [H, W] plane in ATen's summation order."""
+    a, pa = _f(plane)
+    H, W = a.shape
+    out = np.empty_like(a)
+    lib().vo_avg_pool2d(pa, C.c_int(H), C.c_int(W), C.c_int(int(k)), out.ctypes.data_as(_f32p))
+    return out
+
+
+def grid_sample(plane, grid_xy):
+    """F.grid_sample(plane[None, None], grid[None], mode='bilinear', padding_mode='border', align_corners=True) for one [H, W] plane and a
+    [H, W, 2] grid of the same size (the reference's use, core/render_3d.py:697-701)."""
+    a, pa = _f(plane)
+    g, pg = _f(grid_xy)
+    H, W = a.shape
+    assert g.shape == (H, W, 2)
+    out = np.empty_like(a)
+    lib().vo_grid_sample(pa, C.c_int(H), C.c_int(W), pg, out.ctypes.data_as(_f32p))
+    return out
+
+
+def linspace(start, end, steps):
+    L = lib()
+    L.vo_linspace.restype = C.c_float
+    return np.array([L.vo_linspace(C.c_float(start), C.c_float(end), C.c_int(steps), C.c_int(i)) for i in range(steps)], np.float32)
+
+
 def quantile(v, q):
     v, pv = _f(np.ravel(v))
     return float(lib().vo_quantile(pv, v.size, C.c_float(np.float32(q))))
