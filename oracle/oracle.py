@@ -141,6 +141,23 @@ def grid_sample(plane, grid_xy):
     return out
 
 
+def gaussian_blur_dense(plane, k, sigma):
+    """torchvision.transforms.functional.gaussian_blur(plane, k, sigma) on one [H, W] plane in the dense k x k order of PyTorch's CPU build."""
+    a, pa = _f(plane)
+    H, W = a.shape
+    out = np.empty_like(a)
+    lib().vo_gaussian_blur_dense(pa, C.c_int(H), C.c_int(W), C.c_int(int(k)), C.c_float(np.float32(sigma)), out.ctypes.data_as(_f32p))
+    return out
+
+
+def sum_aten(v):
+    """torch.sum of a contiguous float32 vector in ATen's CPU order (sum_aten_f32)."""
+    a, pa = _f(np.ravel(v))
+    L = lib()
+    L.vo_sum_aten.restype = C.c_float
+    return np.float32(L.vo_sum_aten(pa, C.c_int(a.size)))
+
+
 def linspace(start, end, steps):
     L = lib()
     L.vo_linspace.restype = C.c_float

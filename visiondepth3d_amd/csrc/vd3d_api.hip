@@ -347,6 +347,48 @@ static float linspace_host(float start, float end, int steps, int i) {
   if (i < steps / 2) return fmaf(step, (float)i, start);
   return fmaf(-step, (float)(steps - 1 - i), end);
 }
+// torch.sum of a contiguous float32 vector in ATen's CPU order (256-bit reduction kernels: 8 lanes, four interleaved vector accumulators, the n % 8 tail
+// first, then the lanes in order; below 8 elements four interleaved scalar accumulators; n < 512) -- what `pdf.sum()` of torchvision's _get_gaussian_kernel1d evaluates to.  Same rule as the oracle's sum_aten_f32
+// (written independently there); tests/test_aten_restatements.py pins both against torch.sum and against each other through vd3d_debug_gaussian_kernel1d.
+static float host_sum_aten(const float* v, int n) {
+  if (n < 8) {   // no full vector: the scalar variant (four interleaved scalar accumulators, leftovers into the first)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
+    for (; i < n; ++i) s0 += v[i];
+    return ((s0 + s1) + s2) + s3;
+  }
+  const int nv = n >> 3, nq = nv >> 2;
+  float acc[4][8];
+  for (int j = 0; j < 4; ++j)
+    for (int l = 0; l < 8; ++l) acc[j][l] = 0.f;
+  for (int i = 0; i < nv; ++i) {
+    float* a = acc[i < 4 * nq ? (i & 3) : 0];
+    for (int l = 0; l < 8; ++l) a[l] += v[8 * i + l];
+  }
+  for (int l = 0; l < 8; ++l) acc[0][l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+  float fin = 0.f;
+  for (int i = 8 * nv; i < n; ++i) fin += v[i];
+  for (int l = 0; l < 8; ++l) fin += acc[0][l];
+  return fin;
+}
+// torchvision _get_gaussian_kernel1d in float32 (core/render_3d.py:798-806): k <= 2 DF_RMAX_HOST + 1 taps into out
+static void host_gaussian_kernel1d(int k, float sigma, float* out) {
+  const float half = (float)((k - 1) * 0.5);
+  for (int i = 0; i < k; ++i) {
+    float x = linspace_host(-half, half, k, i);
+    float t = x / sigma;
+    out[i] = (float)exp((double)(-0.5f * (t * t)));
+  }
+  const float sum = host_sum_aten(out, k);
+  for (int i = 0; i < k; ++i) out[i] = out[i] / sum;
+}
+VD3D_EXPORT int vd3d_debug_gaussian_kernel1d(int k, float sigma, float* out_host) {   // host-only (no GPU needed): the weights the DOF kernels are given
+  if (k < 1 || k > 2 * DF_RMAX_HOST + 1 || !(k & 1) || !out_host || !(sigma > 0.f)) return set_err(VD3D_E_INVALID, "gaussian_kernel1d: odd k <= %d, sigma > 0", 2 * DF_RMAX_HOST + 1);
+  host_gaussian_kernel1d(k, sigma, out_host);
+  return 0;
+}
+
 static int make_finish_consts(const vd3d_render_params* p, vd_finish_consts* fc) {
   memset(fc, 0, sizeof *fc);
   const int NL = 5;
@@ -357,15 +399,7 @@ static int make_finish_consts(const vd3d_render_params* p, vd_finish_consts* fc)
       int k = (int)(2 * ceil(2 * (double)sigma) + 1);
       if (k > 2 * DF_RMAX_HOST + 1) return set_err(VD3D_E_UNSUPPORTED, "dof_strength %.3f needs a %d-tap Gaussian (> %d)", p->dof_strength, k, 2 * DF_RMAX_HOST + 1);
       fc->ksz[l - 1] = k;
-      const float half = (float)((k - 1) * 0.5);
-      float sum = 0.f;
-      for (int i = 0; i < k; ++i) {
-        float x = linspace_host(-half, half, k, i);
-        float t = x / sigma;
-        fc->kern[l - 1][i] = (float)exp((double)(-0.5f * (t * t)));
-        sum += fc->kern[l - 1][i];
-      }
-      for (int i = 0; i < k; ++i) fc->kern[l - 1][i] = fc->kern[l - 1][i] / sum;
+      host_gaussian_kernel1d(k, sigma, fc->kern[l - 1]);
       if (k <= 9)   // dense association: weight of tap (i, j) = the float32 product of the two 1-D weights (what torchvision's outer product holds)
         for (int i = 0; i < k; ++i)
           for (int j = 0; j < k; ++j) fc->w2[l - 1][i * k + j] = fc->kern[l - 1][i] * fc->kern[l - 1][j];
