@@ -9,6 +9,17 @@ torch = pytest.importorskip("torch")
 F = torch.nn.functional
 
 
+def _same_cpu_kernels():
+    try:
+        return torch.backends.cpu.get_cpu_capability() == "AVX512" and torch.backends.mkl.is_available()
+    except Exception:
+        return False
+
+
+# the restatements pin the ATen / MKL code paths of the build the reference fixtures were generated with (AVX-512 dispatch, oneMKL)
+pytestmark = pytest.mark.skipif(not _same_cpu_kernels(), reason="torch CPU kernels of a different ISA level")
+
+
 @pytest.fixture(autouse=True)
 def _threads():
     n = torch.get_num_threads()

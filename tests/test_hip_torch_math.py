@@ -63,7 +63,6 @@ def test_sqrt_device_equals_oracle(R, oracle):
 
 
 def test_torch_math_rejects_bad_arguments(R):
-    from visiondepth3d_amd._lib import Vd3dError
     with pytest.raises(KeyError):
         R.torch_math("exp", torch.zeros(4))
     import ctypes as C
