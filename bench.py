@@ -143,20 +143,48 @@ class Env:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != max(args.gpus, 1) and self.world > 1:
+        if self.world != max(args.gpus, 1):
             raise SystemExit(f"WORLD_SIZE={self.world} but --gpus {args.gpus}")
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
-        torch.cuda.set_device(self.local_rank)
+        self.oracle_gloo = args.backend == "oracle-gloo"
+        have_gpu = torch.cuda.is_available() and not self.oracle_gloo
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world)
+            dist.init_process_group("nccl" if have_gpu else "gloo", rank=self.rank, world_size=self.world)
+        if not have_gpu and not self.oracle_gloo:
+            if self.world > 1:
+                # no GPU here: prove that the launcher started every rank and that they can talk, then stop cleanly (exit code 0 so
+                # that "does `bench.py --gpus N` start N ranks" can be checked without hardware; there is still no CPU fallback)
+                seen = [None] * self.world
+                dist.all_gather_object(seen, (self.rank, os.getpid()))
+                if self.rank == 0:
+                    print(json.dumps({"error": "no GPU visible: bench.py needs MI355Xs (the HIP path has no CPU fallback)",
+                                      "n_gpus": self.world, "ranks_started": len({r for r, _ in seen}), "rank_pids": [p for _, p in seen],
+                                      "rendezvous": "gloo over 127.0.0.1 (the GPU run uses nccl = RCCL)"}), flush=True)
+                dist.destroy_process_group()
+                raise SystemExit(0)
+            raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+        if have_gpu:
+            if self.local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {torch.cuda.device_count()} GPUs are visible")
+            torch.cuda.set_device(self.local_rank)
 
     def fence(self):
-        self.torch.cuda.synchronize()
+        if not self.oracle_gloo:
+            self.torch.cuda.synchronize()
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        if not self.oracle_gloo:
+            self.torch.cuda.synchronize()
+
+
+def _p1_wait(env, sharders):
+    """P1-chain wait per step (sharded.ChunkSharder.p1_wait_ms), the maximum over slot sets and ranks (rank 0 never waits inside a step)."""
+    if not sharders or env.world == 1:
+        return None
+    v = max([s.p1_wait_ms() or 0.0 for s in sharders])
+    t = env.torch.tensor([v], dtype=env.torch.float64, device="cpu" if env.oracle_gloo else "cuda")
+    env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
+    return round(float(t.item()), 4)
 
 
 def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_dtype: str = "f32", profile: bool = True,
@@ -179,8 +207,11 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     r.new_clip()
     B = args.batch
 
-    # synthetic clip resident in HBM (each rank renders its own clip: frame indices offset by rank)
-    frames_np, depths_np = synth.synth_clip(args.clip, sh, sw, start=rank * 1000)
+    # ONE synthetic clip, cut into contiguous chunks across the ranks (sharded.py): step k holds the clip's frames
+    # [k * world * B, (k + 1) * world * B) and rank g owns [g * B, (g + 1) * B) of them, so this rank's local frame L is the clip's frame
+    # (L // B) * world * B + g * B + L % B.  Only the own frames are resident in this rank's HBM (world 1: frames 0 .. clip - 1).
+    gidx = [(L // args.batch) * world * args.batch + rank * args.batch + L % args.batch for L in range(args.clip)]
+    frames_np, depths_np = zip(*[synth.synth_frame(t, sh, sw) for t in gidx])
     frames = torch.stack([torch.from_numpy(f) for f in frames_np]).cuda()          # [C,h,w,3] u8
     depths = torch.stack([torch.from_numpy(d) for d in depths_np]).cuda()          # [C,h,w] f32
     outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
@@ -308,7 +339,8 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     res = dict(workload=workload, desc=desc, sh=sh, sw=sw, model=model_name, B=B, steps=steps, warmup=warmup, dt=dt,
                frames_total=world * steps * B, stage_ms=stage_ms, iso_ms=iso_ms, net_ms=net_ms, flops_per_frame=flops,
                N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), depth_dtype=depth_dtype if model_name else None,
-               host_io=host_io, clip=args.clip,
+               host_io=host_io, clip=args.clip, clip_frames_global=world * args.clip,
+               p1_wait_ms=_p1_wait(env, shr2),
                shard_bytes=(shr2[0].bytes_per_step() if (shr2 and hasattr(shr2[0], "bytes_per_step")) else None))
     del pipe
     r.close()
@@ -406,6 +438,78 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
                                      "achieved": round(flops[0] / (net_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                      "frac": round(flops[0] / (net_ms * 1e-3) / 1e12 / 2500.0, 4), "flops_per_frame": flops[0],
                                      "avg_forward_ms": round(net_ms, 3), "library_only_forward_ms": round(lib_ms, 3)}}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run, one rank per GPU of this
+    node (rendezvous on 127.0.0.1, a free port; HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only does dmabuf IPC).  Rank 0 prints the
+    JSON line on the inherited stdout; the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def run_oracle_gloo(env, args, sh=72, sw=128):
+    """TEST MODE (--backend oracle-gloo; tests/test_bench_launcher.py): the launcher, the clip layout, the chunked step protocol
+    (visiondepth3d_amd.sharded.ChunkSharder: point-to-point plane hand-off + two record all-gathers) and the barrier / max-over-ranks timing
+    of the GPU benchmark, with tests/oracle_chunk.OracleChunkBackend (the CPU oracle) as the sharder's backend over gloo on a tiny clip.
+    Proves without hardware that `bench.py --gpus N` runs N cooperating ranks; NOT a benchmark result and labelled as such."""
+    torch, dist = env.torch, env.dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_chunk import OracleChunkBackend          # test infrastructure (imports oracle/)
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    from visiondepth3d_amd.sharded import ChunkSharder
+    torch.set_num_threads(1)
+    B, world, rank = min(args.batch, 2), env.world, env.rank
+    p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
+    be = OracleChunkBackend(p)
+    shr = ChunkSharder(be, rank, world, B)
+    be.new_clip()
+    nsteps = args.warmup + args.steps
+    clip = {}
+    for k in range(nsteps):
+        for j in range(B):
+            t = k * world * B + rank * B + j
+            f, d = synth.synth_frame(t, sh, sw)
+            clip[(k, j)] = (torch.from_numpy(f), torch.from_numpy(synth.depth_to_u8_bgr(d)[..., 0].copy()))
+    sums = {}
+
+    def step(k):
+        fl = [clip[(k, j)][0] for j in range(B)]
+        dl = [clip[(k, j)][1] for j in range(B)]
+        return shr.render_step(fl, dl, first_step=(k == 0), more_steps=(k + 1 < nsteps))
+    for k in range(args.warmup):
+        step(k)
+    env.fence()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, nsteps):
+        for j, o in enumerate(step(k)):   # a checksum per muxed frame, keyed by the frame's index in the clip
+            sums[k * world * B + rank * B + j] = int(o.numpy().astype(np.uint64).sum()) * 31 + int(o.numpy()[::3, ::5].astype(np.uint64).sum())
+    env.fence()
+    dt = time.perf_counter() - t0
+    parts = [sums]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        parts = [None] * world
+        dist.all_gather_object(parts, sums)
+    sums = {str(t): v for part in parts for t, v in part.items()}
+    return {"metric": "stereo-pairs/sec end-to-end (depth+warp+fill+mux)", "value": round(world * args.steps * B / dt, 3), "unit": "stereo-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "TEST MODE: CPU oracle backend over gloo on a tiny synthetic clip -- launcher / protocol check, not a benchmark result",
+            "config": {"workload": f"oracle-gloo-{sw}x{sh}", "frames_per_step": B, "rccl_ranks": None, "gloo_ranks": world,
+                       "comm_per_step_per_rank": shr.bytes_per_step(), "clip_layout": "one clip, contiguous chunks of frames_per_step per rank and step",
+                       "p1_chain_wait_ms_per_step": _p1_wait(env, [shr])},
+            "frame_checksums": dict(sorted(sums.items(), key=lambda kv: int(kv[0])))}
 
 
 def copy_yardstick(env):
@@ -537,9 +641,22 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     ap.add_argument("--upscale-only", action="store_true", help="measure only the configs[4] sub-record (1080p depth + DIBR + Real-ESRGAN x4)")
+    ap.add_argument("--backend", default="hip", choices=("hip", "oracle-gloo"),
+                    help="hip: the product (libvd3d_hip.so, nccl = RCCL for --gpus > 1).  oracle-gloo: TEST MODE for tests/test_bench_launcher.py -- "
+                    "the same rank launcher, clip layout, step protocol and record assembly with the CPU oracle as the sharder's backend over gloo on a "
+                    "tiny clip; its line is labelled and is never a benchmark result")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))   # `python bench.py --gpus N` starts its own N ranks (one per GPU)
     env = Env(args)
+    if env.oracle_gloo:
+        rec = run_oracle_gloo(env, args)
+        if env.rank == 0:
+            print(json.dumps(rec), flush=True)
+        if env.world > 1:
+            env.dist.destroy_process_group()
+        return
     if args.upscale_only:
         print(json.dumps(run_upscale_chain(env, args)), flush=True)
         return
@@ -589,7 +706,9 @@ def main():
                                    "(bit-identical to 1 GPU)" if env.world > 1 else None,
                        "rccl_ranks": env.world if env.world > 1 else None,
                        "comm_per_step_per_rank": head.get("shard_bytes") if env.world > 1 else None,
-                       "distinct_frames_per_rank": head.get("clip"),
+                       "distinct_frames_per_rank": head.get("clip"), "clip_frames_all_ranks": head.get("clip_frames_global"),
+                       "clip_layout": "one clip, contiguous chunks of frames_per_step per rank and step" if env.world > 1 else None,
+                       "p1_chain_wait_ms_per_step": head.get("p1_wait_ms") if env.world > 1 else None,
                        "params": "render_cli.py defaults + dof_strength 2.0; DOF levels in the reference's dense convolution order (parity mode)"},
         }
         hr = rooflines(head, copy_gbs)
@@ -628,25 +747,32 @@ def main():
             sr[up_rec["workload"]] = up_rec
             res["sub_records"] = sr
         if env.world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(sh, sw, seconds_budget=12.0, max_frames=8 if sh > 1080 else 30)
+            # cpu_baseline = the oracle on ALL host cores (one independent clip per process: the CPU path's whole-socket rate, the fair
+            # comparison for a whole GPU); the 1-core figure of the same port rides along as `single_core`
+            def both(h, w, frames_per_core, budget, maxf, timeout_s):
+                one = cpu_baseline(h, w, seconds_budget=budget, max_frames=maxf)
+                try:
+                    allc = cpu_baseline_allcores(h, w, frames_per_core, timeout_s=timeout_s)
+                except Exception as e:
+                    allc = {"error": str(e)[:200]}
+                if "error" in allc:
+                    one["all_cores"] = allc
+                    return one
+                allc["single_core"] = one
+                return allc
+            cb = both(sh, sw, 1 if sh > 1080 else 2, 12.0, 8 if sh > 1080 else 30, 120.0)
             if subs and wl == HEADLINE:
                 cb["gpu_same_work"] = {"workload": "4k-dibr", "value": sub_record(subs["4k-dibr"][0])["value"], "unit": "stereo-pairs/s",
                                        "note": "DIBR chain only on one MI355X: the same work as this CPU figure (`value` also holds the depth net)"}
             res["cpu_baseline"] = cb
             if subs:
-                c1 = cpu_baseline(1080, 1920, seconds_budget=8.0)
+                c1 = both(1080, 1920, 2, 8.0, 30, 90.0)
                 c1["gpu_same_work"] = {"workload": "1080p-dibr", "value": sub_record(subs["1080p-dibr"][0])["value"], "unit": "stereo-pairs/s"}
                 res["cpu_baseline_1080p"] = c1
                 try:
                     res["cpu_depth_net"] = cpu_depth_net(model_name, sh, sw) if model_name else None
                 except Exception as e:
                     res["cpu_depth_net"] = {"error": str(e)[:200]}
-            try:   # same port on all host cores (bounded: a few frames per core), at 1080p (configs[1]) and 4K (configs[3])
-                res["cpu_baseline_allcores"] = cpu_baseline_allcores(1080, 1920, 2)
-                if subs:
-                    res["cpu_baseline_allcores_4k"] = cpu_baseline_allcores(2160, 3840, 1, timeout_s=120.0)
-            except Exception as e:   # the single-core figure above is the contract's baseline; this one is additional context
-                res["cpu_baseline_allcores"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
     if env.world > 1:
         env.dist.destroy_process_group()

@@ -25,6 +25,8 @@ orchestration over gloo with the CPU oracle as backend (numerics, not a recordin
 """
 from __future__ import annotations
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -84,6 +86,7 @@ class ChunkSharder:
         """``twin_of``: the sharder of the other slot set on the same backend (they share the chunk hand-off state)."""
         self.b, self.rank, self.world, self.B, self.group = backend, int(rank), int(world), int(frames_per_rank), group
         self._shared = twin_of._shared if twin_of is not None else {"pending": None}   # rank 0: plane received from rank world-1
+        self._wait = []   # P1-chain waits of this slot set: (event, event) pairs on the GPU, seconds on the CPU (p1_wait_ms)
         self.slot_base = int(slot_base)
         if world * frames_per_rank > 512:
             raise ValueError("a sharded step holds at most 512 frames")
@@ -114,13 +117,39 @@ class ChunkSharder:
         return {"ranks": self.world, "frames_per_step": n, "p2p_plane_bytes_sent": 0 if self.world == 1 else int(ph) * int(pw) * 4,
                 "p2p_plane_bytes_received": 0 if self.world == 1 else int(ph) * int(pw) * 4,
                 "allgather_bytes_received": 0 if self.world == 1 else n * (2 * 4 + 4 * 8),
-                "collectives_per_step": 0 if self.world == 1 else 2, "backend": "nccl (RCCL over xGMI)" if self.world > 1 else None}
+                "collectives_per_step": 0 if self.world == 1 else 2, "backend": (("nccl (RCCL over xGMI)" if dist.get_backend(self.group) == "nccl" else dist.get_backend(self.group)) if self.world > 1 else None)}
 
     def _send(self, t, dst):
         dist.send(t.contiguous(), dst, group=self.group)
 
     def _recv(self, t, src):
         dist.recv(t, src, group=self.group)
+
+    def _recv_plane(self, t, src):
+        """The chunk hand-off receive, timed: how long this rank's stream sits behind the previous chunk's P1 (the serial part of the
+        protocol) plus the plane transfer itself.  GPU: an event pair on the current stream around the receive; CPU: wall clock."""
+        if t.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._recv(t, src)
+            e1.record()
+            self._wait.append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            self._recv(t, src)
+            self._wait.append(time.perf_counter() - t0)
+        del self._wait[:-64]
+
+    def p1_wait_ms(self):
+        """Mean milliseconds per step this rank waited for (and received) the plane of the previous chunk; None if it never received."""
+        if not self._wait:
+            return None
+        if isinstance(self._wait[0], tuple):
+            self._wait[-1][1].synchronize()
+            v = [a.elapsed_time(b) for a, b in self._wait]
+        else:
+            v = [1e3 * w for w in self._wait]
+        return round(sum(v) / len(v), 4)
 
     def _nv(self, n_valid):
         n = self.world * self.B if n_valid is None else int(n_valid)
@@ -143,7 +172,7 @@ class ChunkSharder:
             # a plane that is handed on is always a valid one: its sender has rendered (or received) at least one frame of the clip
             if g > 0:
                 buf = torch.empty(self.b.plane_shape(), dtype=torch.float32, device=self.b.device)
-                self._recv(buf, g - 1)
+                self._recv_plane(buf, g - 1)
                 self.b.plane_import(buf, valid=True)
             elif not first_step and self._shared["pending"] is not None:
                 self.b.plane_import(self._shared["pending"], valid=True)
