@@ -178,6 +178,10 @@ void vd3d_render_params_default(vd3d_render_params* p);
 int vd3d_ctx_create(int device, void* stream, vd3d_ctx** out);
 int vd3d_ctx_destroy(vd3d_ctx* ctx);
 int vd3d_sync(vd3d_ctx* ctx);                            /* hipStreamSynchronize */
+/* The context's stream handle.  ESCAPE SEMANTICS: for a VD3D_STREAM_PRIVATE context the handle is from now on assumed to be held by the
+ * caller (PyTorch wraps it and may record events on it when tensors marked with record_stream() are freed, possibly after the context
+ * is gone), so vd3d_ctx_destroy no longer destroys that stream -- it is left to the process.  Query it once and keep it; a context whose
+ * stream was never queried destroys it.  The same holds for vd3d_ctx_pixel_stream. */
 void* vd3d_ctx_stream(vd3d_ctx* ctx);
 /* re-target a context created on a caller-owned stream (not VD3D_STREAM_PRIVATE): later calls enqueue on `stream`, which is first
  * ordered behind everything the context has enqueued so far */

@@ -68,7 +68,10 @@ struct vd3d_ctx {
   hipEvent_t ev_chain = nullptr, ev_pix_last = nullptr;
   std::vector<hipEvent_t> slot_done; std::vector<char> slot_busy;
   // dense DOF weight table of the fused finishing kernel (vd_finish_consts::w2) in device memory + the host copy it was uploaded from
-  float* d_w2 = nullptr; float w2_host[4][81]; bool w2_valid = false;
+  // Tables are never overwritten (a finish kernel of an earlier dof_strength may still be queued on any of the context's streams): every new
+  // parameter set gets its own 1.3 KB device table, filled before anything can read it
+  struct w2_tab { float host[4][81]; float* dev; };
+  std::vector<w2_tab> w2_tabs; int w2_cur = -1;
   // profiling
   bool profiling = false;
   std::vector<vd_prof_rec> recs;
@@ -202,7 +205,8 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->d_w2};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
+  for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
     for (float* q : *v) (void)hipFree(q);
@@ -445,16 +449,29 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
   StageTimer t(c, "finish");
   if (!wk) wk = c->work;
   const int dense = (p->dof_dense_conv && fc.nlev) ? 1 : 0;   // the reference's dense k x k conv order
-  if (dense && (!c->w2_valid || memcmp(c->w2_host, fc.w2, sizeof fc.w2) != 0)) {
-    // first frame or a new dof_strength: the table changes (rare) -> drain whatever may still read the old one, then replace it
-    if (!c->d_w2) HIPCHK(hipMalloc((void**)&c->d_w2, sizeof fc.w2));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
-    memcpy(c->w2_host, fc.w2, sizeof fc.w2);
-    HIPCHK(hipMemcpy(c->d_w2, c->w2_host, sizeof fc.w2, hipMemcpyHostToDevice));
-    c->w2_valid = true;
+  const float* d_w2 = nullptr;
+  if (dense) {
+    if (c->w2_cur < 0 || memcmp(c->w2_tabs[c->w2_cur].host, fc.w2, sizeof fc.w2) != 0) {   // first frame or a new dof_strength (rare)
+      c->w2_cur = -1;
+      for (size_t i = 0; i < c->w2_tabs.size(); ++i)
+        if (memcmp(c->w2_tabs[i].host, fc.w2, sizeof fc.w2) == 0) c->w2_cur = (int)i;
+      if (c->w2_cur < 0) {
+        if (c->w2_tabs.size() >= 64) {   // a caller sweeping the slider: drain every stream of the context once, then recycle all tables
+          HIPCHK(hipDeviceSynchronize());
+          for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
+          c->w2_tabs.clear();
+        }
+        vd3d_ctx::w2_tab t;
+        memcpy(t.host, fc.w2, sizeof fc.w2);
+        HIPCHK(hipMalloc((void**)&t.dev, sizeof fc.w2));
+        HIPCHK(hipMemcpy(t.dev, t.host, sizeof fc.w2, hipMemcpyHostToDevice));   // a fresh buffer: nothing queued reads it yet
+        c->w2_tabs.push_back(t);
+        c->w2_cur = (int)c->w2_tabs.size() - 1;
+      }
+    }
+    d_w2 = c->w2_tabs[c->w2_cur].dev;
   }
-  if (vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out, dense, c->d_w2)) {
+  if (vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, *p, fc, wk, focal, use_override, bw, bs, out, dense, d_w2)) {
     HIPCHK(hipGetLastError());
     return 0;
   }

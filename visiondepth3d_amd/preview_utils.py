@@ -95,8 +95,11 @@ def generate_preview_image(preview_type, left, right, shift_map, w, h):
     if preview_type == "Overlay Arrows":
         sm = shift_map if torch.is_tensor(shift_map) else torch.from_numpy(np.asarray(shift_map))
         H, W = int(left.shape[0]), int(left.shape[1])
-        if int(h) > H or int(w) > W:   # the reference indexes shift_np[y, x] over range(0, h) x range(0, w) (:77-79)
-            raise IndexError("Overlay Arrows: (w, h) exceeds the frame")
+        SH_, SW_ = int(sm.shape[-2]), int(sm.shape[-1])
+        # the reference indexes shift_np[y, x] at the grid points range(0, h, 20) x range(0, w, 20) only (:77-79): the LAST grid point has
+        # to exist in the shift map, (w, h) itself may exceed it
+        if int(h) > 0 and int(w) > 0 and (((int(h) - 1) // 20) * 20 >= SH_ or ((int(w) - 1) // 20) * 20 >= SW_):
+            raise IndexError("Overlay Arrows: a grid point of (w, h) lies outside the shift map")
         if (int(h), int(w)) != (H, W):   # arrows start only inside the (w, h) grid: a zero shift draws nothing (|dx| <= 1)
             sm = sm.clone()
             sm[..., int(h):, :] = 0

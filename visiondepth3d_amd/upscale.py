@@ -327,8 +327,11 @@ class Upscaler:
         if self.device.type == "cuda":
             self.net = self.net.to(memory_format=torch.channels_last)
         self._body = None
+        # the all-HIP path is built for the reference's compact networks: 3 input channels, 64 features, a tail of <= 64 channels,
+        # x2 / x4 (vd3d_esr_tail_f32); anything else a caller hands in runs through the module graph
         if (hip_body and self.device.type == "cuda" and dtype == torch.float16 and isinstance(self.net, SRVGGNetCompact)
-                and self.net.body[0].out_channels == 64):
+                and self.net.body[0].out_channels == 64 and self.net.body[0].in_channels == 3
+                and int(getattr(self.net, "upscale", 0)) in (2, 4) and self.net.body[-1].out_channels <= 64):
             self._body = self._prepare_body()
 
     def _prepare_body(self):
@@ -411,7 +414,7 @@ class Upscaler:
                 R.esr_postprocess(pred, out=out, window=(y - y0, x - x0, th, tw), dst_yx=(y, x))
         return out
 
-    def run_esrgan(self, frame, blend_mode="OFF", input_res_pct=100, model_name=None, target_size=None, tile=None, tile_pad=8):
+    def run_esrgan(self, frame, blend_mode="OFF", input_res_pct=100, model_name="RealESR_Gx4_fp16", target_size=None, tile=None, tile_pad=8):
         """core/merged_pipeline.py:237-264.  ``frame``: uint8 BGR [H,W,3] (tensor or array); returns a uint8 BGR tensor on the device."""
         R = self.renderer
         original = frame if torch.is_tensor(frame) else torch.from_numpy(np.ascontiguousarray(frame))
@@ -425,7 +428,7 @@ class Upscaler:
             upscaled = self._esrgan_tiled(frame, int(tile), int(tile_pad))
         else:
             upscaled = R.esr_postprocess(self._infer(frame))
-        scale = 2 if "x2" in str(model_name or self.model_name).lower() else 4    # :259: from the CALL's model name, like the reference
+        scale = 2 if "x2" in str(model_name).lower() else 4    # :259: from the CALL's model name (default literal 'RealESR_Gx4_fp16'), like the reference
         fh, fw = int(frame.shape[0]), int(frame.shape[1])
         upscaled = R.resize_cubic_u8(upscaled, fh * scale, fw * scale)
         upscaled = R.resize_cubic_u8(upscaled, int(original.shape[0]), int(original.shape[1]))
