@@ -177,6 +177,17 @@ class Env:
             self.torch.cuda.synchronize()
 
 
+_CLIP_CACHE = {}
+
+
+def _synth_cached(synth, t, sh, sw):
+    """synthetic frames are pure functions of (index, size) and cost seconds of host time at 4K: the workloads of one invocation share them"""
+    k = (t, sh, sw)
+    if k not in _CLIP_CACHE:
+        _CLIP_CACHE[k] = synth.synth_frame(t, sh, sw)
+    return _CLIP_CACHE[k]
+
+
 def _p1_wait(env, sharders):
     """P1-chain wait per step (sharded.ChunkSharder.p1_wait_ms), the maximum over slot sets and ranks (rank 0 never waits inside a step)."""
     if not sharders or env.world == 1:
@@ -211,7 +222,7 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     # [k * world * B, (k + 1) * world * B) and rank g owns [g * B, (g + 1) * B) of them, so this rank's local frame L is the clip's frame
     # (L // B) * world * B + g * B + L % B.  Only the own frames are resident in this rank's HBM (world 1: frames 0 .. clip - 1).
     gidx = [(L // args.batch) * world * args.batch + rank * args.batch + L % args.batch for L in range(args.clip)]
-    frames_np, depths_np = zip(*[synth.synth_frame(t, sh, sw) for t in gidx])
+    frames_np, depths_np = zip(*[_synth_cached(synth, t, sh, sw) for t in gidx])
     frames = torch.stack([torch.from_numpy(f) for f in frames_np]).cuda()          # [C,h,w,3] u8
     depths = torch.stack([torch.from_numpy(d) for d in depths_np]).cuda()          # [C,h,w] f32
     outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
@@ -230,7 +241,7 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
         shr2 = [ChunkSharder(be, rank, world, B)]
         if pix_ov:
             shr2.append(ChunkSharder(be, rank, world, B, slot_base=B, twin_of=shr2[0]))
-            r.set_pixel_overlap(True)
+            r.set_pixel_overlap(1 if host_io else max(1, int(args.pix_streams)))   # frames' pixel passes round-robin over this many streams
 
     pipe = None
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16}[depth_dtype]
@@ -638,6 +649,8 @@ def main():
                     help="two slot sets + vd3d_set_pixel_overlap: the pixel kernels of step i run on a second stream of the renderer while "
                     "the (latency-bound) measurement chain of step i+1 runs on the first (the default)")
     ap.add_argument("--no-pixel-overlap", dest="pixel_overlap", action="store_false")
+    ap.add_argument("--pix-streams", type=int, default=2, help="pixel streams of the renderer (vd3d_set_pixel_overlap(ctx, n)): consecutive frames' "
+                    "k_shift / W1 / E1 go round-robin over n streams so that neighbouring frames' kernels share the CUs")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     ap.add_argument("--upscale-only", action="store_true", help="measure only the configs[4] sub-record (1080p depth + DIBR + Real-ESRGAN x4)")

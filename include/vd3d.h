@@ -187,6 +187,7 @@ void* vd3d_ctx_stream(vd3d_ctx* ctx);
  * ordered behind everything the context has enqueued so far */
 int vd3d_ctx_set_stream(vd3d_ctx* ctx, void* stream);
 void* vd3d_ctx_pixel_stream(vd3d_ctx* ctx);              /* second stream of vd3d_set_pixel_overlap (NULL before it was enabled) */
+void* vd3d_ctx_pixel_stream_k(vd3d_ctx* ctx, int k);     /* pixel stream k of vd3d_set_pixel_overlap(ctx, n), k < n <= 4 (k = 0: the one above) */
 
 /* ---- tracker state (replaces the module singletons; lets ranks exchange it) -- */
 int vd3d_state_reset(vd3d_ctx* ctx);                     /* fresh process + fresh render */
@@ -239,6 +240,9 @@ int vd3d_shard_pixels_blank(vd3d_ctx* ctx, int slot, const uint8_t* frame_bgr, c
  * measurement chain of the next step (vd3d_shard2_p1 .. r2; latency-bound scans) then overlaps the pixel kernels of this one.  A call
  * that overwrites a slot first waits for the pixel pass still reading it, so callers alternate between two slot sets to get the overlap.
  * Outputs are complete after vd3d_sync, or -- for consumers ordered on the context's stream -- after vd3d_join_pixels. */
+/* enable = 0: off; 1: one pixel stream; 2 .. 4: consecutive pixel passes go round-robin over that many streams, each with its own shift
+ * plane and warped eyes, so the kernels of neighbouring frames share the CUs (a consumer of the muxed frames orders itself behind
+ * vd3d_join_pixels / vd3d_wait_pixels, or behind every vd3d_ctx_pixel_stream_k). */
 int vd3d_set_pixel_overlap(vd3d_ctx* ctx, int enable);
 int vd3d_join_pixels(vd3d_ctx* ctx);
 int vd3d_wait_pixels(vd3d_ctx* ctx, int slot);   /* host waits for the outstanding overlapped pixel pass of `slot` (no-op if none) */
@@ -255,6 +259,13 @@ int vd3d_tdf_plane_export(vd3d_ctx* ctx, float* dst_dev, int eye_h, int eye_w);
 int vd3d_tdf_plane_import(vd3d_ctx* ctx, const float* src_dev, int eye_h, int eye_w, int valid);
 int vd3d_shard2_r1(vd3d_ctx* ctx, const float* q_all_dev, int n);
 int vd3d_shard2_p3(vd3d_ctx* ctx, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev);
+/* Batched forms for the own frames of a step, which are consecutive (slots slot0 .. slot0 + n - 1, step indices step_idx0 ..,
+ * n <= 16): P1 in two launches (the plane EMA -- a per-pixel recurrence of core/render_3d.py:225-229 -- walks the frames inside the
+ * ingest kernel, the exact-quantile passes of the n frames run side by side), P3 in five launches for all n frames.  Same results
+ * as n single calls; frames_bgr / depths are HOST arrays of n device pointers, q_out_dev = float[n][2], m_out_dev = int64[n][4]. */
+int vd3d_shard2_p1_batch(vd3d_ctx* ctx, const uint8_t* const* frames_bgr, const void* const* depths, int depth_fmt,
+                         const vd3d_render_params* p, int step_idx0, int slot0, int n, float* q_out_dev);
+int vd3d_shard2_p3_batch(vd3d_ctx* ctx, int slot0, int step_idx0, int n, const vd3d_render_params* p, long long* m_out_dev);
 /* blank_host_or_null[t] != 0: frame t of the step is in the skip_blank_frames set (no ipd scaling, no focal / FloatingWindowTracker
  * update for it, core/render_3d.py:1278-1281,1334-1337) */
 int vd3d_shard2_r2(vd3d_ctx* ctx, const long long* m_all_dev, const int* own_slot_host, const uint8_t* blank_host_or_null, int n,
@@ -401,6 +412,8 @@ int vd3d_torch_math(vd3d_ctx* ctx, int op, const float* x, float param, float* o
  * "select_s1", "warp" (= "shift" + "w1", the fused warp kernel alone), "finish", "handoff", "advance", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
  * profiling was enabled (-1 if never seen); both getters synchronise. */
 int vd3d_set_profiling(vd3d_ctx* ctx, int enable);
+/* development probe: launch-shape knobs of the batched select chain (0: workgroup divisor per frame, 1: frames per P3 group); results never depend on them */
+int vd3d_debug_tune(int which, int value);
 float vd3d_last_stage_ms(vd3d_ctx* ctx, const char* stage);
 long vd3d_stage_calls(vd3d_ctx* ctx, const char* stage);
 /* host-only (works without a GPU): the float32 Gaussian weights the DOF kernels receive for one blur level -- torchvision's _get_gaussian_kernel1d as torch

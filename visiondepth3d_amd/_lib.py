@@ -14,12 +14,12 @@ LIB_PATH = os.environ.get("VD3D_LIB_PATH") or os.path.join(_HERE, "libvd3d_hip.s
 # every symbol include/vd3d.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = (
     "vd3d_abi_version", "vd3d_last_error", "vd3d_shift_params_default", "vd3d_render_params_default",
-    "vd3d_ctx_create", "vd3d_ctx_destroy", "vd3d_sync", "vd3d_ctx_stream", "vd3d_ctx_set_stream", "vd3d_ctx_pixel_stream",
+    "vd3d_ctx_create", "vd3d_ctx_destroy", "vd3d_sync", "vd3d_ctx_stream", "vd3d_ctx_set_stream", "vd3d_ctx_pixel_stream", "vd3d_ctx_pixel_stream_k",
     "vd3d_state_reset", "vd3d_state_new_clip", "vd3d_state_export", "vd3d_state_import", "vd3d_state_planes",
     "vd3d_last_scalars", "vd3d_pixel_shift", "vd3d_render_frame", "vd3d_render_frame_blank", "vd3d_depth_handoff", "vd3d_heal_missing_pixels", "vd3d_preview_heatmap", "vd3d_preview_arrows", "vd3d_conv3x3_c64_f16", "vd3d_conv3x3_head_f16", "vd3d_esr_tail_f32", "vd3d_nv12_to_bgr", "vd3d_bgr_to_nv12", "vd3d_resize_cubic_u8", "vd3d_resize_area_u8", "vd3d_esr_preprocess", "vd3d_esr_postprocess", "vd3d_add_weighted_u8", "vd3d_rife_preprocess", "vd3d_rife_postprocess",
     "vd3d_shard_begin", "vd3d_shard_pixels", "vd3d_shard_pixels_blank", "vd3d_tdf_plane_export", "vd3d_tdf_plane_import", "vd3d_set_pixel_overlap", "vd3d_join_pixels", "vd3d_wait_pixels", "vd3d_finish_frame", "vd3d_quantiles",
-    "vd3d_subject_depth", "vd3d_shard2_p0", "vd3d_shard2_set_crops", "vd3d_shard2_p1", "vd3d_shard2_r1", "vd3d_shard2_p3", "vd3d_shard2_r2", "vd3d_depth_preprocess", "vd3d_add_layernorm", "vd3d_upsample_bilinear_nhwc", "vd3d_preview_image", "vd3d_detect_black_bars", "vd3d_stream_copy", "vd3d_torch_math", "vd3d_debug_gaussian_kernel1d", "vd3d_set_profiling", "vd3d_last_stage_ms", "vd3d_stage_calls",
-    "vd3d_debug_planes",
+    "vd3d_subject_depth", "vd3d_shard2_p0", "vd3d_shard2_set_crops", "vd3d_shard2_p1", "vd3d_shard2_p1_batch", "vd3d_shard2_r1", "vd3d_shard2_p3", "vd3d_shard2_p3_batch", "vd3d_shard2_r2", "vd3d_depth_preprocess", "vd3d_add_layernorm", "vd3d_upsample_bilinear_nhwc", "vd3d_preview_image", "vd3d_detect_black_bars", "vd3d_stream_copy", "vd3d_torch_math", "vd3d_debug_gaussian_kernel1d", "vd3d_set_profiling", "vd3d_last_stage_ms", "vd3d_stage_calls",
+    "vd3d_debug_planes", "vd3d_debug_tune",
 )
 
 _lib = None
@@ -51,6 +51,8 @@ def lib():
     L.vd3d_ctx_set_stream.argtypes = [vp, vp]
     L.vd3d_ctx_pixel_stream.argtypes = [vp]
     L.vd3d_ctx_pixel_stream.restype = vp
+    L.vd3d_ctx_pixel_stream_k.argtypes = [vp, i32]
+    L.vd3d_ctx_pixel_stream_k.restype = vp
     for n in ("vd3d_state_reset", "vd3d_state_new_clip"):
         getattr(L, n).argtypes = [vp]
     L.vd3d_state_export.argtypes = [vp, C.POINTER(State)]
@@ -90,6 +92,8 @@ def lib():
     L.vd3d_shard2_p0.argtypes = [vp, vp, vp, vp]
     L.vd3d_shard2_set_crops.argtypes = [vp, vp, i32]
     L.vd3d_shard2_p1.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
+    L.vd3d_shard2_p1_batch.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp]
+    L.vd3d_shard2_p3_batch.argtypes = [vp, i32, i32, i32, vp, vp]
     L.vd3d_shard2_r1.argtypes = [vp, vp, i32]
     L.vd3d_shard2_p3.argtypes = [vp, i32, i32, vp, vp]
     L.vd3d_shard2_r2.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_uint8), i32, vp]
@@ -101,6 +105,7 @@ def lib():
     L.vd3d_stream_copy.argtypes = [vp, vp, vp, C.c_size_t]
     L.vd3d_torch_math.argtypes = [vp, i32, vp, C.c_float, vp, C.c_longlong]
     L.vd3d_debug_gaussian_kernel1d.argtypes = [i32, C.c_float, vp]
+    L.vd3d_debug_tune.argtypes = [i32, i32]
     L.vd3d_set_profiling.argtypes = [vp, i32]
     L.vd3d_last_stage_ms.argtypes = [vp, C.c_char_p]
     L.vd3d_last_stage_ms.restype = C.c_float

@@ -58,6 +58,10 @@ struct vd3d_ctx {
   int n_slots = 0, slot_eh = 0, slot_ew = 0, slot_H = 0, slot_W = 0;
   std::vector<float*> slot_rgb, slot_dn, slot_D;
   std::vector<float*> slot_tdf, slot_tdfp;   // measure/replay protocol: filtered plane of the own frame and of the frame before it
+  std::vector<const float*> slot_prev;       // where P1 left "the filtered plane of the frame before slot's frame" (slot_tdfp[slot], or the previous slot's slot_tdf inside a batch)
+  // batched steps: per frame of a batch (<= VD_MAX_BATCH) its own histogram arena and curved-depth plane, so that the frames' chain
+  // kernels run side by side in one launch
+  int n_batch = 0; uint32_t* bhist = nullptr; std::vector<float*> bdc;
   float* etab = nullptr;                     // [VD_MAX_STEP + 1][VD_ETAB] replayed normalisation table of the current step
   int* crop_tab = nullptr;                   // [VD_MAX_STEP][4] exchanged auto-crop rectangles of the current step
   bool crop_tab_set = false;
@@ -66,6 +70,18 @@ struct vd3d_ctx {
   // NEXT step, which stays on `stream`; slot_done[slot] guards the slot's planes against being overwritten too early
   hipStream_t pix_stream = nullptr; bool pix_overlap = false; bool pix_pending = false; bool pix_stream_escaped = false;
   hipEvent_t ev_chain = nullptr, ev_pix_last = nullptr;
+  // more than one pixel stream (vd3d_set_pixel_overlap(ctx, n), n = 2 .. VD_MAX_PIX): consecutive pixel passes go round-robin over n
+  // streams, each with its own shift plane and warped eyes, so the kernels of neighbouring frames (k_shift / W1 / E1: different LDS, VGPR and
+  // latency profiles) share the CUs and the tail of one launch is covered by the next frame's kernels.  Stream 0 = pix_stream with the
+  // context's S / L / R.  A pass that needs the context's SHARED fallback planes (unfused warp / finish) first waits for the other
+  // streams and is waited for by every later pass (pix_excl_*).
+#define VD_MAX_PIX 4
+  int n_pix = 1; unsigned pix_rr = 0; int cur_pix = -1; bool cur_excl = false;
+  hipStream_t pix_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; bool pix_x_escaped[VD_MAX_PIX - 1] = {false, false, false};
+  hipEvent_t ev_pix_last_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; bool pix_pending_x[VD_MAX_PIX - 1] = {false, false, false};
+  float* S_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; uint8_t* L_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; uint8_t* R_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr};
+  int x_H = 0, x_W = 0;
+  hipEvent_t ev_excl = nullptr; bool excl_set = false;
   std::vector<hipEvent_t> slot_done; std::vector<char> slot_busy;
   // dense DOF weight table of the fused finishing kernel (vd_finish_consts::w2) in device memory + the host copy it was uploaded from
   // Tables are never overwritten (a finish kernel of an earlier dof_strength may still be queued on any of the context's streams): every new
@@ -117,11 +133,28 @@ static int wait_slot(vd3d_ctx* c, int slot) {
 }
 // main stream waits for every outstanding overlapped pixel pass (they share L / R / S and write the caller's outputs)
 static int join_pixels(vd3d_ctx* c) {
+  bool any = c->pix_pending;
   if (c->pix_pending) {
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pix_last, 0));
     c->pix_pending = false;
-    std::fill(c->slot_busy.begin(), c->slot_busy.end(), 0);
   }
+  for (int k = 0; k < VD_MAX_PIX - 1; ++k)
+    if (c->pix_pending_x[k]) {
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pix_last_x[k], 0));
+      c->pix_pending_x[k] = false; any = true;
+    }
+  if (any) std::fill(c->slot_busy.begin(), c->slot_busy.end(), 0);
+  c->excl_set = false;
+  return 0;
+}
+// A pixel pass on one of several pixel streams is about to touch the context's shared fallback planes (e2 / b / graded eyes): order it
+// behind the passes already enqueued on the other pixel streams; the caller records ev_excl afterwards, which every later pass waits for.
+static int pix_exclusive(vd3d_ctx* c) {
+  if (c->cur_pix < 0 || c->n_pix < 2 || c->cur_excl) return 0;
+  if (c->cur_pix != 0 && c->pix_pending) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pix_last, 0));
+  for (int k = 0; k < VD_MAX_PIX - 1; ++k)
+    if (k + 1 != c->cur_pix && c->pix_pending_x[k]) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pix_last_x[k], 0));
+  c->cur_excl = true;
   return 0;
 }
 
@@ -211,6 +244,16 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
     for (float* q : *v) (void)hipFree(q);
   if (c->slot_work) (void)hipFree(c->slot_work);
+  for (float* q : c->bdc) (void)hipFree(q);
+  if (c->bhist) (void)hipFree(c->bhist);
+  for (int k = 0; k < VD_MAX_PIX - 1; ++k) {
+    if (c->pix_x[k]) { (void)hipStreamSynchronize(c->pix_x[k]); if (!c->pix_x_escaped[k]) (void)hipStreamDestroy(c->pix_x[k]); }
+    if (c->ev_pix_last_x[k]) (void)hipEventDestroy(c->ev_pix_last_x[k]);
+    if (c->S_x[k]) (void)hipFree(c->S_x[k]);
+    if (c->L_x[k]) (void)hipFree(c->L_x[k]);
+    if (c->R_x[k]) (void)hipFree(c->R_x[k]);
+  }
+  if (c->ev_excl) (void)hipEventDestroy(c->ev_excl);
   if (c->pix_stream) { (void)hipStreamSynchronize(c->pix_stream); if (!c->pix_stream_escaped) (void)hipStreamDestroy(c->pix_stream); }
   for (auto e : c->slot_done) (void)hipEventDestroy(e);
   if (c->ev_chain) (void)hipEventDestroy(c->ev_chain);
@@ -221,6 +264,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
 }
 VD3D_EXPORT int vd3d_sync(vd3d_ctx* c) {
   if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
+  for (int k = 0; k < VD_MAX_PIX - 1; ++k) if (c->pix_x[k]) HIPCHK(hipStreamSynchronize(c->pix_x[k]));
   HIPCHK(hipStreamSynchronize(c->stream));
   prof_collect(c);
   return 0;
@@ -252,6 +296,13 @@ VD3D_EXPORT void* vd3d_ctx_pixel_stream(vd3d_ctx* c) {
   if (!c) return nullptr;
   if (c->pix_stream) c->pix_stream_escaped = true;
   return (void*)c->pix_stream;
+}
+// pixel stream k of vd3d_set_pixel_overlap(ctx, n) (k = 0: vd3d_ctx_pixel_stream); NULL beyond the streams created so far
+VD3D_EXPORT void* vd3d_ctx_pixel_stream_k(vd3d_ctx* c, int k) {
+  if (!c || k < 0 || k >= VD_MAX_PIX) return nullptr;
+  if (k == 0) return vd3d_ctx_pixel_stream(c);
+  if (c->pix_x[k - 1]) c->pix_x_escaped[k - 1] = true;
+  return (void*)c->pix_x[k - 1];
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -296,14 +347,27 @@ static int check_shift_params(const vd3d_shift_params* p, int H, int W) {
   return 0;
 }
 
+// the context's own planes and control block as a batch of one frame (sequential entry points)
+static vd_batch batch_of_one(vd3d_ctx* c) {
+  vd_batch b;
+  memset(&b, 0, sizeof b);
+  b.n = 1; b.w_main = c->work;
+  vd_batch_frame& F = b.f[0];
+  F.w = c->work; F.histA = c->histA; F.histB = c->histB;
+  F.rgb_eye = c->rgb_eye; F.tdf = c->tdf; F.tdf_prev = c->tdf;   // the plane EMA updates c->tdf in place
+  F.dc = c->dc; F.D = c->D;
+  return b;
+}
+
 static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_plane, int ih, int iw, int W, int H,
                               const vd3d_shift_params& sp, vd_stage_args a, bool skip_pixels = false) {
   hipStream_t s = c->stream;
   {
     StageTimer t(c, "select_dc");   // fused chain: norm + stage1 (A1), b1 (B1), shape (+A2), b2 (B2)
-    vd_launch_chain_work(s, a.have_eye, a.have_eye ? c->tdf : depth_plane, a.have_eye ? const_cast<float*>(depth_plane) : nullptr,
-                         a.have_eye ? c->dn[c->dn_cur ^ 1] : nullptr, ih, iw, H, W, c->work, (float)sp.depth_pop_mid,
-                         (float)sp.depth_pop_gamma, c->dc, c->D, c->histA, c->histB, a);
+    vd_batch b = batch_of_one(c);   // render path: depth_plane = dn_cur (written by K3a from c->tdf); bare pixel_shift_cuda: the caller's plane
+    b.f[0].dn = const_cast<float*>(depth_plane);
+    b.f[0].dn_prev = a.have_eye ? c->dn[c->dn_cur ^ 1] : nullptr;
+    vd_launch_chain_work(s, b, a.have_eye, ih, iw, H, W, (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, a);
   }
   if (!skip_pixels) { StageTimer t(c, "warp");
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
@@ -475,6 +539,7 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
     HIPCHK(hipGetLastError());
     return 0;
   }
+  { int rcx = pix_exclusive(c); if (rcx) return rcx; }   // gL / gR are shared by the context's pixel streams
   vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense);
   vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense);
   vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
@@ -549,7 +614,9 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   {
     StageTimer t(c, "select_eye");   // fused chain: ingest (+A0), b0 (B0); eye stats ride on the next launch
     HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
-    vd_launch_chain_eye(s, frame_bgr, depth, depth_fmt, *p, c->work, c->rgb_eye, c->tdf, c->histA, c->histB, a);
+    vd_batch b = batch_of_one(c);
+    b.f[0].frame = frame_bgr; b.f[0].depth = depth;
+    vd_launch_chain_eye(s, b, depth_fmt, *p, a);
   }
   // a blank frame still runs the whole select chain (its eye-res half carries the filters and the bars; the work-res half only
   // computes unused pop-shaping constants -- blank frames are rare and this keeps one code path), but no shift map and no warp
@@ -593,7 +660,8 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
   const bool same = c->n_slots >= n_slots && c->slot_eh == p->eye_h && c->slot_ew == p->eye_w && c->slot_H == p->warp_h && c->slot_W == p->warp_w;
   if (same) return 0;
   if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
-  c->pix_pending = false; std::fill(c->slot_busy.begin(), c->slot_busy.end(), 0);
+  for (int k = 0; k < VD_MAX_PIX - 1; ++k) { if (c->pix_x[k]) HIPCHK(hipStreamSynchronize(c->pix_x[k])); c->pix_pending_x[k] = false; }
+  c->pix_pending = false; c->excl_set = false; std::fill(c->slot_busy.begin(), c->slot_busy.end(), 0);
   HIPCHK(hipStreamSynchronize(c->stream));
   for (auto q : c->slot_rgb) (void)hipFree(q);
   for (auto q : c->slot_dn) (void)hipFree(q);
@@ -601,6 +669,10 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
   for (auto q : c->slot_tdf) (void)hipFree(q);
   for (auto q : c->slot_tdfp) (void)hipFree(q);
   c->slot_rgb.clear(); c->slot_dn.clear(); c->slot_D.clear(); c->slot_tdf.clear(); c->slot_tdfp.clear();
+  for (auto q : c->bdc) (void)hipFree(q);
+  c->bdc.clear();
+  if (c->bhist) { (void)hipFree(c->bhist); c->bhist = nullptr; }
+  c->n_batch = 0;
   const size_t ne = (size_t)p->eye_h * p->eye_w, n = (size_t)p->warp_h * p->warp_w;
   for (int i = 0; i < n_slots; ++i) {
     float *a = nullptr, *b = nullptr, *d = nullptr, *t0 = nullptr, *t1 = nullptr;
@@ -612,6 +684,11 @@ VD3D_EXPORT int vd3d_shard_begin(vd3d_ctx* c, const vd3d_render_params* p, int n
   if (!c->etab) HIPCHK(hipMalloc((void**)&c->etab, (size_t)(VD_MAX_STEP + 1) * VD_ETAB * sizeof(float)));
   if (!c->crop_tab) HIPCHK(hipMalloc((void**)&c->crop_tab, (size_t)VD_MAX_STEP * 4 * sizeof(int)));
   HIPCHK(re_alloc(&c->slot_work, (size_t)n_slots));
+  c->slot_prev.assign((size_t)n_slots, nullptr);
+  for (int i = 0; i < n_slots; ++i) c->slot_prev[i] = c->slot_tdfp[i];
+  c->n_batch = n_slots < VD_MAX_BATCH ? n_slots : VD_MAX_BATCH;
+  HIPCHK(hipMalloc((void**)&c->bhist, (size_t)c->n_batch * c->hist_bytes));
+  for (int i = 0; i < c->n_batch; ++i) { float* q = nullptr; HIPCHK(hipMalloc((void**)&q, n * sizeof(float))); c->bdc.push_back(q); }
   c->n_slots = n_slots; c->slot_eh = p->eye_h; c->slot_ew = p->eye_w; c->slot_H = p->warp_h; c->slot_W = p->warp_w;
   return 0;
 }
@@ -637,20 +714,41 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
   struct StreamSwap {
     vd3d_ctx* c; hipStream_t saved;
     explicit StreamSwap(vd3d_ctx* ctx) : c(ctx), saved(ctx->stream) {}
-    ~StreamSwap() { c->stream = saved; }
+    ~StreamSwap() { c->stream = saved; c->cur_pix = -1; c->cur_excl = false; }
   } swap(c);
+  const int H = p->warp_h, W = p->warp_w;
+  int k = 0;
+  float* S = c->S; uint8_t* L = c->L; uint8_t* R = c->R;
   if (c->pix_overlap) {
     while ((int)c->slot_done.size() <= slot) {
       hipEvent_t e;
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       c->slot_done.push_back(e); c->slot_busy.push_back(0);
     }
+    if (c->n_pix > 1 && !blank_frame_bgr) {
+      k = (int)(c->pix_rr++ % (unsigned)c->n_pix);
+      if (c->x_H != H || c->x_W != W) {   // the extra streams' planes follow the warp size (rare: drain them first)
+        for (int j = 0; j < VD_MAX_PIX - 1; ++j) {
+          if (c->pix_x[j]) HIPCHK(hipStreamSynchronize(c->pix_x[j]));
+          HIPCHK(re_alloc(&c->S_x[j], (size_t)0)); HIPCHK(re_alloc(&c->L_x[j], (size_t)0)); HIPCHK(re_alloc(&c->R_x[j], (size_t)0));
+        }
+        c->x_H = H; c->x_W = W;
+      }
+      if (k > 0) {
+        const size_t n = (size_t)H * W;
+        if (!c->S_x[k - 1]) { HIPCHK(re_alloc(&c->S_x[k - 1], n)); HIPCHK(re_alloc(&c->L_x[k - 1], 3 * n)); HIPCHK(re_alloc(&c->R_x[k - 1], 3 * n)); }
+        S = c->S_x[k - 1]; L = c->L_x[k - 1]; R = c->R_x[k - 1];
+      }
+    }
+    hipStream_t sk = k == 0 ? c->pix_stream : c->pix_x[k - 1];
     HIPCHK(hipEventRecord(c->ev_chain, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->pix_stream, c->ev_chain, 0));
-    c->stream = c->pix_stream;
+    HIPCHK(hipStreamWaitEvent(sk, c->ev_chain, 0));
+    if (c->excl_set) HIPCHK(hipStreamWaitEvent(sk, c->ev_excl, 0));   // a pass that used the shared fallback planes is still the latest such user
+    c->stream = sk;
+    c->cur_pix = k; c->cur_excl = false;
+    if (blank_frame_bgr) { int rcx = pix_exclusive(c); if (rcx) return rcx; }   // blank_eye is a shared plane
   }
   hipStream_t s = c->stream;
-  const int H = p->warp_h, W = p->warp_w;
   const vd_dev_work* wk = &c->slot_work[slot];
   if (blank_frame_bgr) {
     StageTimer t(c, "finish");
@@ -661,25 +759,28 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
     HIPCHK(hipGetLastError());
   } else {
   { StageTimer t(c, "warp");
-    { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, c->S); }
+    { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
     bool fused;
-    { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], c->S, H, W, sp, c->L, c->R); }
+    { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], S, H, W, sp, L, R); }
     if (!fused) {
+      if ((rc = pix_exclusive(c))) return rc;
       if (sp.enable_feathering) {
-        vd_launch_e2(s, c->slot_D[slot], c->S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
+        vd_launch_e2(s, c->slot_D[slot], S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
         vd_launch_pool(s, c->e2L, c->e2R, H, W, sp.blur_ksize, c->bL, c->bR);
       }
-      vd_launch_warp(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->S, c->bL, c->bR, H, W, sp.enable_feathering ? 1 : 0, c->L, c->R);
+      vd_launch_warp(s, c->slot_rgb[slot], p->eye_h, p->eye_w, S, c->bL, c->bR, H, W, sp.enable_feathering ? 1 : 0, L, R);
     }
   }
   HIPCHK(hipGetLastError());
-  rc = run_finish(c, c->L, c->R, c->slot_dn[slot], p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr, wk);
+  rc = run_finish(c, L, R, c->slot_dn[slot], p->eye_h, p->eye_w, p, fc, 0.f, 0, 0, 0, out_bgr, wk);
   if (rc) return rc;
   }
   if (c->pix_overlap) {
-    HIPCHK(hipEventRecord(c->slot_done[slot], c->pix_stream));
-    HIPCHK(hipEventRecord(c->ev_pix_last, c->pix_stream));
-    c->slot_busy[slot] = 1; c->pix_pending = true;
+    HIPCHK(hipEventRecord(c->slot_done[slot], c->stream));
+    if (k == 0) { HIPCHK(hipEventRecord(c->ev_pix_last, c->stream)); c->pix_pending = true; }
+    else { HIPCHK(hipEventRecord(c->ev_pix_last_x[k - 1], c->stream)); c->pix_pending_x[k - 1] = true; }
+    if (c->cur_excl) { HIPCHK(hipEventRecord(c->ev_excl, c->stream)); c->excl_set = true; }
+    c->slot_busy[slot] = 1;
   }
   return 0;
 }
@@ -700,6 +801,7 @@ VD3D_EXPORT int vd3d_shard_pixels_blank(vd3d_ctx* c, int slot, const uint8_t* fr
 // complete after vd3d_sync, or, for consumers ordered on the context's stream, after vd3d_join_pixels.
 VD3D_EXPORT int vd3d_set_pixel_overlap(vd3d_ctx* c, int enable) {
   if (!c) return set_err(VD3D_E_INVALID, "NULL context");
+  if (enable < 0 || enable > VD_MAX_PIX) return set_err(VD3D_E_INVALID, "vd3d_set_pixel_overlap: 0 (off) or 1 .. %d pixel streams", VD_MAX_PIX);
   HIPCHK(hipSetDevice(c->device));
   int rc = join_pixels(c);
   if (rc) return rc;
@@ -707,8 +809,15 @@ VD3D_EXPORT int vd3d_set_pixel_overlap(vd3d_ctx* c, int enable) {
     HIPCHK(hipStreamCreateWithFlags(&c->pix_stream, hipStreamNonBlocking));   // stream priorities: measured, no effect either way
     HIPCHK(hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_pix_last, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_excl, hipEventDisableTiming));
   }
+  for (int k = 1; k < enable; ++k)
+    if (!c->pix_x[k - 1]) {
+      HIPCHK(hipStreamCreateWithFlags(&c->pix_x[k - 1], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->ev_pix_last_x[k - 1], hipEventDisableTiming));
+    }
   c->pix_overlap = enable != 0;
+  c->n_pix = enable > 1 ? enable : 1;
   return 0;
 }
 VD3D_EXPORT int vd3d_join_pixels(vd3d_ctx* c) {
@@ -742,30 +851,57 @@ static void shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args*
 // TemporalDepthFilter plane EMA, exact q.02 / q.98 of the filtered plane written to q_out_dev[0..1]; the filtered planes of this
 // frame and of the frame before it are kept in the slot.  The plane EMA carries over from the previous frame of the clip, wherever
 // it was rendered: vd3d_tdf_plane_import installs the plane the previous chunk's owner exported.
-VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params* p,
-                               int step_idx, int slot, float* q_out_dev) {
-  if (!c || !depth || !p || step_idx < 0 || step_idx >= VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
-  if (slot < 0 || slot >= c->n_slots) return set_err(VD3D_E_INVALID, "slot %d out of range (vd3d_shard_begin)", slot);
-  if (!frame_bgr || !q_out_dev) return set_err(VD3D_E_INVALID, "an own frame needs the frame and a destination for its quantiles");
+// Batched form: n consecutive own frames (slots slot0 .. slot0 + n - 1, step indices step_idx0 ..) in TWO launches -- K1 walks the
+// frames inside every workgroup (the EMA is a per-pixel recurrence), K2 runs the frames side by side; per-launch costs are paid once.
+static int shard2_p1_impl(vd3d_ctx* c, const uint8_t* const* frames_bgr, const void* const* depths, int depth_fmt, const vd3d_render_params* p,
+                          int step_idx0, int slot0, int n, float* q_out_dev) {
+  if (!c || !frames_bgr || !depths || !p || !q_out_dev || n < 1 || step_idx0 < 0 || step_idx0 + n > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+  if (slot0 < 0 || slot0 + n > c->n_slots) return set_err(VD3D_E_INVALID, "slots %d..%d out of range (vd3d_shard_begin)", slot0, slot0 + n - 1);
+  if (n > c->n_batch) return set_err(VD3D_E_INVALID, "batch of %d frames > %d", n, c->n_batch);
+  for (int j = 0; j < n; ++j) if (!frames_bgr[j] || !depths[j]) return set_err(VD3D_E_INVALID, "an own frame needs the frame and its depth plane");
   if (depth_fmt < 0 || depth_fmt > VD3D_DEPTH_GRAY_U8) return set_err(VD3D_E_INVALID, "bad depth_fmt %d", depth_fmt);
   if (p->auto_crop_black_bars && !c->crop_tab_set)
     return set_err(VD3D_E_INVALID, "auto_crop_black_bars in a sharded step: call vd3d_shard2_p0 on the own frames and vd3d_shard2_set_crops first");
   HIPCHK(hipSetDevice(c->device));
-  { int rcw = wait_slot(c, slot); if (rcw) return rcw; }
+  for (int j = 0; j < n; ++j) { int rcw = wait_slot(c, slot0 + j); if (rcw) return rcw; }
   hipStream_t s = c->stream;
   vd_stage_args a; vd3d_shift_params sp;
   shard2_args(c, p, &a, &sp);
-  a.shard_idx = step_idx;
   a.crop_tab = p->auto_crop_black_bars ? c->crop_tab : nullptr;
   const size_t ne = (size_t)p->eye_h * p->eye_w;
   StageTimer t(c, "p1_own");
-  a.shard = 3; a.q_out = q_out_dev;
-  HIPCHK(hipMemcpyAsync(c->slot_tdfp[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));
-  vd_launch_chain_eye(s, frame_bgr, depth, depth_fmt, *p, c->work, c->slot_rgb[slot], c->tdf, c->histA, c->histB, a);
-  HIPCHK(hipMemcpyAsync(c->slot_tdf[slot], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+  a.shard = 3;
+  // the plane before the first frame of the batch is the context's filter state; inside the batch every frame reads its predecessor's slot
+  HIPCHK(hipMemcpyAsync(c->slot_tdfp[slot0], c->tdf, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(&c->slot_work[slot0], 0, (size_t)n * sizeof(vd_dev_work), s));   // tickets, fixed-point sums, select jobs of the frames
+  HIPCHK(hipMemsetAsync(c->bhist, 0, (size_t)n * c->hist_bytes, s));
+  vd_batch b;
+  memset(&b, 0, sizeof b);
+  b.n = n; b.w_main = c->work;
+  const size_t nA = (size_t)VD_NJOBS * VD_NB_A;
+  for (int j = 0; j < n; ++j) {
+    vd_batch_frame& F = b.f[j];
+    const int slot = slot0 + j;
+    F.w = &c->slot_work[slot];
+    F.histA = c->bhist + (size_t)j * (c->hist_bytes / sizeof(uint32_t)); F.histB = F.histA + nA;
+    F.frame = frames_bgr[j]; F.depth = depths[j];
+    F.rgb_eye = c->slot_rgb[slot]; F.tdf = c->slot_tdf[slot];
+    F.tdf_prev = j == 0 ? c->slot_tdfp[slot0] : c->slot_tdf[slot - 1];
+    c->slot_prev[slot] = F.tdf_prev;
+    F.q_out = q_out_dev + 2 * j; F.shard_idx = step_idx0 + j;
+  }
+  vd_launch_chain_eye(s, b, depth_fmt, *p, a);
+  HIPCHK(hipMemcpyAsync(c->tdf, c->slot_tdf[slot0 + n - 1], ne * sizeof(float), hipMemcpyDeviceToDevice, s));   // the filter state after the batch
   HIPCHK(hipGetLastError());
   return 0;
+}
+VD3D_EXPORT int vd3d_shard2_p1(vd3d_ctx* c, const uint8_t* frame_bgr, const void* depth, int depth_fmt, const vd3d_render_params* p,
+                               int step_idx, int slot, float* q_out_dev) {
+  return shard2_p1_impl(c, &frame_bgr, &depth, depth_fmt, p, step_idx, slot, 1, q_out_dev);
+}
+VD3D_EXPORT int vd3d_shard2_p1_batch(vd3d_ctx* c, const uint8_t* const* frames_bgr, const void* const* depths, int depth_fmt,
+                                     const vd3d_render_params* p, int step_idx0, int slot0, int n, float* q_out_dev) {
+  return shard2_p1_impl(c, frames_bgr, depths, depth_fmt, p, step_idx0, slot0, n, q_out_dev);
 }
 // The chunk hand-off of the plane state (one eye-size float32 plane per chunk boundary): export copies
 // TemporalDepthFilter.prev_depth to a caller buffer (which the caller sends to the owner of the next chunk), import installs a
@@ -813,23 +949,51 @@ VD3D_EXPORT int vd3d_shard2_r1(vd3d_ctx* c, const float* q_all_dev, int n) {
 }
 // P3, own frames only: normalise, eye-res statistics, warp-res select chain, shaped depth plane, s1 -> measurements
 // m_out_dev[0..3] = {sum1, sum2, sum_mad, (s_norm | s1 << 32)}; planes and shape constants stay in the slot.
-VD3D_EXPORT int vd3d_shard2_p3(vd3d_ctx* c, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev) {
-  if (!c || !p || !m_out_dev || slot < 0 || slot >= c->n_slots || step_idx < 0 || step_idx >= VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+// Batched form: the frames are independent once R1 has replayed the normalisation table, so n frames go through K3a ... K6 side by side
+// (five launches per group of `VD3D_CHAIN_GROUP` frames; a group's curved-depth planes stay cache-resident between its launches).
+static int g_chain_group = -1;   // frames per group of the batched P3 (VD3D_CHAIN_GROUP / vd3d_debug_tune)
+static int shard2_p3_impl(vd3d_ctx* c, int slot0, int step_idx0, int n, const vd3d_render_params* p, long long* m_out_dev) {
+  if (!c || !p || !m_out_dev || n < 1 || slot0 < 0 || slot0 + n > c->n_slots || step_idx0 < 0 || step_idx0 + n > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
+  if (n > c->n_batch) return set_err(VD3D_E_INVALID, "batch of %d frames > %d", n, c->n_batch);
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   vd_stage_args a; vd3d_shift_params sp;
   shard2_args(c, p, &a, &sp);
   int rc;
   if ((rc = check_shift_params(&sp, p->warp_h, p->warp_w))) return rc;
-  a.shard = 3; a.shard_idx = step_idx; a.m_out = m_out_dev;
-  if ((rc = wait_slot(c, slot))) return rc;
+  a.shard = 3;
+  for (int j = 0; j < n; ++j) if ((rc = wait_slot(c, slot0 + j))) return rc;
+  int& group = g_chain_group;
+  if (group < 0) { const char* e = getenv("VD3D_CHAIN_GROUP"); group = e ? atoi(e) : VD_MAX_BATCH; }
+  if (group < 1) group = 1;
+  if (group > VD_MAX_BATCH) group = VD_MAX_BATCH;
   StageTimer t(c, "p3_own");
-  HIPCHK(hipMemsetAsync(c->histA, 0, c->hist_bytes, s));   // the select jobs of this frame start from empty histograms
-  vd_launch_chain_work(s, 1, c->slot_tdf[slot], c->slot_dn[slot], c->slot_tdfp[slot], p->eye_h, p->eye_w, p->warp_h, p->warp_w, c->work,
-                       (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, c->dc, c->slot_D[slot], c->histA, c->histB, a);
-  HIPCHK(hipMemcpyAsync(&c->slot_work[slot], c->work, sizeof(vd_dev_work), hipMemcpyDeviceToDevice, s));
+  const size_t nA = (size_t)VD_NJOBS * VD_NB_A;
+  for (int j0 = 0; j0 < n; j0 += group) {
+    const int g = n - j0 < group ? n - j0 : group;
+    HIPCHK(hipMemsetAsync(c->bhist, 0, (size_t)g * c->hist_bytes, s));   // the select jobs of these frames start from empty histograms
+    vd_batch b;
+    memset(&b, 0, sizeof b);
+    b.n = g; b.w_main = c->work;
+    for (int j = 0; j < g; ++j) {
+      vd_batch_frame& F = b.f[j];
+      const int slot = slot0 + j0 + j;
+      F.w = &c->slot_work[slot];
+      F.histA = c->bhist + (size_t)j * (c->hist_bytes / sizeof(uint32_t)); F.histB = F.histA + nA;
+      F.tdf = c->slot_tdf[slot]; F.dn = c->slot_dn[slot]; F.dn_prev = c->slot_prev[slot];
+      F.dc = c->bdc[j]; F.D = c->slot_D[slot];
+      F.m_out = m_out_dev + 4 * (j0 + j); F.shard_idx = step_idx0 + j0 + j;
+    }
+    vd_launch_chain_work(s, b, 1, p->eye_h, p->eye_w, p->warp_h, p->warp_w, (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, a);
+  }
   HIPCHK(hipGetLastError());
   return 0;
+}
+VD3D_EXPORT int vd3d_shard2_p3(vd3d_ctx* c, int slot, int step_idx, const vd3d_render_params* p, long long* m_out_dev) {
+  return shard2_p3_impl(c, slot, step_idx, 1, p, m_out_dev);
+}
+VD3D_EXPORT int vd3d_shard2_p3_batch(vd3d_ctx* c, int slot0, int step_idx0, int n, const vd3d_render_params* p, long long* m_out_dev) {
+  return shard2_p3_impl(c, slot0, step_idx0, n, p, m_out_dev);
 }
 // R2: replay every remaining tracker over the n frames of the step from the exchanged measurements m_all_dev[n][4] (frame order);
 // own_slot_host[t] = slot of frame t on this rank or -1.  Afterwards vd3d_shard_pixels(slot) renders the own frames.
@@ -1137,6 +1301,14 @@ VD3D_EXPORT int vd3d_torch_math(vd3d_ctx* c, int op, const float* x, float param
   HIPCHK(hipSetDevice(c->device));
   if (n) vd_launch_torch_math(c->stream, op, x, param, out, n);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// development probe (tools/probe_step.py): 0 = workgroup divisor of the batched chain kernels, 1 = frames per P3 group
+VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
+  if (which == 0) vd_set_batch_grid_div(value);
+  else if (which == 1) g_chain_group = value;
+  else return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
   return 0;
 }
 

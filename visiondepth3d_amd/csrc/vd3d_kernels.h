@@ -30,6 +30,35 @@ struct vd_stage_args {
   vd3d_shift_params shift;
 };
 
+// One frame of a (possibly batched) select-chain launch: every chain kernel takes a vd_batch by value and workgroup row blockIdx.y (K1: a
+// loop inside the workgroup, the plane EMA being a recurrence over the frames) works on frame f[blockIdx.y].  The sequential entry points pass
+// a batch of one (w = the context's control block, planes = the context's); the sharded step passes the own frames of the step, each with
+// its slot's control block, histograms and planes, so that the per-launch costs (launch gap, last-workgroup scan, scalar stage) are paid
+// once per step and the scans of the frames run side by side.
+#define VD_MAX_BATCH 16
+struct vd_batch_frame {
+  vd_dev_work* w;          // control block of this frame (tickets, select jobs, fixed-point sums, derived constants)
+  uint32_t* histA;         // [VD_NJOBS][VD_NB_A]
+  uint32_t* histB;         // [VD_NJOBS][VD_MAX_T][VD_NB_B] + coarse level
+  const uint8_t* frame;    // K1: source frame (u8 BGR) and depth plane
+  const void* depth;
+  float* rgb_eye;          // K1 writes [3][eh][ew]
+  float* tdf;              // filtered depth plane of THIS frame (K1 writes; K2 / K3a read)
+  const float* tdf_prev;   // filtered plane of the frame before (K1: the EMA's previous value; may alias tdf: in-place update)
+  float* dn;               // normalised eye-res plane (K3a writes; K3b / K4 read); bare pixel_shift_cuda: the caller's depth plane
+  const float* dn_prev;    // K3a MAD: previous normalised plane (sequential) / previous FILTERED plane (measure-replay sharding)
+  float* dc;               // curved depth, warp resolution (K3b writes; K4 / K5 read)
+  float* D;                // shaped depth, warp resolution (K5 writes; K6 and the pixel pass read)
+  float* q_out;            // shard == 3: {q_lo, q_hi} of this frame
+  long long* m_out;        // shard == 3: the frame's measurement record
+  int shard_idx, pad_;
+};
+struct vd_batch {
+  int n, pad_;
+  vd_dev_work* w_main;     // the context's control block: TemporalDepthFilter validity before frame 0; marked valid by K2's last workgroup
+  vd_batch_frame f[VD_MAX_BATCH];
+};
+
 #ifdef __HIPCC__
 #include "vd3d_dev.h"
 // enhance_curvature(.,0.08) + clamp (core/render_3d.py:599-601) of the bilinearly resized depth (:596)
@@ -58,7 +87,7 @@ VD_DEV float vd_depth_at(const void* depth, int fmt, size_t idx) {
   return vd_u8_unit((float)g);
 }
 VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt, const vd3d_render_params& p,
-                             int tdf_valid, float* __restrict__ rgb_eye, float* __restrict__ tdf, int ey, int ex) {
+                             int tdf_valid, float* __restrict__ rgb_eye, const float* tdf_prev, float* tdf, int ey, int ex) {
   const vd_tap ty = vd_interp_tap(p.crop_h, p.eye_h, ey), tx = vd_interp_tap(p.crop_w, p.eye_w, ex);
   const size_t i00 = (size_t)(ty.i0 + p.crop_y) * p.src_w + (tx.i0 + p.crop_x);
   const size_t i01 = (size_t)(ty.i0 + p.crop_y) * p.src_w + (tx.i1 + p.crop_x);
@@ -76,7 +105,7 @@ VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __re
   }
   const float cur = vd_bilerp(vd_depth_at(depth, fmt, i00), vd_depth_at(depth, fmt, i01), vd_depth_at(depth, fmt, i10),
                               vd_depth_at(depth, fmt, i11), tx.w0, tx.w1, ty.w0, ty.w1);
-  const float prev = tdf_valid ? tdf[o] : cur;
+  const float prev = tdf_valid ? tdf_prev[o] : cur;   // tdf_prev may be tdf itself (in-place) or the plane this thread wrote one frame ago
   const float nv = 0.5f * prev + (float)(1 - 0.5) * cur;
   tdf[o] = nv;
   return nv;
@@ -89,10 +118,11 @@ void vd_launch_shard2_r2(hipStream_t s, vd_dev_work* w, const long long* m_all, 
                          const uint8_t* blank_host_or_null, int n, vd_dev_work* slot_work, const vd_stage_args& a);
 void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, double target_ratio, uint32_t* rowflag, vd_dev_work* w,
                         int* crop_out = nullptr);   // crop_out: optional device int[4] copy of the rectangle (sharded steps)
-void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w,
-                         float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a);
-void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
-                          vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
+void vd_set_batch_grid_div(int v);   // tuning probe (vd3d_debug_tune)
+// K1 + K2 over the frames of b in frame order (one launch each)
+void vd_launch_chain_eye(hipStream_t s, const vd_batch& b, int fmt, const vd3d_render_params& p, const vd_stage_args& a);
+// K3a (have_eye) + K3b + K4 + K5 + K6 over the frames of b side by side (one launch each, grid.y = b.n)
+void vd_launch_chain_work(hipStream_t s, const vd_batch& b, int have_eye, int ih, int iw, int H, int W, float mid, float gamma,
                           const vd_stage_args& a);
 
 // ---- vd3d_select.hip

@@ -693,51 +693,69 @@ void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, doub
   hipLaunchKernelGGL(k_autocrop, dim3((h + 3) / 4), dim3(256), 0, s, frame, h, wd, target_ratio, rowflag, w, crop_out);
 }
 
-// K1: ingest (+ TemporalDepthFilter) + pass A of J0; last workgroup: scan A0
-__global__ __launch_bounds__(1024) void k_chain_ingest(const uint8_t* __restrict__ frame, const void* __restrict__ depth, int fmt,
-                                                       vd3d_render_params p, vd_dev_work* w, float* __restrict__ rgb_eye,
-                                                       float* __restrict__ tdf, uint32_t* histA, const uint32_t* histB,
-                                                       vd_stage_args a) {
+// per-frame view of the launch arguments: the record destinations and the step index of frame F
+VD_DEV vd_stage_args frame_args(vd_stage_args a, const vd_batch_frame& F, int stage) {
+  a.stage = stage; a.shard_idx = F.shard_idx; a.q_out = F.q_out; a.m_out = F.m_out;
+  return a;
+}
+
+// K1: ingest (+ TemporalDepthFilter) + pass A of J0; last workgroup: scan A0.  The plane EMA is a per-pixel recurrence over the frames,
+// so a batched launch walks its frames INSIDE the workgroup, in order: the thread that wrote pixel o of frame f - 1 is the one that
+// reads it as the previous value of frame f (same thread, same address: program order), every frame has its own LDS histogram round,
+// ticket and scan.
+__global__ __launch_bounds__(1024) void k_chain_ingest(vd_batch b, int fmt, vd3d_render_params p, vd_stage_args a) {
   __shared__ uint32_t h0[NBL];
   __shared__ uint32_t sm[128];
-  for (int b = threadIdx.x; b < NBL; b += 1024) h0[b] = 0;
-  __syncthreads();
   const long long n = (long long)p.eye_h * p.eye_w;
-  const int tdf_valid = w->st.tdf_valid;
-  if (p.auto_crop_black_bars) {   // per-frame rectangle: k_autocrop's (sequential) or the exchanged table of a sharded step
-    const int* cr = a.crop_tab ? a.crop_tab + 4 * a.shard_idx : w->acrop;
-    p.crop_x = cr[0]; p.crop_y = cr[1]; p.crop_w = cr[2]; p.crop_h = cr[3];
-  }
-  for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
-    const long long i = base + threadIdx.x;
-    float v = 0.f;
-    if (i < n) {
-      const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
-      v = vd_ingest_pixel(frame, depth, fmt, p, tdf_valid, rgb_eye, tdf, ey, ex);
+  const int valid0 = b.w_main->st.tdf_valid;
+  for (int fi = 0; fi < b.n; ++fi) {
+    const vd_batch_frame& F = b.f[fi];
+    for (int bb = threadIdx.x; bb < NBL; bb += 1024) h0[bb] = 0;
+    __syncthreads();
+    const int tdf_valid = fi == 0 ? valid0 : 1;
+    if (p.auto_crop_black_bars) {   // per-frame rectangle: k_autocrop's (sequential) or the exchanged table of a sharded step
+      const int* cr = a.crop_tab ? a.crop_tab + 4 * F.shard_idx : F.w->acrop;
+      p.crop_x = cr[0]; p.crop_y = cr[1]; p.crop_w = cr[2]; p.crop_h = cr[3];
     }
-    vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
+    const uint8_t* frame = F.frame; const void* depth = F.depth;
+    float* rgb_eye = F.rgb_eye; float* tdf = F.tdf; const float* tdf_prev = F.tdf_prev;
+    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+      const long long i = base + threadIdx.x;
+      float v = 0.f;
+      if (i < n) {
+        const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
+        v = vd_ingest_pixel(frame, depth, fmt, p, tdf_valid, rgb_eye, tdf_prev, tdf, ey, ex);
+      }
+      vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
+    }
+    __syncthreads();
+    lds_hist_flush(h0, F.histA + (size_t)VD_J_EYE_Q * VD_NB_A);
+    if (last_workgroup(&F.w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(F.w, F.histA, F.histB, frame_args(a, F, VD_ST_A0), sm);
+    __syncthreads();   // h0 / sm are reused by the next frame
   }
-  __syncthreads();
-  lds_hist_flush(h0, histA + (size_t)VD_J_EYE_Q * VD_NB_A);
-  if (last_workgroup(&w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A0; run_scalar_stage(w, histA, histB, a, sm); }
 }
 
 // K2: pass B of J0; last workgroup: scan B0 + DepthPercentileEMA
-__global__ __launch_bounds__(1024) void k_chain_b0(const float* __restrict__ tdf, long long n, vd_dev_work* w, const uint32_t* histA,
-                                                   uint32_t* histB, vd_stage_args a) {
+__global__ __launch_bounds__(1024) void k_chain_b0(vd_batch b, long long n, vd_stage_args a) {
   __shared__ uint32_t sm[128];
+  const vd_batch_frame& F = b.f[blockIdx.y];
+  vd_dev_work* w = F.w;
+  uint32_t* histB = F.histB;
   const vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
   const uint32_t nt = c->ntargets;
   uint32_t tp[VD_MAX_T];
   for (int t = 0; t < VD_MAX_T; ++t) tp[t] = c->tprefix[t];
-  vd_plane_walk<false>(tdf, n, (n & 3) == 0 ? 4 : 1, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, float d) {
+  vd_plane_walk<false>(F.tdf, n, (n & 3) == 0 ? 4 : 1, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, float d) {
     const unsigned bits = ok ? __float_as_uint(vd_clamp(d, 0.f, 1.f)) : 0u;
     bool hit = false; unsigned key = 0;
     for (uint32_t t = 0; t < nt; ++t) if (ok && (bits >> 16) == tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
     vd_hist_add_agg(histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, key, hit);
     vd_hist_add_agg(vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, key >> 8, hit);
   });
-  if (last_workgroup(&w->ticket[1], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B0; run_scalar_stage(w, histA, histB, a, sm); }
+  if (last_workgroup(&w->ticket[1], &sm[127], a.dbg) && !(a.dbg & 1)) {
+    run_scalar_stage(w, F.histA, histB, frame_args(a, F, VD_ST_B0), sm);
+    if (threadIdx.x == 0 && b.w_main != w) b.w_main->st.tdf_valid = 1;   // batched step: the filter state lives in the context's block
+  }
 }
 
 // curved depth at warp resolution straight from the filtered plane (normalisation recomputed per tap, so this
@@ -793,11 +811,13 @@ struct FWorkSrc {
 
 // K3a (eye resolution; skipped by the bare pixel_shift_cuda entry point): normalise the filtered plane -> dn_cur, the exact centre-crop sums,
 //     the MAD against the previous plane, pass A of J1.  No ticket: its scan runs with K3b's.
-__global__ __launch_bounds__(1024) void k_chain_norm(const float* __restrict__ tdf, float* __restrict__ dn_cur,
-                                                     const float* __restrict__ dn_prev, int eh, int ew, vd_dev_work* w, uint32_t* histA,
-                                                     vd_stage_args a) {
+__global__ __launch_bounds__(1024) void k_chain_norm(vd_batch b, int eh, int ew, vd_stage_args a) {
   __shared__ uint32_t h1[NBL];
   __shared__ long long part[3][16];
+  const vd_batch_frame& F = b.f[blockIdx.y];
+  const float* __restrict__ tdf = F.tdf; float* __restrict__ dn_cur = F.dn; const float* __restrict__ dn_prev = F.dn_prev;
+  vd_dev_work* w = F.w; uint32_t* histA = F.histA;
+  a.shard_idx = F.shard_idx;
   // normalisation scalars: stage B0's (device) or, in the measure/replay sharding, this frame's row of the replayed table;
   // there dn_prev is the PREVIOUS FILTERED plane and is normalised on the fly with the previous frame's row
   const bool m3 = a.shard == 3;
@@ -850,10 +870,12 @@ __global__ __launch_bounds__(1024) void k_chain_norm(const float* __restrict__ t
 // crop (a workgroup sees at most VD_K3_MAX_PX < 65536 pixels: the host sizes the grid), so a pixel costs ONE ds_add and the kernel needs
 // 65 KB of LDS instead of 130 KB -- two workgroups per CU.  With the exact 2:1 resize of Half-SBS four pixels share their taps (at4_21).
 #define VD_K3_MAX_PX 61440
-__global__ __launch_bounds__(1024) void k_chain_stage1(FWorkSrc f, float* __restrict__ dc, vd_dev_work* w, uint32_t* histA,
-                                                       const uint32_t* histB, vd_stage_args a) {
+__global__ __launch_bounds__(1024) void k_chain_stage1(vd_batch b, FWorkSrc f, vd_stage_args a) {
   __shared__ uint32_t hp[NBL];
   __shared__ uint32_t sm[128];
+  const vd_batch_frame& F = b.f[blockIdx.y];
+  f.src = F.dn;
+  float* __restrict__ dc = F.dc; vd_dev_work* w = F.w; uint32_t* histA = F.histA; const uint32_t* histB = F.histB;
   for (int b = threadIdx.x; b < NBL; b += 1024) hp[b] = 0;
   __syncthreads();
   const long long n = (long long)f.H * f.W;
@@ -894,7 +916,7 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(FWorkSrc f, float* __rest
     if (c & 0xffffu) atomicAdd(&histA[(size_t)VD_J_WORK_Q * VD_NB_A + b], c & 0xffffu);
     if (c >> 16) atomicAdd(&histA[(size_t)VD_J_WORK_S0 * VD_NB_A + b], c >> 16);
   }
-  if (last_workgroup(&w->ticket[2], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A1; run_scalar_stage(w, histA, histB, a, sm); }
+  if (last_workgroup(&w->ticket[2], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(w, histA, histB, frame_args(a, F, VD_ST_A1), sm);
 }
 
 struct vd_targets { uint32_t nt, tp[VD_MAX_T]; };
@@ -913,10 +935,11 @@ VD_DEV void hist_b_add(uint32_t* histB, int job, const vd_targets& c, float v, b
 }
 
 // K4: [eye] pass B of J1 on the stored dn plane | [work] pass B of J2 + J3 ; last workgroup: scan B1 + its scalar stage
-__global__ __launch_bounds__(1024) void k_chain_b1(const float* __restrict__ dn_cur, int eh, int ew, int n_eye_wg, FWorkSrc f,
-                                                   const float* __restrict__ dc, vd_dev_work* w, const uint32_t* histA,
-                                                   uint32_t* histB, vd_stage_args a) {
+__global__ __launch_bounds__(1024) void k_chain_b1(vd_batch b, int eh, int ew, int n_eye_wg, FWorkSrc f, vd_stage_args a) {
   __shared__ uint32_t sm[128];
+  const vd_batch_frame& F = b.f[blockIdx.y];
+  const float* __restrict__ dn_cur = F.dn; const float* __restrict__ dc = F.dc;
+  vd_dev_work* w = F.w; const uint32_t* histA = F.histA; uint32_t* histB = F.histB;
   const vd_targets t_eye = load_targets(&w->job[VD_J_EYE_SUBJ]), t_q = load_targets(&w->job[VD_J_WORK_Q]),
                    t_s0 = load_targets(&w->job[VD_J_WORK_S0]);
   if ((int)blockIdx.x < n_eye_wg) {
@@ -929,15 +952,16 @@ __global__ __launch_bounds__(1024) void k_chain_b1(const float* __restrict__ dn_
       hist_b_add(histB, VD_J_WORK_S0, t_s0, v, ok && vd_in_subject_crop(y, x, f.H, f.W, v));
     });
   }
-  if (last_workgroup(&w->ticket[3], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B1; run_scalar_stage(w, histA, histB, a, sm); }
+  if (last_workgroup(&w->ticket[3], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(w, histA, histB, frame_args(a, F, VD_ST_B1), sm);
 }
 
 // K5: shape_depth_for_pop -> D plane + pass A of J4 ; last workgroup: scan A2
-__global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* __restrict__ dc, vd_dev_work* w, float mid, float gamma,
-                                                      float* __restrict__ D,
-                                                      uint32_t* histA, const uint32_t* histB, vd_stage_args a) {
+__global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, float mid, float gamma, vd_stage_args a) {
   __shared__ uint32_t h1[NBL];
   __shared__ uint32_t sm[128];
+  const vd_batch_frame& F = b.f[blockIdx.y];
+  const float* __restrict__ dc = F.dc; float* __restrict__ D = F.D;
+  vd_dev_work* w = F.w; uint32_t* histA = F.histA; const uint32_t* histB = F.histB;
   for (int b = threadIdx.x; b < NBL; b += 1024) h1[b] = 0;
   __syncthreads();
   const long long n = (long long)f.H * f.W;
@@ -982,19 +1006,20 @@ __global__ __launch_bounds__(1024) void k_chain_shape(FWorkSrc f, const float* _
   }
   __syncthreads();
   lds_hist_flush(h1, histA + (size_t)VD_J_WORK_S1 * VD_NB_A);
-  if (last_workgroup(&w->ticket[4], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_A2; run_scalar_stage(w, histA, histB, a, sm); }
+  if (last_workgroup(&w->ticket[4], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(w, histA, histB, frame_args(a, F, VD_ST_A2), sm);
 }
 
 // K6: pass B of J4 on the D plane ; last workgroup: scan B2 + tracker recurrences
-__global__ __launch_bounds__(1024) void k_chain_b2(const float* __restrict__ D, int H, int W, vd_dev_work* w, const uint32_t* histA,
-                                                   uint32_t* histB, vd_stage_args a) {
+__global__ __launch_bounds__(1024) void k_chain_b2(vd_batch b, int H, int W, vd_stage_args a) {
   __shared__ uint32_t sm[128];
+  const vd_batch_frame& F = b.f[blockIdx.y];
+  const float* __restrict__ D = F.D; vd_dev_work* w = F.w; const uint32_t* histA = F.histA; uint32_t* histB = F.histB;
   const long long n = (long long)H * W;
   const vd_targets t_s1 = load_targets(&w->job[VD_J_WORK_S1]);
   vd_plane_walk<false>(D, n, W, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int y, int x, float v) {
     hist_b_add(histB, VD_J_WORK_S1, t_s1, v, ok && vd_in_subject_crop(y, x, H, W, v));
   });
-  if (last_workgroup(&w->ticket[5], &sm[127], a.dbg) && !(a.dbg & 1)) { a.stage = VD_ST_B2; run_scalar_stage(w, histA, histB, a, sm); }
+  if (last_workgroup(&w->ticket[5], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(w, histA, histB, frame_args(a, F, VD_ST_B2), sm);
 }
 
 static inline int chain_grid(long long n, int per_wg, int cap) {
@@ -1002,36 +1027,44 @@ static inline int chain_grid(long long n, int per_wg, int cap) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-void vd_launch_chain_eye(hipStream_t s, const uint8_t* frame, const void* depth, int fmt, const vd3d_render_params& p, vd_dev_work* w,
-                         float* rgb_eye, float* tdf, uint32_t* histA, uint32_t* histB, const vd_stage_args& a) {
-  const long long ne = (long long)p.eye_h * p.eye_w;
-  hipLaunchKernelGGL(k_chain_ingest, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, frame, depth, fmt, p, w, rgb_eye, tdf, histA,
-                     histB, a);
-  hipLaunchKernelGGL(k_chain_b0, dim3(chain_grid(ne, 4096, 256)), dim3(1024), 0, s, tdf, ne, w, histA, histB, a);
+// workgroups per frame of a batched launch: `per_wg` elements per workgroup, at most `cap`, shrunk when many frames share the launch
+// (the frames of a step fill the chip together: fewer, longer workgroups per frame = fewer LDS histogram flushes and tickets)
+static int g_batch_div = -1;
+void vd_set_batch_grid_div(int v) { g_batch_div = v < 1 ? 1 : v; }
+static inline int batch_grid(long long n, int per_wg, int cap, int nframes) {
+  if (g_batch_div < 0) { const char* e = getenv("VD3D_BATCH_GRID_DIV"); g_batch_div = e ? atoi(e) : 2; if (g_batch_div < 1) g_batch_div = 1; }
+  int g = chain_grid(n, per_wg, cap);
+  if (nframes >= 4) g = (g + g_batch_div - 1) / g_batch_div;
+  return g < 1 ? 1 : g;
 }
 
-// src = the filtered plane (render path: have_eye) or the caller's depth plane (bare pixel_shift_cuda)
-void vd_launch_chain_work(hipStream_t s, int have_eye, const float* src, float* dn_cur, const float* dn_prev, int ih, int iw, int H, int W,
-                          vd_dev_work* w, float mid, float gamma, float* dc, float* D, uint32_t* histA, uint32_t* histB,
+void vd_launch_chain_eye(hipStream_t s, const vd_batch& b, int fmt, const vd3d_render_params& p, const vd_stage_args& a) {
+  const long long ne = (long long)p.eye_h * p.eye_w;
+  hipLaunchKernelGGL(k_chain_ingest, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, b, fmt, p, a);
+  hipLaunchKernelGGL(k_chain_b0, dim3(batch_grid(ne, 4096, 256, b.n), b.n), dim3(1024), 0, s, b, ne, a);
+}
+
+// have_eye: the render path (F.tdf = filtered plane -> F.dn normalised); else the bare pixel_shift_cuda entry point (F.dn = the caller's plane)
+void vd_launch_chain_work(hipStream_t s, const vd_batch& b, int have_eye, int ih, int iw, int H, int W, float mid, float gamma,
                           const vd_stage_args& a) {
   FWorkSrc f;
-  f.src = src; f.ih = ih; f.iw = iw; f.H = H; f.W = W; f.norm = have_eye ? 1 : 0; f.collapse = 0; f.lo = 0.f; f.den = 1.f;
+  f.src = nullptr; f.ih = ih; f.iw = iw; f.H = H; f.W = W; f.norm = 0; f.collapse = 0; f.lo = 0.f; f.den = 1.f;
   f.scale_h = (float)ih / (float)H; f.scale_w = (float)iw / (float)W;
   f.step_x = W > 1 ? (1.f - (-1.f)) / (float)(W - 1) : 0.f; f.step_y = H > 1 ? (1.f - (-1.f)) / (float)(H - 1) : 0.f;
   const long long ne = (long long)ih * iw, n = (long long)H * W;
-  const int eye_wg = have_eye ? chain_grid(ne, 4096, 256) : 0;
+  const unsigned nf = (unsigned)b.n;
+  const int eye_wg = have_eye ? batch_grid(ne, 4096, 256, b.n) : 0;
   // K3b: 65 KB of LDS -> two workgroups per CU; every workgroup walks <= VD_K3_MAX_PX pixels (its packed histogram counts in 16 bits)
-  int work_wg = chain_grid(n, 16384, 512);
+  int work_wg = batch_grid(n, 16384, 512, b.n);
   { const long long need = (n + VD_K3_MAX_PX - 4096 - 1) / (VD_K3_MAX_PX - 4096); if (work_wg < need) work_wg = (int)need; }
-  const int eye_wg_b = have_eye ? chain_grid(ne, 4096, 128) : 0;
-  const int work_wg_b = chain_grid(n, 4096, 512);   // K4: streams the stored curved-depth plane (one release fence per workgroup)
+  const int eye_wg_b = have_eye ? batch_grid(ne, 4096, 128, b.n) : 0;
+  const int work_wg_b = batch_grid(n, 4096, 512, b.n);   // K4: streams the stored curved-depth plane (one release fence per workgroup)
   // K3a normalises the eye-res plane (its own launch: K3b then samples plain values -- no per-tap division, taps shared by four pixels)
-  if (have_eye) hipLaunchKernelGGL(k_chain_norm, dim3(eye_wg), dim3(1024), 0, s, src, dn_cur, dn_prev, ih, iw, w, histA, a);
-  f.src = have_eye ? dn_cur : src; f.norm = 0;
-  hipLaunchKernelGGL(k_chain_stage1, dim3(work_wg), dim3(1024), 0, s, f, dc, w, histA, histB, a);
-  hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b), dim3(1024), 0, s, dn_cur, ih, iw, eye_wg_b, f, dc, w, histA, histB, a);
-  hipLaunchKernelGGL(k_chain_shape, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, f, dc, w, mid, gamma, D, histA, histB, a);
-  hipLaunchKernelGGL(k_chain_b2, dim3(chain_grid(n, 4096, 512)), dim3(1024), 0, s, D, H, W, w, histA, histB, a);
+  if (have_eye) hipLaunchKernelGGL(k_chain_norm, dim3(eye_wg, nf), dim3(1024), 0, s, b, ih, iw, a);
+  hipLaunchKernelGGL(k_chain_stage1, dim3(work_wg, nf), dim3(1024), 0, s, b, f, a);
+  hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b, nf), dim3(1024), 0, s, b, ih, iw, eye_wg_b, f, a);
+  hipLaunchKernelGGL(k_chain_shape, dim3(batch_grid(n, 4096, 512, b.n), nf), dim3(1024), 0, s, b, f, mid, gamma, a);
+  hipLaunchKernelGGL(k_chain_b2, dim3(batch_grid(n, 4096, 512, b.n), nf), dim3(1024), 0, s, b, H, W, a);
 }
 
 struct vd_own_slots { short v[VD_MAX_STEP]; unsigned char blank[VD_MAX_STEP]; };  // by value in the kernel arguments (1.5 KB): no staging copy

@@ -110,6 +110,16 @@ class Renderer:
         ptr = self._L.vd3d_ctx_pixel_stream(self._ctx)
         return torch.cuda.ExternalStream(int(ptr), device=self.device) if ptr else None
 
+    @property
+    def pixel_streams(self):
+        """Every pixel stream created so far (``set_pixel_overlap(n)``), as torch stream objects."""
+        out = []
+        for k in range(4):
+            ptr = self._L.vd3d_ctx_pixel_stream_k(self._ctx, k)
+            if ptr:
+                out.append(torch.cuda.ExternalStream(int(ptr), device=self.device))
+        return out
+
     def close(self):
         if self._ctx:
             self._L.vd3d_ctx_destroy(self._ctx)
@@ -235,6 +245,30 @@ class Renderer:
         _lib.check(self._L.vd3d_shard2_p1(self._ctx, _ptr(f), _ptr(d), self._depth_fmt(d), C.byref(params), int(step_idx), int(slot),
                                           _ptr(q_out)))
 
+    MAX_BATCH = 16   # VD_MAX_BATCH of libvd3d_hip.so
+
+    def shard2_p1_batch(self, frames, depths, params: RenderParams, step_idx0: int, slot0: int, q_out: torch.Tensor):
+        """P1 of n consecutive own frames in two launches (``vd3d_shard2_p1_batch``); ``q_out``: float32 [n, 2] on the device."""
+        n = len(frames)
+        fs = [f.to(self.device).contiguous() for f in frames]
+        ds = [d.to(self.device).contiguous() for d in depths]
+        fmt = self._depth_fmt(ds[0])
+        if any(self._depth_fmt(d) != fmt for d in ds):
+            raise AssertionError("the depth planes of one batch share one format")
+        if not q_out.is_contiguous() or q_out.numel() < 2 * n:
+            raise AssertionError("q_out: contiguous float32 [n, 2]")
+        self._enter(q_out, *fs, *ds)
+        fp = (C.c_void_p * n)(*[f.data_ptr() for f in fs])
+        dp = (C.c_void_p * n)(*[d.data_ptr() for d in ds])
+        _lib.check(self._L.vd3d_shard2_p1_batch(self._ctx, fp, dp, fmt, C.byref(params), int(step_idx0), int(slot0), n, _ptr(q_out)))
+
+    def shard2_p3_batch(self, slot0: int, step_idx0: int, n: int, params: RenderParams, m_out: torch.Tensor):
+        """P3 of n consecutive own frames side by side (``vd3d_shard2_p3_batch``); ``m_out``: int64 [n, 4] on the device."""
+        if not m_out.is_contiguous() or m_out.numel() < 4 * n:
+            raise AssertionError("m_out: contiguous int64 [n, 4]")
+        self._enter(m_out)
+        _lib.check(self._L.vd3d_shard2_p3_batch(self._ctx, int(slot0), int(step_idx0), int(n), C.byref(params), _ptr(m_out)))
+
     def tdf_plane_export(self, params: RenderParams, out: torch.Tensor | None = None) -> torch.Tensor:
         """TemporalDepthFilter.prev_depth -> float32 [eye_h, eye_w] tensor (the chunk-boundary hand-off of a sharded clip)."""
         if out is None:
@@ -268,7 +302,7 @@ class Renderer:
     def set_pixel_overlap(self, on: bool):
         """Run ``shard_pixels`` on a second stream of the context, behind the measurement chain of the next step
         (``vd3d_set_pixel_overlap``).  Outputs are complete after ``sync()`` / ``join_pixels()``."""
-        _lib.check(self._L.vd3d_set_pixel_overlap(self._ctx, 1 if on else 0))
+        _lib.check(self._L.vd3d_set_pixel_overlap(self._ctx, int(on)))   # True = one pixel stream, 2 .. 4 = that many (round-robin over frames)
 
     def join_pixels(self):
         """Order the context's stream after every outstanding overlapped pixel pass."""
@@ -293,6 +327,9 @@ class Renderer:
             return out
         self._enter(out)
         _lib.check(self._L.vd3d_shard_pixels(self._ctx, int(slot), C.byref(params), _ptr(out)))
+        if self._private and self._auto_order:
+            for ps in self.pixel_streams:   # the pass may run on any of the pixel streams: `out` must outlive all of them
+                out.record_stream(ps)
         return out
 
     def depth_handoff(self, pred: torch.Tensor, H: int, W: int, invert: bool = False, out: torch.Tensor | None = None):

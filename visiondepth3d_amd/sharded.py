@@ -63,6 +63,20 @@ class HipChunkBackend:
     def p1(self, frame, depth, step_idx, slot, q_out):
         self.r.shard2_p1(frame, depth, self.p, step_idx, slot, q_out)
 
+    MAX_BATCH = 16   # frames per batched launch (VD_MAX_BATCH)
+
+    def p1_batch(self, frames, depths, step_idx0, slot0, q_out):
+        """P1 of consecutive own frames: two launches per <= 16 frames instead of two per frame (the plane EMA walks the frames inside
+        the ingest kernel; the quantile passes of the frames run side by side)."""
+        for j0 in range(0, len(frames), self.MAX_BATCH):
+            j1 = min(len(frames), j0 + self.MAX_BATCH)
+            self.r.shard2_p1_batch(frames[j0:j1], depths[j0:j1], self.p, step_idx0 + j0, slot0 + j0, q_out[j0:j1])
+
+    def p3_batch(self, slot0, step_idx0, n, m_out):
+        for j0 in range(0, n, self.MAX_BATCH):
+            j1 = min(n, j0 + self.MAX_BATCH)
+            self.r.shard2_p3_batch(slot0 + j0, step_idx0 + j0, j1 - j0, self.p, m_out[j0:j1])
+
     def r1(self, q_all):
         self.r.shard2_r1(q_all)
 
@@ -196,14 +210,22 @@ class ChunkSharder:
             for j in own:
                 self.b.p0(frames_local[j], self.crops[g * self.B + j])
             self.b.set_crops(self.crops[:self._nv(n_valid)])
-        for j in own:
-            self.b.p1(frames_local[j], depths_local[j], g * self.B + j, self.slot_base + j, self.q_local[j])
+        if hasattr(self.b, "p1_batch") and len(own):   # own frames are consecutive: batched launches
+            self.b.p1_batch([frames_local[j] for j in own], [depths_local[j] for j in own], g * self.B + own[0], self.slot_base + own[0],
+                            self.q_local)
+        else:
+            for j in own:
+                self.b.p1(frames_local[j], depths_local[j], g * self.B + j, self.slot_base + j, self.q_local[j])
 
     def r1(self, q_all, n_valid=None):
         self.b.r1(q_all[:self._nv(n_valid)])
 
     def p3(self, n_valid=None):
-        for j in self.own_range(n_valid):
+        own = self.own_range(n_valid)
+        if hasattr(self.b, "p3_batch") and len(own):
+            self.b.p3_batch(self.slot_base + own[0], self.rank * self.B + own[0], len(own), self.m_local)
+            return
+        for j in own:
             self.b.p3(self.slot_base + j, self.rank * self.B + j, self.m_local[j])
 
     def r2(self, m_all, n_valid=None, blank=None):
