@@ -419,6 +419,8 @@ long vd3d_stage_calls(vd3d_ctx* ctx, const char* stage);
 /* host-only (works without a GPU): the float32 Gaussian weights the DOF kernels receive for one blur level -- torchvision's _get_gaussian_kernel1d as torch
  * evaluates it on the CPU, incl. torch.sum's summation order (core/render_3d.py:798-806); odd k <= 31.  Tests compare it with torch and the oracle. */
 int vd3d_debug_gaussian_kernel1d(int k, float sigma, float* out_host);
+/* host-only: the library's restatement of torch.exp on a float32 CPU tensor (oneMKL vsExp, not the rounded exponential) that the DOF weights use */
+int vd3d_debug_exp_torch(const float* x_host, float* out_host, long long n);
 /* internal planes of the last call (device pointers owned by ctx; tests only) */
 int vd3d_debug_planes(vd3d_ctx* ctx, float** D, float** S, uint8_t** L, uint8_t** R, float** rgb_eye, float** dn_cur);
 

@@ -115,7 +115,7 @@ def torch_math(op, x, param=0.0):
     sqrt_torch of vd3d_oracle.c), elementwise."""
     x, px = _f(x)
     out = np.empty_like(x)
-    lib().vo_torch_math(C.c_int({"pow": 0, "sigmoid": 1, "sqrt": 2}[op]), px, C.c_float(np.float32(param)), out.ctypes.data_as(_f32p),
+    lib().vo_torch_math(C.c_int({"pow": 0, "sigmoid": 1, "sqrt": 2, "exp": 3}[op]), px, C.c_float(np.float32(param)), out.ctypes.data_as(_f32p),
                         C.c_longlong(x.size))
     return out
 

@@ -440,16 +440,54 @@ static float host_sum_aten(const float* v, int n) {
   for (int l = 0; l < 8; ++l) fin += acc[0][l];
   return fin;
 }
+// torch.exp of a float32 on the CPU = oneMKL VML vsExp (high accuracy, AVX-512 path): a table-driven float32 routine, NOT the rounded
+// exponential (1.4 % of the inputs of [-8, 0] are an ULP off).  Host-side restatement for the DOF weights (the oracle holds an independent one
+// with literal tables; tests/test_aten_restatements.py compares both with torch on every blur level): 2^(j/32) as a float32 head and a
+// relative float32 tail, both derived here from their definitions in extended precision; range reduction t = floor(32 x log2 e) / 32 (the
+// library's fused multiply-add rounds toward zero onto a positive shifter), r = x - t ln 2 in two fused steps, a degree-3 polynomial tail.
+static float host_exp_torch(float x) {
+  if (!(fabsf(x) < 87.0f)) return (float)exp((double)x);   // the library's special-case path is not restated (never reached: x in [-8.5, 0])
+  static float th[32], tl[32];
+  static bool init = false;
+  if (!init) {
+    for (int j = 0; j < 32; ++j) {
+      const long double v = exp2l((long double)j / 32.0L);
+      th[j] = (float)v;
+      tl[j] = (float)((v - (long double)th[j]) / (long double)th[j]);
+    }
+    init = true;
+  }
+  union { uint32_t u; float f; } c;
+  c.u = 0x3fb8aa3bu; const float l2e = c.f;            // log2(e) as the library rounds it
+  c.u = 0x3f317218u; const float ln2_hi = c.f;         // ln 2 = ln2_hi - 1.9046542e-09
+  c.u = 0x3e2aabf3u; const float c3 = c.f;
+  c.u = 0x3f0000f6u; const float c2 = c.f;
+  const double t = floor((double)x * (double)l2e * 32.0) * (1.0 / 32.0);
+  const long long m32 = (long long)floor((double)x * (double)l2e * 32.0);
+  const int j = (int)(m32 & 31);                        // two's complement: the non-negative residue
+  const float n = (float)t;
+  float r = fmaf(n, -ln2_hi, x);
+  r = fmaf(n, 1.9046542e-09f, r);
+  const float q = fmaf(fmaf(r, c3, c2), r * r, tl[j] + r);
+  const float sc = ldexpf(th[j], (int)floor(t));
+  return fmaf(q, sc, sc);
+}
 // torchvision _get_gaussian_kernel1d in float32 (core/render_3d.py:798-806): k <= 2 DF_RMAX_HOST + 1 taps into out
 static void host_gaussian_kernel1d(int k, float sigma, float* out) {
   const float half = (float)((k - 1) * 0.5);
   for (int i = 0; i < k; ++i) {
     float x = linspace_host(-half, half, k, i);
     float t = x / sigma;
-    out[i] = (float)exp((double)(-0.5f * (t * t)));
+    out[i] = host_exp_torch(-0.5f * (t * t));
   }
   const float sum = host_sum_aten(out, k);
   for (int i = 0; i < k; ++i) out[i] = out[i] / sum;
+}
+// host-only: the product's restatement of torch.exp (MKL vsExp) on n floats -- compared with torch and with the oracle's on the CPU
+VD3D_EXPORT int vd3d_debug_exp_torch(const float* x_host, float* out_host, long long n) {
+  if (n < 0 || (n > 0 && (!x_host || !out_host))) return set_err(VD3D_E_INVALID, "vd3d_debug_exp_torch: host pointers");
+  for (long long i = 0; i < n; ++i) out_host[i] = host_exp_torch(x_host[i]);
+  return 0;
 }
 VD3D_EXPORT int vd3d_debug_gaussian_kernel1d(int k, float sigma, float* out_host) {   // host-only (no GPU needed): the weights the DOF kernels are given
   if (k < 1 || k > 2 * DF_RMAX_HOST + 1 || !(k & 1) || !out_host || !(sigma > 0.f)) return set_err(VD3D_E_INVALID, "gaussian_kernel1d: odd k <= %d, sigma > 0", 2 * DF_RMAX_HOST + 1);
@@ -846,6 +884,7 @@ static void shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args*
   a->have_eye = 1; a->W = p->warp_w; a->H = p->warp_h; a->n_eye = (long long)p->eye_h * p->eye_w;
   a->n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a->ipd_factor = p->ipd_factor; a->shift = *sp; a->etab = c->etab;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VD3D_DBG"); dbg = e ? atoi(e) : 0; } a->dbg = dbg; }   // timing probes only (vd3d_kernels.h)
 }
 // P1, for every OWN frame of the step in frame order (a rank owns a contiguous chunk of the step): ingest (RGB kept in the slot),
 // TemporalDepthFilter plane EMA, exact q.02 / q.98 of the filtered plane written to q_out_dev[0..1]; the filtered planes of this

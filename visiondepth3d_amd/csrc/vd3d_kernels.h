@@ -25,7 +25,8 @@ struct vd_stage_args {
   const int* crop_tab; // shard 3/4 with auto_crop_black_bars: per-frame crop rectangles {x, y, w, h} of the step (device), else NULL
   const float* etab;   // shard == 3: per-frame normalisation table of the step, VD_ETAB floats per entry:
                        // entry t = {ema_lo, ema_den, collapse, have_prev, ema_hi} in force BEFORE frame t
-  int dbg;             // development probes: bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket + fences
+  int dbg;             // development probes (timing only, results are garbage): bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket +
+                       // fences, bit2 = skip the LDS -> global histogram flush, bit3 = skip the LDS histogram adds
   int blank;           // skip_blank_frames hit (core/render_3d.py:1278-1281): no ipd scaling, no FloatingWindowTracker / focal update
   vd3d_shift_params shift;
 };

@@ -726,10 +726,10 @@ __global__ __launch_bounds__(1024) void k_chain_ingest(vd_batch b, int fmt, vd3d
         const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
         v = vd_ingest_pixel(frame, depth, fmt, p, tdf_valid, rgb_eye, tdf_prev, tdf, ey, ex);
       }
-      vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n);
+      vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n && !(a.dbg & 8));
     }
     __syncthreads();
-    lds_hist_flush(h0, F.histA + (size_t)VD_J_EYE_Q * VD_NB_A);
+    if (!(a.dbg & 4)) lds_hist_flush(h0, F.histA + (size_t)VD_J_EYE_Q * VD_NB_A);
     if (last_workgroup(&F.w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(F.w, F.histA, F.histB, frame_args(a, F, VD_ST_A0), sm);
     __syncthreads();   // h0 / sm are reused by the next frame
   }
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(1024) void k_chain_norm(vd_batch b, int eh, int ew,
       }
       in_crop = vd_in_subject_crop(y, x, eh, ew, v);
     }
-    vd_lds_hist_add(h1, key_a(v), in_crop);
+    vd_lds_hist_add(h1, key_a(v), in_crop && !(a.dbg & 8));
   }
   s1 = vd_wave_sum_ll(s1); s2 = vd_wave_sum_ll(s2); sd = vd_wave_sum_ll(sd);
   if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s1; part[1][threadIdx.x >> 6] = s2; part[2][threadIdx.x >> 6] = sd; }
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(1024) void k_chain_norm(vd_batch b, int eh, int ew,
     long long* dst = threadIdx.x == 0 ? &w->sum1 : (threadIdx.x == 1 ? &w->sum2 : &w->sum_mad);
     if (v) atomicAdd((unsigned long long*)dst, (unsigned long long)v);
   }
-  lds_hist_flush(h1, histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A);
+  if (!(a.dbg & 4)) lds_hist_flush(h1, histA + (size_t)VD_J_EYE_SUBJ * VD_NB_A);
 }
 
 // K3b (warp resolution): curved depth of the NORMALISED plane -> dc, pass A of J2 (all pixels) + J3 (subject crop); last workgroup: scan A1.
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(vd_batch b, FWorkSrc f, v
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (ok) atomicAdd(&hp[key_a(v[q])], vd_in_subject_crop(y, x + q, f.H, f.W, v[q]) ? 0x10001u : 1u);
+        if (ok && !(a.dbg & 8)) atomicAdd(&hp[key_a(v[q])], vd_in_subject_crop(y, x + q, f.H, f.W, v[q]) ? 0x10001u : 1u);
     }
   } else {
     for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
@@ -911,6 +911,7 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(vd_batch b, FWorkSrc f, v
     }
   }
   __syncthreads();
+  if (!(a.dbg & 4))
   for (int b = threadIdx.x; b < NBL; b += 1024) {
     const uint32_t c = hp[b];
     if (c & 0xffffu) atomicAdd(&histA[(size_t)VD_J_WORK_Q * VD_NB_A + b], c & 0xffffu);
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, fl
         y = (int)(i / (unsigned)f.W); x = (int)(i - (unsigned)y * (unsigned)f.W);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) vd_lds_hist_add(h1, key_a(v[q]), ok && vd_in_subject_crop(y, x + q, f.H, f.W, v[q]));
+      for (int q = 0; q < 4; ++q) vd_lds_hist_add(h1, key_a(v[q]), ok && !(a.dbg & 8) && vd_in_subject_crop(y, x + q, f.H, f.W, v[q]));
     }
   } else {
     for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
@@ -1005,7 +1006,7 @@ __global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, fl
     }
   }
   __syncthreads();
-  lds_hist_flush(h1, histA + (size_t)VD_J_WORK_S1 * VD_NB_A);
+  if (!(a.dbg & 4)) lds_hist_flush(h1, histA + (size_t)VD_J_WORK_S1 * VD_NB_A);
   if (last_workgroup(&w->ticket[4], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(w, histA, histB, frame_args(a, F, VD_ST_A2), sm);
 }
 
