@@ -265,8 +265,18 @@ LOOP_CASES = {
 }
 
 
-def run_loop(name, reset=True):
-    sh, sw, n, kw = LOOP_CASES[name]
+# DOF strengths beyond the defaults (round 4): 0.7 / 2.1 / 4.2 are strengths where MKL's vsExp is NOT the rounded exponential on
+# some (2.1, 4.2: on all four) blur levels; 3.0 and 5.0 (the GUI slider's maximum, 21-tap Gaussian) run Gaussians beyond the fused kernel's 9 taps
+_DOF_COMMON = dict(output_format="Half-SBS", output_height=108, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
+                   feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
+LOOP_CASES_DOF = {f"half_sbs_dof{str(s).replace('.', 'p')}": (108, 192, 3, dict(_DOF_COMMON, dof_strength=s)) for s in (0.7, 2.1, 3.0, 4.2, 5.0)}
+LOOP_CASES_DOF["anaglyph_dof3p0"] = (120, 160, 2, dict(_DOF_COMMON, output_format="Red-Cyan Anaglyph", output_height=90, dof_strength=3.0))
+LOOP_CASES_DOF["full_sbs_dof2p6"] = (90, 160, 2, dict(_DOF_COMMON, output_format="Full-SBS", output_height=90, dof_strength=2.6,
+                                                      preserve_original_aspect=True, original_video_width=160, original_video_height=90))
+
+
+def run_loop(name, reset=True, cases=None):
+    sh, sw, n, kw = (cases or LOOP_CASES)[name]
     frames, depths = synth.synth_clip(n, sh, sw)
     ref_stubs._Clip.clips["in.mp4"] = frames
     ref_stubs._Clip.clips["depth.mp4"] = [synth.depth_to_u8_bgr(d) for d in depths]
@@ -296,6 +306,16 @@ def gen_loops():
     out["half_sbs_cli__second_render_frames"] = np.stack(w2)
     out["cases_json"] = np.frombuffer(json.dumps(LOOP_CASES).encode(), dtype=np.uint8)
     save("render_loop.npz", **out)
+
+
+def gen_dof():
+    out = {}
+    for name in LOOP_CASES_DOF:
+        written = run_loop(name, cases=LOOP_CASES_DOF)
+        out[f"{name}__frames"] = np.stack(written)
+        print(f"  dof loop {name}: {len(written)} frames of {written[0].shape}")
+    out["cases_json"] = np.frombuffer(json.dumps(LOOP_CASES_DOF).encode(), dtype=np.uint8)
+    save("dof_levels.npz", **out)
 
 
 # ------------------------------------------------------------------------------------------
@@ -624,3 +644,5 @@ if __name__ == "__main__":
         gen_helpers()
     if "loops" in which:
         gen_loops()
+    if "dof" in which:
+        gen_dof()

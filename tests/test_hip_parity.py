@@ -207,6 +207,18 @@ def test_render_loop_bit_exact_vs_oracle_and_golden(R, oracle):
         assert_parity(name, *u8_diff_stats(got, g[f"{name}__frames"]))
 
 
+def test_dof_strength_fixtures_bit_exact(R, oracle):
+    """DOF strengths 0.7 / 2.1 / 2.6 / 3.0 / 4.2 / 5.0 (tests/golden/dof_levels.npz, generated by the live reference): levels whose vsExp value is
+    not the rounded exponential, Gaussians of up to 21 taps (beyond the fused finishing kernel's 9: the unfused DOF kernels), anaglyph."""
+    g = load_golden("dof_levels.npz")
+    for name, (sh, sw, n, kw) in golden_json(g, "cases_json").items():
+        R.reset_state()
+        got, _, _ = _run_loop_hip(R, sh, sw, n, kw)
+        exp, _, _ = _run_loop_oracle(oracle, sh, sw, n, kw)
+        assert np.array_equal(got, exp), (name, u8_diff_stats(got, exp))
+        assert np.array_equal(got, g[f"{name}__frames"]), (name, u8_diff_stats(got, g[f"{name}__frames"]))
+
+
 def test_singleton_state_leak_and_export_import(R, oracle):
     g = load_golden("render_loop.npz")
     sh, sw, n, kw = golden_json(g, "cases_json")["half_sbs_cli"]
@@ -418,10 +430,11 @@ def test_full_size_properties(R, oracle, hw):
     R.reset_state(); R.new_clip()
     z = R.render_frame(ft, dt, p0)
     assert torch.equal(z[:, : sw // 2], z[:, sw // 2:])
-    if sh == 1080:  # the oracle takes a few seconds at 1080p: one full-size bit-exact frame
-        ro = oracle.RenderOracle(p); ro.new_clip()
-        exp = ro.render(f, d, 0)
-        assert np.array_equal(a.cpu().numpy(), exp), u8_diff_stats(a.cpu().numpy(), exp)
+    # one full-size bit-exact frame against the oracle with the configuration's OWN input type, float32 precomputed depth (BASELINE
+    # configs[2] at 3840x2160: ~6 s of oracle time)
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    exp = ro.render(f, d, 0)
+    assert np.array_equal(a.cpu().numpy(), exp), u8_diff_stats(a.cpu().numpy(), exp)
 
 
 # ------------------------------------------------------------------------------------------ B2 attribution on the GPU
