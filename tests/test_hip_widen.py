@@ -274,6 +274,30 @@ def test_blank_frame_loops(R, oracle):
         assert R.export_state().as_dict() == ro.state.as_dict(), name
 
 
+def test_render_clip_batched_steps_equal_frame_by_frame(R):
+    """render_pairs in steps of `batch` frames (the default of the file-to-file loop: sharded.ChunkSharder at world 1, two slot sets, two pixel
+    streams) == one vd3d_render_frame per pair (batch=1): 11 frames in steps of 3 (a partial last step), a blank frame, float32 depth and the
+    uint8 depth-video format; the renderer is back in sequential mode afterwards."""
+    from visiondepth3d_amd.render_3d import render_clip
+    sh, sw, n = 216, 384, 12
+    kw = dict(output_format="Half-SBS", output_height=sh, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
+              feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True, skip_blank_frames=True)
+    frames, depths = synth.synth_clip(n, sh, sw)
+    for dl in (depths, [synth.depth_to_u8_bgr(d) for d in depths]):
+        R.reset_state()
+        seq = list(render_clip(frames, dl, renderer=R, blank_frames=[4], batch=1, **kw))
+        st_seq = R.export_state().as_dict()
+        for b in (3, 8):
+            R.reset_state()
+            got = list(render_clip(frames, dl, renderer=R, blank_frames=[4], batch=b, **kw))
+            assert len(got) == len(seq) == n - 1
+            assert all(np.array_equal(a, c) for a, c in zip(got, seq)), b
+            assert R.export_state().as_dict() == st_seq
+    f, d = T(frames[0]), T(depths[0])
+    p = render_kwargs_to_params(sw, sh, **{k: v for k, v in kw.items()})
+    R.render_frame(f, d, p)   # sequential entry point still works after the batched loops
+
+
 def test_render_clip_blank_list(R, oracle):
     """render_clip(skip_blank_frames=True, blank_frames=[...]) == the per-frame calls; without the flag the list is ignored."""
     from visiondepth3d_amd.render_3d import render_clip

@@ -3,7 +3,7 @@ set -e
 NAME=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 B=$R/gpurun_out/ab_build_$NAME; mkdir -p $B $R/visiondepth3d_amd/ab
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden -Wno-unused-function"
 cd $R/visiondepth3d_amd/csrc
 for f in *.hip; do /opt/rocm/bin/hipcc $FLAGS "$@" -c $f -o $B/${f%.hip}.o & done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/visiondepth3d_amd/ab/libvd3d_hip_$NAME.so $B/*.o

@@ -1,5 +1,5 @@
 """Development probe: 4K (or any size) DIBR-only step throughput of the sharded / batched path for several launch shapes in ONE process
-(the synthetic clip is built once).  python tools/probe_step.py [--size 2160x3840] [--B 16] [--steps 8] cfg ...   cfg = pix_streams:group:div
+(the synthetic clip is built once).  python tools/probe_step.py [--size 2160x3840] [--B 16] [--steps 8] cfg ...   cfg = pix_streams:group:div[:w1_tile_height]
 Prints pairs/s per configuration and the per-frame stage times (HIP events; profiling on = a second, untimed pass)."""
 import argparse
 import os
@@ -61,9 +61,10 @@ def main():
         r.set_pixel_overlap(0)
         r.close()
     for cfg in a.cfgs:
-        ps, grp, div = [int(v) for v in cfg.split(":")]
+        ps, grp, div, *rest = [int(v) for v in cfg.split(":")]
         L.vd3d_debug_tune(0, div)
         L.vd3d_debug_tune(1, grp)
+        L.vd3d_debug_tune(2, rest[0] if rest else 32)   # W1 tile height (precomputed-mask variants)
         r = Renderer(0)
         r.new_clip()
         be = HipChunkBackend(r, p)
@@ -91,7 +92,7 @@ def main():
             step(i)
         st = {k: round(r.stage_ms(k) * 1e3, 1) for k in ("p1_own", "p3_own", "replay", "shift", "w1", "finish")}
         r.set_profiling(False)
-        print(f"cfg pix_streams={ps} group={grp} div={div}: {a.steps * B / dt:8.1f} pairs/s  {dt / (a.steps * B) * 1e6:7.1f} us/frame   stage us per call {st}", flush=True)
+        print(f"cfg pix_streams={ps} group={grp} div={div} w1th={rest[0] if rest else 32}: {a.steps * B / dt:8.1f} pairs/s  {dt / (a.steps * B) * 1e6:7.1f} us/frame   stage us per call {st}", flush=True)
         if ps > 0:
             r.set_pixel_overlap(0)
         r.close()

@@ -49,6 +49,7 @@ struct vd3d_ctx {
   int H = 0, W = 0;
   float *dc = nullptr;   // curved depth plane (fused chain)
   float *D = nullptr, *S = nullptr, *e2L = nullptr, *e2R = nullptr, *bL = nullptr, *bR = nullptr;
+  float *E2 = nullptr;   // [H][W][2]: gradient mask of both eyes, k_e2w -> W1
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
   uint32_t* mm = nullptr; int mm_cap = 0;
   uint32_t* rowflag = nullptr; int rowflag_cap = 0;   // k_autocrop: one flag per source row
@@ -79,6 +80,7 @@ struct vd3d_ctx {
   int n_pix = 1; unsigned pix_rr = 0; int cur_pix = -1; bool cur_excl = false;
   hipStream_t pix_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; bool pix_x_escaped[VD_MAX_PIX - 1] = {false, false, false};
   hipEvent_t ev_pix_last_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; bool pix_pending_x[VD_MAX_PIX - 1] = {false, false, false};
+  float* E2_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr};
   float* S_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; uint8_t* L_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr}; uint8_t* R_x[VD_MAX_PIX - 1] = {nullptr, nullptr, nullptr};
   int x_H = 0, x_W = 0;
   hipEvent_t ev_excl = nullptr; bool excl_set = false;
@@ -182,7 +184,7 @@ static int ensure_work(vd3d_ctx* c, int H, int W) {
   if (c->H == H && c->W == W) return 0;
   size_t n = (size_t)H * W;
   HIPCHK(re_alloc(&c->D, n)); HIPCHK(re_alloc(&c->S, n)); HIPCHK(re_alloc(&c->dc, n));
-  HIPCHK(re_alloc(&c->e2L, n)); HIPCHK(re_alloc(&c->e2R, n));
+  HIPCHK(re_alloc(&c->e2L, n)); HIPCHK(re_alloc(&c->e2R, n)); HIPCHK(re_alloc(&c->E2, 2 * n));
   HIPCHK(re_alloc(&c->bL, n)); HIPCHK(re_alloc(&c->bR, n));
   HIPCHK(re_alloc(&c->L, 3 * n)); HIPCHK(re_alloc(&c->R, 3 * n));
   HIPCHK(re_alloc(&c->gL, 3 * n)); HIPCHK(re_alloc(&c->gR, 3 * n));
@@ -238,7 +240,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
   for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
@@ -250,6 +252,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
     if (c->pix_x[k]) { (void)hipStreamSynchronize(c->pix_x[k]); if (!c->pix_x_escaped[k]) (void)hipStreamDestroy(c->pix_x[k]); }
     if (c->ev_pix_last_x[k]) (void)hipEventDestroy(c->ev_pix_last_x[k]);
     if (c->S_x[k]) (void)hipFree(c->S_x[k]);
+    if (c->E2_x[k]) (void)hipFree(c->E2_x[k]);
     if (c->L_x[k]) (void)hipFree(c->L_x[k]);
     if (c->R_x[k]) (void)hipFree(c->R_x[k]);
   }
@@ -370,9 +373,12 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     vd_launch_chain_work(s, b, a.have_eye, ih, iw, H, W, (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, a);
   }
   if (!skip_pixels) { StageTimer t(c, "warp");
+    const bool pre = sp.enable_feathering && vd_warp_fused_ok(ih, iw, H, W, sp);   // k_e2w -> W1 (see shard_pixels_impl)
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
     bool fused = false;
-    { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R); }
+    { StageTimer t2(c, "w1");
+      if (pre) vd_launch_e2w(s, c->D, c->S, H, W, (float)sp.feather_strength, c->E2);
+      fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R, pre ? c->E2 : nullptr); }
     if (!fused) {   // blur sizes / frame sizes the fused kernel refuses (its LDS tile would not fit): one stage per kernel
     if (sp.enable_feathering) {
       vd_launch_e2(s, c->D, c->S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
@@ -756,7 +762,7 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
   } swap(c);
   const int H = p->warp_h, W = p->warp_w;
   int k = 0;
-  float* S = c->S; uint8_t* L = c->L; uint8_t* R = c->R;
+  float* S = c->S; uint8_t* L = c->L; uint8_t* R = c->R; float* E2 = c->E2;
   if (c->pix_overlap) {
     while ((int)c->slot_done.size() <= slot) {
       hipEvent_t e;
@@ -769,13 +775,17 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
         for (int j = 0; j < VD_MAX_PIX - 1; ++j) {
           if (c->pix_x[j]) HIPCHK(hipStreamSynchronize(c->pix_x[j]));
           HIPCHK(re_alloc(&c->S_x[j], (size_t)0)); HIPCHK(re_alloc(&c->L_x[j], (size_t)0)); HIPCHK(re_alloc(&c->R_x[j], (size_t)0));
+          HIPCHK(re_alloc(&c->E2_x[j], (size_t)0));
         }
         c->x_H = H; c->x_W = W;
       }
       if (k > 0) {
         const size_t n = (size_t)H * W;
-        if (!c->S_x[k - 1]) { HIPCHK(re_alloc(&c->S_x[k - 1], n)); HIPCHK(re_alloc(&c->L_x[k - 1], 3 * n)); HIPCHK(re_alloc(&c->R_x[k - 1], 3 * n)); }
-        S = c->S_x[k - 1]; L = c->L_x[k - 1]; R = c->R_x[k - 1];
+        if (!c->S_x[k - 1]) {
+          HIPCHK(re_alloc(&c->S_x[k - 1], n)); HIPCHK(re_alloc(&c->L_x[k - 1], 3 * n)); HIPCHK(re_alloc(&c->R_x[k - 1], 3 * n));
+          HIPCHK(re_alloc(&c->E2_x[k - 1], 2 * n));
+        }
+        S = c->S_x[k - 1]; L = c->L_x[k - 1]; R = c->R_x[k - 1]; E2 = c->E2_x[k - 1];
       }
     }
     hipStream_t sk = k == 0 ? c->pix_stream : c->pix_x[k - 1];
@@ -797,9 +807,13 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
     HIPCHK(hipGetLastError());
   } else {
   { StageTimer t(c, "warp");
+    // fused path with feathering: k_e2w writes the gradient mask of both eyes, W1 starts at its window sums
+    const bool pre = sp.enable_feathering && vd_warp_fused_ok(p->eye_h, p->eye_w, H, W, sp);
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
     bool fused;
-    { StageTimer t2(c, "w1"); fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], S, H, W, sp, L, R); }
+    { StageTimer t2(c, "w1");
+      if (pre) vd_launch_e2w(s, c->slot_D[slot], S, H, W, (float)sp.feather_strength, E2);
+      fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], S, H, W, sp, L, R, pre ? E2 : nullptr); }
     if (!fused) {
       if ((rc = pix_exclusive(c))) return rc;
       if (sp.enable_feathering) {
@@ -1347,6 +1361,7 @@ VD3D_EXPORT int vd3d_torch_math(vd3d_ctx* c, int op, const float* x, float param
 VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
   if (which == 0) vd_set_batch_grid_div(value);
   else if (which == 1) g_chain_group = value;
+  else if (which == 2) vd_set_warp_pre_th(value);
   else return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
   return 0;
 }

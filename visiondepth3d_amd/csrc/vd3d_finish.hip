@@ -73,11 +73,21 @@ VD_DEV float ff_from_right(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 
+// The two levels a pixel blends (:822-834: level lo and lo + 1, weight alpha) arrive in ascending order, so ONE running value per pixel and
+// channel is enough: it starts as the unblurred pixel (level 0), is replaced when level lo arrives and becomes (1 - alpha) lo + alpha hi --
+// the reference's expression, same operations -- when level lo + 1 does (every pixel's hi level is in its tile's level set).  Half the
+// registers of keeping lo and hi apart (24 -> 12 per strip).
+VD_DEV float ff_fold(float res, float o, float alpha, int level, int lo) {
+  if (level == lo) res = o;
+  if (level == lo + 1) res = (1.0f - alpha) * res + alpha * o;
+  return res;
+}
+
 // one Gaussian level: K = 9 - 2*OFF taps, vertical then horizontal.  Executed by every lane of the wave (the DPP exchange
 // needs the neighbours' vertical sums); `mine` = this strip blends with this level.
 template <int OFF, int IH>
 VD_DEV void ff_level(const float (*tile)[IH][FF_IW], const float* __restrict__ kern, bool active, bool mine, int sy, int ss, int level,
-                     const int lo[4], vd_f4 vlo[3], vd_f4 vhi[3]) {
+                     const int lo[4], const vd_f4& alpha, vd_f4 vres[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
   float kw[K];
 #pragma unroll
@@ -109,8 +119,7 @@ VD_DEV void ff_level(const float (*tile)[IH][FF_IW], const float* __restrict__ k
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float o = vd_gauss_sym<K, float>(kw, &win[q + OFF]);
-        if (level == lo[q]) vlo[c][q] = o;
-        if (level == lo[q] + 1) vhi[c][q] = o;
+        vres[c][q] = ff_fold(vres[c][q], o, alpha[q], level, lo[q]);
       }
     }
   }
@@ -123,15 +132,12 @@ VD_DEV void ff_level(const float (*tile)[IH][FF_IW], const float* __restrict__ k
 // blend with this level run it.
 template <int OFF, int IH>
 VD_DEV void ff_level_dense(const float (*tile)[IH][FF_IW], const float* __restrict__ w2, bool mine, int sy, int ss, int level, const int lo[4],
-                           vd_f4 vlo[3], vd_f4 vhi[3]) {
+                           const vd_f4& alpha, vd_f4 vres[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
   if (!mine) return;
-  vd_f4 acc[3];      // scalar FMAs on purpose: v_pk_fma_f32 issues at half the rate of v_fma_f32 on gfx950 (tools/ubench_valu.hip: +9 % at best)
+  vd_f4 acc[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) acc[c] = (vd_f4){0.f, 0.f, 0.f, 0.f};
-  // window groups (tap row i, channel c), software-pipelined: the three 16-byte reads of the next group are issued before the 4 K FMAs of
-  // the current one, so a wave meets one exposed LDS latency per level instead of 3 K (+4 registers; folding the two level values into one
-  // running blend value to pay for more was tried: hipcc then spills -- 168 VGPRs + scratch -- so lo / hi stay separate)
   const float* rp0 = &tile[0][sy + OFF][4 * ss - 4];
   vd_f4 n0 = *reinterpret_cast<const vd_f4*>(rp0), n1 = *reinterpret_cast<const vd_f4*>(rp0 + 4), n2 = *reinterpret_cast<const vd_f4*>(rp0 + 8);
 #pragma unroll
@@ -143,11 +149,11 @@ VD_DEV void ff_level_dense(const float (*tile)[IH][FF_IW], const float* __restri
         const float* rp = &tile[c + 1 < 3 ? c + 1 : 0][sy + OFF + (c + 1 < 3 ? i : i + 1)][4 * ss - 4];
         n0 = *reinterpret_cast<const vd_f4*>(rp); n1 = *reinterpret_cast<const vd_f4*>(rp + 4); n2 = *reinterpret_cast<const vd_f4*>(rp + 8);
       }
-      __builtin_amdgcn_sched_barrier(0);   // the prefetch stays in front of this group's arithmetic
+      __builtin_amdgcn_sched_barrier(0);
       const float win[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        const float wt = w2[i * K + j];   // fl(k1[i] * k1[j]) from the host: a scalar operand of the FMAs
+        const float wt = w2[i * K + j];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[c][q] = vd_fma(win[q + OFF + j], wt, acc[c][q]);
       }
@@ -157,17 +163,14 @@ VD_DEV void ff_level_dense(const float (*tile)[IH][FF_IW], const float* __restri
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (level == lo[q]) vlo[c][q] = acc[c][q];
-      if (level == lo[q] + 1) vhi[c][q] = acc[c][q];
-    }
+    for (int q = 0; q < 4; ++q) vres[c][q] = ff_fold(vres[c][q], acc[c][q], alpha[q], level, lo[q]);
 }
 
 // One pixel of a halo column (graded row sy, side 0 = column x0 - 1 / 1 = column x0 + 64) in the same dense association, from the
-// 9-column halo windows `hal` (see the kernel): single-dword LDS reads, one accumulation chain per channel.  Result in element 0 of vlo / vhi.
+// 9-column halo windows `hal` (see the kernel): single-dword LDS reads, one accumulation chain per channel.  Result folded into element 0 of vres.
 template <int OFF, int FF_HS>
 VD_DEV void ff_level_dense_px(const float* __restrict__ hal, const float* __restrict__ w2, bool mine, int sy, int side, int level, int lo0,
-                              vd_f4 vlo[3], vd_f4 vhi[3]) {
+                              float alpha0, vd_f4 vres[3]) {
   constexpr int K = 2 * (FF_R - OFF) + 1;
   if (!mine) return;
   float acc[3] = {0.f, 0.f, 0.f};
@@ -182,10 +185,7 @@ VD_DEV void ff_level_dense_px(const float* __restrict__ hal, const float* __rest
     __builtin_amdgcn_sched_barrier(0);   // keep one window row of loads in flight: the kernel is register-limited (2 workgroups per CU)
   }
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    if (level == lo0) vlo[c][0] = acc[c];
-    if (level == lo0 + 1) vhi[c][0] = acc[c];
-  }
+  for (int c = 0; c < 3; ++c) vres[c][0] = ff_fold(vres[c][0], acc[c], alpha0, level, lo0);
 }
 
 VD_DEV float ff_byte(uint32_t v, int sh) { return (float)((v >> sh) & 0xffu); }   // v_cvt_f32_ubyteN
@@ -415,12 +415,11 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       if (__ballot((my_mask >> l) & 1)) wmask |= 1 << l;
     if ((tid & 63) == 0 && wmask) atomicOr(&lvl_mask, wmask);
   }
-  vd_f4 vlo[3], vhi[3];
+  vd_f4 vres[3];   // level 0 = the pixel itself; ff_fold turns it into the blend of the two levels the pixel needs
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    vlo[c] = *reinterpret_cast<const vd_f4*>(&tile[c][sy + FF_R][4 * ss]);
-    if (WIDE && halo_px && hq == 3) vlo[c][0] = vlo[c][3];
-    vhi[c] = vlo[c];
+    vres[c] = *reinterpret_cast<const vd_f4*>(&tile[c][sy + FF_R][4 * ss]);
+    if (WIDE && halo_px && hq == 3) vres[c][0] = vres[c][3];
   }
   __syncthreads();
   VD_STAMP(ff_stamps, 2, false);
@@ -433,26 +432,26 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       if (WIDE && wv == FF_NSW) {   // wave-uniform: the halo-pixel wave
         const int side = lane & 1;
         switch (off) {
-          case 0: ff_level_dense_px<0, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
-          case 1: ff_level_dense_px<1, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
-          case 2: ff_level_dense_px<2, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
-          default: ff_level_dense_px<3, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], vlo, vhi); break;
+          case 0: ff_level_dense_px<0, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
+          case 1: ff_level_dense_px<1, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
+          case 2: ff_level_dense_px<2, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
+          default: ff_level_dense_px<3, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
         }
         continue;
       }
       switch (off) {
-        case 0: ff_level_dense<0, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-        case 1: ff_level_dense<1, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-        case 2: ff_level_dense<2, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-        default: ff_level_dense<3, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+        case 0: ff_level_dense<0, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
+        case 1: ff_level_dense<1, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
+        case 2: ff_level_dense<2, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
+        default: ff_level_dense<3, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
       }
       continue;
     }
     switch (off) {  // compile-time tap count => all register indexing is static
-      case 0: ff_level<0, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-      case 1: ff_level<1, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-      case 2: ff_level<2, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
-      default: ff_level<3, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, vlo, vhi); break;
+      case 0: ff_level<0, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, alpha, vres); break;
+      case 1: ff_level<1, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, alpha, vres); break;
+      case 2: ff_level<2, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, alpha, vres); break;
+      default: ff_level<3, FF_IH>(tile, fc.kern[l], active, mine, sy, ss, l + 1, lo, alpha, vres); break;
     }
   }
   VD_STAMP(ff_stamps, 3, false);
@@ -461,9 +460,8 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
     vd_f4 rgbv[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      vd_f4 v = vlo[c];
+      vd_f4 v = vres[c];
       if (fc.nlev) {
-        v = (1.0f - alpha) * vlo[c] + alpha * vhi[c];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = vd_clamp_fin(v[q], 0.f, 1.f);
       }

@@ -149,7 +149,11 @@ void vd_launch_pool(hipStream_t s, const float* e2L, const float* e2R, int H, in
 void vd_launch_warp(hipStream_t s, const float* rgb, int ih, int iw, const float* S, const float* bL, const float* bR, int H, int W,
                     int feather, uint8_t* L, uint8_t* R);
 bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
-                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R);
+                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2 = nullptr);
+bool vd_warp_fused_ok(int ih, int iw, int H, int W, const vd3d_shift_params& p);
+// k_e2w (vd3d_warp.hip): gradient mask plane E2[H][W][2] (left, right eye) of feather_shift_edges from the shaped depth and the shift plane
+void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, float feather_strength, float* E2);
+void vd_set_warp_pre_th(int th);
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
                          int bar_width, int bar_side, uint8_t* eye_out, int dense = 0);

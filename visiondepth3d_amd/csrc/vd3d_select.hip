@@ -643,6 +643,42 @@ VD_DEV void vd_plane_walk(const float* __restrict__ p, long long n, int W, int w
   }
 }
 
+// Walk of the sub-rectangle rows [y0, y1) x columns [xa, xb) of a float plane with row length W in 16-byte elements (W, xa, xb multiples
+// of 4, base 16-byte aligned: vd_walk4_ok).  Element e of the rectangle = row y0 + e / wq, columns xa + 4 (e % wq) .. + 3, wq = (xb - xa) / 4;
+// workgroup wg of nwg takes elements wg * NT + tid + k * nwg * NT, (row, column) are carried incrementally (ONE integer division per thread,
+// the per-element division of vd_plane_walk was a fifth of the pass-B kernels' instructions), two 16-byte loads are in flight per thread
+// (the 4-byte walk reached 1.6 - 2.6 TB/s).  body(ok, y, x, v): x = column of v.x; called uniformly by every lane (it may ballot).
+VD_DEV bool vd_walk4_ok(const float* p, int W) { return (W & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+template <int NT = 1024, class Body>
+VD_DEV void vd_rect_walk4(const float* __restrict__ p, int W, int y0, int y1, int xa, int xb, int wg, int nwg, Body body) {
+  const unsigned wq = (unsigned)(xb - xa) >> 2;
+  const unsigned ne = (y1 > y0 && wq) ? (unsigned)(y1 - y0) * wq : 0u;
+  const unsigned stride = (unsigned)nwg * NT;
+  const unsigned sy = wq ? stride / wq : 0u, sx = wq ? stride - sy * wq : 0u;
+  unsigned e = (unsigned)wg * NT + threadIdx.x;
+  unsigned r = wq ? e / wq : 0u, c = wq ? e - r * wq : 0u;
+  for (unsigned base = (unsigned)wg * NT; base < ne; base += 2u * stride, e += 2u * stride) {
+    unsigned r1 = r + sy, c1 = c + sx;
+    if (c1 >= wq) { c1 -= wq; ++r1; }
+    const bool ok0 = e < ne, ok1 = e + stride < ne;
+    vd_f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    const int ya = y0 + (int)r, xa0 = xa + 4 * (int)c, yb = y0 + (int)r1, xb0 = xa + 4 * (int)c1;
+    if (ok0) v0 = *reinterpret_cast<const vd_f4*>(p + (size_t)ya * W + xa0);
+    if (ok1) v1 = *reinterpret_cast<const vd_f4*>(p + (size_t)yb * W + xb0);
+    body(ok0, ya, xa0, v0);
+    body(ok1, yb, xb0, v1);
+    r = r1 + sy; c = c1 + sx;
+    if (c >= wq) { c -= wq; ++r; }
+  }
+}
+// bounding rectangle (columns rounded out to multiples of 4) of vd_in_subject_crop's region
+VD_DEV void vd_subject_rect(int H, int W, int* y0, int* y1, int* xa, int* xb) {
+  *y0 = H / 5; *y1 = H * 4 / 5;
+  *xa = (W / 5) & ~3;
+  const int xe = (W * 4 / 5 + 3) & ~3;
+  *xb = xe < W ? xe : W;
+}
+
 
 // K0 (only when auto_crop_black_bars): detect_black_bars (:293-316) + crop_black_bars_torch (:318-326) + the aspect crop of
 // :1236-1248, decided on device.  One wave per source row: integer sum of the cv2 RGB2GRAY of the frame after the
@@ -693,64 +729,172 @@ void vd_launch_autocrop(hipStream_t s, const uint8_t* frame, int h, int wd, doub
   hipLaunchKernelGGL(k_autocrop, dim3((h + 3) / 4), dim3(256), 0, s, frame, h, wd, target_ratio, rowflag, w, crop_out);
 }
 
+struct vd_targets { uint32_t nt, tp[VD_MAX_T], tmin, tspan; };   // tmin / tspan: hull of the target prefixes (empty: tmin = ~0)
+VD_DEV vd_targets load_targets(const vd_sel_ctl* c, int dbg = 0) {
+  vd_targets t; t.nt = (dbg & 16) ? 0u : c->ntargets;   // timing probe: bit4 = no pass-B hits at all (no global atomics)
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  for (int i = 0; i < VD_MAX_T; ++i) {
+    t.tp[i] = c->tprefix[i];
+    if ((uint32_t)i < t.nt) { lo = t.tp[i] < lo ? t.tp[i] : lo; hi = t.tp[i] > hi ? t.tp[i] : hi; }
+  }
+  t.tmin = lo; t.tspan = t.nt ? hi - lo : 0u;
+  return t;
+}
+VD_DEV void hist_b_add(uint32_t* histB, int job, const vd_targets& c, float v, bool member) {
+  const unsigned bits = __float_as_uint(v);
+  bool hit = false; unsigned key = 0;
+  for (uint32_t t = 0; t < c.nt; ++t) if (member && (bits >> 16) == c.tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
+  if (!__any(hit)) return;   // the hits are one value band of a smooth plane: most waves have none
+  vd_hist_add_agg(histB + (size_t)job * VD_MAX_T * VD_NB_B, key, hit);
+  vd_hist_add_agg(vd_histbc(histB) + (size_t)job * VD_MAX_T * VD_NB_BC, key >> 8, hit);
+}
+
+// four consecutive elements of one row: one range test per element against the hull of the job's target prefixes decides whether the wave
+// has any candidate at all (a smooth plane: almost never); only then the per-element path with its membership test runs
+template <class Member>   // member(q) -> bool, evaluated for candidates only
+VD_DEV void hist_b_add4(uint32_t* histB, int job, const vd_targets& c, vd_f4 v, bool ok, Member member) {
+  bool cand = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cand |= ((__float_as_uint(v[q]) >> 16) - c.tmin) <= c.tspan;
+  if (!__any(ok && cand)) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hist_b_add(histB, job, c, v[q], ok && member(q));
+}
+
 // per-frame view of the launch arguments: the record destinations and the step index of frame F
 VD_DEV vd_stage_args frame_args(vd_stage_args a, const vd_batch_frame& F, int stage) {
   a.stage = stage; a.shard_idx = F.shard_idx; a.q_out = F.q_out; a.m_out = F.m_out;
   return a;
 }
 
-// K1: ingest (+ TemporalDepthFilter) + pass A of J0; last workgroup: scan A0.  The plane EMA is a per-pixel recurrence over the frames,
-// so a batched launch walks its frames INSIDE the workgroup, in order: the thread that wrote pixel o of frame f - 1 is the one that
-// reads it as the previous value of frame f (same thread, same address: program order), every frame has its own LDS histogram round,
-// ticket and scan.
-__global__ __launch_bounds__(1024) void k_chain_ingest(vd_batch b, int fmt, vd3d_render_params p, vd_stage_args a) {
-  __shared__ uint32_t h0[NBL];
-  __shared__ uint32_t sm[128];
-  const long long n = (long long)p.eye_h * p.eye_w;
+// K1: ingest (+ TemporalDepthFilter): a pure streaming kernel since round 4 (pass A of J0 is K1a below -- with the histogram, its flush
+// and the ticket's release fence inside, a batched launch paid them once per frame and workgroup: 51 us per 4K frame for 91 MB).  The plane
+// EMA is a per-pixel recurrence over the frames, so a batched launch walks its frames INSIDE the thread, in order: the thread that wrote
+// pixel o of frame f - 1 is the one that reads it as the previous value of frame f (same thread, same address: program order).
+// Fast path (the render loop's exact 2:1 eye resize, rows 8-byte aligned): one thread = 4 consecutive eye pixels = a 2 x 8 block of source
+// pixels, fetched with 8-byte (frame: 24 B per row) and 16-byte (float32 depth: 32 B per row) loads; same float32 expressions as
+// vd_ingest_pixel (vd_interp_tap(2 n, n, o) = taps 2 o, 2 o + 1 with weights 1 - 0.5, 0.5).
+struct vd_ingest_fast { int on; };
+VD_DEV float vd_depth_u8(unsigned g) { return vd_u8_unit((float)g); }
+__global__ __launch_bounds__(256) void k_chain_ingest(vd_batch b, int fmt, vd3d_render_params p, vd_stage_args a, int fast) {
   const int valid0 = b.w_main->st.tdf_valid;
-  for (int fi = 0; fi < b.n; ++fi) {
-    const vd_batch_frame& F = b.f[fi];
-    for (int bb = threadIdx.x; bb < NBL; bb += 1024) h0[bb] = 0;
-    __syncthreads();
-    const int tdf_valid = fi == 0 ? valid0 : 1;
-    if (p.auto_crop_black_bars) {   // per-frame rectangle: k_autocrop's (sequential) or the exchanged table of a sharded step
-      const int* cr = a.crop_tab ? a.crop_tab + 4 * F.shard_idx : F.w->acrop;
-      p.crop_x = cr[0]; p.crop_y = cr[1]; p.crop_w = cr[2]; p.crop_h = cr[3];
-    }
-    const uint8_t* frame = F.frame; const void* depth = F.depth;
-    float* rgb_eye = F.rgb_eye; float* tdf = F.tdf; const float* tdf_prev = F.tdf_prev;
-    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
-      const long long i = base + threadIdx.x;
-      float v = 0.f;
-      if (i < n) {
-        const int ey = (int)((unsigned)i / (unsigned)p.eye_w), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)p.eye_w);
-        v = vd_ingest_pixel(frame, depth, fmt, p, tdf_valid, rgb_eye, tdf_prev, tdf, ey, ex);
+  const int ew = p.eye_w, eh = p.eye_h;
+  if (fast) {
+    const unsigned gpr = (unsigned)ew >> 2, ng = gpr * (unsigned)eh;          // groups of 4 eye pixels
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < ng; g += gridDim.x * 256u) {
+      const unsigned ey = g / gpr, ex = (g - ey * gpr) * 4u;
+      const size_t o = (size_t)ey * ew + ex, ne = (size_t)eh * ew;
+      const float w1 = 0.5f, w0 = 1.f - w1;
+      for (int fi = 0; fi < b.n; ++fi) {
+        const vd_batch_frame& F = b.f[fi];
+        const size_t srow = (size_t)(2 * ey + p.crop_y) * p.src_w + (2 * ex + p.crop_x);
+        // ---- frame: 8 BGR pixels of two source rows
+        uint32_t fr[2][6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const uint2* q = reinterpret_cast<const uint2*>(F.frame + (srow + (size_t)r * p.src_w) * 3);
+          const uint2 q0 = q[0], q1 = q[1], q2 = q[2];
+          fr[r][0] = q0.x; fr[r][1] = q0.y; fr[r][2] = q1.x; fr[r][3] = q1.y; fr[r][4] = q2.x; fr[r][5] = q2.y;
+        }
+        // ---- depth: 8 samples of two source rows
+        float dp[2][8];
+        if (fmt == VD3D_DEPTH_F32) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const vd_f4* q = reinterpret_cast<const vd_f4*>((const float*)F.depth + srow + (size_t)r * p.src_w);
+            const vd_f4 a0 = q[0], a1 = q[1];
+            dp[r][0] = a0.x; dp[r][1] = a0.y; dp[r][2] = a0.z; dp[r][3] = a0.w; dp[r][4] = a1.x; dp[r][5] = a1.y; dp[r][6] = a1.z; dp[r][7] = a1.w;
+          }
+        } else {   // VD3D_DEPTH_GRAY_U8: 8 bytes per row
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const uint2 q = *reinterpret_cast<const uint2*>((const uint8_t*)F.depth + srow + (size_t)r * p.src_w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dp[r][k] = vd_depth_u8((q.x >> (8 * k)) & 0xffu); dp[r][4 + k] = vd_depth_u8((q.y >> (8 * k)) & 0xffu); }
+          }
+        }
+        const int tdf_valid = fi == 0 ? valid0 : 1;
+        vd_f4 prev = {0.f, 0.f, 0.f, 0.f};
+        if (tdf_valid) prev = *reinterpret_cast<const vd_f4*>(F.tdf_prev + o);
+        // byte k of a row's 24: pixel k / 3, channel BGR[k % 3]
+        auto fb = [&](int r, int k) { return vd_u8_unit((float)((fr[r][k >> 2] >> (8 * (k & 3))) & 0xffu)); };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {   // output plane c = R, G, B; source byte 2 - c
+          vd_f4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k0 = 3 * (2 * q) + (2 - c), k1 = 3 * (2 * q + 1) + (2 - c);
+            v[q] = vd_bilerp(fb(0, k0), fb(0, k1), fb(1, k0), fb(1, k1), w0, w1, w0, w1);
+          }
+          *reinterpret_cast<vd_f4*>(F.rgb_eye + (size_t)c * ne + o) = v;
+        }
+        vd_f4 nv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float cur = vd_bilerp(dp[0][2 * q], dp[0][2 * q + 1], dp[1][2 * q], dp[1][2 * q + 1], w0, w1, w0, w1);
+          const float pv = tdf_valid ? prev[q] : cur;
+          nv[q] = 0.5f * pv + (float)(1 - 0.5) * cur;
+        }
+        *reinterpret_cast<vd_f4*>(F.tdf + o) = nv;
       }
-      vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n && !(a.dbg & 8));
     }
-    __syncthreads();
-    if (!(a.dbg & 4)) lds_hist_flush(h0, F.histA + (size_t)VD_J_EYE_Q * VD_NB_A);
-    if (last_workgroup(&F.w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(F.w, F.histA, F.histB, frame_args(a, F, VD_ST_A0), sm);
-    __syncthreads();   // h0 / sm are reused by the next frame
+    return;
+  }
+  const long long n = (long long)eh * ew;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int ey = (int)((unsigned)i / (unsigned)ew), ex = (int)((unsigned)i - (unsigned)ey * (unsigned)ew);
+    for (int fi = 0; fi < b.n; ++fi) {
+      const vd_batch_frame& F = b.f[fi];
+      if (p.auto_crop_black_bars) {   // per-frame rectangle: k_autocrop's (sequential) or the exchanged table of a sharded step
+        const int* cr = a.crop_tab ? a.crop_tab + 4 * F.shard_idx : F.w->acrop;
+        p.crop_x = cr[0]; p.crop_y = cr[1]; p.crop_w = cr[2]; p.crop_h = cr[3];
+      }
+      vd_ingest_pixel(F.frame, F.depth, fmt, p, fi == 0 ? valid0 : 1, F.rgb_eye, F.tdf_prev, F.tdf, ey, ex);
+    }
   }
 }
 
+// K1a: pass A of J0 (q.02 / q.98 of the clamped filtered plane) over the frames of the batch side by side; last workgroup: scan A0
+__global__ __launch_bounds__(1024) void k_chain_a0(vd_batch b, long long n, int ew, vd_stage_args a) {
+  __shared__ uint32_t h0[NBL];
+  __shared__ uint32_t sm[128];
+  const vd_batch_frame& F = b.f[blockIdx.y];
+  for (int bb = threadIdx.x; bb < NBL; bb += 1024) h0[bb] = 0;
+  __syncthreads();
+  if (ew > 0 && vd_walk4_ok(F.tdf, ew)) {
+    vd_rect_walk4(F.tdf, ew, 0, (int)(n / ew), 0, ew, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, vd_f4 d) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vd_lds_hist_add(h0, key_a(vd_clamp(d[q], 0.f, 1.f)), ok && !(a.dbg & 8));
+    });
+  } else {
+    for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
+      const long long i = base + threadIdx.x;
+      const float v = i < n ? F.tdf[i] : 0.f;
+      vd_lds_hist_add(h0, key_a(vd_clamp(v, 0.f, 1.f)), i < n && !(a.dbg & 8));
+    }
+  }
+  __syncthreads();
+  if (!(a.dbg & 4)) lds_hist_flush(h0, F.histA + (size_t)VD_J_EYE_Q * VD_NB_A);
+  if (last_workgroup(&F.w->ticket[0], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(F.w, F.histA, F.histB, frame_args(a, F, VD_ST_A0), sm);
+}
+
 // K2: pass B of J0; last workgroup: scan B0 + DepthPercentileEMA
-__global__ __launch_bounds__(1024) void k_chain_b0(vd_batch b, long long n, vd_stage_args a) {
+__global__ __launch_bounds__(1024) void k_chain_b0(vd_batch b, long long n, int ew, vd_stage_args a) {
   __shared__ uint32_t sm[128];
   const vd_batch_frame& F = b.f[blockIdx.y];
   vd_dev_work* w = F.w;
   uint32_t* histB = F.histB;
-  const vd_sel_ctl* c = &w->job[VD_J_EYE_Q];
-  const uint32_t nt = c->ntargets;
-  uint32_t tp[VD_MAX_T];
-  for (int t = 0; t < VD_MAX_T; ++t) tp[t] = c->tprefix[t];
-  vd_plane_walk<false>(F.tdf, n, (n & 3) == 0 ? 4 : 1, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, float d) {
-    const unsigned bits = ok ? __float_as_uint(vd_clamp(d, 0.f, 1.f)) : 0u;
-    bool hit = false; unsigned key = 0;
-    for (uint32_t t = 0; t < nt; ++t) if (ok && (bits >> 16) == tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
-    vd_hist_add_agg(histB + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_B, key, hit);
-    vd_hist_add_agg(vd_histbc(histB) + (size_t)VD_J_EYE_Q * VD_MAX_T * VD_NB_BC, key >> 8, hit);
+  const vd_targets tq = load_targets(&w->job[VD_J_EYE_Q], a.dbg);
+  if (ew > 0 && vd_walk4_ok(F.tdf, ew)) {
+    vd_rect_walk4(F.tdf, ew, 0, (int)(n / ew), 0, ew, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, vd_f4 d) {
+      vd_f4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = vd_clamp(d[q], 0.f, 1.f);
+      hist_b_add4(histB, VD_J_EYE_Q, tq, v, ok, [&](int) { return true; });
+    });
+  } else
+  vd_plane_walk<false>(F.tdf, n, 1, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, float d) {
+    hist_b_add(histB, VD_J_EYE_Q, tq, vd_clamp(d, 0.f, 1.f), ok);
   });
   if (last_workgroup(&w->ticket[1], &sm[127], a.dbg) && !(a.dbg & 1)) {
     run_scalar_stage(w, F.histA, histB, frame_args(a, F, VD_ST_B0), sm);
@@ -920,34 +1064,32 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(vd_batch b, FWorkSrc f, v
   if (last_workgroup(&w->ticket[2], &sm[127], a.dbg) && !(a.dbg & 1)) run_scalar_stage(w, histA, histB, frame_args(a, F, VD_ST_A1), sm);
 }
 
-struct vd_targets { uint32_t nt, tp[VD_MAX_T]; };
-VD_DEV vd_targets load_targets(const vd_sel_ctl* c) {
-  vd_targets t; t.nt = c->ntargets;
-  for (int i = 0; i < VD_MAX_T; ++i) t.tp[i] = c->tprefix[i];
-  return t;
-}
-VD_DEV void hist_b_add(uint32_t* histB, int job, const vd_targets& c, float v, bool member) {
-  const unsigned bits = __float_as_uint(v);
-  bool hit = false; unsigned key = 0;
-  for (uint32_t t = 0; t < c.nt; ++t) if (member && (bits >> 16) == c.tp[t]) { hit = true; key = (t << 16) | (bits & 0xffffu); }
-  if (!__any(hit)) return;   // the hits are one value band of a smooth plane: most waves have none
-  vd_hist_add_agg(histB + (size_t)job * VD_MAX_T * VD_NB_B, key, hit);
-  vd_hist_add_agg(vd_histbc(histB) + (size_t)job * VD_MAX_T * VD_NB_BC, key >> 8, hit);
-}
-
 // K4: [eye] pass B of J1 on the stored dn plane | [work] pass B of J2 + J3 ; last workgroup: scan B1 + its scalar stage
 __global__ __launch_bounds__(1024) void k_chain_b1(vd_batch b, int eh, int ew, int n_eye_wg, FWorkSrc f, vd_stage_args a) {
   __shared__ uint32_t sm[128];
   const vd_batch_frame& F = b.f[blockIdx.y];
   const float* __restrict__ dn_cur = F.dn; const float* __restrict__ dc = F.dc;
   vd_dev_work* w = F.w; const uint32_t* histA = F.histA; uint32_t* histB = F.histB;
-  const vd_targets t_eye = load_targets(&w->job[VD_J_EYE_SUBJ]), t_q = load_targets(&w->job[VD_J_WORK_Q]),
-                   t_s0 = load_targets(&w->job[VD_J_WORK_S0]);
+  const vd_targets t_eye = load_targets(&w->job[VD_J_EYE_SUBJ], a.dbg), t_q = load_targets(&w->job[VD_J_WORK_Q], a.dbg),
+                   t_s0 = load_targets(&w->job[VD_J_WORK_S0], a.dbg);
   if ((int)blockIdx.x < n_eye_wg) {
+    if (vd_walk4_ok(dn_cur, ew)) {   // the eye-res subject job only counts pixels of the centre crop: walk that rectangle
+      int y0, y1, xa, xb;
+      vd_subject_rect(eh, ew, &y0, &y1, &xa, &xb);
+      vd_rect_walk4(dn_cur, ew, y0, y1, xa, xb, (int)blockIdx.x, n_eye_wg, [&](bool ok, int y, int x, vd_f4 v) {
+        hist_b_add4(histB, VD_J_EYE_SUBJ, t_eye, v, ok, [&](int q) { return vd_in_subject_crop(y, x + q, eh, ew, v[q]); });
+      });
+    } else
     vd_plane_walk<false>(dn_cur, (long long)eh * ew, ew, (int)blockIdx.x, n_eye_wg, [&](bool ok, int y, int x, float v) {
       hist_b_add(histB, VD_J_EYE_SUBJ, t_eye, v, ok && vd_in_subject_crop(y, x, eh, ew, v));
     });
   } else {
+    if (vd_walk4_ok(dc, f.W)) {
+      vd_rect_walk4(dc, f.W, 0, f.H, 0, f.W, (int)blockIdx.x - n_eye_wg, (int)gridDim.x - n_eye_wg, [&](bool ok, int y, int x, vd_f4 v) {
+        hist_b_add4(histB, VD_J_WORK_Q, t_q, v, ok, [&](int) { return true; });
+        hist_b_add4(histB, VD_J_WORK_S0, t_s0, v, ok, [&](int q) { return vd_in_subject_crop(y, x + q, f.H, f.W, v[q]); });
+      });
+    } else
     vd_plane_walk<false>(dc, (long long)f.H * f.W, f.W, (int)blockIdx.x - n_eye_wg, (int)gridDim.x - n_eye_wg, [&](bool ok, int y, int x, float v) {
       hist_b_add(histB, VD_J_WORK_Q, t_q, v, ok);
       hist_b_add(histB, VD_J_WORK_S0, t_s0, v, ok && vd_in_subject_crop(y, x, f.H, f.W, v));
@@ -1016,7 +1158,14 @@ __global__ __launch_bounds__(1024) void k_chain_b2(vd_batch b, int H, int W, vd_
   const vd_batch_frame& F = b.f[blockIdx.y];
   const float* __restrict__ D = F.D; vd_dev_work* w = F.w; const uint32_t* histA = F.histA; uint32_t* histB = F.histB;
   const long long n = (long long)H * W;
-  const vd_targets t_s1 = load_targets(&w->job[VD_J_WORK_S1]);
+  const vd_targets t_s1 = load_targets(&w->job[VD_J_WORK_S1], a.dbg);
+  if (vd_walk4_ok(D, W)) {   // the shaped-depth subject job only counts pixels of the centre crop: walk that rectangle (36 % of the plane)
+    int y0, y1, xa, xb;
+    vd_subject_rect(H, W, &y0, &y1, &xa, &xb);
+    vd_rect_walk4(D, W, y0, y1, xa, xb, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int y, int x, vd_f4 v) {
+      hist_b_add4(histB, VD_J_WORK_S1, t_s1, v, ok, [&](int q) { return vd_in_subject_crop(y, x + q, H, W, v[q]); });
+    });
+  } else
   vd_plane_walk<false>(D, n, W, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int y, int x, float v) {
     hist_b_add(histB, VD_J_WORK_S1, t_s1, v, ok && vd_in_subject_crop(y, x, H, W, v));
   });
@@ -1033,7 +1182,7 @@ static inline int chain_grid(long long n, int per_wg, int cap) {
 static int g_batch_div = -1;
 void vd_set_batch_grid_div(int v) { g_batch_div = v < 1 ? 1 : v; }
 static inline int batch_grid(long long n, int per_wg, int cap, int nframes) {
-  if (g_batch_div < 0) { const char* e = getenv("VD3D_BATCH_GRID_DIV"); g_batch_div = e ? atoi(e) : 2; if (g_batch_div < 1) g_batch_div = 1; }
+  if (g_batch_div < 0) { const char* e = getenv("VD3D_BATCH_GRID_DIV"); g_batch_div = e ? atoi(e) : 8; if (g_batch_div < 1) g_batch_div = 1; }   // 8: measured best of 1 .. 64 at 4K, 16 frames (profiles/r04_chain_batched.md)
   int g = chain_grid(n, per_wg, cap);
   if (nframes >= 4) g = (g + g_batch_div - 1) / g_batch_div;
   return g < 1 ? 1 : g;
@@ -1041,8 +1190,21 @@ static inline int batch_grid(long long n, int per_wg, int cap, int nframes) {
 
 void vd_launch_chain_eye(hipStream_t s, const vd_batch& b, int fmt, const vd3d_render_params& p, const vd_stage_args& a) {
   const long long ne = (long long)p.eye_h * p.eye_w;
-  hipLaunchKernelGGL(k_chain_ingest, dim3(chain_grid(ne, 2048, 512)), dim3(1024), 0, s, b, fmt, p, a);
-  hipLaunchKernelGGL(k_chain_b0, dim3(batch_grid(ne, 4096, 256, b.n), b.n), dim3(1024), 0, s, b, ne, a);
+  // K1 fast path: exact 2:1 eye resize of a fixed crop window, 4 eye pixels per thread through 8- / 16-byte loads
+  int fast = !p.auto_crop_black_bars && p.crop_w == 2 * p.eye_w && p.crop_h == 2 * p.eye_h && (p.eye_w & 3) == 0 &&
+             (fmt == VD3D_DEPTH_F32 || fmt == VD3D_DEPTH_GRAY_U8) && ((3 * (long long)p.src_w) & 7) == 0 &&
+             ((3 * ((long long)p.crop_y * p.src_w + p.crop_x)) & 7) == 0;
+  const long long dsz = fmt == VD3D_DEPTH_F32 ? 4 : 1;
+  if (fast && (((dsz * p.src_w) & (fmt == VD3D_DEPTH_F32 ? 15 : 7)) || ((dsz * ((long long)p.crop_y * p.src_w + p.crop_x)) & (fmt == VD3D_DEPTH_F32 ? 15 : 7)))) fast = 0;
+  for (int j = 0; fast && j < b.n; ++j) {
+    const vd_batch_frame& F = b.f[j];
+    if ((reinterpret_cast<uintptr_t>(F.frame) & 7) || (reinterpret_cast<uintptr_t>(F.depth) & 15) || (reinterpret_cast<uintptr_t>(F.rgb_eye) & 15) ||
+        (reinterpret_cast<uintptr_t>(F.tdf) & 15) || (reinterpret_cast<uintptr_t>(F.tdf_prev) & 15) || ((ne * 4) & 15)) fast = 0;
+  }
+  const long long items = fast ? ne / 4 : ne;
+  hipLaunchKernelGGL(k_chain_ingest, dim3(chain_grid(items, 256, 4096)), dim3(256), 0, s, b, fmt, p, a, fast);
+  hipLaunchKernelGGL(k_chain_a0, dim3(batch_grid(ne, 8192, 256, b.n), b.n), dim3(1024), 0, s, b, ne, p.eye_w, a);
+  hipLaunchKernelGGL(k_chain_b0, dim3(batch_grid(ne, 4096, 256, b.n), b.n), dim3(1024), 0, s, b, ne, p.eye_w, a);
 }
 
 // have_eye: the render path (F.tdf = filtered plane -> F.dn normalised); else the bare pixel_shift_cuda entry point (F.dn = the caller's plane)

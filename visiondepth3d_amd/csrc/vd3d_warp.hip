@@ -160,10 +160,97 @@ VD_DEV float wf_sqrt_torch(float x, const int2* __restrict__ tab) {
   if (x < 0x1p-100f) r = sqrtf(x);
   return r;
 }
-template <bool RESIZE, bool FEATHER, int WF_TH>
+// ================================================================================================================================
+// W0 `k_e2w` (round 4): the feather gradient mask of both eyes as its own launch -- phases A and B of W1 moved out of its tile.  In W1 they
+// ran on the (TH + k) x (TW + k) halo of every tile (1.46x the pixels at 4K / k = 9) behind two dependent global round trips (S, then the
+// D gathers) that three resident workgroups could not cover (33 % + 20 % of a workgroup's life: 56 us of 164 per 4K frame).  Here:
+//   wd    grid_sample(D, x -/+ S) of both eyes (:700-701) on the tile + one row / column (the gradient's neighbours): 1.05x, 17 KB of LDS,
+//         every thread's S loads, then all its D gathers, in flight together
+//   e2    clamp(|grad wd| * feather_strength, 0, 1) (:347-352) -> E2[y][x] = (left, right), 8 bytes per pixel; one thread = 4 pixels
+// W1 then starts at its phase C with a plain, coalesced tile load of E2.  Same expressions as W1's phases A / B (which the unfused
+// fallback and the no-mask variants keep).  (A first version also folded the shift plane itself in -- k_shift_e2: its edge-term tile and
+// pow chains had to be recomputed on the mask's halo and the launch took 177 us against k_shift's 64 + this kernel's: not kept.)
+#define EW_TW 64
+#define EW_TH 32
+#define EW_NT 512
+#define EW_U 5                         // positions per thread: ceil((TH + 1) (TW + 1) / NT)
+struct vd_ew_args { int H, W, vec; float fs, step_x, step_y; };
+__global__ __launch_bounds__(EW_NT) void k_e2w(const float* __restrict__ D, const float* __restrict__ S, vd_ew_args a, vd_f2* __restrict__ E2) {
+  constexpr int PW = EW_TW + 1, PH = EW_TH + 1, NP = PW * PH;
+  static_assert(EW_U * EW_NT >= NP, "positions per thread");
+  __shared__ __attribute__((aligned(16))) vd_f2 wd[PH][PW + 3];      // pitch 68 pairs: rows stay 16-byte aligned
+  __shared__ int2 rs14[64];
+  const int H = a.H, W = a.W;
+  const int x0 = blockIdx.x * EW_TW, y0 = blockIdx.y * EW_TH;
+  const int tid = threadIdx.x;
+  vd_stage_rs14(rs14, tid, EW_NT);
+  // positions (row r, column c) of the (TH + 1) x (TW + 1) region: image pixel (y0 - 1 + r, x0 - 1 + c)
+  float sv[EW_U]; int py[EW_U], px[EW_U]; bool ok[EW_U];
+#pragma unroll
+  for (int u = 0; u < EW_U; ++u) {
+    const int t = tid + u * EW_NT;
+    const int r = t / PW, c = t - r * PW;
+    py[u] = y0 - 1 + r; px[u] = x0 - 1 + c;
+    ok[u] = t < NP && py[u] >= 0 && py[u] < H && px[u] >= 0 && px[u] < W;
+    sv[u] = ok[u] ? S[(unsigned)py[u] * (unsigned)W + (unsigned)px[u]] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < EW_U; ++u) {
+    const int t = tid + u * EW_NT;
+    if (t >= NP) continue;
+    const int r = t / PW, c = t - r * PW;
+    vd_f2 v = {0.f, 0.f};
+    if (ok[u]) {   // W1 phase A: wf_gs_row + wf_warped_depth
+      int yn; float n, sr; bool s_ok;
+      wf_gs_row(vd_lin11_step(a.step_y, H, py[u]), H, &yn, &n, &sr, &s_ok);
+      v = wf_warped_depth(D + (unsigned)yn * (unsigned)W, sv[u], vd_lin11_step(a.step_x, W, px[u]), n, sr, s_ok && n != 0.f, W);
+    }
+    wd[r][c] = v;
+  }
+  __syncthreads();
+  // e2: thread = (tile row, strip of 4 pixels)
+  const int ty = tid >> 4, tx = (tid & 15) * 4;
+  const int y = y0 + ty, xs = x0 + tx;
+  if (y >= H || xs >= W) return;
+  vd_f2 e[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = xs + q;
+    e[q] = vd_f2{0.f, 0.f};
+    if (x < W) {
+      const vd_f2 cc = wd[ty + 1][tx + q + 1];
+      const vd_f2 z = {0.f, 0.f};
+      const vd_f2 gx = x > 0 ? cc - wd[ty + 1][tx + q] : z;
+      const vd_f2 gy = y > 0 ? cc - wd[ty][tx + q + 1] : z;
+      const vd_f2 qq = gx * gx + gy * gy;
+      const vd_f2 m = vd_f2{wf_sqrt_torch(qq.x, rs14), wf_sqrt_torch(qq.y, rs14)} * a.fs;   // torch.sqrt = MKL vsSqrt, not the rounded root
+      e[q].x = vd_clamp_fin(m.x, 0.f, 1.f); e[q].y = vd_clamp_fin(m.y, 0.f, 1.f);
+    }
+  }
+  const size_t o = (size_t)y * W + xs;
+  if (a.vec) {
+    vd_f4* dst = reinterpret_cast<vd_f4*>(E2 + o);
+    dst[0] = vd_f4{e[0].x, e[0].y, e[1].x, e[1].y};
+    dst[1] = vd_f4{e[2].x, e[2].y, e[3].x, e[3].y};
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (xs + q < W) E2[o + q] = e[q];
+  }
+}
+void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, float fs, float* E2) {
+  vd_ew_args a;
+  a.H = H; a.W = W; a.fs = fs;
+  a.vec = ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(E2) & 31) == 0) ? 1 : 0;
+  a.step_x = (1.f - (-1.f)) / (float)(W - 1); a.step_y = (1.f - (-1.f)) / (float)(H - 1);
+  hipLaunchKernelGGL(k_e2w, dim3((W + EW_TW - 1) / EW_TW, (H + EW_TH - 1) / EW_TH), dim3(EW_NT), 0, s, D, S, a, reinterpret_cast<vd_f2*>(E2));
+}
+
+// PRE (round 4): the gradient mask e2 of both eyes comes from the E2 plane k_e2w wrote (8 bytes per pixel); the tile's e2 region is a
+// plain coalesced load and the kernel starts at phase C -- no rowA table, no phase A / B, no D plane.
+template <bool RESIZE, bool FEATHER, int WF_TH, bool PRE>
 __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
-                                                      uint8_t* __restrict__ R) {
+                                                      uint8_t* __restrict__ R, const vd_f2* __restrict__ E2) {
   constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
   extern __shared__ float lds[];
   __shared__ int2 rs14[64];                          // VRSQRT14 table of vd_sqrt_torch (phase B)
@@ -198,7 +285,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   int er0 = 0;
   if (RESIZE) er0 = wf_tap(a.ih, H, a.scale_h, max(y0 - 1, 0)).i0;  // first eye-res row the tile touches
   // ---- tables
-  if (tid < wh) {   // phase-A rows
+  if (!PRE && tid < wh) {   // phase-A rows
     const int y = wy0 + tid;
     int yn = 0; float n = 0.f, sr = 1.f; bool s_ok = false;
     if (y >= 0 && y < H) wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
@@ -216,10 +303,30 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     t[8] = __int_as_float((t1.i0 - er0) * rp); t[9] = __int_as_float((t1.i1 - er0) * rp); t[10] = t1.w0; t[11] = t1.w1;
     t[12] = n; t[13] = sr; t[14] = __int_as_float((s_ok && n != 0.f) ? 1 : 0); t[15] = __int_as_float(yn);
   }
-  if (FEATHER && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
+  if (FEATHER && !PRE && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
+  if (FEATHER && PRE) {
+    // the e2 region of the tile straight from the E2 plane (zero outside the image = avg_pool2d's padding); all loads of a thread in flight
+    constexpr int NLD = 6;
+    for (int t0 = tid; t0 < eh * ew; t0 += NLD * WF_NT) {
+      vd_f2 ev[NLD]; int dst[NLD];
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) {
+        const int t = t0 + j * WF_NT;
+        ev[j] = vd_f2{0.f, 0.f}; dst[j] = -1;
+        if (t < eh * ew) {
+          const int ty = wf_div(t, a.m_ew), tx = t - ty * ew;
+          const int y = y0 - r + ty, x = x0 - r + tx;
+          dst[j] = ty * ewp + tx;
+          if (y >= 0 && y < H && x >= 0 && x < W) ev[j] = E2[(unsigned)y * (unsigned)W + (unsigned)x];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) if (dst[j] >= 0) e2[dst[j]] = ev[j];
+    }
+  }
   __syncthreads();
   VD_STAMP(wf_stamps, 1, false);
-  if (FEATHER) {
+  if (FEATHER && !PRE) {
     // phase A, main block: wave = halo row (scalar row part), lane = the first 64 halo columns (gx once per lane).  The phase is
     // LATENCY-bound (two dependent global round trips per position: S, then the D gathers), so WF_AB rows are walked together: all
     // their S loads are issued first, then all their D gathers, then the combines (measured: 12 -> 4 exposed round trips per wave).
@@ -283,9 +390,9 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       }
     }
   }
-  __syncthreads();
+  if (!PRE) __syncthreads();
   VD_STAMP(wf_stamps, 2, false);
-  if (FEATHER) {
+  if (FEATHER && !PRE) {
     // phase B: e2 = clamp(|grad WD| * fs, 0, 1) (:347-352), zero outside the image (avg_pool2d zero padding)
     const int bq = WF_NT / ew, br = WF_NT - bq * ew;
     int ty = wf_div(tid, a.m_ew), tx = tid - ty * ew;
@@ -307,7 +414,9 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       if (tx >= ew) { tx -= ew; ++ty; }
     }
     __syncthreads();
-    VD_STAMP(wf_stamps, 3, false);
+  }
+  VD_STAMP(wf_stamps, 3, false);
+  if (FEATHER) {
     // phase C: blend weights b (see the header) into the dead wd buffer; thread = (tile row, strip of 4 pixels), both eyes packed
     {
       vd_f2* bb = wd;   // [WF_TH][WF_TW]
@@ -530,10 +639,18 @@ static bool wf_fastdiv_ok(int k) {   // every float in [0, k*k] checked; inexact
   return !((bad >> k) & 1ull);
 }
 
-// returns false when the fused kernel cannot be used (tiles would not fit the 160 KB LDS): caller falls back to v0
-bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
-                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R) {
-  constexpr int WF_TH = 32, WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
+// tile height of W1 with a precomputed mask (tuning probe: vd3d_debug_tune(2, 16 | 32)); without the mask phases in the tile the halo no longer
+// multiplies their arithmetic, so flatter tiles (less LDS per workgroup, more workgroups per CU) become an option
+static int g_wf_pre_th = 32;
+void vd_set_warp_pre_th(int th) { g_wf_pre_th = th == 16 ? 16 : 32; }
+
+// returns false when the fused kernel cannot be used (tiles would not fit the 160 KB LDS): caller falls back to v0.
+// E2 != NULL: the gradient mask was computed by k_e2w (PRE variants); plan_only: decide, do not launch.
+template <int WF_TH>
+static bool warp_fused_impl(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
+                            const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2, bool plan_only) {
+  constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
+  const bool pre = E2 != nullptr && p.enable_feathering;
   vd_wf_args a;
   a.ih = ih; a.iw = iw; a.H = H; a.W = W; a.k = p.enable_feathering ? p.blur_ksize : 1; a.feather = p.enable_feathering ? 1 : 0;
   a.fs = (float)p.feather_strength;
@@ -566,26 +683,29 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
     if ((a.nch + 63) / 64 > WF_NW) return false;   // one wave per 64-column chunk of the Hh build
     sz_hh = (size_t)3 * a.er_max * a.nch;
   }
-  // aliased layout (see the kernel): max(wd2 + e2_2, Hh) when feathering, else Hh alone
+  // aliased layout (see the kernel): max(wd2 + e2_2, Hh) when feathering, else Hh alone; with a precomputed mask wd2 is only the bb2 buffer
   size_t fl = sz_hh;
   if (a.feather) {
     const int ew = WF_TW + k - 1, ewp = ew + ((2 - ew) & 3);
-    const size_t sz_wd = ((size_t)2 * (WF_TH + k) * (WF_TW + k) + 3) & ~(size_t)3, sz_e2 = (size_t)2 * (WF_TH + k - 1) * ewp;
+    const size_t sz_wd = pre ? (size_t)2 * WF_TH * WF_TW : (((size_t)2 * (WF_TH + k) * (WF_TW + k) + 3) & ~(size_t)3);
+    const size_t sz_e2 = (size_t)2 * (WF_TH + k - 1) * ewp;
     a.e2_off = (int)sz_wd;
     fl = sz_wd + sz_e2 > sz_hh ? sz_wd + sz_e2 : sz_hh;
   }
   fl = (fl + 3) & ~(size_t)3;            // tables start 16 B aligned (ds_read_b128)
   a.tab_off = (int)fl;
-  const size_t t_rowA = (size_t)(WF_TH + k) * 4, t_colT = (size_t)2 * a.nch;
+  const size_t t_rowA = pre ? 0 : (size_t)(WF_TH + k) * 4, t_colT = (size_t)2 * a.nch;
   fl += (size_t)WF_TH * WF_RD + (t_rowA > t_colT ? t_rowA : t_colT);
   if (fl & 3) fl += 4 - (fl & 3);
   a.step_x = (1.f - (-1.f)) / (float)(W - 1); a.step_y = (1.f - (-1.f)) / (float)(H - 1);
   auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
   a.m_ew = magic(WF_TW + k - 1);
   if ((WF_TH + k) * (WF_TW + k) >= 65536) return false;
+  if (WF_TH + k > WF_NT || 128 + WF_TH > WF_NT) return false;   // the table phase maps one thread per halo row / tile row
   if (H >= (1 << 24) || W >= (1 << 24) || (unsigned long long)H * W * 3ull >= (1ull << 32) || (unsigned long long)ih * iw * 3ull >= (1ull << 32)) return false;  // 32-bit offsets
   const size_t bytes = fl * sizeof(float);
   if (bytes > 78 * 1024) return false;  // keep >= 2 workgroups per CU (3 when <= 53 KB: 4K / k = 9 needs 51 KB)
+  if (plan_only) return true;
   a.ntx = (W + WF_TW - 1) / WF_TW;
   a.ntiles = a.ntx * ((H + WF_TH - 1) / WF_TH);
   a.xcd = 1;
@@ -597,30 +717,39 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
   if (dev >= 0 && dev < 64 && !attr[dev]) {
     // dynamic LDS limit = the CU's 160 KB minus the kernel's static LDS (the VRSQRT14 table); a failed call would otherwise surface as a
     // sticky "invalid argument" at the next hipGetLastError
-#define WF_ATTR(R_, F_, T_)                                                                                                        \
+#define WF_ATTR(R_, F_, P_)                                                                                                        \
   do {                                                                                                                             \
     hipFuncAttributes fa_;                                                                                                         \
     size_t st_ = 0;                                                                                                                \
-    if (hipFuncGetAttributes(&fa_, (const void*)k_warp_fused<R_, F_, T_>) == hipSuccess) st_ = fa_.sharedSizeBytes;                \
-    if (hipFuncSetAttribute((const void*)k_warp_fused<R_, F_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize,                     \
+    if (hipFuncGetAttributes(&fa_, (const void*)k_warp_fused<R_, F_, WF_TH, P_>) == hipSuccess) st_ = fa_.sharedSizeBytes;         \
+    if (hipFuncSetAttribute((const void*)k_warp_fused<R_, F_, WF_TH, P_>, hipFuncAttributeMaxDynamicSharedMemorySize,              \
                             (int)(160 * 1024 - st_)) != hipSuccess) {                                                              \
       (void)hipGetLastError();                                                                                                     \
       fprintf(stderr, "vd3d: hipFuncSetAttribute(k_warp_fused, max dynamic LDS) failed; using the unfused warp kernels\n");        \
       return false;                                                                                                                \
     }                                                                                                                              \
   } while (0)
-    WF_ATTR(true, true, 32); WF_ATTR(true, false, 32); WF_ATTR(false, true, 32); WF_ATTR(false, false, 32);
+    WF_ATTR(true, true, false); WF_ATTR(true, false, false); WF_ATTR(false, true, false); WF_ATTR(false, false, false);
+    WF_ATTR(true, true, true); WF_ATTR(false, true, true);
 #undef WF_ATTR
     attr[dev] = true;
   }
-#define WF_LAUNCH(T_)                                                                                                              \
-  do {                                                                                                                             \
-    if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);       \
-    else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);              \
-    else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);           \
-    else hipLaunchKernelGGL((k_warp_fused<false, false, T_>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R);                         \
-  } while (0)
-  WF_LAUNCH(32);
-#undef WF_LAUNCH
+  const vd_f2* e2p = reinterpret_cast<const vd_f2*>(E2);
+  if (resize && a.feather && pre) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
+  else if (a.feather && pre) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
+  else if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
+  else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
+  else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
+  else hipLaunchKernelGGL((k_warp_fused<false, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
   return true;
+}
+bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
+                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2) {
+  if (E2 && p.enable_feathering && g_wf_pre_th == 16 && warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, true))
+    return warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, false);
+  return warp_fused_impl<32>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, false);
+}
+// would vd_launch_warp_fused take this frame?  (the caller then runs k_e2w for the mask plane first)
+bool vd_warp_fused_ok(int ih, int iw, int H, int W, const vd3d_shift_params& p) {
+  return warp_fused_impl<32>(nullptr, nullptr, ih, iw, nullptr, nullptr, H, W, p, nullptr, nullptr, reinterpret_cast<const float*>(16), true);
 }

@@ -651,17 +651,25 @@ def render_clip(frames, depths, **kw):
 
 
 def render_pairs(pairs, *, renderer: Renderer | None = None, target_ratio=16 / 9, keep_on_device=False,
-                 blank_frames=None, start_frame_idx=0, skip_first=True, **kw):
+                 blank_frames=None, start_frame_idx=0, skip_first=True, batch=8, **kw):
     """``render_clip`` over ONE iterable of (frame, depth) pairs.  ``skip_first=False``: the caller has already consumed the
     clip's first frame (render_sbs_3d's capture shell does, like the reference).
 
     ``skip_blank_frames=True`` uses ``blank_frames`` (absolute frame indices, what the reference's
     ``detect_black_white_frames`` returns; tested as ``start_frame_idx + loop index`` like :1063,1278); without a
-    list it renders every frame, which is what the reference does when its detection fails (:1058-1060)."""
+    list it renders every frame, which is what the reference does when its detection fails (:1058-1060).
+
+    ``batch`` > 1 (default 8): frames go through the renderer in STEPS of ``batch`` frames (``sharded.ChunkSharder`` at world 1: the
+    select chain of a step in a dozen launches instead of eight per frame, its pixel kernels on two streams behind the next step's
+    chain) -- bit-identical to the frame-by-frame loop (``batch=1``: one ``vd3d_render_frame`` per pair), frames are yielded in order,
+    up to two steps late."""
     r = renderer or default_renderer()
     blank = set(blank_frames or ()) if kw.get("skip_blank_frames") else set()
     it = iter(pairs)
     if skip_first and next(it, None) is None:
+        return
+    if int(batch) > 1 and hasattr(r, "shard2_p1_batch"):   # a renderer without the step entry points (a test double) takes the frame-by-frame loop
+        yield from _render_pairs_batched(r, it, int(batch), target_ratio, keep_on_device, blank, start_frame_idx, kw)
         return
     params = None
     for idx, (f, d) in enumerate(it):
@@ -675,6 +683,54 @@ def render_pairs(pairs, *, renderer: Renderer | None = None, target_ratio=16 / 9
         if getattr(r, "_private", False):   # the consumer (a D2H copy below, or the caller's own kernels on torch's stream) runs behind the renderer's stream
             r.ordered_after()
         yield out if keep_on_device else out.cpu().numpy()
+
+
+def _render_pairs_batched(r, it, B, target_ratio, keep_on_device, blank, start_frame_idx, kw):
+    """The loop of ``render_pairs`` in steps of B frames on two alternating slot sets (module docstring of ``sharded``)."""
+    from .sharded import ChunkSharder, HipChunkBackend
+    sets, params, pending, idx0 = None, None, [], 0
+
+    def drain(step):
+        sh, outs = step
+        for j, o in enumerate(outs):
+            r.wait_pixels(sh.slot_base + j)      # host wait: the frame's pixel pass has written it
+            yield o if keep_on_device else o.cpu().numpy()
+    k = 0
+    try:
+        while True:
+            chunk = []
+            for f, d in it:
+                chunk.append((f, d))
+                if len(chunk) == B:
+                    break
+            if not chunk:
+                break
+            if params is None:
+                f0 = chunk[0][0]
+                params = render_kwargs_to_params(int(f0.shape[1]), int(f0.shape[0]), target_ratio=target_ratio, **kw)
+                r.new_clip()
+                be = HipChunkBackend(r, params)
+                first = ChunkSharder(be, 0, 1, B)
+                sets = [first, ChunkSharder(be, 0, 1, B, slot_base=B, twin_of=first)]
+                r.set_pixel_overlap(2)
+            T = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(r.device, non_blocking=True)
+            fl, dl = [T(f) for f, _ in chunk], [T(d) for _, d in chunk]
+            flags = [(start_frame_idx + idx0 + j) in blank for j in range(len(chunk))] if blank else None
+            sh = sets[k % 2]
+            outs = sh.render_step(fl, dl, n_valid=len(chunk), blank=flags, first_step=(k == 0), more_steps=True)
+            pending.append((sh, outs))
+            if len(pending) == 2:                 # step k - 1 is complete once step k has been enqueued behind it
+                yield from drain(pending.pop(0))
+            idx0 += len(chunk)
+            k += 1
+        for step in pending:
+            yield from drain(step)
+        pending = []
+    finally:
+        if sets is not None:
+            r.set_pixel_overlap(0)               # joins whatever is still in flight; the renderer is back in sequential mode
+            if getattr(r, "_private", False):
+                r.ordered_after()
 
 
 from .video_io import render_sbs_3d  # noqa: E402,F401  (the reference module exports it, core/render_3d.py:933)

@@ -44,6 +44,7 @@ def _backend():
 
 # Wire format of the encoder pipe: "bgr24" is the reference's (:1146); "nv12" (opt-in) converts on the device and halves the bytes that
 # cross PCIe and the pipe -- ffmpeg then skips its own RGB -> YUV pass for the yuv420p output.
+RENDER_BATCH = 8     # frames per renderer step (render_3d.render_pairs): 1 = one vd3d_render_frame per frame; results are identical
 PIPE_PIX_FMT = "bgr24"
 
 
@@ -233,6 +234,8 @@ def render_sbs_3d(
                     return
                 yield fr
 
+        pos_log = []   # capture position right after frame i was decoded: the batched renderer reads ahead of what it has delivered
+
         def paired():   # cancel / pause are honoured BEFORE the next pair of frames is decoded (:1196-1222)
             fi, di = frames_of(cap), frames_of(dcap)
             while True:
@@ -243,9 +246,10 @@ def render_sbs_3d(
                 f, d = next(fi, None), next(di, None)
                 if f is None or d is None:
                     return
+                pos_log.append(int(cap.get(cv.CAP_PROP_POS_FRAMES)))
                 yield f, d
 
-        clip = render_pairs(paired(), renderer=renderer, keep_on_device=sink.nv12,
+        clip = render_pairs(paired(), renderer=renderer, keep_on_device=sink.nv12, batch=RENDER_BATCH,
                            target_ratio=target_ratio, blank_frames=blank, start_frame_idx=first_idx, skip_first=False,
                            output_height=output_height, fg_shift=fg_shift, mg_shift=mg_shift, bg_shift=bg_shift,
                            sharpness_factor=sharpness_factor, output_format=output_format, dof_strength=dof_strength,
@@ -265,7 +269,7 @@ def render_sbs_3d(
         for i, muxed in enumerate(clip):
             if not sink.write(muxed):
                 break
-            if end_s is not None and int(cap.get(cv.CAP_PROP_POS_FRAMES)) >= end_idx:
+            if end_s is not None and pos_log[i] >= end_idx:   # :1429-1431 with the position the capture had when THIS frame had been read
                 break
             now = time.time()
             if now > t_prev:
