@@ -42,12 +42,18 @@ WORKLOADS = {
     "4k-dav2b-dibr": (2160, 3840, "depth-anything-v2-base", "BASELINE configs[3] per-GPU slice: 4K, DA-V2-Base + DIBR"),
     "4k-dibr-sepdof": (2160, 3840, None, "4K DIBR only with dof_dense_conv=0: separable DOF levels instead of the reference's dense k x k "
                        "convolution order (faster finishing kernel; differs from the reference on ~0.5 % of samples, max 4)"),
+    "4k-dibr-dof3": (2160, 3840, None, "4K DIBR only with dof_strength 3.0 (13-tap Gaussian: beyond the fused finishing kernel's 9 taps, the unfused "
+                     "DOF + sharpen / mux kernels run)"),
+    "4k-dibr-anaglyph": (2160, 3840, None, "4K DIBR only, Red-Cyan Anaglyph output (fused finishing kernel since round 4)"),
 }
+# render keyword overrides of the variants above (everything else: RENDER_KW)
+WORKLOAD_KW = {"4k-dibr-dof3": dict(dof_strength=3.0), "4k-dibr-anaglyph": dict(output_format="Red-Cyan Anaglyph")}
 HEADLINE = "4k-dav2b-dibr"
 RENDER_KW = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
                  feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)  # render_cli.py:24-33
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense f32-input MFMA (= vector rate) / dense bf16
+VALU_SPEC_LANE_OPS = 78.6e12   # data sheet: 157.3 TFLOP/s float32 vector = 78.6 T lane-FMAs/s at 2.4 GHz (256 CUs x 4 SIMDs x 32 lanes / clock)
 VALU_PEAK_LANE_OPS = 50.2e12   # MEASURED v_fma_f32 issue rate of the chip (tools/ubench_valu.hip, 8 waves / SIMD: 100.3 TFLOP/s = 50.2 T lane-FMAs/s;
                                # a wave64 VALU instruction issues every ~2.3 cycles per SIMD at the 1.77 GHz the chip sustains under that load --
                                # the data sheet's 157 TFLOP/s assumes 2.4 GHz).  Until round 3 this was 256 x 4 x 16 x 2.4e9 = 39.3 T, which the
@@ -210,7 +216,8 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
 
     sh, sw, model_name, desc = WORKLOADS[workload]
     host_io = bool(args.host_io) if host_io is None else bool(host_io)
-    p = render_kwargs_to_params(sw, sh, output_height=sh, dof_dense_conv=not workload.endswith("-sepdof"), **RENDER_KW)
+    p = render_kwargs_to_params(sw, sh, output_height=sh, dof_dense_conv=not workload.endswith("-sepdof"),
+                                **dict(RENDER_KW, **WORKLOAD_KW.get(workload, {})))
     overlap = (not args.no_overlap) and model_name is not None
     r = Renderer(local_rank, private_stream=overlap, auto_order=False)   # bench orders its streams by hand; DIBR chain on its own stream when a depth net shares the GPU
     rh = Renderer(local_rank) if overlap else r        # depth hand-off stays on the depth net's (torch) stream
@@ -326,7 +333,7 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
 
     stage_ms = {}
     if profile:
-        for name in ("frame", "ingest", "select_eye", "select_dc", "shape", "select_s1", "shift", "w1", "warp", "finish",
+        for name in ("frame", "ingest", "select_eye", "select_dc", "shape", "select_s1", "shift", "w1", "e2w", "warp", "finish",
                      "p1_own", "p3_own", "replay"):
             v = r.stage_ms(name)
             if v >= 0:
@@ -343,13 +350,15 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
         for j in range(min(B, 8, len(depths))):
             r.render_frame(frames[j], depths[j], p, out=outs[j])
         r.sync()
-        iso_ms = {"w1": round(r.stage_ms("w1"), 5), "finish": round(r.stage_ms("finish"), 5), "frame": round(r.stage_ms("frame"), 5)}
+        iso_ms = {"w1": round(r.stage_ms("w1"), 5), "e2w": round(r.stage_ms("e2w"), 5), "finish": round(r.stage_ms("finish"), 5),
+                  "frame": round(r.stage_ms("frame"), 5)}
         r.set_profiling(False)
 
     flops = pipe.flops_per_frame(sh, sw) if (pipe is not None and rank == 0) else None
     res = dict(workload=workload, desc=desc, sh=sh, sw=sw, model=model_name, B=B, steps=steps, warmup=warmup, dt=dt,
                frames_total=world * steps * B, stage_ms=stage_ms, iso_ms=iso_ms, net_ms=net_ms, flops_per_frame=flops,
-               N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), depth_dtype=depth_dtype if model_name else None,
+               N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), pix_streams=(1 if host_io else max(1, int(args.pix_streams))) if pix_ov else 0,
+               depth_dtype=depth_dtype if model_name else None,
                host_io=host_io, clip=args.clip, clip_frames_global=world * args.clip,
                p1_wait_ms=_p1_wait(env, shr2),
                shard_bytes=(shr2[0].bytes_per_step() if (shr2 and hasattr(shr2[0], "bytes_per_step")) else None))
@@ -561,7 +570,9 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
         ach = alg / (w1_ms * 1e-3) / 1e9
         w1 = pm.get("k_warp_fused", pm if "corrected_bytes_per_launch" in pm else {})
         lane = w1.get("valu_lane_instr_per_launch")
-        rf = {"bound": "valu" if lane else "hbm", "kernel": "k_warp_fused (W1: feather mask + pool + warp + blend, one launch)",
+        rf = {"bound": "valu" if lane else "hbm", "kernel": "W1 = k_e2w (warped-depth gradient mask of both eyes) + k_warp_fused (window sums + warp + "
+                                                           "blend): the same work as round 3's single launch, two launches since round 4",
+              "k_e2w_avg_launch_ms": st.get("e2w"), "k_warp_fused_avg_launch_ms": (round(w1_ms - st["e2w"], 5) if st.get("e2w", -1) > 0 else None),
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
               "traffic": w1.get("corrected_bytes_per_launch"), "traffic_source": w1.get("source"),
               "traffic_taken_at_commit": (_pmc("commit") or None),
@@ -576,8 +587,9 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
                       "sequential DIBR-only pass after the timed region"}
         if lane:
             t = (iso.get("w1") or w1_ms) * 1e-3
-            rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                          "frac_of_valu_peak_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4), "source": w1.get("source")}
+            rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "measured_v_fma_rate_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                          "spec_lane_ops_per_s": VALU_SPEC_LANE_OPS, "frac_of_measured_rate_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4),
+                          "frac_of_spec_rate_isolated": round(lane / t / VALU_SPEC_LANE_OPS, 4), "source": w1.get("source")}
         out["roofline"] = rf
     fin_ms = st.get("finish", -1)
     if fin_ms > 0:  # E1: 6N eyes in + N eye-res depth + 3N Half-SBS out
@@ -592,13 +604,15 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
               "isolated_frac": round(alg / (iso["finish"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso.get("finish", 0) > 0 else None}
         if lane:   # E1 against BOTH bounds (HBM above, fp32 ALU here)
             t = (iso.get("finish") or fin_ms) * 1e-3
-            rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                          "frac_of_valu_peak_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4), "source": e1.get("source")}
+            rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "measured_v_fma_rate_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                          "spec_lane_ops_per_s": VALU_SPEC_LANE_OPS, "frac_of_measured_rate_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4),
+                          "frac_of_spec_rate_isolated": round(lane / t / VALU_SPEC_LANE_OPS, 4), "source": e1.get("source")}
         out["roofline_e1"] = rf
     fr_ms, note = st.get("frame", -1), "sequential frame: K1-K6, k_shift, W1, E1"
     if fr_ms <= 0 and all(st.get(k, -1) > 0 for k in ("p1_own", "p3_own", "warp", "finish")):
-        fr_ms = st["p1_own"] + st["p3_own"] + st["warp"] + st["finish"] + max(st.get("replay", 0.0), 0.0) / res["B"]
-        note = "sum of the frame's stage durations: P1 + P3 (K1-K6 in measure mode) + replay/B + k_shift + W1 + E1, on two streams"
+        fr_ms = (st["p1_own"] + st["p3_own"] + max(st.get("replay", 0.0), 0.0)) / res["B"] + st["warp"] + st["finish"]
+        note = ("sum of the frame's stage durations: (P1 + P3 + replay) / B -- the select chain runs batched over the B frames of a step since round 4 -- "
+                "+ k_shift + k_e2w + W1 + E1; chain and pixel kernels share the GPU on separate streams, so the stage durations overlap")
     if fr_ms > 0:  # whole DIBR chain = RGB 3N + depth 4N twice + two u8 eyes 6N = 17 N per stereo pair
         ch = 17 * N / (fr_ms * 1e-3) / 1e9
         out["roofline_chain"] = {"bound": "latency", "kernel": "whole DIBR frame (" + note + ")", "achieved": round(ch, 2),
@@ -685,12 +699,14 @@ def main():
         r1d = run_workload(env, args, "1080p-dibr", 10, 3, profile=prof)
         rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
         rdn = run_workload(env, args, "4k-dibr-sepdof", 4, 2, profile=prof, isolated_pass=False)
+        rd3 = run_workload(env, args, "4k-dibr-dof3", 4, 2, profile=prof, isolated_pass=False)
+        ran = run_workload(env, args, "4k-dibr-anaglyph", 4, 2, profile=prof, isolated_pass=False)
         rhi = run_workload(env, args, "4k-dibr", 6, 2, profile=False, isolated_pass=False, host_io=True)   # host-I/O-included figure
         rhi["workload"] = "4k-dibr-hostio"
         rhi["desc"] = ("4K DIBR only with the frames starting in pinned host memory and the muxed frames copied back to pinned host memory "
                        "(frame_io.PinnedRing, three slots: H2D, render and D2H of consecutive steps overlap): the PCIe-inclusive rate, never `value`")
         subs = {"4k-dibr": (r4, None), "1080p-dav2s-dibr": (r1e, None), "1080p-dibr": (r1d, None), "4k-dav2b-dibr-bf16": (rbf, None),
-                "4k-dibr-sepdof": (rdn, None), "4k-dibr-hostio": (rhi, None)}
+                "4k-dibr-sepdof": (rdn, None), "4k-dibr-dof3": (rd3, None), "4k-dibr-anaglyph": (ran, None), "4k-dibr-hostio": (rhi, None)}
         roof_src = r4
         try:
             up_rec = run_upscale_chain(env, args)
@@ -714,7 +730,7 @@ def main():
                        "depth_net_dtype": ({"f32": "float32 (the reference's precision)", "bf16": "bfloat16"}[args.depth_dtype]
                                            if model_name else None),
                        "arithmetic": "u8 in/out, float32 DIBR kernels, float64 scalar trackers",
-                       "pixel_overlap": head["pix_ov"],
+                       "pixel_overlap": head["pix_ov"], "pixel_streams": head.get("pix_streams"),
                        "sharding": "contiguous frame chunks per rank; scalar records all-gathered and trackers replayed on every rank "
                                    "(bit-identical to 1 GPU)" if env.world > 1 else None,
                        "rccl_ranks": env.world if env.world > 1 else None,

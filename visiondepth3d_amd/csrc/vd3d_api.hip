@@ -377,7 +377,7 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
     bool fused = false;
     { StageTimer t2(c, "w1");
-      if (pre) vd_launch_e2w(s, c->D, c->S, H, W, (float)sp.feather_strength, c->E2);
+      if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->D, c->S, H, W, (float)sp.feather_strength, c->E2); }
       fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R, pre ? c->E2 : nullptr); }
     if (!fused) {   // blur sizes / frame sizes the fused kernel refuses (its LDS tile would not fit): one stage per kernel
     if (sp.enable_feathering) {
@@ -812,7 +812,7 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
     bool fused;
     { StageTimer t2(c, "w1");
-      if (pre) vd_launch_e2w(s, c->slot_D[slot], S, H, W, (float)sp.feather_strength, E2);
+      if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->slot_D[slot], S, H, W, (float)sp.feather_strength, E2); }
       fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], S, H, W, sp, L, R, pre ? E2 : nullptr); }
     if (!fused) {
       if ((rc = pix_exclusive(c))) return rc;

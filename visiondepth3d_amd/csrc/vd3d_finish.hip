@@ -23,7 +23,9 @@
 //           interior tiles with fit (1,1) / (2,1) take the vector path, everything else the generic per-pixel one.
 // Arithmetic identical to k_dof_grade / k_sharp_mux and the oracle.
 // Fast path conditions (else the unfused kernels run): Gaussian taps <= 9 (dof_strength <= 2), fit factors in {1,2,4},
-// format in {Half-SBS, Full-SBS, Passive Interlaced}.
+// format in {Half-SBS, Full-SBS, Passive Interlaced, Red-Cyan Anaglyph (round 4: each eye's workgroups store their own bytes of the anaglyph)}.
+// (Round 4, measured and not kept: writing the halo-column windows during the tile load and publishing the level set per wave, i.e. ONE barrier
+// between the load phase and the levels instead of two: 252 -> 259 us at 4K.)
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 
@@ -211,6 +213,27 @@ VD_DEV void ff_sharp4(const uint32_t (*gb)[FF_GP], int gy, int gc, float kn, flo
     acc = acc + kn * d;
 #pragma unroll
     for (int q = 0; q < 4; ++q) s[c][q] = (int)vd_sat_rne_u8(acc[q]);
+  }
+}
+
+// Red-Cyan anaglyph of generate_anaglyph_3d (:866-883) on the sharpened / fitted values fv[c][q] (c = byte order of the eye, B G R) of up to 4
+// consecutive output pixels: the reference splits the BGR frame and CALLS the planes r, g, b, so output byte 0 is a function of the left eye's three
+// bytes only and output bytes 1 and 2 of the right eye's only -- each eye's workgroup stores its own bytes, no cross-eye exchange.  Same
+// expressions as k_sharp_mux.
+VD_DEV void ff_anaglyph_store(uint8_t* o, int eye, const int fv[3][4], int nvalid) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q >= nvalid) break;
+    const float p0 = vd_u8_unit((float)fv[0][q]), p1 = vd_u8_unit((float)fv[1][q]), p2 = vd_u8_unit((float)fv[2][q]);
+    if (eye == 0) {
+      const float red = ((float)0.4561 * p0 + (float)0.5005 * p1) + (float)0.1762 * p2;
+      o[3 * q] = (uint8_t)(vd_clamp(red, 0.f, 1.f) * 255.0f);
+    } else {
+      const float green = ((float)0.3764 * p0 + (float)0.7616 * p1) - (float)0.1876 * p2;
+      const float blue = ((float)-0.0401 * p0 - (float)0.1126 * p1) + (float)1.2723 * p2;
+      o[3 * q + 1] = (uint8_t)(vd_clamp(green, 0.f, 1.f) * 255.0f);
+      o[3 * q + 2] = (uint8_t)(vd_clamp(blue, 0.f, 1.f) * 255.0f);
+    }
   }
 }
 
@@ -505,13 +528,9 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       const int oy = oy0 + ty;
       if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
       uint32_t pack[3] = {0, 0, 0};
+      int fv[3][4];
       if (a.fx == 1) {
-        int s[3][4];
-        ff_sharp4(gb, ty + 1, 4 + 4 * m, kn, kc, s);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { const int bi = 3 * q + c; pack[bi >> 2] |= (uint32_t)s[c][q] << (8 * (bi & 3)); }
+        ff_sharp4(gb, ty + 1, 4 + 4 * m, kn, kc, fv);
       } else {
         int s0[3][4], s1[3][4];
         ff_sharp4(gb, ty + 1, 4 + 8 * m, kn, kc, s0);
@@ -521,13 +540,17 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const int sum = q < 2 ? s0[c][2 * q] + s0[c][2 * q + 1] : s1[c][2 * q - 4] + s1[c][2 * q - 3];
-            const uint32_t v = vd_sat_rne_u8((float)sum * 0.5f);
-            const int bi = 3 * q + c;
-            pack[bi >> 2] |= v << (8 * (bi & 3));
+            fv[c][q] = (int)vd_sat_rne_u8((float)sum * 0.5f);
           }
       }
-      const int oxq = ox0 + 4 * m + a.xo + ((a.format == VD3D_FMT_INTERLACED) ? 0 : eye * a.fit_w);
+      const bool single = a.format == VD3D_FMT_INTERLACED || a.format == VD3D_FMT_ANAGLYPH;   // one eye-sized canvas
+      const int oxq = ox0 + 4 * m + a.xo + (single ? 0 : eye * a.fit_w);
       uint8_t* o = out + ((size_t)(oy + a.yo) * a.out_w + oxq) * 3;
+      if (a.format == VD3D_FMT_ANAGLYPH) { ff_anaglyph_store(o, eye, fv, 4); continue; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const int bi = 3 * q + c; pack[bi >> 2] |= (uint32_t)fv[c][q] << (8 * (bi & 3)); }
       if ((reinterpret_cast<uintptr_t>(o) & 3) == 0) {
         uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
         o32[0] = pack[0]; o32[1] = pack[1]; o32[2] = pack[2];
@@ -545,6 +568,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
     const int oy = oy0 + ty;
     if (oy >= a.in_h) continue;
     uint32_t pack[3] = {0, 0, 0};
+    int fv[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     int nvalid = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -578,11 +602,14 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
         else v = vd_sat_rne_u8((float)sum[c] * scale);
         const int bi = 3 * q + c;
         pack[bi >> 2] |= (uint32_t)v << (8 * (bi & 3));
+        fv[c][q] = (int)v;
       }
     }
     if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
-    const int oxq = ox0 + tq * 4 + a.xo + ((a.format == VD3D_FMT_INTERLACED) ? 0 : eye * a.fit_w);
+    const bool single = a.format == VD3D_FMT_INTERLACED || a.format == VD3D_FMT_ANAGLYPH;
+    const int oxq = ox0 + tq * 4 + a.xo + (single ? 0 : eye * a.fit_w);
     uint8_t* o = out + ((size_t)(oy + a.yo) * a.out_w + oxq) * 3;
+    if (a.format == VD3D_FMT_ANAGLYPH) { ff_anaglyph_store(o, eye, fv, nvalid); continue; }
     if (nvalid == 4 && ((size_t)(o - out) & 3) == 0) {
       uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
       o32[0] = pack[0]; o32[1] = pack[1]; o32[2] = pack[2];
@@ -598,7 +625,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
 bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
                             int use_override, int bar_w, int bar_s, uint8_t* out, int dense, const float* w2_dev) {
-  if (!(p.format == VD3D_FMT_HALF_SBS || p.format == VD3D_FMT_FULL_SBS || p.format == VD3D_FMT_INTERLACED)) return false;
+  if (!(p.format == VD3D_FMT_HALF_SBS || p.format == VD3D_FMT_FULL_SBS || p.format == VD3D_FMT_INTERLACED || p.format == VD3D_FMT_ANAGLYPH)) return false;
   for (int l = 0; l < fc.nlev; ++l) if (fc.ksz[l] > 2 * FF_R + 1 || fc.ksz[l] < 3) return false;
   vd_ff_args a;
   a.H = p.warp_h; a.W = p.warp_w; a.eh = eh; a.ew = ew;
