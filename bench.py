@@ -242,7 +242,7 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     # host-io: measured slower with the overlapped passes (the copy engines then compete with two compute streams)
     pix_ov = (not host_io) if args.pixel_overlap is None else bool(args.pixel_overlap)
     shr2 = None
-    if world > 1 or args.sharded or pix_ov:
+    if world > 1 or args.sharded or pix_ov or not args.per_frame:   # the step protocol (batched select chain) is the default DIBR path at any world size
         from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
         be = HipChunkBackend(r, p)
         shr2 = [ChunkSharder(be, rank, world, B)]
@@ -656,7 +656,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="headline only")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
-    ap.add_argument("--sharded", action="store_true", help="use the chunk-sharding step protocol even at N=1 without pixel overlap")
+    ap.add_argument("--sharded", action="store_true", help="use the chunk-sharding step protocol even at N=1 without pixel overlap (the default since round 4)")
+    ap.add_argument("--per-frame", action="store_true", help="one vd3d_render_frame call per frame instead of the batched step protocol (N = 1, no pixel overlap)")
     ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
                     "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
     ap.add_argument("--pixel-overlap", dest="pixel_overlap", action="store_true", default=None,

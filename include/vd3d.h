@@ -298,6 +298,12 @@ int vd3d_resize_cubic_u8(vd3d_ctx* ctx, const uint8_t* src, int sh, int sw, int 
 /* cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) on uint8 BGR (3 interleaved channels): run_esrgan's input_res_pct < 100
  * (core/merged_pipeline.py:246-248) and pad_to_aspect_ratio (core/render_3d.py:121).  Down-scale ratios up to 10. */
 int vd3d_resize_area_u8(vd3d_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, uint8_t* dst_bgr, int dh, int dw);
+/* cv2.resize(src, (dw, dh)) with OpenCV's default interpolation (INTER_LINEAR, fixed point) on uint8 BGR: format_3d_output's VR branch */
+int vd3d_resize_linear_u8(vd3d_ctx* ctx, const uint8_t* src_bgr, int sh, int sw, uint8_t* dst_bgr, int dh, int dw);
+/* format_3d_output(left, right, fmt) (core/render_3d.py:837-860) on two uint8 BGR eyes of h x w (device pointers).  out_bgr: [h][2 w][3] for the
+ * SBS formats, [1600][2880][3] for VR (eyes of another size are resized with INTER_LINEAR first, like the reference), [h][w][3] for anaglyph
+ * and interlaced. */
+int vd3d_format_3d_output(vd3d_ctx* ctx, const uint8_t* left_bgr, const uint8_t* right_bgr, int h, int w, int format, uint8_t* out_bgr);
 
 /* ---- up-scale stage glue (core/merged_pipeline.py:219-236).  The network between the two calls is the caller's
  * (visiondepth3d_amd.upscale runs it on PyTorch-ROCm).

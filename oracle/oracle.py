@@ -313,7 +313,7 @@ def format_output(L, R, fmt):
     L, pl = _u(L)
     R, pr = _u(R)
     h, w = L.shape[:2]
-    out = np.empty((h, 2 * w, 3) if fmt in (0, 1, 2) else (h, w, 3), np.uint8)
+    out = np.empty((1600, 2880, 3) if fmt == 2 else ((h, 2 * w, 3) if fmt in (0, 1) else (h, w, 3)), np.uint8)
     rc = lib().vo_format_output(pl, pr, h, w, int(fmt), out.ctypes.data_as(_u8p))
     if rc:
         raise NotImplementedError(f"oracle: format {fmt}")
@@ -414,6 +414,14 @@ class RenderOracle:
         if rc:
             raise NotImplementedError("oracle: unsupported fit/format")
         return (out, L, R) if want_eyes else out
+
+
+def resize_linear_u8(src, dh, dw):
+    """cv2.resize(src, (dw, dh)) (INTER_LINEAR, the default) on uint8 [h,w,3] (unpinned: OpenCV's published fixed-point algorithm)."""
+    s = np.ascontiguousarray(src, np.uint8)
+    out = np.empty((dh, dw, 3), np.uint8)
+    lib().vo_resize_linear_u8(s.ctypes.data_as(_u8p), s.shape[0], s.shape[1], out.ctypes.data_as(_u8p), int(dh), int(dw))
+    return out
 
 
 def resize_cubic_u8(src, dh, dw):

@@ -317,3 +317,32 @@ def test_render_clip_blank_list(R, oracle):
     R.reset_state()
     outs3 = np.stack(list(render_clip(frames, d8, renderer=R, blank_frames=blank, **kw2)))
     assert not np.array_equal(outs3[blank[0]], outs[blank[0]])
+
+
+def test_format_3d_output_and_linear_resize(R, oracle):
+    """format_3d_output (core/render_3d.py:837-860) as an entry point of its own (vd3d_format_3d_output) for every format, incl. VR eyes that are not
+    1440x1600 (cv2.resize INTER_LINEAR first, :846-849; unpinned OpenCV arithmetic: HIP == oracle bit for bit), and the linear resize alone for
+    up- and down-scaling shapes; the module-level format_3d_output / generate_anaglyph_3d take and return NumPy arrays like the reference's."""
+    from visiondepth3d_amd import render_3d as r3
+    rng = np.random.default_rng(5)
+    L = rng.integers(0, 256, (90, 160, 3), dtype=np.uint8)
+    Rr = rng.integers(0, 256, (90, 160, 3), dtype=np.uint8)
+    for name, code in (("Half-SBS", 0), ("Full-SBS", 1), ("VR", 2), ("Red-Cyan Anaglyph", 3), ("Passive Interlaced", 4)):
+        got = R.format_3d_output(T(L), T(Rr), name).cpu().numpy()
+        exp = oracle.format_output(L, Rr, code)
+        assert got.shape == exp.shape and np.array_equal(got, exp), name
+    assert np.array_equal(R.format_3d_output(T(L), T(Rr), "no such format").cpu().numpy(), np.hstack((L, Rr)))   # :860 fallback
+    Lv = rng.integers(0, 256, (1600, 1440, 3), dtype=np.uint8)
+    assert np.array_equal(R.format_3d_output(T(Lv), T(Lv[::-1].copy()), "VR").cpu().numpy(), np.hstack((Lv, Lv[::-1])))   # identity resize
+    for (sh, sw), (dh, dw) in (((90, 160), (1600, 1440)), ((270, 480), (135, 240)), ((37, 53), (80, 31)), ((64, 64), (64, 64)), ((5, 7), (11, 3))):
+        src = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        assert np.array_equal(R.resize_linear_u8(T(src), dh, dw).cpu().numpy(), oracle.resize_linear_u8(src, dh, dw)), (sh, sw, dh, dw)
+    flat = np.full((20, 30, 3), 77, np.uint8)
+    assert np.all(oracle.resize_linear_u8(flat, 50, 41) == 77)   # a constant image stays constant (weights sum to 2048)
+    prev = r3._default
+    r3._default = R
+    try:
+        assert np.array_equal(r3.format_3d_output(L, Rr, "Passive Interlaced"), oracle.format_output(L, Rr, 4))
+        assert np.array_equal(r3.generate_anaglyph_3d(L, Rr), oracle.format_output(L, Rr, 3))
+    finally:
+        r3._default = prev

@@ -1149,6 +1149,46 @@ VD3D_EXPORT int vd3d_resize_area_u8(vd3d_ctx* c, const uint8_t* src_bgr, int sh,
   return 0;
 }
 
+// cv2.resize(src, (dw, dh)) -- INTER_LINEAR, OpenCV's default -- on uint8 BGR: format_3d_output's VR branch (core/render_3d.py:846-849)
+VD3D_EXPORT int vd3d_resize_linear_u8(vd3d_ctx* c, const uint8_t* src_bgr, int sh, int sw, uint8_t* dst_bgr, int dh, int dw) {
+  if (!c || !src_bgr || !dst_bgr || sh < 1 || sw < 1 || dh < 1 || dw < 1 || src_bgr == dst_bgr) return set_err(VD3D_E_INVALID, "bad argument");
+  if ((long long)sh * sw * 3 >= (1ll << 31) || (long long)dh * dw * 3 >= (1ll << 31)) return set_err(VD3D_E_INVALID, "image too large");
+  HIPCHK(hipSetDevice(c->device));
+  vd_launch_resize_linear_u8(c->stream, src_bgr, sh, sw, dst_bgr, dh, dw);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// format_3d_output(left, right, fmt), core/render_3d.py:837-860, on two uint8 BGR eyes of h x w: Half-/Full-SBS = side by side, VR = both eyes
+// resized to 1440 x 1600 (INTER_LINEAR) side by side, Red-Cyan Anaglyph = generate_anaglyph_3d, Passive Interlaced = even rows left / odd rows
+// right.  out: [h][2w][3] (SBS), [1600][2880][3] (VR), [h][w][3] (anaglyph, interlaced).  The mux runs through k_sharp_mux with the identity
+// sharpen kernel (kc = 1, kn = 0: exact) and a 1:1 fit.
+VD3D_EXPORT int vd3d_format_3d_output(vd3d_ctx* c, const uint8_t* left_bgr, const uint8_t* right_bgr, int h, int w, int format, uint8_t* out_bgr) {
+  if (!c || !left_bgr || !right_bgr || !out_bgr || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  if (format < 0 || format > VD3D_FMT_INTERLACED) return set_err(VD3D_E_INVALID, "unknown format %d", format);
+  HIPCHK(hipSetDevice(c->device));
+  int rc = join_pixels(c);
+  if (rc) return rc;
+  const uint8_t *L = left_bgr, *R = right_bgr;
+  int eh = h, ew = w;
+  if (format == VD3D_FMT_VR && (h != 1600 || w != 1440)) {
+    if ((rc = ensure_work(c, 1600, 1440))) return rc;   // gL / gR: two 1440 x 1600 eyes
+    vd_launch_resize_linear_u8(c->stream, left_bgr, h, w, c->gL, 1600, 1440);
+    vd_launch_resize_linear_u8(c->stream, right_bgr, h, w, c->gR, 1600, 1440);
+    L = c->gL; R = c->gR; eh = 1600; ew = 1440;
+  }
+  vd3d_render_params p;
+  vd3d_render_params_default(&p);
+  p.format = format; p.warp_w = ew; p.warp_h = eh; p.fit_w = ew; p.fit_h = eh;
+  p.out_w = (format == VD3D_FMT_HALF_SBS || format == VD3D_FMT_FULL_SBS || format == VD3D_FMT_VR) ? 2 * ew : ew; p.out_h = eh;
+  vd_finish_consts fc;
+  memset(&fc, 0, sizeof fc);
+  fc.sharp_kn = 0.f; fc.sharp_kc = 1.f;
+  vd_launch_sharp_mux(c->stream, L, R, p, fc, out_bgr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // preprocess_esr / postprocess_esr / blend_images, core/merged_pipeline.py:219-236
 VD3D_EXPORT int vd3d_esr_preprocess(vd3d_ctx* c, int dtype, const uint8_t* frame_bgr, long long pitch_bytes, int h, int w, int channels_last,
                                     void* out_rgb) {

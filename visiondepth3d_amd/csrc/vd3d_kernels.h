@@ -193,6 +193,7 @@ void vd_launch_preview_arrows(hipStream_t s, const uint8_t* left, const float* s
 // ---- vd3d_upscale.hip
 bool vd_launch_resize_cubic_u8(hipStream_t s, const uint8_t* src, int sh, int sw, int cn, uint8_t* dst, int dh, int dw);
 bool vd_launch_resize_area_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
+void vd_launch_resize_linear_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 bool vd_launch_rife_pre(hipStream_t s, int dtype, const uint8_t* f1, const uint8_t* f2, int h, int w, int hwc, void* out);
 void vd_launch_rife_post(hipStream_t s, const float* pred, int h, int w, int hwc, uint8_t* dst);
 bool vd_launch_esr_pre(hipStream_t s, int dtype, const uint8_t* src, long long pitch, int h, int w, int hwc, void* out);

@@ -232,10 +232,7 @@ void vd_launch_warp(hipStream_t s, const float* rgb, int ih, int iw, const float
 #define DF_TW 32
 #define DF_TH 16
 #define DF_RMAX 15
-// DENSE = true: the Gaussian levels as the reference's dense k x k depthwise convolution in the order PyTorch's CPU build runs it
-// (row-major taps, one fused multiply-add per tap from 0, 2-D kernel = float32 outer product): bit-exact against the CPU
-// reference, 4x the arithmetic of the separable default (vd3d_render_params::dof_dense_conv).
-template <bool DENSE>
+// Separable levels (vd3d_render_params::dof_dense_conv = 0: a throughput mode outside the 1-LSB bar); the reference's dense order is k_dof_grade4 below.
 __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ eye_in, const float* __restrict__ dn, int eh, int ew,
                                                    int H, int W, vd_finish_consts fc, const vd_dev_work* __restrict__ w,
                                                    float focal_override, int use_override, int bar_width_o, int bar_side_o,
@@ -244,17 +241,8 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
   float* tile = lds;                        // [3][th][tw]
-  float* vb = lds + (size_t)3 * th * tw;    // separable: [3][DF_TH][tw] vertical sums (the vertical pass runs first)
-                                            // dense    : [nlev][k*k] 2-D kernels (outer products ky[i] * kx[j])
+  float* vb = lds + (size_t)3 * th * tw;    // [3][DF_TH][tw] vertical sums (the vertical pass runs first)
   const int x0 = blockIdx.x * DF_TW, y0 = blockIdx.y * DF_TH;
-  if (DENSE) {
-    int off = 0;
-    for (int l = 0; l < fc.nlev; ++l) {
-      const int k = fc.ksz[l];
-      for (int t = threadIdx.x; t < k * k; t += 512) vb[off + t] = fc.kern[l][t / k] * fc.kern[l][t - (t / k) * k];
-      off += k * k;
-    }
-  }
   for (int t = threadIdx.x; t < th * tw; t += 512) {
     const int ty = t / tw, tx = t - ty * tw;
     const int y = vd_reflect(y0 - R + ty, H), x = vd_reflect(x0 - R + tx, W);
@@ -290,23 +278,6 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) { vlo[c] = tile[c * th * tw + (ty + R) * tw + tx + R]; vhi[c] = vlo[c]; }
-  if (DENSE) {
-    int off = 0;
-    for (int l = 0; l < fc.nlev; ++l) {
-      const int k = fc.ksz[l], r = k / 2;
-      if (l + 1 == lo || l + 1 == lo + 1) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float* t0 = tile + (size_t)c * th * tw + (ty + R - r) * tw + tx + R - r;
-          float acc = 0.f;
-          for (int i = 0; i < k; ++i)
-            for (int j = 0; j < k; ++j) acc = vd_fma(t0[i * tw + j], vb[off + i * k + j], acc);
-          if (l + 1 == lo) vlo[c] = acc; else vhi[c] = acc;
-        }
-      }
-      off += k * k;
-    }
-  } else
   for (int l = 0; l < fc.nlev; ++l) {  // level l+1 of the reference's stack
     const int k = fc.ksz[l], r = k / 2;
     __syncthreads();
@@ -348,22 +319,151 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
     out[2 - c] = masked ? (uint8_t)0 : (uint8_t)(v * 255.0f);
   }
 }
+// Dense levels (the reference's order: one k x k window per output, taps row-major, one FMA per tap from 0, weight = fl(k1[i] * k1[j]);
+// vd3d_render_params::dof_dense_conv = 1, the default) for the Gaussians the fused finishing kernel does not take: more than 9 taps (dof_strength
+// > 2, up to 31 taps), VR / fractional fits.  Round 4: one thread = 4 consecutive pixels (64 x 32 tile, 512 threads).  For every tap row the K + 3
+// window columns are read ONCE (a single LDS dword each) and feed the four outputs' chains with a sliding window of four weights (LDS broadcast
+// reads; zero weights pad the row ends: fma(v, 0, acc) is exact here -- acc never is -0): 2 LDS reads per 4 FMAs instead of 2 per FMA (one pixel
+// per thread until round 3: 1 387 us per 4K frame pair at dof_strength 3.0 against the fused kernel's 252 at 2.0).  Each output's taps still
+// arrive in ascending (i, j) order: same bits.
+#define D4_TW 64
+#define D4_TH 32
+__global__ __launch_bounds__(512) void k_dof_grade4(const uint8_t* __restrict__ eye_in, const float* __restrict__ dn, int eh, int ew,
+                                                    int H, int W, vd_finish_consts fc, const vd_dev_work* __restrict__ w,
+                                                    float focal_override, int use_override, int bar_width_o, int bar_side_o,
+                                                    uint8_t* __restrict__ eye_out, int twp) {
+  extern __shared__ float lds[];
+  const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
+  const int tw = D4_TW + 2 * R, th = D4_TH + 2 * R;
+  float* tile = lds;                          // [3][th][twp], twp = 1 mod 4: the four rows of a wave's lanes fall into distinct banks
+  float* wk = lds + (size_t)3 * th * twp;     // per level: k rows of (3 zeros, k weights, 3 zeros)
+  const int x0 = blockIdx.x * D4_TW, y0 = blockIdx.y * D4_TH;
+  {
+    int off = 0;
+    for (int l = 0; l < fc.nlev; ++l) {
+      const int k = fc.ksz[l], kp = k + 6;
+      for (int t = threadIdx.x; t < k * kp; t += 512) {
+        const int i = t / kp, jj = t - i * kp - 3;
+        wk[off + t] = (jj >= 0 && jj < k) ? fc.kern[l][i] * fc.kern[l][jj] : 0.f;
+      }
+      off += k * kp;
+    }
+  }
+  for (int t = threadIdx.x; t < th * tw; t += 512) {
+    const int ty = t / tw, tx = t - ty * tw;
+    const int y = vd_reflect(y0 - R + ty, H), x = vd_reflect(x0 - R + tx, W);
+    const uint8_t* px = eye_in + ((size_t)y * W + x) * 3;
+    tile[(0 * th + ty) * twp + tx] = vd_u8_unit((float)px[2]);
+    tile[(1 * th + ty) * twp + tx] = vd_u8_unit((float)px[1]);
+    tile[(2 * th + ty) * twp + tx] = vd_u8_unit((float)px[0]);
+  }
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
+  const int y = y0 + ty, xs = x0 + tx;
+  if (y >= H || xs >= W) return;
+  int lo[4] = {0, 0, 0, 0};
+  float alpha[4] = {0.f, 0.f, 0.f, 0.f};
+  int need = 0;   // bit l: level l is the lo or the hi level of one of the four pixels
+  if (fc.nlev) {
+    const float focal = use_override ? focal_override : w->focal;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int x = min(xs + q, W - 1);
+      float dd;   // depth_for_dof = F.interpolate(depth_tensor -> (H,W)) :1347-1350
+      if (eh == H && ew == W) dd = dn[(size_t)y * W + x];
+      else {
+        const vd_tap ay = vd_interp_tap(eh, H, y), ax = vd_interp_tap(ew, W, x);
+        const float* r0 = dn + (size_t)ay.i0 * ew;
+        const float* r1 = dn + (size_t)ay.i1 * ew;
+        dd = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
+      }
+      const float bw = vd_clamp(fabsf(dd - focal) / fc.fw, 0.f, 1.f);
+      const float bi = vd_clamp(bw * (float)fc.nlev, 0.f, fc.imax);
+      int l = (int)floorf(bi);
+      l = l > fc.nlev - 1 ? fc.nlev - 1 : (l < 0 ? 0 : l);
+      lo[q] = l; alpha[q] = bi - (float)l;
+      need |= (1 << l) | (1 << (l + 1));
+    }
+  }
+  float res[3][4];   // level 0 = the pixel itself; replaced by level lo, then blended with level lo + 1 (levels arrive in ascending order)
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) res[c][q] = tile[(c * th + ty + R) * twp + tx + R + q];
+  int off = 0;
+  for (int l = 0; l < fc.nlev; ++l) {
+    const int k = fc.ksz[l], r = k / 2, kp = k + 6;
+    if ((need >> (l + 1)) & 1) {
+      for (int c = 0; c < 3; ++c) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int i = 0; i < k; ++i) {
+          const float* t0 = tile + (size_t)(c * th + ty + R - r + i) * twp + tx + R - r;   // window column 0 = tap 0 of pixel 0
+          const float* wr = wk + off + i * kp + 3;                                        // wr[j] = weight (i, j); wr[-3 .. -1] = wr[k .. k + 2] = 0
+          float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+          for (int jj = 0; jj < k + 3; ++jj) {   // window column jj: tap jj of pixel 0, jj - 1 of pixel 1, ...
+            const float v = t0[jj], w0 = wr[jj];
+            a0 = vd_fma(v, w0, a0); a1 = vd_fma(v, w1, a1); a2 = vd_fma(v, w2, a2); a3 = vd_fma(v, w3, a3);
+            w3 = w2; w2 = w1; w1 = w0;
+          }
+        }
+        const float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (l + 1 == lo[q]) res[c][q] = acc[q];
+          if (l + 1 == lo[q] + 1) res[c][q] = (1.0f - alpha[q]) * res[c][q] + alpha[q] * acc[q];
+        }
+      }
+    }
+    off += k * kp;
+  }
+  const int bar_w = use_override ? bar_width_o : w->bar_width, bar_s = use_override ? bar_side_o : w->bar_side;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = xs + q;
+    if (x >= W) break;
+    float rgbv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgbv[c] = fc.nlev ? vd_clamp(res[c][q], 0.f, 1.f) : res[c][q];
+    // apply_color_grade :750-767
+    const float luma = ((float)0.2126 * rgbv[0] + (float)0.7152 * rgbv[1]) + (float)0.0722 * rgbv[2];
+    const bool masked = bar_w > 0 && ((bar_s == 2 && x < bar_w) || (bar_s == 1 && x >= W - bar_w));
+    uint8_t* out = eye_out + ((size_t)y * W + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = luma + (rgbv[c] - luma) * fc.sat;
+      v = 0.5f + (v - 0.5f) * fc.con;
+      v = v + fc.bri;
+      v = vd_clamp(v, 0.f, 1.f);
+      out[2 - c] = masked ? (uint8_t)0 : (uint8_t)(v * 255.0f);
+    }
+  }
+}
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
                          int bar_width, int bar_side, uint8_t* eye_out, int dense) {
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
-  const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
-  const dim3 g((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH);
   if (dense) {
-    size_t k2 = 0;
-    for (int l = 0; l < fc.nlev; ++l) k2 += (size_t)fc.ksz[l] * fc.ksz[l];
-    const size_t lds = sizeof(float) * (3 * (size_t)th * tw + k2);
-    hipLaunchKernelGGL(k_dof_grade<true>, g, dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w, focal_override, use_override, bar_width,
-                       bar_side, eye_out);
+    const int tw = D4_TW + 2 * R, th = D4_TH + 2 * R;
+    int twp = tw;
+    while ((twp & 3) != 1) ++twp;
+    size_t kw = 0;
+    for (int l = 0; l < fc.nlev; ++l) kw += (size_t)fc.ksz[l] * (fc.ksz[l] + 6);
+    const size_t lds = sizeof(float) * (3 * (size_t)th * twp + kw);
+    static bool attr[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
+      (void)hipFuncSetAttribute((const void*)k_dof_grade4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr[dev] = true;
+    }
+    hipLaunchKernelGGL(k_dof_grade4, dim3((W + D4_TW - 1) / D4_TW, (H + D4_TH - 1) / D4_TH), dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w,
+                       focal_override, use_override, bar_width, bar_side, eye_out, twp);
     return;
   }
+  const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
+  const dim3 g((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH);
   const size_t lds = sizeof(float) * 3 * ((size_t)th * tw + (size_t)DF_TH * tw);
-  hipLaunchKernelGGL(k_dof_grade<false>, g, dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w, focal_override, use_override, bar_width,
+  hipLaunchKernelGGL(k_dof_grade, g, dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w, focal_override, use_override, bar_width,
                      bar_side, eye_out);
 }
 

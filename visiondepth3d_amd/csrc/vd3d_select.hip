@@ -595,6 +595,17 @@ VD_DEV bool last_workgroup(uint32_t* counter, uint32_t* sflag, int dbg = 0) {
 VD_DEV void lds_hist_flush(const uint32_t* h, uint32_t* g) {
   for (int b = threadIdx.x; b < NBL; b += blockDim.x) { const uint32_t c = h[b]; if (c) atomicAdd(&g[b], c); }
 }
+// LDS histogram adds of four consecutive pixels: neighbours of a smooth plane mostly share their bin, so runs of equal keys are merged into one
+// atomic with the summed increment (increments add linearly, also the packed 0x10001 ones): up to 4x fewer LDS atomics and bank-conflict cycles
+// (K3b: 4.8e7 conflict cycles per 16-frame launch before)
+VD_DEV void vd_lds_hist_add4(uint32_t* hist, const unsigned k[4], unsigned inc[4]) {
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if (k[q] == k[q - 1]) { inc[q] += inc[q - 1]; inc[q - 1] = 0u; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (inc[q]) atomicAdd(&hist[k[q]], inc[q]);
+}
 VD_DEV unsigned key_a(float v) { unsigned k = __float_as_uint(v) >> 16; return k < (NBL - 1) ? k : (NBL - 1); }
 
 // Grid-stride walk over a float plane for the pass kernels: 4 consecutive pixels per thread and iteration (one 16-byte load, one
@@ -749,6 +760,9 @@ VD_DEV void hist_b_add(uint32_t* histB, int job, const vd_targets& c, float v, b
   vd_hist_add_agg(vd_histbc(histB) + (size_t)job * VD_MAX_T * VD_NB_BC, key >> 8, hit);
 }
 
+// (Round 4, measured and not kept: pass B as per-job candidate LISTS -- wave-aggregated (key, count) entries behind one returning atomic per wave, the
+// ranks resolved by the scanning workgroup with two LDS histogram passes over the list.  The device-scope atomics of the hits do bound these kernels
+// (hits muted: K4 398 -> 212 us per 16 frames), but the single-workgroup list scan cost more than it saved: K4 866, K6 322 us.)
 // four consecutive elements of one row: one range test per element against the hull of the job's target prefixes decides whether the wave
 // has any candidate at all (a smooth plane: almost never); only then the per-element path with its membership test runs
 template <class Member>   // member(q) -> bool, evaluated for candidates only
@@ -863,8 +877,10 @@ __global__ __launch_bounds__(1024) void k_chain_a0(vd_batch b, long long n, int 
   __syncthreads();
   if (ew > 0 && vd_walk4_ok(F.tdf, ew)) {
     vd_rect_walk4(F.tdf, ew, 0, (int)(n / ew), 0, ew, (int)blockIdx.x, (int)gridDim.x, [&](bool ok, int, int, vd_f4 d) {
+      unsigned k[4], inc[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) vd_lds_hist_add(h0, key_a(vd_clamp(d[q], 0.f, 1.f)), ok && !(a.dbg & 8));
+      for (int q = 0; q < 4; ++q) { k[q] = key_a(vd_clamp(d[q], 0.f, 1.f)); inc[q] = (ok && !(a.dbg & 8)) ? 1u : 0u; }
+      vd_lds_hist_add4(h0, k, inc);
     });
   } else {
     for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {
@@ -1039,9 +1055,13 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(vd_batch b, FWorkSrc f, v
         else { v.x = f.at(y, x); v.y = f.at(y, x + 1); v.z = f.at(y, x + 2); v.w = f.at(y, x + 3); }
         reinterpret_cast<vd_f4*>(dc)[i4] = v;   // curved depth plane: pass B and the shape kernel stream it
       }
+      unsigned k[4], inc[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (ok && !(a.dbg & 8)) atomicAdd(&hp[key_a(v[q])], vd_in_subject_crop(y, x + q, f.H, f.W, v[q]) ? 0x10001u : 1u);
+      for (int q = 0; q < 4; ++q) {
+        k[q] = key_a(v[q]);
+        inc[q] = (ok && !(a.dbg & 8)) ? (vd_in_subject_crop(y, x + q, f.H, f.W, v[q]) ? 0x10001u : 1u) : 0u;
+      }
+      vd_lds_hist_add4(hp, k, inc);
     }
   } else {
     for (long long base = (long long)wg * 1024; base < n; base += (long long)nwg * 1024) {
@@ -1131,8 +1151,10 @@ __global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, fl
         const unsigned i = (unsigned)i4 * 4u;
         y = (int)(i / (unsigned)f.W); x = (int)(i - (unsigned)y * (unsigned)f.W);
       }
+      unsigned k[4], inc[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) vd_lds_hist_add(h1, key_a(v[q]), ok && !(a.dbg & 8) && vd_in_subject_crop(y, x + q, f.H, f.W, v[q]));
+      for (int q = 0; q < 4; ++q) { k[q] = key_a(v[q]); inc[q] = (ok && !(a.dbg & 8) && vd_in_subject_crop(y, x + q, f.H, f.W, v[q])) ? 1u : 0u; }
+      vd_lds_hist_add4(h1, k, inc);
     }
   } else {
     for (long long base = (long long)blockIdx.x * 1024; base < n; base += (long long)gridDim.x * 1024) {

@@ -142,6 +142,53 @@ bool vd_launch_resize_area_u8(hipStream_t s, const uint8_t* src, int sh, int sw,
   return true;
 }
 
+// ---- cv2.resize(src, (dw, dh)) with the default interpolation INTER_LINEAR on 3-channel uint8 (format_3d_output's VR branch,
+// core/render_3d.py:846-849): OpenCV's fixed-point path -- coefficients (1 - f, f) * 2048 rounded to nearest-even, horizontal pass in int, vertical
+// combine ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2 (the vector form real builds run; same machinery as the INTER_AREA
+// up-scale above, other coefficients).  Horizontal: f is zeroed where the tap would leave the row; vertical: row indices are clipped.  UNPINNED
+// (no cv2 in the build image; the published algorithm).
+VD_DEV void vd_lin_coef_x(int ssize, int dsize, int d, int* idx, int* a0, int* a1) {
+  const double scale = 1.0 / ((double)dsize / ssize);
+  float fx = (float)((d + 0.5) * scale - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+  *idx = sx;
+  *a0 = (int)rintf((1.f - fx) * 2048.f);
+  *a1 = (int)rintf(fx * 2048.f);
+}
+VD_DEV void vd_lin_coef_y(int ssize, int dsize, int d, int* i0, int* i1, int* b0, int* b1) {
+  const double scale = 1.0 / ((double)dsize / ssize);
+  float fy = (float)((d + 0.5) * scale - 0.5);
+  const int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  *i0 = sy < 0 ? 0 : (sy > ssize - 1 ? ssize - 1 : sy);
+  *i1 = sy + 1 < 0 ? 0 : (sy + 1 > ssize - 1 ? ssize - 1 : sy + 1);
+  *b0 = (int)rintf((1.f - fy) * 2048.f);
+  *b1 = (int)rintf(fy * 2048.f);
+}
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, int sh, int sw, uint8_t* __restrict__ dst, int dh, int dw) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  int xi, xa0, xa1, y0, y1, yb0, yb1;
+  vd_lin_coef_x(sw, dw, x, &xi, &xa0, &xa1);
+  vd_lin_coef_y(sh, dh, y, &y0, &y1, &yb0, &yb1);
+  const int x1 = xi + 1 < sw ? xi + 1 : sw - 1;
+  uint8_t* o = dst + ((size_t)y * dw + x) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int r0 = (int)src[((size_t)y0 * sw + xi) * 3 + c] * xa0 + (int)src[((size_t)y0 * sw + x1) * 3 + c] * xa1;
+    const int r1 = (int)src[((size_t)y1 * sw + xi) * 3 + c] * xa0 + (int)src[((size_t)y1 * sw + x1) * 3 + c] * xa1;
+    const int q = (((yb0 * (r0 >> 4)) >> 16) + ((yb1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    o[c] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+  }
+}
+void vd_launch_resize_linear_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw) {
+  if (sh == dh && sw == dw) { (void)hipMemcpyAsync(dst, src, (size_t)sh * sw * 3, hipMemcpyDeviceToDevice, s); return; }   // cv2.resize to the same size copies
+  hipLaunchKernelGGL(k_resize_linear_u8, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, s, src, sh, sw, dst, dh, dw);
+}
+
 // ---- preprocess_esr / postprocess_esr ------------------------------------------------------------------------------------
 template <typename T> VD_DEV T esr_cast(float v);
 template <> VD_DEV float esr_cast<float>(float v) { return v; }

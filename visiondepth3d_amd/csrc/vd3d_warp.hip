@@ -146,7 +146,10 @@ VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
 #ifndef WF_OCC_ATTR
 #define WF_OCC_ATTR   // A/B builds: -DWF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))'
 #endif
-#define WF_HB 6   // Hh rows a wave builds together (2 * WF_HB loads in flight)
+#ifndef WF_HB
+#define WF_HB 6   // Hh rows a wave builds together (2 * WF_HB loads in flight).  Round 4: 14 rows cost no registers (phase C holds the kernel's
+                  // maximum) and were measured slower, 110.8 vs 107.3 us at 4K with the precomputed mask
+#endif
 VD_STAMP_DECL(wf_stamps);
 #ifdef VD_PHASE_STAMPS
 extern "C" __attribute__((visibility("default"))) int vd3d_debug_stamps_w1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_stamps), sizeof(wf_stamps)); }
@@ -179,11 +182,18 @@ __global__ __launch_bounds__(EW_NT) void k_e2w(const float* __restrict__ D, cons
   constexpr int PW = EW_TW + 1, PH = EW_TH + 1, NP = PW * PH;
   static_assert(EW_U * EW_NT >= NP, "positions per thread");
   __shared__ __attribute__((aligned(16))) vd_f2 wd[PH][PW + 3];      // pitch 68 pairs: rows stay 16-byte aligned
+  __shared__ __attribute__((aligned(16))) vd_f4 rowT[PH];            // per region row: grid_sample row part (yn, n, 1 - n, south flag)
   __shared__ int2 rs14[64];
   const int H = a.H, W = a.W;
   const int x0 = blockIdx.x * EW_TW, y0 = blockIdx.y * EW_TH;
   const int tid = threadIdx.x;
   vd_stage_rs14(rs14, tid, EW_NT);
+  if (tid >= EW_NT - PH) {   // the last PH threads: one region row each
+    const int r = tid - (EW_NT - PH), yy = y0 - 1 + r;
+    int yn = 0; float n = 0.f, sr = 1.f; bool s_ok = false;
+    if (yy >= 0 && yy < H) wf_gs_row(vd_lin11_step(a.step_y, H, yy), H, &yn, &n, &sr, &s_ok);
+    rowT[r] = vd_f4{__int_as_float(yn), n, sr, __int_as_float((s_ok && n != 0.f) ? 1 : 0)};
+  }
   // positions (row r, column c) of the (TH + 1) x (TW + 1) region: image pixel (y0 - 1 + r, x0 - 1 + c)
   float sv[EW_U]; int py[EW_U], px[EW_U]; bool ok[EW_U];
 #pragma unroll
@@ -194,16 +204,17 @@ __global__ __launch_bounds__(EW_NT) void k_e2w(const float* __restrict__ D, cons
     ok[u] = t < NP && py[u] >= 0 && py[u] < H && px[u] >= 0 && px[u] < W;
     sv[u] = ok[u] ? S[(unsigned)py[u] * (unsigned)W + (unsigned)px[u]] : 0.f;
   }
+  __syncthreads();   // row table complete (the S loads above are in flight across it)
 #pragma unroll
   for (int u = 0; u < EW_U; ++u) {
     const int t = tid + u * EW_NT;
     if (t >= NP) continue;
     const int r = t / PW, c = t - r * PW;
     vd_f2 v = {0.f, 0.f};
-    if (ok[u]) {   // W1 phase A: wf_gs_row + wf_warped_depth
-      int yn; float n, sr; bool s_ok;
-      wf_gs_row(vd_lin11_step(a.step_y, H, py[u]), H, &yn, &n, &sr, &s_ok);
-      v = wf_warped_depth(D + (unsigned)yn * (unsigned)W, sv[u], vd_lin11_step(a.step_x, W, px[u]), n, sr, s_ok && n != 0.f, W);
+    if (ok[u]) {   // W1 phase A: row part from the table (wf_gs_row), then wf_warped_depth
+      const vd_f4 rt = rowT[r];
+      v = wf_warped_depth(D + (unsigned)__float_as_int(rt.x) * (unsigned)W, sv[u], vd_lin11_step(a.step_x, W, px[u]), rt.y, rt.z,
+                          __float_as_int(rt.w) != 0, W);
     }
     wd[r][c] = v;
   }

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, DT_BF16, DT_F16, DT_F32, FrameScalars, RenderParams, ShiftParams, State
+from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, DT_BF16, DT_F16, DT_F32, FORMAT_IDS, FrameScalars, RenderParams, ShiftParams, State
 from .geometry import aspect_ratios  # noqa: F401  (re-exported like the reference module does)
 from .params import render_kwargs_to_params, shift_params_from_kwargs
 
@@ -386,6 +386,30 @@ class Renderer:
         _lib.check(self._L.vd3d_resize_cubic_u8(self._ctx, _ptr(s), int(s.shape[0]), int(s.shape[1]), cn, _ptr(out), int(dh), int(dw)))
         return out
 
+    def resize_linear_u8(self, src: torch.Tensor, dh: int, dw: int) -> torch.Tensor:
+        """cv2.resize(src, (dw, dh)) -- INTER_LINEAR, OpenCV's default -- for uint8 BGR [h,w,3] (format_3d_output's VR branch, core/render_3d.py:846-849)."""
+        if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
+            raise AssertionError("resize_linear_u8 takes uint8 [h,w,3]")
+        s = src.to(self.device).contiguous()
+        out = torch.empty((int(dh), int(dw), 3), dtype=torch.uint8, device=self.device)
+        self._enter(s, out)
+        _lib.check(self._L.vd3d_resize_linear_u8(self._ctx, _ptr(s), int(s.shape[0]), int(s.shape[1]), _ptr(out), int(dh), int(dw)))
+        return out
+
+    def format_3d_output(self, left: torch.Tensor, right: torch.Tensor, fmt) -> torch.Tensor:
+        """format_3d_output(left, right, fmt) (core/render_3d.py:837-860) on the device: uint8 BGR eyes [h,w,3] -> the muxed frame (``fmt``: the
+        reference's format string or a VD3D_FMT_* code; unknown strings fall back to side-by-side like the reference)."""
+        code = fmt if isinstance(fmt, int) else FORMAT_IDS.get(str(fmt), 1)
+        l_, r_ = left.to(self.device).contiguous(), right.to(self.device).contiguous()
+        if l_.dtype != torch.uint8 or l_.dim() != 3 or l_.shape[2] != 3 or tuple(l_.shape) != tuple(r_.shape):
+            raise AssertionError("format_3d_output takes two uint8 [h,w,3] eyes of one size")
+        h, w = int(l_.shape[0]), int(l_.shape[1])
+        shape = (1600, 2880, 3) if code == 2 else ((h, 2 * w, 3) if code in (0, 1) else (h, w, 3))
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        self._enter(l_, r_, out)
+        _lib.check(self._L.vd3d_format_3d_output(self._ctx, _ptr(l_), _ptr(r_), h, w, int(code), _ptr(out)))
+        return out
+
     def resize_area_u8(self, src: torch.Tensor, dh: int, dw: int) -> torch.Tensor:
         """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) for uint8 BGR [h,w,3] (core/merged_pipeline.py:246-248)."""
         if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
@@ -635,6 +659,18 @@ def pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg_shift, mg_shi
     if return_shift_map:
         return r.to_host(res[0]).numpy(), r.to_host(res[1]).numpy(), r.to_host(res[2])
     return r.to_host(res[0]).numpy(), r.to_host(res[1]).numpy()
+
+
+def format_3d_output(left, right, fmt):
+    """Same signature as the reference (core/render_3d.py:837): NumPy BGR eyes in, the muxed NumPy frame out."""
+    r = default_renderer()
+    out = r.format_3d_output(torch.from_numpy(np.ascontiguousarray(left)), torch.from_numpy(np.ascontiguousarray(right)), fmt)
+    return r.to_host(out).numpy()
+
+
+def generate_anaglyph_3d(left_frame, right_frame):
+    """Same signature as the reference (core/render_3d.py:862): Dubois-style red-cyan anaglyph of two BGR frames."""
+    return format_3d_output(left_frame, right_frame, "Red-Cyan Anaglyph")
 
 
 def heal_missing_pixels(warped_frame, warped_depth, original_frame, edge_mask, heal_strength=0.5):
