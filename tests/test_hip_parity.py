@@ -219,6 +219,25 @@ def test_dof_strength_fixtures_bit_exact(R, oracle):
         assert np.array_equal(got, g[f"{name}__frames"]), (name, u8_diff_stats(got, g[f"{name}__frames"]))
 
 
+def test_large_shifts_reach_every_hh_chunk(R, oracle):
+    """W1 builds only the 64-column chunks of its pre-interpolated rows that the tile's largest |shift| can reach (round 4): a wide frame with layer
+    shifts that run into a +-8 % clamp (77 px at 960: four chunks per tile) next to flat regions (one or two chunks) must still equal the oracle."""
+    sh, sw = 540, 960
+    kw = dict(output_format="Half-SBS", output_height=sh, fg_shift=90.0, mg_shift=-20.0, bg_shift=-80.0, sharpness_factor=0.15, dof_strength=2.0,
+              feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True, max_pixel_shift_percent=0.08)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    assert (p.warp_w, p.warp_h) == (sw, sh)
+    frames, depths = synth.synth_clip(2, sh, sw)
+    R.reset_state(); R.new_clip()
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    for f, d in zip(frames, depths):
+        got = R.render_frame(T(f), T(d), p).cpu().numpy()
+        exp = ro.render(f, d, 0)
+        assert np.array_equal(got, exp), u8_diff_stats(got, exp)
+    S = R.debug_planes(p.warp_h, p.warp_w, p.eye_h, p.eye_w)["S"]
+    assert float(S.abs().max()) * (p.warp_w - 1) / 2 > 50.0   # the clip does exercise shifts that reach three to four chunks
+
+
 def test_singleton_state_leak_and_export_import(R, oracle):
     g = load_golden("render_loop.npz")
     sh, sw, n, kw = golden_json(g, "cases_json")["half_sbs_cli"]

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
                                                       uint8_t* __restrict__ R, const vd_f2* __restrict__ E2) {
   constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int2 rs14[64];                          // VRSQRT14 table of vd_sqrt_torch (phase B)
   const int H = a.H, W = a.W, k = a.k, r = k / 2;
   const int tile = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
@@ -288,6 +288,19 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   VD_STAMP(wf_stamps, 0, false);
   VD_OCC_IN(wf_occ);
   const int lane = tid & 63, wv = wf_uni(tid >> 6);
+  // The shift values of this wave's phase-D rows are requested NOW (consumed after phase C): their maximum over the tile decides which 64-column
+  // chunks of the pre-interpolated rows Hh phase D1 has to build at all (round 4) -- the LDS holds the worst case the parameters allow (+- 79 px at
+  // 4K), a tile of an ordinary frame samples +- 10 .. 20 px around itself.
+  __shared__ __attribute__((aligned(16))) unsigned smax_slot[4];   // 16 bytes: the dynamic LDS behind it must stay 16-byte aligned (ds_read_b128 everywhere;
+                                                                   // a 4-byte static variable in front of it cost 3x the kernel time: misaligned 16-byte LDS accesses)
+  unsigned& smax_bits = smax_slot[0];
+  if (tid == 0) smax_bits = 0u;
+  float sD[WF_TH / WF_NW];
+#pragma unroll
+  for (int j = 0; j < WF_TH / WF_NW; ++j) {
+    const int y = y0 + wv + j * WF_NW, x = x0 + lane;
+    sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
+  }
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
   const int cb = max(x0 - a.bound, 0);                              // first warp-res column of Hh / colT
   const int nch = a.nch;
@@ -470,12 +483,13 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       dst[1] = vd_f4{sv[2].x, sv[2].y, sv[3].x, sv[3].y};
     }
   }
-  // the shift values of this wave's phase-D rows: issued early so that their latency overlaps the Hh build
-  float sD[WF_TH / WF_NW];
+  {   // tile maximum of |S| (non-negative floats order like their bit patterns; a NaN would sort above everything -> the full range is built)
+    float m = 0.f;
 #pragma unroll
-  for (int j = 0; j < WF_TH / WF_NW; ++j) {
-    const int y = y0 + wv + j * WF_NW, x = x0 + lane;
-    sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
+    for (int j = 0; j < WF_TH / WF_NW; ++j) m = fmaxf(m, fabsf(sD[j]));
+    unsigned mb = __float_as_uint(m);
+    for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off, 64));
+    if (lane == 0) atomicMax(&smax_bits, mb);
   }
   __syncthreads();
   VD_STAMP(wf_stamps, 4, false);
@@ -500,8 +514,14 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     // once and shared by every sample that needs it (~4.4 per element) instead of inside each of them.  One wave = one 64-column
     // chunk (its column taps live in two registers), WF_HB rows of loads in flight.
     {
-      const int nchk = (nch + 63) >> 6;
-      const int chunk = wv % nchk, rstart = wv / nchk, rstep = (WF_NW - chunk + nchk - 1) / nchk;
+      // columns of Hh this tile can sample: its own 64 plus the tile's largest shift in pixels (same margin rule as the host's `bound`) plus the east
+      // neighbour of the bilinear pair; chunks outside are never read and are not built
+      const float smax = __uint_as_float((unsigned)wf_uni((int)smax_bits));   // wave-uniform: the chunk / row assignment below stays scalar
+      int bt = a.bound;
+      if (smax < 1.0f) bt = min(a.bound, (int)ceilf(smax * ((float)(W - 1) * 0.5f) * 1.0001f) + 3);
+      const int c_lo = max(x0 - bt - 1 - cb, 0) >> 6, c_hi = min(x0 + WF_TW + bt + 1 - cb, nch - 1) >> 6;
+      const int nchk = c_hi - c_lo + 1;                       // 1 .. (nch + 63) / 64 chunks to build (<= WF_NW: host check)
+      const int cw = wv % nchk, chunk = c_lo + cw, rstart = wv / nchk, rstep = (WF_NW - cw + nchk - 1) / nchk;
       const int X = chunk * 64 + lane;
       const bool xok = X < nch;
       const vd_f2 ct = xok ? reinterpret_cast<const vd_f2*>(colT)[X] : vd_f2{0.f, 0.f};
