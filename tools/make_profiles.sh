@@ -3,9 +3,9 @@
 #      configs[4] chain (1080p depth + DIBR + Real-ESRGAN x4)
 #   2. three separate PMC passes (FETCH_SIZE | WRITE_SIZE | SQ counters) of the 4K DIBR-only run -- never combined with trace domains
 #      other than --kernel-trace (MI355X_MICROARCH.md HBM / rocprofv3 section)
-# usage: VD3D_COMMIT=<git short hash> bash tools/make_profiles.sh r03
+# usage: VD3D_COMMIT=<git short hash> bash tools/make_profiles.sh r04
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD; O=$R/gpurun_out/profiles_$TAG; mkdir -p $O
 cd /tmp
 DIBR="python $R/bench.py --workload 4k-dibr --steps 6 --warmup 2 --no-cpu-baseline --no-profile"
