@@ -393,14 +393,18 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     ev = []
     last = [None]
 
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
+    shr = ChunkSharder(HipChunkBackend(r, p), 0, 1, B)       # the DIBR frames of a step go through the batched step path (no pixel overlap: serial chain)
+    nstep = [0]
+
     def step(timed):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         pred = pipe.infer_bgr_u8(frames, raw=True)
         r.depth_handoff(pred, sh, sw, out=dbuf)
         e[1].record()
-        for j in range(B):
-            r.render_frame(frames[j], dbuf[j], p, out=outs[j])
+        shr.render_step(frames, dbuf, outs=outs, first_step=(nstep[0] == 0))
+        nstep[0] += 1
         e[2].record()
         for j in range(B):
             last[0] = up.run_esrgan(outs[j], input_res_pct=50, target_size=(3840, 2160))
@@ -449,7 +453,7 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     torch.cuda.empty_cache()
     return {"workload": "1080p-dav2s-dibr-esrgan4k",
             "description": "BASELINE configs[4] on one GPU: 1080p, DA-V2-Small (float32) + DIBR Half-SBS + Real-ESRGAN x4 (RealESR_Gx4, fp16 like "
-                           "the reference's ONNX export) through run_esrgan(input_res_pct=50, target_size=(3840, 2160)); serial chain, one stream",
+                           "the reference's ONNX export) through run_esrgan(input_res_pct=50, target_size=(3840, 2160)); serial chain, one stream (DIBR through the batched step path)",
             "value": round(steps * B / dt, 3), "unit": "stereo-pairs/s", "steps": steps, "warmup": warmup, "frames_timed": steps * B,
             "ms_per_step": round(dt / steps * 1e3, 3), "dtype": "f32 depth net + f32 DIBR + fp16 up-scale net (the reference's precisions)",
             "output": out_shape, "stage_ms_per_frame": {"depth_net+handoff": round(ms[0], 3), "dibr": round(ms[1], 3), "run_esrgan": round(ms[2], 3)},

@@ -2,7 +2,7 @@
 # register / LDS census of the kernels of one .hip file, offline (no GPU):  tools/vgpr.sh visiondepth3d_amd/csrc/vd3d_finish.hip [extra hipcc flags]
 F=$(realpath $1); shift
 D=$(mktemp -d); cd $D
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function -I$(dirname $F) "$@" -c $F -o x.o --save-temps 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden -Wno-unused-function -I$(dirname $F) "$@" -c $F -o x.o --save-temps 2>/dev/null
 python3 - <<'PY'
 import re,glob
 s=open(glob.glob('*gfx950.s')[0]).read()
