@@ -1,0 +1,53 @@
+"""Register / LDS budgets of the two pixel kernels, checked offline from hipcc's own metadata (no GPU needed).  E1's three resident workgroups
+per CU rest on 80 VGPRs (6 waves per SIMD x 80 <= 512) and 3 x LDS <= 160 KB; W1's three on its LDS footprint.  The numbers moved with compiler
+flags and harmless-looking source changes during round 4 (the SLP vectorizer: 146; a refactor into lambdas: 81), so the budget is a test."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _census(src):
+    flags = None
+    for ln in open(os.path.join(ROOT, "visiondepth3d_amd", "csrc", "Makefile")):
+        if ln.startswith("FLAGS"):
+            flags = ln.split("=", 1)[1].replace("$(ARCH)", "gfx950").split()
+    assert flags and "-fno-slp-vectorize" in flags
+    d = tempfile.mkdtemp()
+    try:
+        subprocess.run([HIPCC, *[f for f in flags if f != "-Wall"], "-I" + os.path.join(ROOT, "visiondepth3d_amd", "csrc"), "-c",
+                        os.path.join(ROOT, "visiondepth3d_amd", "csrc", src), "-o", "x.o", "--save-temps"], cwd=d, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        asm = open(glob.glob(os.path.join(d, "*gfx950.s"))[0]).read()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for m in re.finditer(r"\.group_segment_fixed_size: (\d+).*?\.name:\s+(\S+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count: (\d+)", asm, re.S):
+        out[m.group(2)] = dict(lds=int(m.group(1)), vgpr=int(m.group(3)), spill=int(m.group(4)))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_e1_fits_three_workgroups_per_cu():
+    k = _census("vd3d_finish.hip")
+    e1 = next(v for n, v in k.items() if n.startswith("_Z14k_finish_fusedILb1ELi26E"))
+    assert e1["spill"] == 0 and e1["vgpr"] <= 80, e1          # 8 waves per workgroup = 2 per SIMD; three workgroups = 6 waves x 80 VGPRs <= 512
+    assert 3 * e1["lds"] <= 160 * 1024, e1
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_w1_and_mask_kernel_budgets():
+    k = _census("vd3d_warp.hip")
+    for n, v in k.items():
+        assert v["spill"] == 0, (n, v)
+    w1 = next(v for n, v in k.items() if n.startswith("_Z12k_warp_fusedILb1ELb1ELi32ELb1E"))
+    assert w1["vgpr"] <= 80 and w1["lds"] % 16 == 0, w1       # static LDS in front of the dynamic array keeps it 16-byte aligned (ds_read_b128)
+    e2w = next(v for n, v in k.items() if n.startswith("_Z5k_e2w"))
+    assert e2w["vgpr"] <= 64 and e2w["lds"] <= 20 * 1024, e2w

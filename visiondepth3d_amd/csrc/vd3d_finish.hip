@@ -25,7 +25,9 @@
 // Fast path conditions (else the unfused kernels run): Gaussian taps <= 9 (dof_strength <= 2), fit factors in {1,2,4},
 // format in {Half-SBS, Full-SBS, Passive Interlaced, Red-Cyan Anaglyph (round 4: each eye's workgroups store their own bytes of the anaglyph)}.
 // (Round 4, measured and not kept: writing the halo-column windows during the tile load and publishing the level set per wave, i.e. ONE barrier
-// between the load phase and the levels instead of two: 252 -> 259 us at 4K.)
+// between the load phase and the levels instead of two: 252 -> 259 us at 4K.  Tile heights 22 / 14 at 80 VGPRs: 300 / 332 us.  Two tiles per
+// workgroup with the second tile's loads requested during the first one's epilogue: hipcc needs 185 VGPRs for the loop, and 81 for the
+// one-tile instantiation of the same source -- one register over the three-workgroup budget -- so the single-tile kernel stays as it is.)
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 
