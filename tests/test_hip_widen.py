@@ -346,3 +346,35 @@ def test_format_3d_output_and_linear_resize(R, oracle):
         assert np.array_equal(r3.generate_anaglyph_3d(L, Rr), oracle.format_output(L, Rr, 3))
     finally:
         r3._default = prev
+
+
+def test_render_sbs_3d_end_to_end_equals_the_reference_loop(R, monkeypatch):
+    """B2's Python face on the GPU: visiondepth3d_amd.video_io.render_sbs_3d with the in-memory video backend (tests/golden/ref_stubs.py -- the
+    same fake cv2 the reference's loop ran on when the fixtures were generated) and the real renderer, i.e. the batched step path of render_pairs
+    (RENDER_BATCH frames per step, two pixel streams): the frames it writes must equal the frames the REFERENCE's render_sbs_3d wrote for the
+    same clips (tests/golden/render_loop.npz, dof_levels.npz), for steps of 8, 2 and 1 frames."""
+    import sys, threading
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_stubs
+    from visiondepth3d_amd import video_io
+    monkeypatch.setattr(video_io, "video_backend", ref_stubs)
+    for gname, names in (("render_loop.npz", ("half_sbs_cli", "full_sbs_preserve", "interlaced", "anaglyph_43crop")), ("dof_levels.npz", ("half_sbs_dof3p0",))):
+        g = load_golden(gname)
+        cases = golden_json(g, "cases_json")
+        for name in names:
+            sh, sw, n, kw = cases[name]
+            frames, depths = synth.synth_clip(n, sh, sw)
+            for batch in (8, 2, 1):
+                monkeypatch.setattr(video_io, "RENDER_BATCH", batch)
+                ref_stubs._Clip.clips["in.mp4"] = frames
+                ref_stubs._Clip.clips["depth.mp4"] = [synth.depth_to_u8_bgr(d) for d in depths]
+                ref_stubs._Clip.written.pop("out.avi", None)
+                R.reset_state()
+                args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0, output_width=sw,
+                            selected_aspect_ratio="Default (16:9)", aspect_ratios={"Default (16:9)": 16 / 9},
+                            suspend_flag=threading.Event(), cancel_flag=threading.Event())
+                args.update(kw)
+                video_io.render_sbs_3d(**args, renderer=R)
+                got = np.stack(ref_stubs._Clip.written["out.avi"])
+                exp = g[f"{name}__frames"]
+                assert got.shape == exp.shape and np.array_equal(got, exp), (name, batch, u8_diff_stats(got, exp) if got.shape == exp.shape else got.shape)
