@@ -254,7 +254,8 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     tdt = {"f32": torch.float32, "bf16": torch.bfloat16}[depth_dtype]
     if model_name:
         from visiondepth3d_amd.depth import DepthPipe
-        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh)   # fused front end + fused backbone glue
+        # fused front end + fused backbone / neck glue; library selection: committed GEMM table + MIOpen find mode (runs during the warm-up)
+        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh, miopen_find=not args.no_miopen_find)
 
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
@@ -359,6 +360,7 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
                frames_total=world * steps * B, stage_ms=stage_ms, iso_ms=iso_ms, net_ms=net_ms, flops_per_frame=flops,
                N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), pix_streams=(1 if host_io else max(1, int(args.pix_streams))) if pix_ov else 0,
                depth_dtype=depth_dtype if model_name else None,
+               lib_sel=({"hipblaslt_solution_table": bool(pipe.tuned_gemm), "miopen_find_mode": bool(pipe.miopen_find)} if pipe is not None else None),
                host_io=host_io, clip=args.clip, clip_frames_global=world * args.clip,
                p1_wait_ms=_p1_wait(env, shr2),
                shard_bytes=(shr2[0].bytes_per_step() if (shr2 and hasattr(shr2[0], "bytes_per_step")) else None))
@@ -660,6 +662,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="headline only")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-stage HIP-event timing inside the timed region")
+    ap.add_argument("--no-miopen-find", action="store_true", help="depth net: MIOpen's immediate-mode solver choice instead of find mode (find mode times every "
+                    "convolution shape's solvers once per process, ~25 s inside the first warm-up step)")
     ap.add_argument("--sharded", action="store_true", help="use the chunk-sharding step protocol even at N=1 without pixel overlap (the default since round 4)")
     ap.add_argument("--per-frame", action="store_true", help="one vd3d_render_frame call per frame instead of the batched step protocol (N = 1, no pixel overlap)")
     ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
@@ -735,6 +739,7 @@ def main():
                        "depth_net_dtype": ({"f32": "float32 (the reference's precision)", "bf16": "bfloat16"}[args.depth_dtype]
                                            if model_name else None),
                        "arithmetic": "u8 in/out, float32 DIBR kernels, float64 scalar trackers",
+                       "depth_net_library_selection": head.get("lib_sel"),
                        "pixel_overlap": head["pix_ov"], "pixel_streams": head.get("pix_streams"),
                        "sharding": "contiguous frame chunks per rank; scalar records all-gathered and trackers replayed on every rank "
                                    "(bit-identical to 1 GPU)" if env.world > 1 else None,

@@ -372,6 +372,18 @@ int vd3d_add_layernorm(vd3d_ctx* ctx, int dtype, const void* x, const void* y_or
  * `dtype`, C a multiple of 8 (bf16) / 4 (f32): the up-samplings of the DPT neck / head (a25). */
 int vd3d_upsample_bilinear_nhwc(vd3d_ctx* ctx, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
 
+/* Float32 glue between the library convolutions of the DPT neck / head (a25; transformers DepthAnythingPreActResidualLayer /
+ * FeatureFusionLayer / DepthEstimationHead as the reference's pipeline runs them, core/render_depth.py:1106-1119).  NHWC maps of n_pix
+ * pixels x C channels (C a multiple of 4).
+ *   vd3d_nhwc_bias_act_f32:  v = y [+ bias[c]] [+ r1]; [v = r2 + v]; [v = max(v, 0)] -> out (may alias y); [relu_out = max(v, 0)]
+ *   vd3d_upsample_bilinear_bias_nhwc_f32:  vd3d_upsample_bilinear_nhwc + bias[c] on the interpolated value (up(conv + b) == up(conv) + b)
+ *   vd3d_dpt_head_tail_f32:  out[p] = max(b3 + sum_c w3[c] * max(y[p][c] + b2[c], 0), 0) * scale -- conv2's bias, ReLU, the 1x1 conv3, its
+ *                            bias, the final ReLU and max_depth of the head in one pass; C in {16, 32, 64} */
+int vd3d_nhwc_bias_act_f32(vd3d_ctx* ctx, const float* y, const float* bias_or_null, const float* r1_or_null, const float* r2_or_null, int relu,
+                           int64_t n_pix, int C, float* out, float* relu_out_or_null);
+int vd3d_upsample_bilinear_bias_nhwc_f32(vd3d_ctx* ctx, const float* in, const float* bias, float* out, int B, int ih, int iw, int oh, int ow, int C);
+int vd3d_dpt_head_tail_f32(vd3d_ctx* ctx, const float* y, const float* b2, const float* w3, float b3, float scale, int64_t n_pix, int C, float* out);
+
 /* ---- preview visualisers: generate_preview_image, core/preview_utils.py:23-84, the exactly defined types.
  * left / right: uint8 BGR [h][w][3] eyes (outputs of vd3d_pixel_shift).  out: [h][w][3], except HSBS: [h][2*(w/2)][3].
  * The colour-mapped heat-maps and the arrow overlay (OpenCV colour-map tables / line rasteriser) return VD3D_E_UNSUPPORTED. */

@@ -1,6 +1,8 @@
 """GPU parity tests (-m gpu) for the round-1 widening rows: black-bar auto crop (core/render_3d.py:293-326,1230-1248),
 fractional / mixed INTER_AREA inside pad_to_aspect_ratio (:101-131) and the VR format (:846-849).
 HIP (through the C ABI) vs the CPU oracle: bit-exact; vs the reference goldens (tests/golden/widen.npz): the B2 bars."""
+import os
+
 import numpy as np
 import pytest
 

@@ -420,3 +420,58 @@ def test_depth_pipe_generic_architecture_dpt_protocol():
     got = pipe([img])[0]["predicted_depth"]
     assert tuple(got.shape) == tuple(exp.shape) == (126, 224)
     assert float((got - exp).abs().mean() / exp.abs().mean()) < 3e-2   # 8-bit rounding of the resized image in the PIL front end
+
+
+def test_dpt_neck_head_rewrite_is_the_module_graph():
+    """DepthPipe._patch_dpt_upsampling in float32 (bias-free convolutions + one glue launch between them, projection before its up-sampling,
+    fused head tail, channels_last reassemble view) against the stock transformers graph on CPU, with a torch double of the three glue
+    entry points that states what each HIP kernel computes (include/vd3d.h: vd3d_nhwc_bias_act_f32, vd3d_upsample_bilinear_bias_nhwc_f32,
+    vd3d_dpt_head_tail_f32).  The GPU tests (tests/test_hip_depth_e2e.py) run the same graph on the kernels themselves."""
+    import torch
+    import torch.nn.functional as F
+    transformers = pytest.importorskip("transformers")
+    from visiondepth3d_amd.depth import DepthPipe, build_config, synthetic_weights_
+
+    class GlueDouble:
+        calls = {"bias_act": 0, "up_bias": 0, "tail": 0, "up": 0}
+
+        def upsample_bilinear(self, x, size):
+            self.calls["up"] += 1
+            return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=True)
+
+        def bias_act(self, y, bias=None, r1=None, r2=None, relu=False, want_relu_copy=False):
+            self.calls["bias_act"] += 1
+            v = y if bias is None else y + bias.view(1, -1, 1, 1)
+            if r1 is not None:
+                v = v + r1
+            if r2 is not None:
+                v = r2 + v
+            if relu:
+                v = torch.relu(v)
+            y.copy_(v)
+            return (y, torch.relu(y)) if want_relu_copy else y
+
+        def upsample_bilinear_bias(self, x, size, bias):
+            self.calls["up_bias"] += 1
+            return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=True) + bias.view(1, -1, 1, 1)
+
+        def dpt_head_tail(self, y, b2, w3, b3, scale):
+            self.calls["tail"] += 1
+            return torch.relu((torch.relu(y + b2.view(1, -1, 1, 1)) * w3.view(1, -1, 1, 1)).sum(1) + b3) * scale
+
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    for name in ("depth-anything-v2-small", "depth-anything-v2-base"):
+        pipe = DepthPipe(name, device="cpu", dtype=torch.float32)
+        pipe.renderer = GlueDouble()
+        GlueDouble.calls = dict.fromkeys(GlueDouble.calls, 0)
+        pipe._patch_dpt_upsampling()
+        model = transformers.DepthAnythingForDepthEstimation(build_config(name)).eval()
+        synthetic_weights_(model, 0)
+        pv = torch.randn(2, 3, 70, 98, generator=torch.Generator().manual_seed(3))
+        with torch.no_grad():
+            a = pipe.model(pixel_values=pv).predicted_depth
+            b = model(pixel_values=pv).predicted_depth
+        assert a.shape == b.shape
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-5, name
+        # 7 residual units x 2 glue launches; 4 projections + head conv1 hand their bias to the up-sampling; one head tail; no plain up-sampling left
+        assert GlueDouble.calls == {"bias_act": 14, "up_bias": 5, "tail": 1, "up": 0}, GlueDouble.calls

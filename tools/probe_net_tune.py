@@ -16,7 +16,7 @@ mode = sys.argv[1]
 table = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/tunable_gemm.csv"
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 R = Renderer(0)
-if mode == "find":
+if mode == "find" or os.environ.get("FIND") == "1":   # FIND=1: find mode under any mode (e.g. FIND=1 ... use table.csv)
     torch.backends.cudnn.benchmark = True
 os.environ["VD3D_TUNED_GEMM"] = "0"      # the probe loads / writes its own table
 pipe = DepthPipe("depth-anything-v2-base", device="cuda", dtype=torch.float32, renderer=R)

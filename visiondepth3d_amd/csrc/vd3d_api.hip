@@ -1281,6 +1281,33 @@ VD3D_EXPORT int vd3d_upsample_bilinear_nhwc(vd3d_ctx* c, int dtype, const void* 
   return 0;
 }
 
+// DPT neck / head glue in float32 (vd3d_netops.hip): NHWC maps of n_pix pixels x C channels
+VD3D_EXPORT int vd3d_nhwc_bias_act_f32(vd3d_ctx* c, const float* y, const float* bias_or_null, const float* r1_or_null, const float* r2_or_null, int relu,
+                                       int64_t n_pix, int C, float* out, float* relu_out_or_null) {
+  if (!c || !y || !out || n_pix < 1 || C < 4) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!vd_launch_bias_act_f32(c->stream, y, bias_or_null, r1_or_null, r2_or_null, relu, (long long)n_pix, C, out, relu_out_or_null))
+    return set_err(VD3D_E_UNSUPPORTED, "nhwc_bias_act: C %d not a multiple of 4", C);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+VD3D_EXPORT int vd3d_upsample_bilinear_bias_nhwc_f32(vd3d_ctx* c, const float* in, const float* bias, float* out, int B, int ih, int iw, int oh, int ow, int C) {
+  if (!c || !in || !bias || !out || B < 1 || ih < 1 || iw < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!vd_launch_upsample_bilinear_bias_nhwc_f32(c->stream, in, bias, out, B, ih, iw, oh, ow, C))
+    return set_err(VD3D_E_UNSUPPORTED, "upsample_bilinear_bias_nhwc: C not a multiple of 4 or output smaller than 2x2");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+VD3D_EXPORT int vd3d_dpt_head_tail_f32(vd3d_ctx* c, const float* y, const float* b2, const float* w3, float b3, float scale, int64_t n_pix, int C, float* out) {
+  if (!c || !y || !b2 || !w3 || !out || n_pix < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!vd_launch_head_tail_f32(c->stream, y, b2, w3, b3, scale, (long long)n_pix, C, out))
+    return set_err(VD3D_E_UNSUPPORTED, "dpt_head_tail: C %d not in {16, 32, 64}", C);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int vd3d_preview_image(vd3d_ctx* c, int type, const uint8_t* left_bgr, const uint8_t* right_bgr, int h, int w, uint8_t* out_bgr) {
   if (!c || !left_bgr || !right_bgr || !out_bgr || h < 1 || w < 1) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));

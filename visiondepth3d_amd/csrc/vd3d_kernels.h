@@ -171,6 +171,10 @@ bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, in
 bool vd_launch_add_layernorm(hipStream_t s, int dtype, const void* x, const void* y, const void* gamma, const void* beta, float eps,
                              long long rows, int cols, void* out_sum, void* out_norm);
 bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);
+bool vd_launch_bias_act_f32(hipStream_t s, const float* y, const float* bias, const float* r1, const float* r2, int relu, long long n_pix, int C,
+                            float* out, float* relu_out);
+bool vd_launch_upsample_bilinear_bias_nhwc_f32(hipStream_t s, const float* in, const float* bias, float* out, int B, int ih, int iw, int oh, int ow, int C);
+bool vd_launch_head_tail_f32(hipStream_t s, const float* y, const float* b2, const float* w3, float b3, float scale, long long n_pix, int C, float* out);
 // ---- vd3d_handoff.hip
 void vd_launch_depth_handoff(hipStream_t s, const float* pred, int B, int ph, int pw, int H, int W, int invert, uint32_t* mm,
                              uint8_t* out);

@@ -190,3 +190,103 @@ bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, int dtype, const void* in, 
                      oh, ow, c8, sh, sw, total);
   return true;
 }
+
+// ---- DPT neck / head glue in float32 (round 4): what sits between MIOpen's convolutions in DepthAnythingPreActResidualLayer /
+// FeatureFusionLayer / DepthEstimationHead (transformers modeling_depth_anything.py).  PyTorch runs each bias, ReLU and residual sum as its
+// own pass over the feature map (bias: a broadcast add behind every MIOpen convolution); at 4K the head-resolution maps are 0.6 - 1.3 GB.
+//
+// k_bias_act: v = y [+ bias[c]] [+ r1] ; [v = r2 + v] ; [v = max(v, 0)] -> out ; [relu_out = max(v, 0)]   (NHWC, one thread = 4 channels)
+//   second convolution of a residual unit: bias + the unit's input (+ the fusion layer's running state) in one pass, and the ReLU'd copy the next
+//   unit's first convolution reads; first convolution: bias + ReLU in place.
+__global__ __launch_bounds__(256) void k_bias_act(const float4* __restrict__ y, const float4* __restrict__ bias, const float4* __restrict__ r1,
+                                                  const float4* __restrict__ r2, int relu, int c4, long long total, float4* __restrict__ out,
+                                                  float4* __restrict__ relu_out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  float4 v = y[idx];
+  if (bias) { const float4 b = bias[(int)(idx % c4)]; v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  if (r1) { const float4 r = r1[idx]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+  if (r2) { const float4 r = r2[idx]; v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
+  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  out[idx] = v;
+  if (relu_out) relu_out[idx] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+bool vd_launch_bias_act_f32(hipStream_t s, const float* y, const float* bias, const float* r1, const float* r2, int relu, long long n_pix, int C,
+                            float* out, float* relu_out) {
+  if (C % 4 || n_pix < 1) return false;
+  const long long total = n_pix * (C / 4);
+  hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)y, (const float4*)bias, (const float4*)r1,
+                     (const float4*)r2, relu, C / 4, total, (float4*)out, (float4*)relu_out);
+  return true;
+}
+
+// k_upsample_bilinear_nhwc_f32 with the producing convolution's bias added to the interpolated value: the interpolation weights sum to one,
+// so up(conv + b) == up(conv) + b; the convolution in front runs without its bias pass.
+__global__ __launch_bounds__(256) void k_upsample_bilinear_bias_nhwc_f32(const float4* __restrict__ in, const float4* __restrict__ bias,
+                                                                         float4* __restrict__ out, int ih, int iw, int oh, int ow, int c4, float sh,
+                                                                         float sw, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % c4);
+  long long r = idx / c4;
+  const int x = (int)(r % ow); r /= ow;
+  const int y = (int)(r % oh);
+  const long long b = r / oh;
+  const float fy = sh * (float)y, fx = sw * (float)x;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < ih - 1 ? 1 : 0), x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+  const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+  const float4* base = in + (size_t)b * ih * iw * c4 + c;
+  const float4 p00 = base[((size_t)y0 * iw + x0) * c4], p01 = base[((size_t)y0 * iw + x1) * c4];
+  const float4 p10 = base[((size_t)y1 * iw + x0) * c4], p11 = base[((size_t)y1 * iw + x1) * c4];
+  const float4 bb = bias[c];
+  float4 o;
+  o.x = (ly0 * (lx0 * p00.x + lx1 * p01.x) + ly1 * (lx0 * p10.x + lx1 * p11.x)) + bb.x;
+  o.y = (ly0 * (lx0 * p00.y + lx1 * p01.y) + ly1 * (lx0 * p10.y + lx1 * p11.y)) + bb.y;
+  o.z = (ly0 * (lx0 * p00.z + lx1 * p01.z) + ly1 * (lx0 * p10.z + lx1 * p11.z)) + bb.z;
+  o.w = (ly0 * (lx0 * p00.w + lx1 * p01.w) + ly1 * (lx0 * p10.w + lx1 * p11.w)) + bb.w;
+  out[idx] = o;
+}
+bool vd_launch_upsample_bilinear_bias_nhwc_f32(hipStream_t s, const float* in, const float* bias, float* out, int B, int ih, int iw, int oh, int ow, int C) {
+  if (C % 4 || oh < 2 || ow < 2 || !bias) return false;
+  const int c4 = C / 4;
+  const long long total = (long long)B * oh * ow * c4;
+  const float sh = (float)(ih - 1) / (float)(oh - 1), sw = (float)(iw - 1) / (float)(ow - 1);
+  hipLaunchKernelGGL(k_upsample_bilinear_bias_nhwc_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)in, (const float4*)bias,
+                     (float4*)out, ih, iw, oh, ow, c4, sh, sw, total);
+  return true;
+}
+
+// k_head_tail: everything behind the head's second convolution -- its bias, ReLU, the 1x1 convolution to ONE channel (a C-term dot product per
+// pixel), its bias, ReLU and max_depth -- in one pass: reads the C-channel map once, writes one float per pixel (PyTorch: bias r+w, ReLU r+w,
+// MIOpen 1x1 r, bias, ReLU, scale).  LPP = C / 4 adjacent lanes share a pixel (coalesced 16-byte loads), partial dot products meet in a butterfly.
+template <int LPP>
+__global__ __launch_bounds__(256) void k_head_tail(const float4* __restrict__ y, const float4* __restrict__ b2, const float4* __restrict__ w3, float b3,
+                                                   float scale, long long n_pix, float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long pix = idx / LPP;
+  const int l = (int)(idx % LPP);
+  float acc = 0.f;
+  if (pix < n_pix) {
+    const float4 v = y[idx], b = b2[l], w = w3[l];
+    acc = fmaxf(v.x + b.x, 0.f) * w.x;
+    acc = vd_fma(fmaxf(v.y + b.y, 0.f), w.y, acc);
+    acc = vd_fma(fmaxf(v.z + b.z, 0.f), w.z, acc);
+    acc = vd_fma(fmaxf(v.w + b.w, 0.f), w.w, acc);
+  }
+#pragma unroll
+  for (int off = LPP / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (l == 0 && pix < n_pix) out[pix] = fmaxf(acc + b3, 0.f) * scale;
+}
+bool vd_launch_head_tail_f32(hipStream_t s, const float* y, const float* b2, const float* w3, float b3, float scale, long long n_pix, int C, float* out) {
+  if (n_pix < 1) return false;
+  const long long total = n_pix * (C / 4);
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  const float4 *yy = (const float4*)y, *bb = (const float4*)b2, *ww = (const float4*)w3;
+  switch (C) {
+    case 16: hipLaunchKernelGGL(k_head_tail<4>, g, b, 0, s, yy, bb, ww, b3, scale, n_pix, out); return true;
+    case 32: hipLaunchKernelGGL(k_head_tail<8>, g, b, 0, s, yy, bb, ww, b3, scale, n_pix, out); return true;
+    case 64: hipLaunchKernelGGL(k_head_tail<16>, g, b, 0, s, yy, bb, ww, b3, scale, n_pix, out); return true;
+    default: return false;
+  }
+}

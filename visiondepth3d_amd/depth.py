@@ -123,13 +123,22 @@ class DepthPipe:
     device-resident batch path."""
 
     def __init__(self, name: str = "depth-anything-v2-small", device="cuda", dtype=torch.float32, seed: int = 0,
-                 channels_last: bool = True, renderer=None, fuse_backbone: bool = True, model=None, processor: dict | None = None):
+                 channels_last: bool = True, renderer=None, fuse_backbone: bool = True, model=None, processor: dict | None = None,
+                 tuned_gemm: bool = True, miopen_find: bool = False):
         """``dtype``: float32 (the reference's precision, default) or bfloat16.
         ``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream); when given the
         image-processor front end, the residual-add + LayerNorm pairs and the DPT up-samplings run as fused HIP launches.
         ``model`` / ``processor``: an already constructed Hugging Face depth model and its image-processor constants
-        (``from_pretrained``); otherwise the architecture ``name`` is built from MODEL_ZOO with synthetic weights."""
+        (``from_pretrained``); otherwise the architecture ``name`` is built from MODEL_ZOO with synthetic weights.
+        Library selection (the GEMMs / convolutions stay library calls, north_star): ``tuned_gemm`` loads the committed hipBLASLt solution
+        table ``tuned/gemm_gfx950.csv`` (PyTorch TunableOp, tuning OFF: a look-up per GEMM shape; written by tools/probe_net_tune.py on an
+        MI355X; ignored when its library-version validators do not match; ``VD3D_TUNED_GEMM=0`` disables).  ``miopen_find``: MIOpen
+        find mode (``torch.backends.cudnn.benchmark``) -- every convolution shape times its applicable solvers once, ~25 s at the
+        first forward of a process, 4.5 % on the 4K float32 forward (profiles/r04_net_library_selection.md); opt-in, bench.py uses it."""
         self.name, self.device, self.dtype = name, torch.device(device), dtype
+        self.tuned_gemm = self.miopen_find = False
+        if self.device.type == "cuda":
+            self._library_selection(tuned_gemm, miopen_find)
         if dtype not in (torch.float32, torch.bfloat16):
             raise TypeError("DepthPipe runs in float32 (reference precision) or bfloat16")
         if model is None:
@@ -157,6 +166,27 @@ class DepthPipe:
                 self._fuse_backbone_layers()
             if self.renderer is not None:
                 self._patch_dpt_upsampling()
+
+    def _library_selection(self, tuned_gemm: bool, miopen_find: bool):
+        if miopen_find:
+            torch.backends.cudnn.benchmark = True
+            self.miopen_find = True
+        table = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
+        if not tuned_gemm or os.environ.get("VD3D_TUNED_GEMM", "1") == "0" or not os.path.exists(table):
+            return
+        try:
+            import tempfile
+            import torch.cuda.tunable as tn
+            if tn.is_enabled():       # the caller drives TunableOp itself (tools/probe_net_tune.py, PYTORCH_TUNABLEOP_ENABLED=1)
+                return
+            tn.enable(True)
+            tn.tuning_enable(False)
+            tn.set_filename(os.path.join(tempfile.gettempdir(), "vd3d_tunableop_%d.csv" % os.getpid()))   # never write into the package
+            self.tuned_gemm = bool(tn.read_file(table))
+            if not self.tuned_gemm:   # other hipBLASLt / rocBLAS / PyTorch build: the solution indices mean nothing there
+                tn.enable(False)
+        except Exception:             # TunableOp missing in this build: the heuristic selection is the same math
+            self.tuned_gemm = False
 
     @classmethod
     def from_pretrained(cls, path: str, device="cuda", dtype=torch.float32, **kw) -> "DepthPipe":
@@ -209,35 +239,85 @@ class DepthPipe:
         emb.interpolate_pos_encoding = cached
 
     def _patch_dpt_upsampling(self):
-        """Route the align_corners=True bilinear up-samplings of the DPT neck / head (transformers
-        DepthAnythingFeatureFusionLayer / DepthAnythingDepthEstimationHead) through vd3d_upsample_bilinear_nhwc; the
-        module graphs are otherwise reproduced verbatim."""
+        """The DPT neck / head between the library convolutions (transformers DepthAnythingReassembleStage / PreActResidualLayer /
+        FeatureFusionLayer / DepthEstimationHead; the module graphs are otherwise reproduced verbatim):
+          * the align_corners=True bilinear up-samplings run on vd3d_upsample_bilinear_nhwc;
+          * float32 (the reference's precision): every convolution runs WITHOUT its bias pass and the glue between two convolutions is one
+            HIP launch -- bias + ReLU in place behind a unit's first convolution; bias + unit input (+ the fusion layer's running state) behind
+            its second one, which also writes the ReLU'd copy the next unit starts from; a convolution in front of an up-sampling hands its bias
+            to the up-sampling kernel (interpolation weights sum to one); the fusion layer's 1x1 projection runs BEFORE its up-sampling (both
+            are linear and per-pixel / per-channel: conv1x1(up(x)) == up(conv1x1(x)), a quarter of the pixels); behind the head's second
+            convolution one launch does bias, ReLU, the 1x1 convolution to one channel, bias, ReLU and max_depth (vd3d_dpt_head_tail_f32);
+          * the reassemble stage hands the token tensor to its 1x1 projection as a channels_last VIEW ([B,T,C] minus CLS is NHWC storage)
+            instead of a NCHW copy that MIOpen converts back.
+        Same function as the module graph up to float32 association (tests/test_hip_depth_e2e.py: 1e-4 of the range on the prediction,
+        identical uint8 planes up to the stated bar)."""
         R = self.renderer
+        f32 = self.dtype == torch.float32 and os.environ.get("VD3D_NECK_GLUE", "1") != "0"   # 0: A/B switch back to the module graph's own passes
+        CL = torch.channels_last
 
         def up(x, size):
-            if x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last):
+            if x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=CL):
                 return R.upsample_bilinear(x, size)
             return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
+        def conv_nb(m, x):   # the module's convolution without its bias
+            return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups).contiguous(memory_format=CL)
+
+        def res_unit(unit, x, x_relu=None, extra=None, want_relu=False):
+            """PreActResidualLayer: conv2(relu(conv1(relu(x)))) + x [then extra + that]; optionally also relu(result)."""
+            x = x.contiguous(memory_format=CL)
+            h = torch.relu(x) if x_relu is None else x_relu
+            y = R.bias_act(conv_nb(unit.convolution1, h), unit.convolution1.bias, relu=True)
+            y = conv_nb(unit.convolution2, y)
+            return R.bias_act(y, unit.convolution2.bias, r1=x, r2=extra, want_relu_copy=want_relu)
+
         for layer in self.model.neck.fusion_stage.layers:
             def fusion_fwd(hidden_state, residual=None, size=None, layer=layer):
+                fused = f32 and hidden_state.dtype == torch.float32 and hidden_state.shape[1] % 4 == 0
                 if residual is not None:
                     if hidden_state.shape != residual.shape:
                         residual = F.interpolate(residual, size=(hidden_state.shape[2], hidden_state.shape[3]), mode="bilinear",
                                                  align_corners=False)
-                    hidden_state = hidden_state + layer.residual_layer1(residual)
-                hidden_state = layer.residual_layer2(hidden_state)
+                    if fused:
+                        hidden_state, hr = res_unit(layer.residual_layer1, residual, extra=hidden_state.contiguous(memory_format=CL), want_relu=True)
+                        hidden_state = res_unit(layer.residual_layer2, hidden_state, x_relu=hr)
+                    else:
+                        hidden_state = layer.residual_layer2(hidden_state + layer.residual_layer1(residual))
+                else:
+                    hidden_state = res_unit(layer.residual_layer2, hidden_state) if fused else layer.residual_layer2(hidden_state)
                 tgt = (2 * hidden_state.shape[2], 2 * hidden_state.shape[3]) if size is None else tuple(size)
+                if fused and layer.projection.bias is not None:
+                    return R.upsample_bilinear_bias(conv_nb(layer.projection, hidden_state), tgt, layer.projection.bias)
                 return layer.projection(up(hidden_state, tgt))
             layer.forward = fusion_fwd
         head = self.model.head
+        tail = None
+        if (f32 and isinstance(head.activation2, torch.nn.ReLU) and head.conv2.out_channels in (16, 32, 64) and head.conv3.kernel_size == (1, 1)
+                and head.conv2.bias is not None and head.conv3.bias is not None and head.conv1.bias is not None):
+            # conv3's operands never change after construction / from_pretrained: read its scalar bias ONCE (no per-call host sync)
+            tail = (head.conv3.weight.detach().reshape(-1).contiguous(), float(head.conv3.bias.detach().float().item()), float(head.max_depth))
 
         def head_fwd(hidden_states, patch_height, patch_width):
-            h = head.conv1(hidden_states[head.head_in_index])
-            h = up(h, (int(patch_height * head.patch_size), int(patch_width * head.patch_size)))
+            x = hidden_states[head.head_in_index]
+            size = (int(patch_height * head.patch_size), int(patch_width * head.patch_size))
+            if tail is not None and x.dtype == torch.float32:
+                h = R.upsample_bilinear_bias(conv_nb(head.conv1, x.contiguous(memory_format=CL)), size, head.conv1.bias)
+                return R.dpt_head_tail(conv_nb(head.conv2, h), head.conv2.bias, tail[0], tail[1], tail[2])
+            h = up(head.conv1(x), size)
             h = head.conv3(head.activation1(head.conv2(h)))
             return (head.activation2(h) * head.max_depth).squeeze(dim=1)
         head.forward = head_fwd
+        stage = self.model.neck.reassemble_stage
+
+        def reassemble_fwd(hidden_states, patch_height=None, patch_width=None):
+            out = []
+            for i, hs in enumerate(hidden_states):
+                B, _, Cn = hs.shape
+                x = hs[:, 1:].reshape(B, patch_height, patch_width, Cn).permute(0, 3, 1, 2)   # NHWC storage, NCHW view: channels_last
+                out.append(stage.layers[i](x))
+            return out
+        stage.forward = reassemble_fwd
 
     @torch.no_grad()
     def _fuse_backbone_layers(self):

@@ -602,6 +602,43 @@ class Renderer:
         _lib.check(self._L.vd3d_upsample_bilinear_nhwc(self._ctx, self._dt(x.dtype), _ptr(x), _ptr(out), B, ih, iw, oh, ow, Cc))
         return out
 
+    # ---- float32 glue between the library convolutions of the DPT neck / head (vd3d_netops.hip); tensors are channels_last [B,C,h,w]
+    @staticmethod
+    def _nhwc_f32(*ts):
+        for t in ts:
+            if t is not None and not (t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
+                raise ValueError("float32 channels_last [B,C,h,w] tensors expected")
+
+    def bias_act(self, y, bias=None, r1=None, r2=None, relu=False, want_relu_copy=False):
+        """In place on ``y``: y = [relu](r2 + ((y + bias[c]) + r1)); returns y, or (y, relu(y)) with ``want_relu_copy``."""
+        self._nhwc_f32(y, r1, r2)
+        B, Cc, h, w = y.shape
+        ro = torch.empty_like(y) if want_relu_copy else None
+        self._enter(y, bias, r1, r2, ro)
+        _lib.check(self._L.vd3d_nhwc_bias_act_f32(self._ctx, _ptr(y), _ptr(bias) if bias is not None else None, _ptr(r1) if r1 is not None else None,
+                                                  _ptr(r2) if r2 is not None else None, int(bool(relu)), B * h * w, Cc, _ptr(y),
+                                                  _ptr(ro) if ro is not None else None))
+        return (y, ro) if want_relu_copy else y
+
+    def upsample_bilinear_bias(self, x, size, bias):
+        """upsample_bilinear(x, size) + bias[c] (the bias of the convolution that produced x, run without it)."""
+        self._nhwc_f32(x)
+        B, Cc, ih, iw = x.shape
+        oh, ow = int(size[0]), int(size[1])
+        out = torch.empty((B, Cc, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        self._enter(x, bias, out)
+        _lib.check(self._L.vd3d_upsample_bilinear_bias_nhwc_f32(self._ctx, _ptr(x), _ptr(bias), _ptr(out), B, ih, iw, oh, ow, Cc))
+        return out
+
+    def dpt_head_tail(self, y, b2, w3, b3: float, scale: float):
+        """[B,C,h,w] (conv2 WITHOUT its bias) -> [B,h,w]: relu(b3 + sum_c w3[c] relu(y + b2[c])) * scale."""
+        self._nhwc_f32(y)
+        B, Cc, h, w = y.shape
+        out = torch.empty((B, h, w), dtype=torch.float32, device=y.device)
+        self._enter(y, b2, w3, out)
+        _lib.check(self._L.vd3d_dpt_head_tail_f32(self._ctx, _ptr(y), _ptr(b2), _ptr(w3), float(b3), float(scale), B * h * w, Cc, _ptr(out)))
+        return out
+
     def detect_black_bars(self, frame_bgr: torch.Tensor):
         """detect_black_bars(frame_to_tensor(frame)) (core/render_3d.py:293-316) on a uint8 BGR frame -> (top, bottom)."""
         f = frame_bgr.to(self.device, torch.uint8).contiguous()
