@@ -475,3 +475,13 @@ def test_dpt_neck_head_rewrite_is_the_module_graph():
         assert float((a - b).abs().max() / b.abs().max()) < 1e-5, name
         # 7 residual units x 2 glue launches; 4 projections + head conv1 hand their bias to the up-sampling; one head tail; no plain up-sampling left
         assert GlueDouble.calls == {"bias_act": 14, "up_bias": 5, "tail": 1, "up": 0}, GlueDouble.calls
+        # flops_per_frame counts what the rewritten graph EXECUTES: the stock count minus 3/4 of the four 1x1 projections (they run before
+        # their up-samplings now); the bias-free convolution calls bypass the module hooks and count themselves
+        stock = DepthPipe(name, device="cpu", dtype=torch.float32).flops_per_frame(126, 224)
+        mine = pipe.flops_per_frame(126, 224)
+        th, tw = pipe.resize_target(126, 224)
+        Cf = pipe.model.config.fusion_hidden_size
+        ph, pw = th // 14, tw // 14
+        px_stock = ph * pw * (1 + 4 + 16 + 64)                                   # the projections' output pixels in the stock graph ...
+        px_mine = -(-ph // 2) * -(-pw // 2) + ph * pw * (1 + 4 + 16)              # ... and their input pixels (the stride-2 reassemble map rounds up)
+        assert abs((stock - mine) - 2.0 * Cf * Cf * (px_stock - px_mine)) <= 1e-9 * stock, (stock, mine)

@@ -5,7 +5,7 @@
                  argv[2] and the forward is timed before / after; the prediction of the tuned run is compared with the untuned one.
   mode `find`  : MIOpen find mode (torch.backends.cudnn.benchmark) over the DPT neck / head convolutions; first-forward cost and the steady time.
   mode `use`   : forward time with the table argv[2] loaded and tuning off (what DepthPipe does with the committed table).
-usage: probe_net_tune.py gemm|find|use [table.csv] [frames]"""
+usage: [MODEL=depth-anything-v2-small] [FRAME=1080x1920] [FIND=1] probe_net_tune.py gemm|find|use [table.csv] [frames per batch]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,8 +19,10 @@ R = Renderer(0)
 if mode == "find" or os.environ.get("FIND") == "1":   # FIND=1: find mode under any mode (e.g. FIND=1 ... use table.csv)
     torch.backends.cudnn.benchmark = True
 os.environ["VD3D_TUNED_GEMM"] = "0"      # the probe loads / writes its own table
-pipe = DepthPipe("depth-anything-v2-base", device="cuda", dtype=torch.float32, renderer=R)
-x = torch.randint(0, 255, (B, 2160, 3840, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+MODEL = os.environ.get("MODEL", "depth-anything-v2-base")
+FH, FW = (int(v) for v in os.environ.get("FRAME", "2160x3840").split("x"))
+pipe = DepthPipe(MODEL, device="cuda", dtype=torch.float32, renderer=R)
+x = torch.randint(0, 255, (B, FH, FW, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
 
 
 def timed(iters=4):

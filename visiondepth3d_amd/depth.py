@@ -137,6 +137,7 @@ class DepthPipe:
         first forward of a process, 4.5 % on the 4K float32 forward (profiles/r04_net_library_selection.md); opt-in, bench.py uses it."""
         self.name, self.device, self.dtype = name, torch.device(device), dtype
         self.tuned_gemm = self.miopen_find = False
+        self._flop_count = None
         if self.device.type == "cuda":
             self._library_selection(tuned_gemm, miopen_find)
         if dtype not in (torch.float32, torch.bfloat16):
@@ -262,7 +263,10 @@ class DepthPipe:
             return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
         def conv_nb(m, x):   # the module's convolution without its bias
-            return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups).contiguous(memory_format=CL)
+            y = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups).contiguous(memory_format=CL)
+            if self._flop_count is not None:   # flops_per_frame: these calls bypass the modules' forward hooks
+                self._flop_count[0] += 2.0 * y.numel() / y.shape[0] * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+            return y
 
         def res_unit(unit, x, x_relu=None, extra=None, want_relu=False):
             """PreActResidualLayer: conv2(relu(conv1(relu(x)))) + x [then extra + that]; optionally also relu(result)."""
@@ -303,7 +307,10 @@ class DepthPipe:
             size = (int(patch_height * head.patch_size), int(patch_width * head.patch_size))
             if tail is not None and x.dtype == torch.float32:
                 h = R.upsample_bilinear_bias(conv_nb(head.conv1, x.contiguous(memory_format=CL)), size, head.conv1.bias)
-                return R.dpt_head_tail(conv_nb(head.conv2, h), head.conv2.bias, tail[0], tail[1], tail[2])
+                y = conv_nb(head.conv2, h)
+                if self._flop_count is not None:
+                    self._flop_count[0] += 2.0 * y.numel() / y.shape[0]   # the 1x1 convolution to one channel inside the tail kernel
+                return R.dpt_head_tail(y, head.conv2.bias, tail[0], tail[1], tail[2])
             h = up(head.conv1(x), size)
             h = head.conv3(head.activation1(head.conv2(h)))
             return (head.activation2(h) * head.max_depth).squeeze(dim=1)
@@ -459,7 +466,7 @@ class DepthPipe:
 
     def flops_per_frame(self, h: int, w: int) -> float:
         """Dense-GEMM flop estimate for MFMA accounting: 2*params_linear*tokens + 4*T^2*d per layer
-        for the backbone, measured conv flops for the DPT head via a counting hook."""
+        for the backbone, the EXECUTED convolution flops of the DPT neck / head counted during one forward."""
         th, tw = self.resize_target(h, w)
         bcfg = getattr(self.model.config, "backbone_config", None) or self.model.config
         ps = int(bcfg.patch_size)
@@ -475,9 +482,15 @@ class DepthPipe:
                 total[0] += 2.0 * out.numel() / out.shape[0] * (mod.in_channels // mod.groups) * k
 
         hs = [m.register_forward_hook(hook) for m in self.model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
-        with torch.no_grad():
-            x = torch.zeros(1, 3, th, tw, device=self.device, dtype=self.dtype)
-            self.model(pixel_values=x)
-        for hnd in hs:
-            hnd.remove()
+        self._flop_count = total   # the bias-free convolution calls of the rewritten neck / head count themselves (EXECUTED flops: the
+        try:                       # fusion layers' projections run before their up-samplings, at a quarter of the pixels)
+            with torch.no_grad():
+                x = torch.zeros(1, 3, th, tw, device=self.device, dtype=self.dtype)
+                if self.device.type == "cuda":
+                    x = x.contiguous(memory_format=torch.channels_last)
+                self.model(pixel_values=x)
+        finally:
+            self._flop_count = None
+            for hnd in hs:
+                hnd.remove()
         return backbone + total[0]
