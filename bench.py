@@ -45,9 +45,12 @@ WORKLOADS = {
     "4k-dibr-dof3": (2160, 3840, None, "4K DIBR only with dof_strength 3.0 (13-tap Gaussian: beyond the fused finishing kernel's 9 taps, the unfused "
                      "DOF + sharpen / mux kernels run)"),
     "4k-dibr-anaglyph": (2160, 3840, None, "4K DIBR only, Red-Cyan Anaglyph output (fused finishing kernel since round 4)"),
+    "4k-dibr-vr": (2160, 3840, None, "4K DIBR only, VR output (1440x1600 canvas per eye: a fractional 8/3 INTER_AREA fit + letterbox, which the fused "
+                   "finishing kernel does not take: the unfused DOF + sharpen / fit / mux kernels run)"),
 }
 # render keyword overrides of the variants above (everything else: RENDER_KW)
-WORKLOAD_KW = {"4k-dibr-dof3": dict(dof_strength=3.0), "4k-dibr-anaglyph": dict(output_format="Red-Cyan Anaglyph")}
+WORKLOAD_KW = {"4k-dibr-dof3": dict(dof_strength=3.0), "4k-dibr-anaglyph": dict(output_format="Red-Cyan Anaglyph"),
+               "4k-dibr-vr": dict(output_format="VR")}
 HEADLINE = "4k-dav2b-dibr"
 RENDER_KW = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
                  feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)  # render_cli.py:24-33
@@ -710,12 +713,19 @@ def main():
         rdn = run_workload(env, args, "4k-dibr-sepdof", 4, 2, profile=prof, isolated_pass=False)
         rd3 = run_workload(env, args, "4k-dibr-dof3", 4, 2, profile=prof, isolated_pass=False)
         ran = run_workload(env, args, "4k-dibr-anaglyph", 4, 2, profile=prof, isolated_pass=False)
+        try:
+            rvr = run_workload(env, args, "4k-dibr-vr", 4, 2, profile=prof, isolated_pass=False)
+        except Exception as e:   # a sub-record must never take the headline down
+            rvr = None
+            print(f"[bench] 4k-dibr-vr failed: {str(e)[:200]}", file=sys.stderr)
         rhi = run_workload(env, args, "4k-dibr", 6, 2, profile=False, isolated_pass=False, host_io=True)   # host-I/O-included figure
         rhi["workload"] = "4k-dibr-hostio"
         rhi["desc"] = ("4K DIBR only with the frames starting in pinned host memory and the muxed frames copied back to pinned host memory "
                        "(frame_io.PinnedRing, three slots: H2D, render and D2H of consecutive steps overlap): the PCIe-inclusive rate, never `value`")
         subs = {"4k-dibr": (r4, None), "1080p-dav2s-dibr": (r1e, None), "1080p-dibr": (r1d, None), "4k-dav2b-dibr-bf16": (rbf, None),
                 "4k-dibr-sepdof": (rdn, None), "4k-dibr-dof3": (rd3, None), "4k-dibr-anaglyph": (ran, None), "4k-dibr-hostio": (rhi, None)}
+        if rvr is not None:
+            subs["4k-dibr-vr"] = (rvr, None)
         roof_src = r4
         try:
             up_rec = run_upscale_chain(env, args)
