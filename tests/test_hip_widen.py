@@ -109,6 +109,39 @@ def test_fractional_fit_finish_vs_oracle(R, oracle):
         assert np.array_equal(got, exp), (fmt, fw, fh, u8_diff_stats(got, exp))
 
 
+def test_fused_finish_in_front_of_any_fit_equals_the_unfused_kernels(R, oracle):
+    """Round 4: a fit the fused finishing kernel does not take (fractional / up-scaling INTER_AREA, the VR canvas) no longer sends the frame to
+    the unfused DOF + grade kernels: E1 runs 1:1 into a side-by-side scratch of sharpened eyes and k_sharp_mux does fit + mux only.  Both
+    routes (vd3d_debug_tune(3, 0) = the unfused one) must produce the oracle's bytes: every padding format, fractional / mixed / up-scaling
+    ratios, frame sizes with ragged tiles, the dense and the separable DOF order, DOF off, and a 13-tap strength that E1 refuses either way."""
+    from visiondepth3d_amd import _lib
+    L_ = _lib.lib()
+    rng = np.random.default_rng(23)
+    try:
+        for (H, W), fmt, (fw, fh), dof, dense in [((72, 128), "Full-SBS", (96, 60), 2.0, True), ((72, 128), "VR", (1440, 1600), 2.0, True),
+                                                   ((90, 160), "Passive Interlaced", (85, 50), 1.5, True), ((62, 100), "Red-Cyan Anaglyph", (51, 40), 2.0, False),
+                                                   ((72, 128), "Full-SBS", (200, 130), 0.0, True), ((270, 480), "Full-SBS", (333, 200), 2.0, True),
+                                                   ((72, 128), "Full-SBS", (96, 60), 3.0, True), ((62, 102), "Full-SBS", (60, 40), 2.0, True)]:
+            Le = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+            Re = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+            dn = rng.random((H, W)).astype(np.float32)
+            p = render_kwargs_to_params(W, H, output_format=fmt, output_height=H, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                        sharpness_factor=0.2, dof_strength=dof, dof_dense_conv=dense, preserve_original_aspect=True,
+                                        original_video_width=W, original_video_height=H)
+            p.fit_w, p.fit_h = fw, fh
+            p.out_w = 2 * fw if fmt in ("Full-SBS", "VR") else fw
+            p.out_h = fh
+            exp = oracle.finish_frame(Le, Re, dn, p, 0.4, 5, 2)
+            outs = []
+            for route in (1, 0):
+                assert L_.vd3d_debug_tune(3, route) == 0
+                outs.append(R.finish_frame(T(Le), T(Re), T(dn), p, 0.4, bar_width=5, bar_side=2).cpu().numpy())
+            assert np.array_equal(outs[0], exp), ("fused + fit", fmt, (H, W), (fw, fh), u8_diff_stats(outs[0], exp))
+            assert np.array_equal(outs[1], exp), ("unfused", fmt, (H, W), (fw, fh), u8_diff_stats(outs[1], exp))
+    finally:
+        L_.vd3d_debug_tune(3, 1)
+
+
 def test_vr_loop_bit_exact_and_golden(R, oracle):
     g = load_golden("widen.npz")
     sh, sw, n, kw, bands = golden_json(g, "cases_json")["vr_1080"]

@@ -51,6 +51,7 @@ struct vd3d_ctx {
   float *D = nullptr, *S = nullptr, *e2L = nullptr, *e2R = nullptr, *bL = nullptr, *bR = nullptr;
   float *E2 = nullptr;   // [H][W][2]: gradient mask of both eyes, k_e2w -> W1
   uint8_t *L = nullptr, *R = nullptr, *gL = nullptr, *gR = nullptr;
+  uint8_t* gLR = nullptr; size_t gLR_cap = 0;   // [H][2W][3] sharpened eyes side by side (E1 in front of a fit it does not take)
   uint32_t* mm = nullptr; int mm_cap = 0;
   uint32_t* rowflag = nullptr; int rowflag_cap = 0;   // k_autocrop: one flag per source row
   uint8_t* blank_eye = nullptr; size_t blank_cap = 0; // skip_blank_frames: the side-masked source frame (source size)
@@ -240,7 +241,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
   for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
@@ -551,6 +552,7 @@ static int check_fit(const vd3d_render_params* p) {
   return 0;
 }
 
+static int g_fused_fit = 1;   // vd3d_debug_tune(3, 0): the unfused DOF / grade kernels in front of every fit E1 does not take (A/B, tests)
 static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                       const vd3d_render_params* p, const vd_finish_consts& fc, float focal, int use_override, int bw, int bs,
                       uint8_t* out, const vd_dev_work* wk = nullptr) {
@@ -583,7 +585,23 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
     HIPCHK(hipGetLastError());
     return 0;
   }
-  { int rcx = pix_exclusive(c); if (rcx) return rcx; }   // gL / gR are shared by the context's pixel streams
+  { int rcx = pix_exclusive(c); if (rcx) return rcx; }   // gL / gR / gLR are shared by the context's pixel streams
+  // E1 refused the FIT only (a fractional or up-scaling INTER_AREA ratio, the VR canvas): it still runs -- 1:1 into a side-by-side scratch of
+  // sharpened eyes -- and the fit / mux kernel reads that instead of sharpening two graded planes itself (round 4; same bytes:
+  // tests/test_hip_widen.py runs both ways)
+  bool taps_ok = g_fused_fit != 0;
+  for (int l = 0; l < fc.nlev; ++l) if (fc.ksz[l] > 9 || fc.ksz[l] < 3) taps_ok = false;
+  if (taps_ok && (p->warp_w & 3) == 0) {
+    vd3d_render_params q = *p;
+    q.format = VD3D_FMT_HALF_SBS; q.fit_w = p->warp_w; q.fit_h = p->warp_h; q.out_w = 2 * p->warp_w; q.out_h = p->warp_h;
+    const size_t need = (size_t)6 * p->warp_w * p->warp_h;
+    if (c->gLR_cap < need) { HIPCHK(hipDeviceSynchronize()); HIPCHK(re_alloc(&c->gLR, need)); c->gLR_cap = need; }
+    if (vd_launch_finish_fused(c->stream, L, R, dn, eh, ew, q, fc, wk, focal, use_override, bw, bs, c->gLR, dense, d_w2)) {
+      vd_launch_sharp_mux(c->stream, c->gLR, c->gLR + (size_t)3 * p->warp_w, *p, fc, out, 2 * p->warp_w);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
+  }
   vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense);
   vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense);
   vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
@@ -1429,6 +1447,7 @@ VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
   if (which == 0) vd_set_batch_grid_div(value);
   else if (which == 1) g_chain_group = value;
   else if (which == 2) vd_set_warp_pre_th(value);
+  else if (which == 3) g_fused_fit = value;
   else return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
   return 0;
 }

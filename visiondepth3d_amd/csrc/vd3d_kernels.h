@@ -157,8 +157,9 @@ void vd_set_warp_pre_th(int th);
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
                          int bar_width, int bar_side, uint8_t* eye_out, int dense = 0);
+// presharp_pitch > 0: gL / gR hold sharpened eyes already (row pitch in pixels): fit + mux only
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
-                         const vd_finish_consts& fc, uint8_t* out);
+                         const vd_finish_consts& fc, uint8_t* out, int presharp_pitch = 0);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
 void vd_launch_torch_math(hipStream_t s, int op, const float* x, float p, float* out, long long n);
 void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const vd_dev_work* wk, uint8_t* dst);

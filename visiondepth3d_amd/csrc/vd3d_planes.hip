@@ -470,7 +470,10 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
 // ------------------------------------------------------------------------------------------------
 // sharpen (filter2D 3x3) + fit (integer-ratio INTER_AREA / pad) + mux
 // ------------------------------------------------------------------------------------------------
-VD_DEV uint8_t sharp_at(const uint8_t* __restrict__ g, int H, int W, int y, int x, int c, float kn, float kc) {
+// pre > 0: g already holds SHARPENED pixels with a row pitch of `pre` pixels (the fused finishing kernel ran 1:1 into a side-by-side scratch,
+// round 4): the fit / mux below is all that is left to do
+VD_DEV uint8_t sharp_at(const uint8_t* __restrict__ g, int H, int W, int pre, int y, int x, int c, float kn, float kc) {
+  if (pre > 0) return g[((size_t)y * pre + x) * 3 + c];
   const int yu = vd_reflect(y - 1, H), yd = vd_reflect(y + 1, H), xl = vd_reflect(x - 1, W), xr = vd_reflect(x + 1, W);
   float s = 0.f;
   s += kn * (float)g[((size_t)yu * W + x) * 3 + c];
@@ -488,6 +491,7 @@ struct vd_mux_geom {
   int fx, fy;          // integer down-scale factors
   int out_w, out_h, format;
   int frac;            // 1: non-integer (or mixed) INTER_AREA down-scale, generic area table path; 2: some dimension up-scales
+  int pre;             // > 0: the inputs are sharpened already, row pitch in pixels (see sharp_at)
   double sx, sy;       // OpenCV's scale = 1./((double)dsize/ssize)
 };
 __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, vd_mux_geom m,
@@ -509,8 +513,8 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
         vd_area_lin_coef(m.W, m.in_w, ix, &xi, &xa0, &xa1);
         vd_area_lin_coef(m.H, m.in_h, iy, &yi, &yb0, &yb1);
         const int x1 = xi + 1 < m.W ? xi + 1 : m.W - 1, y1 = yi + 1 < m.H ? yi + 1 : m.H - 1;
-        const int r0 = (int)sharp_at(g, m.H, m.W, yi, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, yi, x1, c, kn, kc) * xa1;
-        const int r1 = (int)sharp_at(g, m.H, m.W, y1, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, y1, x1, c, kn, kc) * xa1;
+        const int r0 = (int)sharp_at(g, m.H, m.W, m.pre, yi, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, m.pre, yi, x1, c, kn, kc) * xa1;
+        const int r1 = (int)sharp_at(g, m.H, m.W, m.pre, y1, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, m.pre, y1, x1, c, kn, kc) * xa1;
         const int q = (((yb0 * (r0 >> 4)) >> 16) + ((yb1 * (r1 >> 4)) >> 16) + 2) >> 2;
         v = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
       } else if (inside && m.frac) {  // ResizeArea_<uchar,float>: per source row sum_k S*alpha (float32), then sum_j row*beta
@@ -520,16 +524,16 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
         float acc = 0.f;
         for (int j = 0; j < ny; ++j) {
           float h = 0.f;
-          for (int k = 0; k < nx; ++k) h = h + (float)sharp_at(g, m.H, m.W, y0s + j, x0s + k, c, kn, kc) * ax[k];
+          for (int k = 0; k < nx; ++k) h = h + (float)sharp_at(g, m.H, m.W, m.pre, y0s + j, x0s + k, c, kn, kc) * ax[k];
           acc = acc + h * ay[j];
         }
         v = vd_sat_rne_u8(acc);
       } else if (inside) {
-        if (m.fx == 1 && m.fy == 1) v = sharp_at(g, m.H, m.W, iy, ix, c, kn, kc);
+        if (m.fx == 1 && m.fy == 1) v = sharp_at(g, m.H, m.W, m.pre, iy, ix, c, kn, kc);
         else {
           int sum = 0;
           for (int j = 0; j < m.fy; ++j)
-            for (int i = 0; i < m.fx; ++i) sum += sharp_at(g, m.H, m.W, iy * m.fy + j, ix * m.fx + i, c, kn, kc);
+            for (int i = 0; i < m.fx; ++i) sum += sharp_at(g, m.H, m.W, m.pre, iy * m.fy + j, ix * m.fx + i, c, kn, kc);
           if (m.fx == 2 && m.fy == 2) v = (uint8_t)((sum + 2) >> 2);
           else v = vd_sat_rne_u8((float)sum * (1.f / (float)(m.fx * m.fy)));
         }
@@ -559,8 +563,9 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
   }
 }
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
-                         const vd_finish_consts& fc, uint8_t* out) {
+                         const vd_finish_consts& fc, uint8_t* out, int presharp_pitch) {
   vd_mux_geom m;
+  m.pre = presharp_pitch;
   m.H = p.warp_h; m.W = p.warp_w; m.fit_w = p.fit_w; m.fit_h = p.fit_h;
   m.out_w = p.out_w; m.out_h = p.out_h; m.format = p.format;
   if (p.format == VD3D_FMT_HALF_SBS) {  // cv2.resize straight to (per_eye_w, per_eye_h) :1413
