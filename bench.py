@@ -258,7 +258,8 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     if model_name:
         from visiondepth3d_amd.depth import DepthPipe
         # fused front end + fused backbone / neck glue; library selection: committed GEMM table + MIOpen find mode (runs during the warm-up)
-        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh, miopen_find=not args.no_miopen_find)
+        # (find mode only where the number is a parity-mode one: the bf16 sub-record keeps MIOpen's immediate mode and its shorter start)
+        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh, miopen_find=(not args.no_miopen_find) and depth_dtype == "f32")
 
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
@@ -389,7 +390,7 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
     r = Renderer(env.local_rank)
     r.new_clip()
-    pipe = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.float32, renderer=r)
+    pipe = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.float32, renderer=r, miopen_find=False)   # the chain is the up-scale net's: no find pass
     up = Upscaler(r, "RealESR_Gx4_fp16")
     frames_np, _ = synth.synth_clip(B, sh, sw, start=0)
     frames = torch.stack([torch.from_numpy(f) for f in frames_np]).cuda()

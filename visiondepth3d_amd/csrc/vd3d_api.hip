@@ -552,7 +552,7 @@ static int check_fit(const vd3d_render_params* p) {
   return 0;
 }
 
-static int g_fused_fit = 1;   // vd3d_debug_tune(3, 0): the unfused DOF / grade kernels in front of every fit E1 does not take (A/B, tests)
+static int g_fused_fit = getenv("VD3D_FUSED_FIT") ? atoi(getenv("VD3D_FUSED_FIT")) : 1;   // VD3D_FUSED_FIT=0 / vd3d_debug_tune(3, 0): the unfused DOF / grade kernels in front of every fit E1 does not take (A/B, tests)
 static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                       const vd3d_render_params* p, const vd_finish_consts& fc, float focal, int use_override, int bw, int bs,
                       uint8_t* out, const vd_dev_work* wk = nullptr) {

@@ -124,7 +124,7 @@ class DepthPipe:
 
     def __init__(self, name: str = "depth-anything-v2-small", device="cuda", dtype=torch.float32, seed: int = 0,
                  channels_last: bool = True, renderer=None, fuse_backbone: bool = True, model=None, processor: dict | None = None,
-                 tuned_gemm: bool = True, miopen_find: bool = False):
+                 tuned_gemm: bool = True, miopen_find: bool | None = None):
         """``dtype``: float32 (the reference's precision, default) or bfloat16.
         ``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream); when given the
         image-processor front end, the residual-add + LayerNorm pairs and the DPT up-samplings run as fused HIP launches.
@@ -134,7 +134,8 @@ class DepthPipe:
         table ``tuned/gemm_gfx950.csv`` (PyTorch TunableOp, tuning OFF: a look-up per GEMM shape; written by tools/probe_net_tune.py on an
         MI355X; ignored when its library-version validators do not match; ``VD3D_TUNED_GEMM=0`` disables).  ``miopen_find``: MIOpen
         find mode (``torch.backends.cudnn.benchmark``) -- every convolution shape times its applicable solvers once, ~25 s at the
-        first forward of a process, 4.5 % on the 4K float32 forward (profiles/r04_net_library_selection.md); opt-in, bench.py uses it."""
+        first forward of a process, 4.5 % on the 4K float32 forward (profiles/r04_net_library_selection.md); opt-in, bench.py uses it.
+        The flag is PyTorch's process-wide one: True / False set it, None (default) leaves it as the caller has it."""
         self.name, self.device, self.dtype = name, torch.device(device), dtype
         self.tuned_gemm = self.miopen_find = False
         self._flop_count = None
@@ -168,10 +169,10 @@ class DepthPipe:
             if self.renderer is not None:
                 self._patch_dpt_upsampling()
 
-    def _library_selection(self, tuned_gemm: bool, miopen_find: bool):
-        if miopen_find:
-            torch.backends.cudnn.benchmark = True
-            self.miopen_find = True
+    def _library_selection(self, tuned_gemm: bool, miopen_find):
+        if miopen_find is not None:
+            torch.backends.cudnn.benchmark = bool(miopen_find)
+        self.miopen_find = bool(torch.backends.cudnn.benchmark)
         table = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
         if not tuned_gemm or os.environ.get("VD3D_TUNED_GEMM", "1") == "0" or not os.path.exists(table):
             return
