@@ -6,15 +6,13 @@ export TMPDIR=/tmp
 O=gpurun_out/final; mkdir -p $O
 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.log
-/usr/bin/time -v python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_default.json
-grep -E "Elapsed" $O/bench_default.err
+T0=$(date +%s); python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_default.json; echo "bench.py wall: $(( $(date +%s) - T0 )) s"
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/final/bench_default.json"))
 print("default:", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("isolated_frac"), d["cpu_baseline"]["value"])
-for s in d.get("sub_records", []):
-    if isinstance(s, dict):
-        print("  ", s.get("workload") or s.get("config", {}).get("workload"), s.get("value"), s.get("error"))
+for k, s in d.get("sub_records", {}).items():
+    print("  ", k, s.get("value"), s.get("error"))
 PY
 for f in 1 0; do
   VD3D_FUSED_FIT=$f python bench.py --workload 4k-dibr-vr --steps 4 --warmup 2 --no-cpu-baseline --no-pixel-overlap 2>/dev/null | tail -1 > $O/vr_fused$f.json
