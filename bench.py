@@ -574,34 +574,46 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
     out = {}
     N, st, iso = res["N"], res["stage_ms"], res["iso_ms"]
     pm = _pmc(pmc_workload or res["workload"]) or {}
-    w1_ms = st.get("w1", -1)
+    # Which duration prices a kernel.  Since round 4 the DIBR step runs on three streams (select chain + two pixel streams): inside the timed
+    # region a launch of W1 / E1 shares the CUs with other kernels, so its HIP-event duration grows with the concurrency while the frame rate
+    # RISES -- it is no longer the kernel's cost.  `frac` / `achieved` / `avg_launch_ms` therefore come from the SEQUENTIAL pass over the same
+    # frames that follows the timed region (HIP events, one kernel on the GPU at a time: what `rocprofv3 --kernel-trace --stats` of
+    # `bench.py --workload 4k-dibr --no-pixel-overlap` reports, profiles/rNN_4k_dibr_kernel_stats.md); the in-step durations stay next to them.
+    def pick(key):
+        seq, instep = iso.get(key, -1) or -1, st.get(key, -1)
+        return (seq, instep, "sequential pass after the timed region") if seq > 0 else (instep, instep, "inside the timed region (no sequential pass in this run)")
+    w1_ms, w1_instep, w1_src = pick("w1")
     if w1_ms > 0:
         alg = 13 * N  # W1 = read RGB 3N + read depth 4N + write two u8 eyes 6N per stereo pair
         ach = alg / (w1_ms * 1e-3) / 1e9
+        e2w_ms = (iso.get("e2w") if w1_src.startswith("sequential") else st.get("e2w")) or -1
         w1 = pm.get("k_warp_fused", pm if "corrected_bytes_per_launch" in pm else {})
         lane = w1.get("valu_lane_instr_per_launch")
         rf = {"bound": "valu" if lane else "hbm", "kernel": "W1 = k_e2w (warped-depth gradient mask of both eyes) + k_warp_fused (window sums + warp + "
                                                            "blend): the same work as round 3's single launch, two launches since round 4",
-              "k_e2w_avg_launch_ms": st.get("e2w"), "k_warp_fused_avg_launch_ms": (round(w1_ms - st["e2w"], 5) if st.get("e2w", -1) > 0 else None),
+              "k_e2w_avg_launch_ms": (e2w_ms if e2w_ms > 0 else None), "k_warp_fused_avg_launch_ms": (round(w1_ms - e2w_ms, 5) if e2w_ms > 0 else None),
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
               "traffic": w1.get("corrected_bytes_per_launch"), "traffic_source": w1.get("source"),
               "traffic_taken_at_commit": (_pmc("commit") or None),
-              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": w1_ms,
-              "isolated_avg_launch_ms": iso.get("w1"),
-              "isolated_frac": round(alg / (iso["w1"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso.get("w1", 0) > 0 else None,
+              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": w1_ms, "avg_launch_measured": w1_src,
+              "in_step_avg_launch_ms": w1_instep if w1_instep > 0 else None,
+              "in_step_frac": round(alg / (w1_instep * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if w1_instep > 0 else None,
               "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
               "note": "frac prices SURVEY 8(d)'s 13 N algorithmic bytes against the 8 TB/s HBM spec (north_star's yardstick); the kernel is "
                       "VALU-issue-bound, not HBM-bound (the reference's nested-bilinear arithmetic is kept bit-exact): `valu` prices the "
-                      "PMC-counted VALU lane-instructions of one launch against the chip's MEASURED v_fma_f32 issue rate (50.2 T lane-ops/s). avg_launch_ms = HIP events "
-                      "inside the timed region (the kernel shares the CUs with the overlapped streams); isolated_* = the same kernel in a "
-                      "sequential DIBR-only pass after the timed region"}
+                      "PMC-counted VALU lane-instructions of one launch against the chip's MEASURED v_fma_f32 issue rate (50.2 T lane-ops/s) and the data sheet's. "
+                      "avg_launch_ms / achieved / frac: HIP events of the sequential pass over the same frames that follows the timed region (one kernel on "
+                      "the GPU at a time: the kernel's cost, what rocprofv3 --kernel-trace of the --no-pixel-overlap run reports); in_step_*: HIP events "
+                      "inside the timed region, where the launch shares the CUs with the chain and the other pixel stream (grows with the concurrency "
+                      "while the frame rate rises). traffic is that of BOTH launches: the E2 plane's round trip (8 N written, 8 N + halo read) is the "
+                      "price of taking the dependent depth gathers out of W1's tile"}
         if lane:
-            t = (iso.get("w1") or w1_ms) * 1e-3
+            t = w1_ms * 1e-3
             rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "measured_v_fma_rate_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                          "spec_lane_ops_per_s": VALU_SPEC_LANE_OPS, "frac_of_measured_rate_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4),
-                          "frac_of_spec_rate_isolated": round(lane / t / VALU_SPEC_LANE_OPS, 4), "source": w1.get("source")}
+                          "spec_lane_ops_per_s": VALU_SPEC_LANE_OPS, "frac_of_measured_rate": round(lane / t / VALU_PEAK_LANE_OPS, 4),
+                          "frac_of_spec_rate": round(lane / t / VALU_SPEC_LANE_OPS, 4), "source": w1.get("source")}
         out["roofline"] = rf
-    fin_ms = st.get("finish", -1)
+    fin_ms, fin_instep, fin_src = pick("finish")
     if fin_ms > 0:  # E1: 6N eyes in + N eye-res depth + 3N Half-SBS out
         alg = 10 * N
         ach = alg / (fin_ms * 1e-3) / 1e9
@@ -610,13 +622,13 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
         rf = {"bound": "valu" if lane else "hbm", "kernel": "k_finish_fused (E1: DOF + grade + sharpen + fit + mux, both eyes)",
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
               "traffic": e1.get("corrected_bytes_per_launch"), "algorithmic_bytes_per_launch": alg, "avg_launch_ms": fin_ms,
-              "isolated_avg_launch_ms": iso.get("finish"),
-              "isolated_frac": round(alg / (iso["finish"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso.get("finish", 0) > 0 else None}
+              "avg_launch_measured": fin_src, "in_step_avg_launch_ms": fin_instep if fin_instep > 0 else None,
+              "in_step_frac": round(alg / (fin_instep * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if fin_instep > 0 else None}
         if lane:   # E1 against BOTH bounds (HBM above, fp32 ALU here)
-            t = (iso.get("finish") or fin_ms) * 1e-3
+            t = fin_ms * 1e-3
             rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "measured_v_fma_rate_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                          "spec_lane_ops_per_s": VALU_SPEC_LANE_OPS, "frac_of_measured_rate_isolated": round(lane / t / VALU_PEAK_LANE_OPS, 4),
-                          "frac_of_spec_rate_isolated": round(lane / t / VALU_SPEC_LANE_OPS, 4), "source": e1.get("source")}
+                          "spec_lane_ops_per_s": VALU_SPEC_LANE_OPS, "frac_of_measured_rate": round(lane / t / VALU_PEAK_LANE_OPS, 4),
+                          "frac_of_spec_rate": round(lane / t / VALU_SPEC_LANE_OPS, 4), "source": e1.get("source")}
         out["roofline_e1"] = rf
     fr_ms, note = st.get("frame", -1), "sequential frame: K1-K6, k_shift, W1, E1"
     if fr_ms <= 0 and all(st.get(k, -1) > 0 for k in ("p1_own", "p3_own", "warp", "finish")):

@@ -10,7 +10,7 @@ T0=$(date +%s); python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_defa
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/final/bench_default.json"))
-print("default:", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("isolated_frac"), d["cpu_baseline"]["value"])
+print("default:", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("in_step_frac"), d["cpu_baseline"]["value"])
 for k, s in d.get("sub_records", {}).items():
     print("  ", k, s.get("value"), s.get("error"))
 PY

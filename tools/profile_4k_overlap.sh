@@ -7,4 +7,4 @@ python tools/rocpd_summary.py $DB > $O/v_4k_kernel_stats.md
 rm -f $DB
 python bench.py --workload 4k-dibr --no-cpu-baseline 2>/dev/null | tail -1 > $O/v_bench_4k-dibr.json
 python -c "
-import json; d=json.load(open('$O/v_bench_4k-dibr.json')); rf=d['roofline']; print(d['value'], rf['frac'], rf.get('isolated_frac'), rf.get('avg_launch_ms'), rf.get('isolated_avg_launch_ms'), d['stage_ms'])"
+import json; d=json.load(open('$O/v_bench_4k-dibr.json')); rf=d['roofline']; print(d['value'], rf['frac'], rf.get("in_step_frac"), rf.get('avg_launch_ms'), rf.get("in_step_avg_launch_ms"), d['stage_ms'])"
