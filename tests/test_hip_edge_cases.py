@@ -139,9 +139,10 @@ def test_finish_frame_padded_canvas_and_unsupported_ratio(R, oracle):
         assert np.array_equal(got, oracle.finish_frame(L_, R_, dn, p, 0.5, 0, 0)), (fw, fh)
 
 
-@pytest.mark.parametrize("dof", [0.0, 0.7, 1.0, 2.0, 3.3, 5.0])
+@pytest.mark.parametrize("dof", [0.0, 0.7, 1.0, 2.0, 3.3, 5.0, 6.5, 7.5])
 def test_dof_strengths(R, oracle, dof):
-    """dof 0 (grade only), radii inside the fused fast path (<= 2.0) and beyond it (falls back to the generic kernel)."""
+    """dof 0 (grade only), radii inside the fused fast path (<= 2.0) and beyond it: the unfused dense kernel with its tap count as a
+    template parameter up to 21 taps (5.0, the GUI slider's maximum) and its run-time loop for 23 .. 31 taps (6.5: 27, 7.5: 31)."""
     _loop_eq(R, oracle, 54, 96, 2, dict(BASE, output_format="Half-SBS", output_height=54, dof_strength=dof,
                                         color_saturation=1.2, color_contrast=1.1, color_brightness=0.03))
 

@@ -91,6 +91,9 @@ struct vd3d_ctx {
   // parameter set gets its own 1.3 KB device table, filled before anything can read it
   struct w2_tab { float host[4][81]; float* dev; };
   std::vector<w2_tab> w2_tabs; int w2_cur = -1;
+  // ... and the general table of the unfused dense kernel (k_dof_grade4: any odd tap count up to 31), same never-overwrite rule
+  struct wk_tab { int ksz[4]; float kern[4][32]; float* dev; };
+  std::vector<wk_tab> wk_tabs; int wk_cur = -1;
   // profiling
   bool profiling = false;
   std::vector<vd_prof_rec> recs;
@@ -243,6 +246,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
   for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
+  for (auto& t : c->wk_tabs) (void)hipFree(t.dev);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto* v : {&c->slot_rgb, &c->slot_dn, &c->slot_D, &c->slot_tdf, &c->slot_tdfp})
     for (float* q : *v) (void)hipFree(q);
@@ -602,8 +606,34 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
       return 0;
     }
   }
-  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense);
-  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense);
+  const float* d_wk = nullptr;
+  if (dense) {   // k_dof_grade4's weights: [level][row][32] device table, looked up / built like d_w2 above
+    auto same = [&](const vd3d_ctx::wk_tab& t) { return memcmp(t.ksz, fc.ksz, sizeof fc.ksz) == 0 && memcmp(t.kern, fc.kern, sizeof fc.kern) == 0; };
+    if (c->wk_cur < 0 || !same(c->wk_tabs[c->wk_cur])) {
+      c->wk_cur = -1;
+      for (size_t i = 0; i < c->wk_tabs.size(); ++i) if (same(c->wk_tabs[i])) c->wk_cur = (int)i;
+      if (c->wk_cur < 0) {
+        if (c->wk_tabs.size() >= 64) {
+          HIPCHK(hipDeviceSynchronize());
+          for (auto& t : c->wk_tabs) (void)hipFree(t.dev);
+          c->wk_tabs.clear();
+        }
+        vd3d_ctx::wk_tab t;
+        memcpy(t.ksz, fc.ksz, sizeof fc.ksz); memcpy(t.kern, fc.kern, sizeof fc.kern);
+        std::vector<float> host(VD_D4_WTAB_FLOATS, 0.f);
+        for (int l = 0; l < fc.nlev; ++l)
+          for (int i = 0; i < fc.ksz[l]; ++i)
+            for (int j = 0; j < fc.ksz[l]; ++j) host[((size_t)l * 31 + i) * 32 + j] = fc.kern[l][i] * fc.kern[l][j];   // float32 product, as torchvision's outer product holds it
+        HIPCHK(hipMalloc((void**)&t.dev, sizeof(float) * VD_D4_WTAB_FLOATS));
+        HIPCHK(hipMemcpy(t.dev, host.data(), sizeof(float) * VD_D4_WTAB_FLOATS, hipMemcpyHostToDevice));   // a fresh buffer: nothing queued reads it yet
+        c->wk_tabs.push_back(t);
+        c->wk_cur = (int)c->wk_tabs.size() - 1;
+      }
+    }
+    d_wk = c->wk_tabs[c->wk_cur].dev;
+  }
+  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense, d_wk);
+  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense, d_wk);
   vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
   HIPCHK(hipGetLastError());
   return 0;

@@ -156,7 +156,8 @@ void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, 
 void vd_set_warp_pre_th(int th);
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
-                         int bar_width, int bar_side, uint8_t* eye_out, int dense = 0);
+                         int bar_width, int bar_side, uint8_t* eye_out, int dense = 0, const float* dense_wtab = nullptr);
+#define VD_D4_WTAB_FLOATS (4 * 31 * 32)   // dense weight table of k_dof_grade4: [level 4][row 31][pitch 32] = fl(k1[i] * k1[j])
 // presharp_pitch > 0: gL / gR hold sharpened eyes already (row pitch in pixels): fit + mux only
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
                          const vd_finish_consts& fc, uint8_t* out, int presharp_pitch = 0);

@@ -326,29 +326,79 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
 // reads; zero weights pad the row ends: fma(v, 0, acc) is exact here -- acc never is -0): 2 LDS reads per 4 FMAs instead of 2 per FMA (one pixel
 // per thread until round 3: 1 387 us per 4K frame pair at dof_strength 3.0 against the fused kernel's 252 at 2.0).  Each output's taps still
 // arrive in ascending (i, j) order: same bits.
+// Round 4 (second pass): the tap count is a template parameter (one instantiation per odd K <= 31) and the weights come from a device table
+// (vd3d_ctx::wk_tabs: [level][row i][32] = fl(k1[i] * k1[j]), row pitch 32 floats) through wave-uniform loads, i.e. as SCALAR operands of the
+// FMAs: the window of K + 3 columns sits in registers, the sliding weights are register names, the zero-weight products at the row ends are
+// not issued (exact: see above) -- 4 K FMAs per tap row and channel next to (K + 3) / 2 ds_read2 and K / 4 scalar loads, where the run-time
+// loop spent 12 instructions per 4 FMAs (two LDS reads, three weight moves, loop control).
 #define D4_TW 64
 #define D4_TH 32
+#define D4_WP 32                    // row pitch of the weight table
+#define D4_WL (31 * D4_WP)          // floats per level
+// level `level` arrives: it replaces the running value of the pixels whose lo level it is, and is blended in where it is lo + 1 (:822-834)
+VD_DEV void d4_fold(float a0, float a1, float a2, float a3, int level, const int lo[4], const float alpha[4], float* res) {
+  const float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (level == lo[q]) res[q] = acc[q];
+    if (level == lo[q] + 1) res[q] = (1.0f - alpha[q]) * res[q] + alpha[q] * acc[q];
+  }
+}
+template <int K>
+VD_DEV void d4_level(const float* __restrict__ tile, int th, int twp, int ty, int tx, int R, const float* __restrict__ wl, int level, const int lo[4],
+                     const float alpha[4], float res[3][4]) {
+  constexpr int r = K / 2;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+      const float* t0 = tile + (size_t)(c * th + ty + R - r + i) * twp + tx + R - r;   // window column 0 = tap 0 of pixel 0
+      const float* wr = wl + i * D4_WP;                                                // wave-uniform: scalar loads
+      float v[K + 3], wv[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) wv[j] = wr[j];
+#pragma unroll
+      for (int jj = 0; jj < K + 3; ++jj) v[jj] = t0[jj];
+#pragma unroll
+      for (int jj = 0; jj < K + 3; ++jj) {   // window column jj: tap jj of pixel 0, jj - 1 of pixel 1, ... (each output's taps in ascending order)
+        if (jj < K) a0 = vd_fma(v[jj], wv[jj], a0);
+        if (jj >= 1 && jj - 1 < K) a1 = vd_fma(v[jj], wv[jj - 1], a1);
+        if (jj >= 2 && jj - 2 < K) a2 = vd_fma(v[jj], wv[jj - 2], a2);
+        if (jj >= 3 && jj - 3 < K) a3 = vd_fma(v[jj], wv[jj - 3], a3);
+      }
+    }
+    d4_fold(a0, a1, a2, a3, level, lo, alpha, res[c]);
+  }
+}
+// any tap count (run-time loops; the instantiations above cover the GUI's range, this one keeps the register budget of the kernel theirs)
+VD_DEV void d4_level_any(int k, const float* __restrict__ tile, int th, int twp, int ty, int tx, int R, const float* __restrict__ wl, int level,
+                         const int lo[4], const float alpha[4], float res[3][4]) {
+  const int r = k / 2;
+  for (int c = 0; c < 3; ++c) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = 0; i < k; ++i) {
+      const float* t0 = tile + (size_t)(c * th + ty + R - r + i) * twp + tx + R - r;
+      const float* wr = wl + i * D4_WP;
+      float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+      for (int jj = 0; jj < k + 3; ++jj) {   // sliding window of four weights; the zero products at the row ends are exact (acc never is -0)
+        const float v = t0[jj], w0 = jj < k ? wr[jj] : 0.f;
+        a0 = vd_fma(v, w0, a0); a1 = vd_fma(v, w1, a1); a2 = vd_fma(v, w2, a2); a3 = vd_fma(v, w3, a3);
+        w3 = w2; w2 = w1; w1 = w0;
+      }
+    }
+    d4_fold(a0, a1, a2, a3, level, lo, alpha, res[c]);
+  }
+}
 __global__ __launch_bounds__(512) void k_dof_grade4(const uint8_t* __restrict__ eye_in, const float* __restrict__ dn, int eh, int ew,
                                                     int H, int W, vd_finish_consts fc, const vd_dev_work* __restrict__ w,
                                                     float focal_override, int use_override, int bar_width_o, int bar_side_o,
-                                                    uint8_t* __restrict__ eye_out, int twp) {
+                                                    uint8_t* __restrict__ eye_out, int twp, const float* __restrict__ wtab) {
   extern __shared__ float lds[];
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   const int tw = D4_TW + 2 * R, th = D4_TH + 2 * R;
   float* tile = lds;                          // [3][th][twp], twp = 1 mod 4: the four rows of a wave's lanes fall into distinct banks
-  float* wk = lds + (size_t)3 * th * twp;     // per level: k rows of (3 zeros, k weights, 3 zeros)
   const int x0 = blockIdx.x * D4_TW, y0 = blockIdx.y * D4_TH;
-  {
-    int off = 0;
-    for (int l = 0; l < fc.nlev; ++l) {
-      const int k = fc.ksz[l], kp = k + 6;
-      for (int t = threadIdx.x; t < k * kp; t += 512) {
-        const int i = t / kp, jj = t - i * kp - 3;
-        wk[off + t] = (jj >= 0 && jj < k) ? fc.kern[l][i] * fc.kern[l][jj] : 0.f;
-      }
-      off += k * kp;
-    }
-  }
   for (int t = threadIdx.x; t < th * tw; t += 512) {
     const int ty = t / tw, tx = t - ty * tw;
     const int y = vd_reflect(y0 - R + ty, H), x = vd_reflect(x0 - R + tx, W);
@@ -390,31 +440,15 @@ __global__ __launch_bounds__(512) void k_dof_grade4(const uint8_t* __restrict__ 
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int q = 0; q < 4; ++q) res[c][q] = tile[(c * th + ty + R) * twp + tx + R + q];
-  int off = 0;
   for (int l = 0; l < fc.nlev; ++l) {
-    const int k = fc.ksz[l], r = k / 2, kp = k + 6;
-    if ((need >> (l + 1)) & 1) {
-      for (int c = 0; c < 3; ++c) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int i = 0; i < k; ++i) {
-          const float* t0 = tile + (size_t)(c * th + ty + R - r + i) * twp + tx + R - r;   // window column 0 = tap 0 of pixel 0
-          const float* wr = wk + off + i * kp + 3;                                        // wr[j] = weight (i, j); wr[-3 .. -1] = wr[k .. k + 2] = 0
-          float w1 = 0.f, w2 = 0.f, w3 = 0.f;
-          for (int jj = 0; jj < k + 3; ++jj) {   // window column jj: tap jj of pixel 0, jj - 1 of pixel 1, ...
-            const float v = t0[jj], w0 = wr[jj];
-            a0 = vd_fma(v, w0, a0); a1 = vd_fma(v, w1, a1); a2 = vd_fma(v, w2, a2); a3 = vd_fma(v, w3, a3);
-            w3 = w2; w2 = w1; w1 = w0;
-          }
-        }
-        const float acc[4] = {a0, a1, a2, a3};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (l + 1 == lo[q]) res[c][q] = acc[q];
-          if (l + 1 == lo[q] + 1) res[c][q] = (1.0f - alpha[q]) * res[c][q] + alpha[q] * acc[q];
-        }
-      }
+    if (!((need >> (l + 1)) & 1)) continue;
+    const float* wl = wtab + (size_t)l * D4_WL;
+    switch (fc.ksz[l]) {   // compile-time tap count per instantiation
+#define D4_CASE(K) case K: d4_level<K>(tile, th, twp, ty, tx, R, wl, l + 1, lo, alpha, res); break;
+      D4_CASE(3) D4_CASE(5) D4_CASE(7) D4_CASE(9) D4_CASE(11) D4_CASE(13) D4_CASE(15) D4_CASE(17) D4_CASE(19) D4_CASE(21)
+#undef D4_CASE
+      default: d4_level_any(fc.ksz[l], tile, th, twp, ty, tx, R, wl, l + 1, lo, alpha, res); break;   // 23 .. 31 taps (dof_strength > 5, beyond the GUI's slider)
     }
-    off += k * kp;
   }
   const int bar_w = use_override ? bar_width_o : w->bar_width, bar_s = use_override ? bar_side_o : w->bar_side;
 #pragma unroll
@@ -440,15 +474,13 @@ __global__ __launch_bounds__(512) void k_dof_grade4(const uint8_t* __restrict__ 
 }
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
-                         int bar_width, int bar_side, uint8_t* eye_out, int dense) {
+                         int bar_width, int bar_side, uint8_t* eye_out, int dense, const float* wtab) {
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   if (dense) {
     const int tw = D4_TW + 2 * R, th = D4_TH + 2 * R;
     int twp = tw;
     while ((twp & 3) != 1) ++twp;
-    size_t kw = 0;
-    for (int l = 0; l < fc.nlev; ++l) kw += (size_t)fc.ksz[l] * (fc.ksz[l] + 6);
-    const size_t lds = sizeof(float) * (3 * (size_t)th * twp + kw);
+    const size_t lds = sizeof(float) * 3 * (size_t)th * twp;
     static bool attr[64] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -457,7 +489,7 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
       attr[dev] = true;
     }
     hipLaunchKernelGGL(k_dof_grade4, dim3((W + D4_TW - 1) / D4_TW, (H + D4_TH - 1) / D4_TH), dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w,
-                       focal_override, use_override, bar_width, bar_side, eye_out, twp);
+                       focal_override, use_override, bar_width, bar_side, eye_out, twp, wtab);
     return;
   }
   const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
