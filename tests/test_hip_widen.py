@@ -121,7 +121,11 @@ def test_fused_finish_in_front_of_any_fit_equals_the_unfused_kernels(R, oracle):
         for (H, W), fmt, (fw, fh), dof, dense in [((72, 128), "Full-SBS", (96, 60), 2.0, True), ((72, 128), "VR", (1440, 1600), 2.0, True),
                                                    ((90, 160), "Passive Interlaced", (85, 50), 1.5, True), ((62, 100), "Red-Cyan Anaglyph", (51, 40), 2.0, False),
                                                    ((72, 128), "Full-SBS", (200, 130), 0.0, True), ((270, 480), "Full-SBS", (333, 200), 2.0, True),
-                                                   ((72, 128), "Full-SBS", (96, 60), 3.0, True), ((62, 102), "Full-SBS", (60, 40), 2.0, True)]:
+                                                   ((72, 128), "Full-SBS", (96, 60), 3.0, True), ((62, 102), "Full-SBS", (60, 40), 2.0, True),
+                                                   # integer fits behind a 13-tap DOF: k_sharp_fit (the fused kernel's epilogue on graded planes)
+                                                   ((90, 160), "Half-SBS", (80, 90), 3.0, True), ((90, 160), "Full-SBS", (160, 90), 3.0, True),
+                                                   ((90, 160), "Passive Interlaced", (160, 90), 3.0, True), ((90, 160), "Red-Cyan Anaglyph", (160, 90), 3.0, True),
+                                                   ((120, 256), "Full-SBS", (64, 30), 3.0, True), ((270, 480), "Half-SBS", (240, 270), 5.0, True)]:
             Le = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
             Re = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
             dn = rng.random((H, W)).astype(np.float32)
@@ -129,17 +133,17 @@ def test_fused_finish_in_front_of_any_fit_equals_the_unfused_kernels(R, oracle):
                                         sharpness_factor=0.2, dof_strength=dof, dof_dense_conv=dense, preserve_original_aspect=True,
                                         original_video_width=W, original_video_height=H)
             p.fit_w, p.fit_h = fw, fh
-            p.out_w = 2 * fw if fmt in ("Full-SBS", "VR") else fw
+            p.out_w = 2 * fw if fmt in ("Half-SBS", "Full-SBS", "VR") else fw
             p.out_h = fh
             exp = oracle.finish_frame(Le, Re, dn, p, 0.4, 5, 2)
             outs = []
-            for route in (1, 0):
+            for route in (3, 1, 0):   # bit 0: E1 in front of the fit; bit 1: k_sharp_fit (E1's epilogue) behind the unfused DOF kernels
                 assert L_.vd3d_debug_tune(3, route) == 0
                 outs.append(R.finish_frame(T(Le), T(Re), T(dn), p, 0.4, bar_width=5, bar_side=2).cpu().numpy())
-            assert np.array_equal(outs[0], exp), ("fused + fit", fmt, (H, W), (fw, fh), u8_diff_stats(outs[0], exp))
-            assert np.array_equal(outs[1], exp), ("unfused", fmt, (H, W), (fw, fh), u8_diff_stats(outs[1], exp))
+            for name, o in zip(("all routes", "fused + fit", "unfused"), outs):
+                assert np.array_equal(o, exp), (name, fmt, (H, W), (fw, fh), u8_diff_stats(o, exp))
     finally:
-        L_.vd3d_debug_tune(3, 1)
+        L_.vd3d_debug_tune(3, 3)
 
 
 def test_vr_loop_bit_exact_and_golden(R, oracle):

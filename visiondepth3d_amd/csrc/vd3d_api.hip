@@ -556,7 +556,7 @@ static int check_fit(const vd3d_render_params* p) {
   return 0;
 }
 
-static int g_fused_fit = getenv("VD3D_FUSED_FIT") ? atoi(getenv("VD3D_FUSED_FIT")) : 1;   // VD3D_FUSED_FIT=0 / vd3d_debug_tune(3, 0): the unfused DOF / grade kernels in front of every fit E1 does not take (A/B, tests)
+static int g_fused_fit = getenv("VD3D_FUSED_FIT") ? atoi(getenv("VD3D_FUSED_FIT")) : 3;   // bit 0: E1 in front of a fit it does not take; bit 1: k_sharp_fit behind k_dof_grade4.  VD3D_FUSED_FIT=0 / vd3d_debug_tune(3, 0): the unfused DOF / grade kernels in front of every fit E1 does not take (A/B, tests)
 static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                       const vd3d_render_params* p, const vd_finish_consts& fc, float focal, int use_override, int bw, int bs,
                       uint8_t* out, const vd_dev_work* wk = nullptr) {
@@ -593,7 +593,7 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
   // E1 refused the FIT only (a fractional or up-scaling INTER_AREA ratio, the VR canvas): it still runs -- 1:1 into a side-by-side scratch of
   // sharpened eyes -- and the fit / mux kernel reads that instead of sharpening two graded planes itself (round 4; same bytes:
   // tests/test_hip_widen.py runs both ways)
-  bool taps_ok = g_fused_fit != 0;
+  bool taps_ok = (g_fused_fit & 1) != 0;
   for (int l = 0; l < fc.nlev; ++l) if (fc.ksz[l] > 9 || fc.ksz[l] < 3) taps_ok = false;
   if (taps_ok && (p->warp_w & 3) == 0) {
     vd3d_render_params q = *p;
@@ -634,7 +634,8 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
   }
   vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense, d_wk);
   vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense, d_wk);
-  vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
+  // graded planes -> sharpen + fit + mux: the fused kernel's epilogue as a kernel of its own where its fit conditions hold, else the per-pixel one
+  if (!((g_fused_fit & 2) && vd_launch_sharp_fit(c->stream, c->gL, c->gR, *p, fc, out))) vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
   HIPCHK(hipGetLastError());
   return 0;
 }

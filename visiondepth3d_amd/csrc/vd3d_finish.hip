@@ -239,6 +239,116 @@ VD_DEV void ff_anaglyph_store(uint8_t* o, int eye, const int fv[3][4], int nvali
   }
 }
 
+// epilogue of the finishing kernels: 3x3 sharpen (:717-732) on the tile of graded dwords `gb` (row 0 = image row gy0, column 0 = image column gx0),
+// integer-ratio INTER_AREA (:1413), mux (SBS halves / interlaced rows / anaglyph bytes).  Called by k_finish_fused behind its grade phase and by
+// k_sharp_fit on planes that are graded already.
+template <int FF_TH, int FF_NT>
+VD_DEV void ff_epilogue(const uint32_t (*gb)[FF_GP], const vd_ff_args& a, const vd_finish_consts& fc, int eye, int x0, int y0, int gx0, int gy0,
+                        int tid, uint8_t* __restrict__ out) {
+  const int H = a.H, W = a.W;
+  // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux
+  const int ow = FF_TW / a.fx, oh = FF_TH / a.fy;      // output pixels produced by this tile
+  const int ox0 = x0 / a.fx, oy0 = y0 / a.fy;
+  const float kn = fc.sharp_kn, kc = fc.sharp_kc;
+  const bool out_interior = x0 >= 1 && x0 + FF_TW <= W - 1 && y0 >= 1 && y0 + FF_TH <= H - 1 && a.fy == 1 &&
+                            (a.fx == 1 || a.fx == 2) && ox0 + ow <= a.in_w && oy0 + oh <= a.in_h;
+  if (out_interior) {
+    // one task = 4 consecutive OUTPUT pixels of one row = fx groups of 4 sharpened pixels; 12-byte packed store
+    const int ngrp = ow / 4;                          // 16 (fx = 1) or 8 (fx = 2)
+    for (int t = tid; t < FF_TH * ngrp; t += FF_NT) {
+      const int ty = t / ngrp, m = t - ty * ngrp;
+      const int oy = oy0 + ty;
+      if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
+      uint32_t pack[3] = {0, 0, 0};
+      int fv[3][4];
+      if (a.fx == 1) {
+        ff_sharp4(gb, ty + 1, 4 + 4 * m, kn, kc, fv);
+      } else {
+        int s0[3][4], s1[3][4];
+        ff_sharp4(gb, ty + 1, 4 + 8 * m, kn, kc, s0);
+        ff_sharp4(gb, ty + 1, 8 + 8 * m, kn, kc, s1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int sum = q < 2 ? s0[c][2 * q] + s0[c][2 * q + 1] : s1[c][2 * q - 4] + s1[c][2 * q - 3];
+            fv[c][q] = (int)vd_sat_rne_u8((float)sum * 0.5f);
+          }
+      }
+      const bool single = a.format == VD3D_FMT_INTERLACED || a.format == VD3D_FMT_ANAGLYPH;   // one eye-sized canvas
+      const int oxq = ox0 + 4 * m + a.xo + (single ? 0 : eye * a.fit_w);
+      uint8_t* o = out + ((size_t)(oy + a.yo) * a.out_w + oxq) * 3;
+      if (a.format == VD3D_FMT_ANAGLYPH) { ff_anaglyph_store(o, eye, fv, 4); continue; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const int bi = 3 * q + c; pack[bi >> 2] |= (uint32_t)fv[c][q] << (8 * (bi & 3)); }
+      if ((reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+        o32[0] = pack[0]; o32[1] = pack[1]; o32[2] = pack[2];
+      } else {
+        for (int bi = 0; bi < 12; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
+      }
+    }
+    return;
+  }
+  const float scale = 1.f / (float)(a.fx * a.fy);
+  for (int t = tid; t < oh * (ow / 4); t += FF_NT) {
+    const int tq = t / oh, ty = t - tq * oh;
+    const int oy = oy0 + ty;
+    if (oy >= a.in_h) continue;
+    uint32_t pack[3] = {0, 0, 0};
+    int fv[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    int nvalid = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ox = ox0 + tq * 4 + q;
+      if (ox >= a.in_w) break;
+      ++nvalid;
+      int sum[3] = {0, 0, 0};
+      for (int j = 0; j < a.fy; ++j)
+        for (int i = 0; i < a.fx; ++i) {
+          const int y = oy * a.fy + j, x = ox * a.fx + i;     // sharpened pixel (inside this tile)
+          const int yu = vd_reflect(y - 1, H), yd = vd_reflect(y + 1, H), xl = vd_reflect(x - 1, W), xr = vd_reflect(x + 1, W);
+          const uint32_t pu = gb[yu - gy0][x - gx0], pl = gb[y - gy0][xl - gx0], pc = gb[y - gy0][x - gx0];
+          const uint32_t pr = gb[y - gy0][xr - gx0], pd = gb[yd - gy0][x - gx0];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int sh = 8 * c;
+            float sacc = 0.f;
+            sacc += kn * (float)((pu >> sh) & 0xffu);
+            sacc += kn * (float)((pl >> sh) & 0xffu);
+            sacc += kc * (float)((pc >> sh) & 0xffu);
+            sacc += kn * (float)((pr >> sh) & 0xffu);
+            sacc += kn * (float)((pd >> sh) & 0xffu);
+            sum[c] += (int)vd_sat_rne_u8(sacc);
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        uint8_t v;
+        if (a.fx == 1 && a.fy == 1) v = (uint8_t)sum[c];
+        else if (a.fx == 2 && a.fy == 2) v = (uint8_t)((sum[c] + 2) >> 2);
+        else v = vd_sat_rne_u8((float)sum[c] * scale);
+        const int bi = 3 * q + c;
+        pack[bi >> 2] |= (uint32_t)v << (8 * (bi & 3));
+        fv[c][q] = (int)v;
+      }
+    }
+    if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
+    const bool single = a.format == VD3D_FMT_INTERLACED || a.format == VD3D_FMT_ANAGLYPH;
+    const int oxq = ox0 + tq * 4 + a.xo + (single ? 0 : eye * a.fit_w);
+    uint8_t* o = out + ((size_t)(oy + a.yo) * a.out_w + oxq) * 3;
+    if (a.format == VD3D_FMT_ANAGLYPH) { ff_anaglyph_store(o, eye, fv, nvalid); continue; }
+    if (nvalid == 4 && ((size_t)(o - out) & 3) == 0) {
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+      o32[0] = pack[0]; o32[1] = pack[1]; o32[2] = pack[2];
+    } else {
+      for (int bi = 0; bi < 3 * nvalid; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
+    }
+  }
+}
+
 #ifndef FF_OCC_ATTR
 #define FF_OCC_ATTR   // A/B builds: -DFF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))' forces the 64-VGPR budget
 #endif
@@ -516,120 +626,41 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   }
   __syncthreads();
   VD_STAMP(ff_stamps, 4, false);
-  // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux
-  const int ow = FF_TW / a.fx, oh = FF_TH / a.fy;      // output pixels produced by this tile
-  const int ox0 = x0 / a.fx, oy0 = y0 / a.fy;
-  const float kn = fc.sharp_kn, kc = fc.sharp_kc;
-  const bool out_interior = x0 >= 1 && x0 + FF_TW <= W - 1 && y0 >= 1 && y0 + FF_TH <= H - 1 && a.fy == 1 &&
-                            (a.fx == 1 || a.fx == 2) && ox0 + ow <= a.in_w && oy0 + oh <= a.in_h;
-  if (out_interior) {
-    // one task = 4 consecutive OUTPUT pixels of one row = fx groups of 4 sharpened pixels; 12-byte packed store
-    const int ngrp = ow / 4;                          // 16 (fx = 1) or 8 (fx = 2)
-    for (int t = tid; t < FF_TH * ngrp; t += FF_NT) {
-      const int ty = t / ngrp, m = t - ty * ngrp;
-      const int oy = oy0 + ty;
-      if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
-      uint32_t pack[3] = {0, 0, 0};
-      int fv[3][4];
-      if (a.fx == 1) {
-        ff_sharp4(gb, ty + 1, 4 + 4 * m, kn, kc, fv);
-      } else {
-        int s0[3][4], s1[3][4];
-        ff_sharp4(gb, ty + 1, 4 + 8 * m, kn, kc, s0);
-        ff_sharp4(gb, ty + 1, 8 + 8 * m, kn, kc, s1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int sum = q < 2 ? s0[c][2 * q] + s0[c][2 * q + 1] : s1[c][2 * q - 4] + s1[c][2 * q - 3];
-            fv[c][q] = (int)vd_sat_rne_u8((float)sum * 0.5f);
-          }
-      }
-      const bool single = a.format == VD3D_FMT_INTERLACED || a.format == VD3D_FMT_ANAGLYPH;   // one eye-sized canvas
-      const int oxq = ox0 + 4 * m + a.xo + (single ? 0 : eye * a.fit_w);
-      uint8_t* o = out + ((size_t)(oy + a.yo) * a.out_w + oxq) * 3;
-      if (a.format == VD3D_FMT_ANAGLYPH) { ff_anaglyph_store(o, eye, fv, 4); continue; }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { const int bi = 3 * q + c; pack[bi >> 2] |= (uint32_t)fv[c][q] << (8 * (bi & 3)); }
-      if ((reinterpret_cast<uintptr_t>(o) & 3) == 0) {
-        uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
-        o32[0] = pack[0]; o32[1] = pack[1]; o32[2] = pack[2];
-      } else {
-        for (int bi = 0; bi < 12; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
-      }
-    }
-    VD_STAMP(ff_stamps, 5, true);
-    VD_OCC_OUT(ff_occ);
-    return;
-  }
-  const float scale = 1.f / (float)(a.fx * a.fy);
-  for (int t = tid; t < oh * (ow / 4); t += FF_NT) {
-    const int tq = t / oh, ty = t - tq * oh;
-    const int oy = oy0 + ty;
-    if (oy >= a.in_h) continue;
-    uint32_t pack[3] = {0, 0, 0};
-    int fv[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    int nvalid = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ox = ox0 + tq * 4 + q;
-      if (ox >= a.in_w) break;
-      ++nvalid;
-      int sum[3] = {0, 0, 0};
-      for (int j = 0; j < a.fy; ++j)
-        for (int i = 0; i < a.fx; ++i) {
-          const int y = oy * a.fy + j, x = ox * a.fx + i;     // sharpened pixel (inside this tile)
-          const int yu = vd_reflect(y - 1, H), yd = vd_reflect(y + 1, H), xl = vd_reflect(x - 1, W), xr = vd_reflect(x + 1, W);
-          const uint32_t pu = gb[yu - gy0][x - gx0], pl = gb[y - gy0][xl - gx0], pc = gb[y - gy0][x - gx0];
-          const uint32_t pr = gb[y - gy0][xr - gx0], pd = gb[yd - gy0][x - gx0];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int sh = 8 * c;
-            float sacc = 0.f;
-            sacc += kn * (float)((pu >> sh) & 0xffu);
-            sacc += kn * (float)((pl >> sh) & 0xffu);
-            sacc += kc * (float)((pc >> sh) & 0xffu);
-            sacc += kn * (float)((pr >> sh) & 0xffu);
-            sacc += kn * (float)((pd >> sh) & 0xffu);
-            sum[c] += (int)vd_sat_rne_u8(sacc);
-          }
-        }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        uint8_t v;
-        if (a.fx == 1 && a.fy == 1) v = (uint8_t)sum[c];
-        else if (a.fx == 2 && a.fy == 2) v = (uint8_t)((sum[c] + 2) >> 2);
-        else v = vd_sat_rne_u8((float)sum[c] * scale);
-        const int bi = 3 * q + c;
-        pack[bi >> 2] |= (uint32_t)v << (8 * (bi & 3));
-        fv[c][q] = (int)v;
-      }
-    }
-    if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
-    const bool single = a.format == VD3D_FMT_INTERLACED || a.format == VD3D_FMT_ANAGLYPH;
-    const int oxq = ox0 + tq * 4 + a.xo + (single ? 0 : eye * a.fit_w);
-    uint8_t* o = out + ((size_t)(oy + a.yo) * a.out_w + oxq) * 3;
-    if (a.format == VD3D_FMT_ANAGLYPH) { ff_anaglyph_store(o, eye, fv, nvalid); continue; }
-    if (nvalid == 4 && ((size_t)(o - out) & 3) == 0) {
-      uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
-      o32[0] = pack[0]; o32[1] = pack[1]; o32[2] = pack[2];
-    } else {
-      for (int bi = 0; bi < 3 * nvalid; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
-    }
-  }
+  ff_epilogue<FF_TH, FF_NT>(gb, a, fc, eye, x0, y0, gx0, gy0, tid, out);
   VD_STAMP(ff_stamps, 5, true);
   VD_OCC_OUT(ff_occ);
 }
 
+// The epilogue alone, for eyes that are graded already (k_dof_grade4's planes: Gaussians beyond the fused kernel's 9 taps): tile of graded dwords
+// straight from the u8 planes, then sharpen + fit + mux as above.  Replaces k_sharp_mux (one thread per output pixel, 120 byte loads each: 236 us
+// per 4K frame pair) wherever the fused kernel's fit conditions hold.
+template <int TH_>
+__global__ __launch_bounds__(512) void k_sharp_fit(const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, vd_finish_consts fc, vd_ff_args a,
+                                                   uint8_t* __restrict__ out) {
+  constexpr int FF_TH = TH_, FF_GH = TH_ + 2, FF_NT = 512;
+  __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
+  int trow, tbx;
+  vd_xcd_tile_rows(blockIdx.x, a.ntx, FF_XG, a.xcd, &trow, &tbx);
+  if (trow >= 2 * a.nty) return;
+  const int eye = trow >= a.nty ? 1 : 0, tby = trow - eye * a.nty;
+  const uint8_t* __restrict__ src = eye == 0 ? gL : gR;
+  const int H = a.H, W = a.W;
+  const int x0 = tbx * FF_TW, y0 = tby * FF_TH, gx0 = x0 - 4, gy0 = y0 - 1;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < FF_GH * FF_GW; t += FF_NT) {
+    const int row = t / FF_GW, col = t - row * FF_GW;
+    const uint8_t* px = src + ((size_t)vd_reflect(gy0 + row, H) * W + vd_reflect(gx0 + col, W)) * 3;
+    gb[row][col] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);   // byte 0 = B, 1 = G, 2 = R (the planes are BGR)
+  }
+  __syncthreads();
+  ff_epilogue<FF_TH, FF_NT>(gb, a, fc, eye, x0, y0, gx0, gy0, tid, out);
+}
+
 // returns false when the fast path does not apply (caller runs the unfused kernels)
-bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
-                            const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
-                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense, const float* w2_dev) {
+// fit / mux geometry of the epilogue; false: a format or fit it does not take (VR, fractional / up-scaling INTER_AREA)
+static bool ff_geometry(const vd3d_render_params& p, int eh, int ew, vd_ff_args* pa) {
   if (!(p.format == VD3D_FMT_HALF_SBS || p.format == VD3D_FMT_FULL_SBS || p.format == VD3D_FMT_INTERLACED || p.format == VD3D_FMT_ANAGLYPH)) return false;
-  for (int l = 0; l < fc.nlev; ++l) if (fc.ksz[l] > 2 * FF_R + 1 || fc.ksz[l] < 3) return false;
-  vd_ff_args a;
+  vd_ff_args& a = *pa;
   a.H = p.warp_h; a.W = p.warp_w; a.eh = eh; a.ew = ew;
   a.fit_w = p.fit_w; a.fit_h = p.fit_h; a.out_w = p.out_w; a.format = p.format;
   if (p.format == VD3D_FMT_HALF_SBS) { a.in_w = p.fit_w; a.in_h = p.fit_h; a.xo = 0; a.yo = 0; }
@@ -639,13 +670,43 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
     else { a.in_h = p.fit_h; a.in_w = (int)(ca * p.fit_h); }
     a.xo = (p.fit_w - a.in_w) / 2; a.yo = (p.fit_h - a.in_h) / 2;
   }
-  if (a.in_w < 1 || a.in_h < 1 || a.in_w > p.warp_w || a.in_h > p.warp_h || p.warp_w % a.in_w || p.warp_h % a.in_h) return false;   // fractional / up-scaling INTER_AREA: unfused path
+  if (a.in_w < 1 || a.in_h < 1 || a.in_w > p.warp_w || a.in_h > p.warp_h || p.warp_w % a.in_w || p.warp_h % a.in_h) return false;   // fractional / up-scaling INTER_AREA
   a.fx = p.warp_w / a.in_w; a.fy = p.warp_h / a.in_h;
   if (!((a.fx == 1 || a.fx == 2 || a.fx == 4) && (a.fy == 1 || a.fy == 2 || a.fy == 4))) return false;
   if ((FF_TW / a.fx) % 4) return false;
-  a.use_override = use_override; a.bar_w = bar_w; a.bar_s = bar_s; a.focal = focal;
+  a.use_override = 0; a.bar_w = 0; a.bar_s = 0; a.focal = 0.f;
+  return true;
+}
+static void ff_grid(const vd3d_render_params& p, int th, vd_ff_args* a, dim3* g) {
+  a->ntx = (p.warp_w + FF_TW - 1) / FF_TW; a->nty = (p.warp_h + th - 1) / th;
+  a->xcd = 1;
+  const int ngrp = (2 * a->nty + FF_XG - 1) / FF_XG;
+  *g = dim3(a->xcd ? 8 * ((ngrp + 7) / 8) * FF_XG * a->ntx : 2 * a->ntx * a->nty);
+}
+static void ff_clear_canvas(hipStream_t s, const vd3d_render_params& p, const vd_ff_args& a, uint8_t* out) {
   if (a.xo || a.yo || a.in_w != p.fit_w || a.in_h != p.fit_h)  // pad_to_aspect_ratio canvas (:124): black background
     (void)hipMemsetAsync(out, 0, (size_t)p.out_w * p.out_h * 3, s);
+}
+// sharpen + fit + mux of two GRADED eyes (k_sharp_fit); false: the fit is not the epilogue's (caller runs k_sharp_mux)
+bool vd_launch_sharp_fit(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p, const vd_finish_consts& fc, uint8_t* out) {
+  vd_ff_args a;
+  if (!ff_geometry(p, p.warp_h, p.warp_w, &a)) return false;
+  constexpr int TH = 28;   // multiple of 4 (fit factor 4), 30 x 76 dwords of LDS
+  ff_clear_canvas(s, p, a, out);
+  dim3 g;
+  ff_grid(p, TH, &a, &g);
+  hipLaunchKernelGGL((k_sharp_fit<TH>), g, dim3(512), 0, s, gL, gR, fc, a, out);
+  return true;
+}
+
+bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
+                            const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
+                            int use_override, int bar_w, int bar_s, uint8_t* out, int dense, const float* w2_dev) {
+  for (int l = 0; l < fc.nlev; ++l) if (fc.ksz[l] > 2 * FF_R + 1 || fc.ksz[l] < 3) return false;
+  vd_ff_args a;
+  if (!ff_geometry(p, eh, ew, &a)) return false;
+  a.use_override = use_override; a.bar_w = bar_w; a.bar_s = bar_s; a.focal = focal;
+  ff_clear_canvas(s, p, a, out);
   // wide geometry: 64x30 tiles.  (64x14 tiles -- 5 waves, 4 workgroups per CU -- measured 414 vs 426 us at 4K with 14 % more instructions
   // and a 2.1x instead of 1.7x input halo: not kept.)  Fit factor 4 keeps the 64x16 geometry.
 #ifdef FF_AB_GEO16   // A/B build (tools/build_ab.sh): dense levels in the 64x16 geometry everywhere
@@ -654,10 +715,8 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
   const bool wide = dense && (FF_WIDE_TH % a.fy) == 0;
 #endif
   const int th = wide ? FF_WIDE_TH : 16;
-  a.ntx = (p.warp_w + FF_TW - 1) / FF_TW; a.nty = (p.warp_h + th - 1) / th;
-  a.xcd = 1;
-  const int ngrp = (2 * a.nty + FF_XG - 1) / FF_XG;
-  dim3 g(a.xcd ? 8 * ((ngrp + 7) / 8) * FF_XG * a.ntx : 2 * a.ntx * a.nty);
+  dim3 g;
+  ff_grid(p, th, &a, &g);
   if (dense && !w2_dev) return false;
   if (wide) hipLaunchKernelGGL((k_finish_fused<true, FF_WIDE_TH>), g, dim3(ff_geo<FF_WIDE_TH>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   else if (dense) hipLaunchKernelGGL((k_finish_fused<true, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);

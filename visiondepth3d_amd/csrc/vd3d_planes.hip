@@ -321,12 +321,13 @@ __global__ __launch_bounds__(512) void k_dof_grade(const uint8_t* __restrict__ e
 }
 // Dense levels (the reference's order: one k x k window per output, taps row-major, one FMA per tap from 0, weight = fl(k1[i] * k1[j]);
 // vd3d_render_params::dof_dense_conv = 1, the default) for the Gaussians the fused finishing kernel does not take: more than 9 taps (dof_strength
-// > 2, up to 31 taps), VR / fractional fits.  Round 4: one thread = 4 consecutive pixels (64 x 32 tile, 512 threads).  For every tap row the K + 3
-// window columns are read ONCE (a single LDS dword each) and feed the four outputs' chains with a sliding window of four weights (LDS broadcast
-// reads; zero weights pad the row ends: fma(v, 0, acc) is exact here -- acc never is -0): 2 LDS reads per 4 FMAs instead of 2 per FMA (one pixel
-// per thread until round 3: 1 387 us per 4K frame pair at dof_strength 3.0 against the fused kernel's 252 at 2.0).  Each output's taps still
-// arrive in ascending (i, j) order: same bits.
-// Round 4 (second pass): the tap count is a template parameter (one instantiation per odd K <= 31) and the weights come from a device table
+// > 2, up to 31 taps; a VR canvas or a fractional fit alone keeps the fused kernel, vd3d_api.hip run_finish).  Round 4: one thread = 4 consecutive
+// pixels (64 x 32 tile, 512 threads).  For every tap row the K + 3 window columns are read ONCE (a single LDS dword each) and feed the four
+// outputs' chains with a sliding window of four weights; a window column outside an output's K taps would meet a zero weight -- fma(v, 0, acc)
+// is exact here, acc never is -0 -- so it can be issued (the run-time loop) or left out (the instantiations): same bits.  (One pixel per thread
+// until round 3: 1 387 us per 4K frame pair at dof_strength 3.0 against the fused kernel's 252 at 2.0.)  Each output's taps arrive in ascending
+// (i, j) order.
+// Second pass: the tap count is a template parameter (one instantiation per odd K <= 21, the GUI slider's range) and the weights come from a device table
 // (vd3d_ctx::wk_tabs: [level][row i][32] = fl(k1[i] * k1[j]), row pitch 32 floats) through wave-uniform loads, i.e. as SCALAR operands of the
 // FMAs: the window of K + 3 columns sits in registers, the sliding weights are register names, the zero-weight products at the row ends are
 // not issued (exact: see above) -- 4 K FMAs per tap row and channel next to (K + 3) / 2 ds_read2 and K / 4 scalar loads, where the run-time
