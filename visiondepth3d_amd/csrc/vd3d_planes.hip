@@ -505,8 +505,9 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
 // ------------------------------------------------------------------------------------------------
 // pre > 0: g already holds SHARPENED pixels with a row pitch of `pre` pixels (the fused finishing kernel ran 1:1 into a side-by-side scratch,
 // round 4): the fit / mux below is all that is left to do
+template <bool PRE>
 VD_DEV uint8_t sharp_at(const uint8_t* __restrict__ g, int H, int W, int pre, int y, int x, int c, float kn, float kc) {
-  if (pre > 0) return g[((size_t)y * pre + x) * 3 + c];
+  if (PRE) return g[((size_t)y * pre + x) * 3 + c];
   const int yu = vd_reflect(y - 1, H), yd = vd_reflect(y + 1, H), xl = vd_reflect(x - 1, W), xr = vd_reflect(x + 1, W);
   float s = 0.f;
   s += kn * (float)g[((size_t)yu * W + x) * 3 + c];
@@ -527,6 +528,7 @@ struct vd_mux_geom {
   int pre;             // > 0: the inputs are sharpened already, row pitch in pixels (see sharp_at)
   double sx, sy;       // OpenCV's scale = 1./((double)dsize/ssize)
 };
+template <bool PRE>
 __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ gL, const uint8_t* __restrict__ gR, vd_mux_geom m,
                                                    float kn, float kc, uint8_t* __restrict__ out) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -546,8 +548,8 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
         vd_area_lin_coef(m.W, m.in_w, ix, &xi, &xa0, &xa1);
         vd_area_lin_coef(m.H, m.in_h, iy, &yi, &yb0, &yb1);
         const int x1 = xi + 1 < m.W ? xi + 1 : m.W - 1, y1 = yi + 1 < m.H ? yi + 1 : m.H - 1;
-        const int r0 = (int)sharp_at(g, m.H, m.W, m.pre, yi, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, m.pre, yi, x1, c, kn, kc) * xa1;
-        const int r1 = (int)sharp_at(g, m.H, m.W, m.pre, y1, xi, c, kn, kc) * xa0 + (int)sharp_at(g, m.H, m.W, m.pre, y1, x1, c, kn, kc) * xa1;
+        const int r0 = (int)sharp_at<PRE>(g, m.H, m.W, m.pre, yi, xi, c, kn, kc) * xa0 + (int)sharp_at<PRE>(g, m.H, m.W, m.pre, yi, x1, c, kn, kc) * xa1;
+        const int r1 = (int)sharp_at<PRE>(g, m.H, m.W, m.pre, y1, xi, c, kn, kc) * xa0 + (int)sharp_at<PRE>(g, m.H, m.W, m.pre, y1, x1, c, kn, kc) * xa1;
         const int q = (((yb0 * (r0 >> 4)) >> 16) + ((yb1 * (r1 >> 4)) >> 16) + 2) >> 2;
         v = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
       } else if (inside && m.frac) {  // ResizeArea_<uchar,float>: per source row sum_k S*alpha (float32), then sum_j row*beta
@@ -557,16 +559,16 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
         float acc = 0.f;
         for (int j = 0; j < ny; ++j) {
           float h = 0.f;
-          for (int k = 0; k < nx; ++k) h = h + (float)sharp_at(g, m.H, m.W, m.pre, y0s + j, x0s + k, c, kn, kc) * ax[k];
+          for (int k = 0; k < nx; ++k) h = h + (float)sharp_at<PRE>(g, m.H, m.W, m.pre, y0s + j, x0s + k, c, kn, kc) * ax[k];
           acc = acc + h * ay[j];
         }
         v = vd_sat_rne_u8(acc);
       } else if (inside) {
-        if (m.fx == 1 && m.fy == 1) v = sharp_at(g, m.H, m.W, m.pre, iy, ix, c, kn, kc);
+        if (m.fx == 1 && m.fy == 1) v = sharp_at<PRE>(g, m.H, m.W, m.pre, iy, ix, c, kn, kc);
         else {
           int sum = 0;
           for (int j = 0; j < m.fy; ++j)
-            for (int i = 0; i < m.fx; ++i) sum += sharp_at(g, m.H, m.W, m.pre, iy * m.fy + j, ix * m.fx + i, c, kn, kc);
+            for (int i = 0; i < m.fx; ++i) sum += sharp_at<PRE>(g, m.H, m.W, m.pre, iy * m.fy + j, ix * m.fx + i, c, kn, kc);
           if (m.fx == 2 && m.fy == 2) v = (uint8_t)((sum + 2) >> 2);
           else v = vd_sat_rne_u8((float)sum * (1.f / (float)(m.fx * m.fy)));
         }
@@ -613,7 +615,9 @@ void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
   m.sx = 1.0 / ((double)m.in_w / p.warp_w); m.sy = 1.0 / ((double)m.in_h / p.warp_h);
   m.frac = (p.warp_w % m.in_w || p.warp_h % m.in_h) ? 1 : 0;
   if (m.in_w > p.warp_w || m.in_h > p.warp_h) m.frac = 2;
-  hipLaunchKernelGGL(k_sharp_mux, dim3((p.fit_w + 63) / 64, (p.fit_h + 3) / 4), dim3(256), 0, s, gL, gR, m, fc.sharp_kn, fc.sharp_kc, out);
+  const dim3 g((p.fit_w + 63) / 64, (p.fit_h + 3) / 4);
+  if (presharp_pitch > 0) hipLaunchKernelGGL(k_sharp_mux<true>, g, dim3(256), 0, s, gL, gR, m, fc.sharp_kn, fc.sharp_kc, out);
+  else hipLaunchKernelGGL(k_sharp_mux<false>, g, dim3(256), 0, s, gL, gR, m, fc.sharp_kn, fc.sharp_kc, out);
 }
 
 // blank frame (skip_blank_frames, core/render_3d.py:1278-1281 + :1398-1403): both eyes are the raw source frame with the floating-window
