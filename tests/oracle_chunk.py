@@ -52,6 +52,7 @@ class OracleChunkBackend:
         self.slots = {}
         self.norm_row = (F32(0), F32(1), 1, 0)    # (lo, den, collapse, have_prev) in force after the last rendered frame
         self.etab = []
+        self.batch_calls = []                     # (stage, frames, step_idx0, slot0) of every batched call (tests look at it)
         L = O.lib()
         L.vo_zero_parallax_raw.argtypes = [C.POINTER(ShiftParams), C.c_int, C.c_float, C.POINTER(C.c_float)]
         L.vo_finish_blank.argtypes = [O._u8p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, O._u8p]
@@ -94,6 +95,24 @@ class OracleChunkBackend:
         q_out[0] = O.quantile(dcl, F32(0.02))
         q_out[1] = O.quantile(dcl, F32(0.98))
         self.slots[slot] = dict(fe=fe, filt=filt, prev_plane=prev_plane, frame=fb)
+
+    # The batched entry points of the HIP backend (vd3d_shard2_p1_batch / _p3_batch: consecutive own frames in launches of <= 16): here the
+    # same per-frame stages in a loop, cut at the same batch boundary, so that the gloo tests drive the branches of ChunkSharder.p1_local / p3
+    # the GPU runs (frame j of the call <-> step index step_idx0 + j, slot slot0 + j, record row j).
+    MAX_BATCH = 16
+
+    def p1_batch(self, frames, depths, step_idx0, slot0, q_out):
+        assert len(frames) == len(depths) and len(frames) >= 1
+        self.batch_calls.append(("p1", len(frames), step_idx0, slot0))
+        for j0 in range(0, len(frames), self.MAX_BATCH):
+            for j in range(j0, min(len(frames), j0 + self.MAX_BATCH)):
+                self.p1(frames[j], depths[j], step_idx0 + j, slot0 + j, q_out[j])
+
+    def p3_batch(self, slot0, step_idx0, n, m_out):
+        assert n >= 1
+        self.batch_calls.append(("p3", n, step_idx0, slot0))
+        for j in range(n):
+            self.p3(slot0 + j, step_idx0 + j, m_out[j])
 
     # ---- R1: DepthPercentileEMA over all frames of the step (vo_percentile_ema_normalize's scalar half)
     def r1(self, q_all):

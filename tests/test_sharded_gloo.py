@@ -115,9 +115,13 @@ def test_chunk_sharding_emulated_in_process(oracle, G):
     seq, st_seq, plane_seq = _sequential(oracle)
     for t in range(NF):
         assert np.array_equal(got[t].numpy(), seq[t]), t
-    for be in bes:
+    for g, be in enumerate(bes):
         assert np.array_equal(_state_vec(be.state), st_seq)
         assert np.array_equal(be.tdf, plane_seq)
+        # the sharder drove the BATCHED stage entry points (what HipChunkBackend offers: one call per stage and step for the consecutive own
+        # frames), with this rank's first step index and the slot set's first slot; partial last steps shorten the batch
+        assert be.batch_calls and {c[0] for c in be.batch_calls} == {"p1", "p3"}
+        assert all(1 <= n <= B and idx0 == g * B and slot0 == 0 for (_, n, idx0, slot0) in be.batch_calls), be.batch_calls
 
 
 def test_protocol_traffic_is_records_plus_one_plane_per_boundary():
