@@ -378,8 +378,9 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
 
 def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     """BASELINE configs[4] on one GPU: 1080p frames -> DA-V2-Small (float32) -> DIBR Half-SBS 1920x1080 -> run_esrgan(input_res_pct=50,
-    target_size=(3840, 2160)) with the reference's default model (RealESR_Gx4_fp16, fp16 like its ONNX export).  A plain serial chain on
-    one stream (no cross-batch overlap): a sub-record, never the headline."""
+    target_size=(3840, 2160)) with the reference's default model (RealESR_Gx4_fp16, fp16 like its ONNX export).  Two streams (round 4): the
+    up-scale net of batch i runs behind depth + DIBR of batch i + 1 (each side with its own renderer context, two stereo-frame buffers,
+    events both ways); `--chain-serial`: everything on one stream.  A sub-record, never the headline."""
     torch = env.torch
     from visiondepth3d_amd import synth
     from visiondepth3d_amd.depth import DepthPipe
@@ -388,14 +389,25 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     from visiondepth3d_amd.upscale import Upscaler
     sh, sw = 1080, 1920
     p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
+    serial = bool(getattr(args, "chain_serial", False))
     r = Renderer(env.local_rank)
     r.new_clip()
+    r_up = r if serial else Renderer(env.local_rank)      # the up-scale side's own context: the two streams never share context scratch
     pipe = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.float32, renderer=r, miopen_find=False)   # the chain is the up-scale net's: no find pass
-    up = Upscaler(r, "RealESR_Gx4_fp16")
+    up = Upscaler(r_up, "RealESR_Gx4_fp16")
     frames_np, _ = synth.synth_clip(B, sh, sw, start=0)
     frames = torch.stack([torch.from_numpy(f) for f in frames_np]).cuda()
     dbuf = torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda")
-    outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
+    NB = 1 if serial else 2
+    outs_set = [torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda") for _ in range(NB)]
+    outs = outs_set[0]
+    s_dibr = torch.cuda.current_stream() if serial else torch.cuda.Stream()
+    s_up = s_dibr if serial else torch.cuda.Stream()
+    if not serial:   # everything set up so far (weights, clip, buffers) was enqueued on the current stream
+        s_dibr.wait_stream(torch.cuda.current_stream())
+        s_up.wait_stream(torch.cuda.current_stream())
+    dibr_done = [torch.cuda.Event() for _ in range(NB)]
+    up_done = [None] * NB
     ev = []
     last = [None]
 
@@ -404,17 +416,28 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     nstep = [0]
 
     def step(timed):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        e[0].record()
-        pred = pipe.infer_bgr_u8(frames, raw=True)
-        r.depth_handoff(pred, sh, sw, out=dbuf)
-        e[1].record()
-        shr.render_step(frames, dbuf, outs=outs, first_step=(nstep[0] == 0))
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        k = nstep[0] % NB
+        o = outs_set[k]
+        with torch.cuda.stream(s_dibr):
+            if up_done[k] is not None:
+                s_dibr.wait_event(up_done[k])          # the up-scale net of two steps ago has read this buffer
+            e[0].record(s_dibr)
+            pred = pipe.infer_bgr_u8(frames, raw=True)
+            r.depth_handoff(pred, sh, sw, out=dbuf)
+            e[1].record(s_dibr)
+            shr.render_step(frames, dbuf, outs=o, first_step=(nstep[0] == 0))
+            e[2].record(s_dibr)
+            dibr_done[k].record(s_dibr)
         nstep[0] += 1
-        e[2].record()
-        for j in range(B):
-            last[0] = up.run_esrgan(outs[j], input_res_pct=50, target_size=(3840, 2160))
-        e[3].record()
+        with torch.cuda.stream(s_up):
+            s_up.wait_event(dibr_done[k])
+            e[3].record(s_up)
+            for j in range(B):
+                last[0] = up.run_esrgan(o[j], input_res_pct=50, target_size=(3840, 2160))
+            e[4].record(s_up)
+            up_done[k] = torch.cuda.Event()
+            up_done[k].record(s_up)
         if timed:
             ev.append(e)
 
@@ -426,7 +449,7 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
         step(True)
     env.fence()
     dt = time.perf_counter() - t0
-    ms = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) / B for i in range(3)]
+    ms = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev) / B for i in (0, 1, 3)]   # per-stream HIP events; with two streams the stages overlap
     # the network alone, for its MFMA figure
     flops = [0.0]
 
@@ -455,11 +478,15 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
     lib_ms = timed(up.net)             # the same network through the library convolutions only (context, not the product)
     out_shape = list(last[0].shape)
     del pipe, up
+    if r_up is not r:
+        r_up.close()
     r.close()
     torch.cuda.empty_cache()
     return {"workload": "1080p-dav2s-dibr-esrgan4k",
             "description": "BASELINE configs[4] on one GPU: 1080p, DA-V2-Small (float32) + DIBR Half-SBS + Real-ESRGAN x4 (RealESR_Gx4, fp16 like "
-                           "the reference's ONNX export) through run_esrgan(input_res_pct=50, target_size=(3840, 2160)); serial chain, one stream (DIBR through the batched step path)",
+                           "the reference's ONNX export) through run_esrgan(input_res_pct=50, target_size=(3840, 2160)); " +
+                           ("serial chain, one stream" if serial else "two streams: the up-scale net of batch i behind depth + DIBR of batch i + 1") + " (DIBR through the batched step path)",
+            "streams": 1 if serial else 2,
             "value": round(steps * B / dt, 3), "unit": "stereo-pairs/s", "steps": steps, "warmup": warmup, "frames_timed": steps * B,
             "ms_per_step": round(dt / steps * 1e3, 3), "dtype": "f32 depth net + f32 DIBR + fp16 up-scale net (the reference's precisions)",
             "output": out_shape, "stage_ms_per_frame": {"depth_net+handoff": round(ms[0], 3), "dibr": round(ms[1], 3), "run_esrgan": round(ms[2], 3)},
@@ -693,6 +720,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the DIBR chain on the depth net's stream instead of a private HIP stream (no cross-batch overlap)")
     ap.add_argument("--upscale-only", action="store_true", help="measure only the configs[4] sub-record (1080p depth + DIBR + Real-ESRGAN x4)")
+    ap.add_argument("--chain-serial", action="store_true", help="configs[4] sub-record: depth, DIBR and the up-scale net on ONE stream (default: the up-scale "
+                    "net of a batch on a second stream behind depth + DIBR of the next)")
     ap.add_argument("--backend", default="hip", choices=("hip", "oracle-gloo"),
                     help="hip: the product (libvd3d_hip.so, nccl = RCCL for --gpus > 1).  oracle-gloo: TEST MODE for tests/test_bench_launcher.py -- "
                     "the same rank launcher, clip layout, step protocol and record assembly with the CPU oracle as the sharder's backend over gloo on a "
