@@ -156,3 +156,52 @@ def test_upsample_bilinear_nhwc_f32_matches_torch(shape):
     assert got.shape == ref.shape and got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
     assert float((got - ref).abs().max()) < 1e-5
     r.close()
+
+
+def test_dpt_neck_head_glue_kernels_match_torch():
+    """vd3d_nhwc_bias_act_f32 / vd3d_upsample_bilinear_bias_nhwc_f32 / vd3d_dpt_head_tail_f32 (round 4: what sits between the library
+    convolutions of the DPT neck / head) against the torch expressions they replace.  The element-wise ones perform the same float32
+    operations in the same order: bit for bit; the head tail sums its C products in another order: 1e-6 of the range."""
+    from visiondepth3d_amd.render_3d import Renderer
+    import torch.nn.functional as F
+    r = Renderer(0)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    CL = torch.channels_last
+
+    def rnd(*shape):
+        return torch.randn(*shape, device="cuda", generator=g)
+    for (B, Cc, h, w) in ((2, 128, 19, 33), (1, 64, 37, 66), (3, 4, 5, 7)):
+        y0, r1, r2 = (rnd(B, Cc, h, w).contiguous(memory_format=CL) for _ in range(3))
+        bias = rnd(Cc)
+        bv = bias.view(1, -1, 1, 1)
+        # bias + ReLU in place
+        y = y0.clone(memory_format=torch.preserve_format)
+        out = r.bias_act(y, bias, relu=True)
+        assert out.data_ptr() == y.data_ptr() and torch.equal(out, torch.relu(y0 + bv))
+        # bias + unit input + running state, and the ReLU'd copy
+        y = y0.clone(memory_format=torch.preserve_format)
+        out, rc = r.bias_act(y, bias, r1=r1, r2=r2, want_relu_copy=True)
+        ref = r2 + ((y0 + bv) + r1)
+        assert torch.equal(out, ref) and torch.equal(rc, torch.relu(ref)) and rc.is_contiguous(memory_format=CL)
+        # no bias, one residual
+        y = y0.clone(memory_format=torch.preserve_format)
+        assert torch.equal(r.bias_act(y, None, r1=r1), y0 + r1)
+        # up-sampling with the producing convolution's bias on the interpolated value
+        oh, ow = 2 * h + 1, 2 * w
+        got = r.upsample_bilinear_bias(y0, (oh, ow), bias)
+        assert got.shape == (B, Cc, oh, ow) and got.is_contiguous(memory_format=CL)
+        assert torch.equal(got, r.upsample_bilinear(y0, (oh, ow)) + bv)
+        assert float((got - (F.interpolate(y0, size=(oh, ow), mode="bilinear", align_corners=True) + bv)).abs().max()) < 1e-5
+    for (B, Cc, h, w) in ((2, 32, 37, 66), (1, 64, 9, 5), (1, 16, 3, 3)):
+        y = rnd(B, Cc, h, w).contiguous(memory_format=CL)
+        b2, w3 = rnd(Cc), rnd(Cc)
+        pre = (torch.relu(y.double() + b2.double().view(1, -1, 1, 1)) * w3.double().view(1, -1, 1, 1)).sum(1)
+        b3, scale = -float(pre.mean()), 1.5          # the 1x1 convolution's bias placed so that the final ReLU clips about half of the pixels
+        got = r.dpt_head_tail(y, b2, w3, b3, scale)
+        ref = torch.relu(pre + b3) * scale
+        assert got.shape == (B, h, w) and got.dtype == torch.float32
+        assert float((got.double() - ref).abs().max()) < 1e-5 * max(1.0, float(pre.abs().max()))
+        assert float(got.min()) >= 0.0 and 0.2 < float((got == 0).float().mean()) < 0.8
+    with pytest.raises(ValueError):
+        r.bias_act(torch.zeros(1, 8, 4, 4, device="cuda"), None)      # NCHW-contiguous: not the kernels' layout
+    r.close()
