@@ -55,7 +55,8 @@ def test_pixel_shift_random_parameters(ref, oracle, seed):
     # SLEEF value the oracle restates), so up to 31 elements can differ by an ULP of a layer weight (6e-8), amplified by
     # amp = (1.2 fg + |mg| + 1.1 |bg|) / (W/2) -- above 1 only for the tiny widths of this sweep.  4e-7 * max(1, amp) in normalised
     # units is < 1e-4 pixel.  (The untailed variant of this sweep below is exact.)
-    # Planes below ~4 K elements (only in sweeps like this one): ATen's CPU bilinear kernel switches to a variant with PREMULTIPLIED
+    # Outputs with H + W <= 128 (ATen UpSampleKernel.cpp `_use_vectorized_kernel_cond_2d`; also 3-channel inputs when torch runs ONE thread;
+    # only in sweeps like this one -- an earlier note here said "below ~4 K elements"): ATen's CPU bilinear kernel switches to a variant with PREMULTIPLIED
     # weights (p01*w01, then fma(p00,w00,.), fma(p10,w10,.), fma(p11,w11,.)) -- identified bit-exactly -- which is 1 ULP away from the
     # nested form it uses for every real frame size (and the oracle uses); a depth edge amplifies that: 1e-6 (worst of 940: 7.3e-7).
     amp = (1.2 * fg + abs(mg) + 1.1 * abs(bg)) / (W / 2)
@@ -390,3 +391,41 @@ def test_even_blur_ksize_window(ref, oracle, k):
         for got, exp in ((o["left"], rl), (o["right"], rr)):
             mx, frac, _ = u8_diff_stats(got, np.asarray(exp))
             assert mx <= 1 and frac < 8e-3, (k, H, W, mx, frac)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_render_loop_dof_slider_and_formats_exact_on_untailed_planes(ref, oracle, seed):
+    """Round 4: the live reference's ``render_sbs_3d`` loop vs the oracle over the WHOLE DOF slider (0.1 ... 5.0: Gaussians of 3 to 21 taps, the
+    strengths where MKL's vsExp is not the rounded exponential among them) in every output format incl. VR, on 16:9 frame sizes whose planes
+    are multiples of 32 elements (no ATen scalar tail: every float32 operator is the SLEEF / MKL vector path the oracle restates; a 2:1 or 3:2
+    source would be cropped to 113-pixel rows whose last elements go through libm -- 3 to 11 samples of such a frame then differ by up to 2
+    levels, the limitation DESIGN.md section 2 names).  Bar: EXACT."""
+    import make_golden as mg
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    rng = np.random.default_rng(9100 + seed)
+    fmt = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph", "VR"][seed % 5]
+    # 16:9 (no aspect crop: a cropped row is a 113-element vector with a scalar tail) and eyes with H + W > 128 (at or below that ATen resizes with
+    # its premultiplied-weight kernel: see test_pixel_shift_random_parameters; a 128 x 72 Half-SBS frame has 64 x 36 eyes and loses 8 samples to it)
+    sh, sw = [(108, 192), (144, 256), (108, 192)][int(rng.integers(0, 3))]
+    dof = float(np.round(rng.uniform(0.1, 5.0), 1)) if seed % 3 else float([2.1, 4.2, 3.7, 0.7][seed // 3 % 4])
+    kw = dict(output_format=fmt, output_height=sh, fg_shift=float(rng.uniform(2, 20)), mg_shift=float(rng.uniform(-6, 2)),
+              bg_shift=float(rng.uniform(-15, 0)), sharpness_factor=float(rng.uniform(0.0, 0.4)), dof_strength=dof,
+              feather_strength=float(rng.uniform(0, 15)), blur_ksize=int(rng.integers(0, 5)) * 2 + 1,
+              use_subject_tracking=bool(rng.integers(0, 2)), use_floating_window=bool(rng.integers(0, 2)),
+              color_saturation=float(rng.uniform(0.9, 1.3)), color_contrast=float(rng.uniform(0.95, 1.1)),
+              color_brightness=float(rng.uniform(-0.03, 0.03)))
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    n = 3
+    name = f"_live_dof_{seed}"
+    mg.LOOP_CASES[name] = (sh, sw, n, kw)
+    try:
+        written = np.stack(mg.run_loop(name))
+    finally:
+        del mg.LOOP_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ro = oracle.RenderOracle(render_kwargs_to_params(sw, sh, **kw))
+    ro.new_clip()
+    got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
+    assert got.shape == written.shape, (got.shape, written.shape, kw)
+    assert np.array_equal(got, written), (seed, fmt, (sh, sw), dof, u8_diff_stats(got, written))
