@@ -429,3 +429,44 @@ def test_render_loop_dof_slider_and_formats_exact_on_untailed_planes(ref, oracle
     got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
     assert got.shape == written.shape, (got.shape, written.shape, kw)
     assert np.array_equal(got, written), (seed, fmt, (sh, sw), dof, u8_diff_stats(got, written))
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_render_loop_every_control_exact_on_untailed_planes(ref, oracle, seed):
+    """The live reference's ``render_sbs_3d`` loop vs the oracle with EVERY control the loop forwards drawn at random -- layer shifts, shift
+    bound, zero-parallax strength, static / dynamic convergence, IPD factor, edge masking / feathering on and off, blur sizes 1 ... 13, feather
+    strength, subject tracking, floating window, DOF, sharpening, colour grade, original-aspect preservation -- on 16:9 frames whose planes are
+    multiples of 32 elements and whose eyes have H + W > 128 (the two ATen code paths the oracle does not restate: see the sweeps above), four
+    rendered frames each (trackers, EMAs and the floating bar evolve).  Bar: EXACT.  (30 seeds run with the suite; an offline run of seeds
+    0 ... 299 at the end of round 4: 300 of 300 exact.)"""
+    import make_golden as mg
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    rng = np.random.default_rng(9500 + seed)
+    fmt = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph", "VR"][int(rng.integers(0, 5))]
+    sh, sw = [(108, 192), (144, 256)][int(rng.integers(0, 2))]
+    kw = dict(output_format=fmt, output_height=sh, fg_shift=float(rng.uniform(0, 30)), mg_shift=float(rng.uniform(-10, 5)),
+              bg_shift=float(rng.uniform(-25, 0)), sharpness_factor=float(rng.uniform(0.0, 0.6)),
+              dof_strength=float([0.0, 1.0, 2.0, 2.0, 3.3][int(rng.integers(0, 5))]), feather_strength=float(rng.uniform(0, 20)),
+              blur_ksize=int(rng.integers(0, 7)) * 2 + 1, use_subject_tracking=bool(rng.integers(0, 2)),
+              use_floating_window=bool(rng.integers(0, 2)), max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)),
+              zero_parallax_strength=float(rng.uniform(0, 0.03)) if rng.integers(0, 2) else 0.0,
+              enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+              convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+              ipd_factor=float([1.0, 0.0, 1.2, 0.8][int(rng.integers(0, 4))]),
+              color_saturation=float(rng.uniform(0.8, 1.4)), color_contrast=float(rng.uniform(0.9, 1.2)),
+              color_brightness=float(rng.uniform(-0.05, 0.05)))
+    if fmt == "Full-SBS" or rng.integers(0, 3) == 0:
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    n = 5
+    name = f"_live_all_{seed}"
+    mg.LOOP_CASES[name] = (sh, sw, n, kw)
+    try:
+        written = np.stack(mg.run_loop(name))
+    finally:
+        del mg.LOOP_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ro = oracle.RenderOracle(render_kwargs_to_params(sw, sh, **kw))
+    ro.new_clip()
+    got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
+    assert got.shape == written.shape, (got.shape, written.shape, kw)
+    assert np.array_equal(got, written), (seed, u8_diff_stats(got, written), kw)
