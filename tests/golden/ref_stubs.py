@@ -119,8 +119,12 @@ def _resize_area(src, dw, dh):
     sx, sy = 1.0 / (dw / sw), 1.0 / (dh / sh)   # hal::resize: scale = 1./inv_scale, inv_scale = (double)dsize/ssize
     isx, isy = int(round(sx)), int(round(sy))
     if sx >= 1 and sy >= 1 and abs(sx - isx) < 2.2e-16 * 4 and abs(sy - isy) < 2.2e-16 * 4:
-        # integer-ratio fast path: int sums * float(1/area) -> saturate_cast
+        # integer-ratio fast path: int sums * float(1/area) -> saturate_cast; the 2 x 2 ratio of 1- / 3- / 4-channel 8-bit images is
+        # ResizeAreaFastVec's fast_mode: (s00 + s01 + s10 + s11 + 2) >> 2, i.e. ties round UP where cvRound would round to even
+        # (modules/imgproc/src/resize.cpp; the oracle and k_sharp_mux / ff_epilogue have had that rule since round 1, this stand-in had not)
         a = src.astype(np.int64).reshape(dh, isy, dw, isx, -1).sum(axis=(1, 3))
+        if isx == 2 and isy == 2 and a.shape[-1] in (1, 3, 4):
+            return ((a + 2) >> 2).astype(np.uint8).reshape(dh, dw, *src.shape[2:])
         scale = np.float32(1.0 / (isx * isy))
         return _rne_u8(a.astype(np.float32) * scale)
     if sx < 1 or sy < 1:

@@ -393,7 +393,7 @@ def test_even_blur_ksize_window(ref, oracle, k):
             assert mx <= 1 and frac < 8e-3, (k, H, W, mx, frac)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(25))
 def test_render_loop_dof_slider_and_formats_exact_on_untailed_planes(ref, oracle, seed):
     """Round 4: the live reference's ``render_sbs_3d`` loop vs the oracle over the WHOLE DOF slider (0.1 ... 5.0: Gaussians of 3 to 21 taps, the
     strengths where MKL's vsExp is not the rounded exponential among them) in every output format incl. VR, on 16:9 frame sizes whose planes
@@ -431,13 +431,13 @@ def test_render_loop_dof_slider_and_formats_exact_on_untailed_planes(ref, oracle
     assert np.array_equal(got, written), (seed, fmt, (sh, sw), dof, u8_diff_stats(got, written))
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(20))
 def test_render_loop_every_control_exact_on_untailed_planes(ref, oracle, seed):
     """The live reference's ``render_sbs_3d`` loop vs the oracle with EVERY control the loop forwards drawn at random -- layer shifts, shift
     bound, zero-parallax strength, static / dynamic convergence, IPD factor, edge masking / feathering on and off, blur sizes 1 ... 13, feather
     strength, subject tracking, floating window, DOF, sharpening, colour grade, original-aspect preservation -- on 16:9 frames whose planes are
     multiples of 32 elements and whose eyes have H + W > 128 (the two ATen code paths the oracle does not restate: see the sweeps above), four
-    rendered frames each (trackers, EMAs and the floating bar evolve).  Bar: EXACT.  (30 seeds run with the suite; an offline run of seeds
+    rendered frames each (trackers, EMAs and the floating bar evolve).  Bar: EXACT.  (20 seeds run with the suite; an offline run of seeds
     0 ... 299 at the end of round 4: 300 of 300 exact.)"""
     import make_golden as mg
     from visiondepth3d_amd.params import render_kwargs_to_params
@@ -470,3 +470,52 @@ def test_render_loop_every_control_exact_on_untailed_planes(ref, oracle, seed):
     got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
     assert got.shape == written.shape, (got.shape, written.shape, kw)
     assert np.array_equal(got, written), (seed, u8_diff_stats(got, written), kw)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_blank_frame_loops_exact_on_untailed_planes(ref, oracle, seed):
+    """skip_blank_frames in the live reference's loop (blackdetect list injected: blank frames keep the SOURCE frame through sharpen / fit / mux
+    and freeze nothing -- the trackers still advance on them) on 16:9 frames with untailed planes and eyes of H + W > 128, every format incl.
+    output heights that differ from the source.  Bar: blank frames EXACT; rendered frames exact up to ONE known cause: the dynamic parallax
+    scale is built on float32 `mean` / `var` reductions, torch's value is that of its cascade sum (and above 32 K elements of its thread
+    partition), the oracle's the correctly rounded sum ("where no order is defined") -- on about one frame in 300 the
+    scale lands one float32 ULP apart (seed 6, frame 1: 0.92083001 / 0.92083007) and ONE eye sample flips by a level, which the sharpen
+    kernel spreads to two output samples.  Allowed: <= 4 samples of a rendered frame, <= 2 levels."""
+    import make_golden as mg
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    rng = np.random.default_rng(11500 + seed)
+    fmt = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph"][int(rng.integers(0, 4))]
+    sh, sw = [(108, 192), (144, 256)][int(rng.integers(0, 2))]
+    oh = [sh, sh, 72, 216][int(rng.integers(0, 4))]
+    kw = dict(output_format=fmt, output_height=oh, fg_shift=float(rng.uniform(2, 20)), mg_shift=float(rng.uniform(-6, 2)),
+              bg_shift=float(rng.uniform(-15, 0)), sharpness_factor=float(rng.uniform(0.0, 0.4)),
+              dof_strength=float([0.0, 2.0, 2.0, 3.0][int(rng.integers(0, 4))]), feather_strength=float(rng.uniform(0, 15)),
+              blur_ksize=int(rng.integers(0, 5)) * 2 + 1, use_subject_tracking=bool(rng.integers(0, 2)),
+              use_floating_window=bool(rng.integers(0, 2)), ipd_factor=float([1.0, 0.0, 1.2][int(rng.integers(0, 3))]),
+              skip_blank_frames=True)
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    n = 7
+    blank = sorted(set(int(v) for v in rng.integers(0, n - 1, size=int(rng.integers(1, 4)))))
+    name = f"_live_blank_x_{seed}"
+    mg.BLANK_CASES[name] = (sh, sw, n, blank, kw)
+    try:
+        written = np.stack(mg.run_blank_loop(name))
+    finally:
+        del mg.BLANK_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    try:
+        ro = oracle.RenderOracle(render_kwargs_to_params(sw, sh, **kw))
+        ro.new_clip()
+        got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1, blank=(i in blank)) for i, (f, d) in enumerate(list(zip(frames, depths))[1:])])
+    except NotImplementedError:
+        pytest.skip("a fit the oracle does not restate")
+    assert got.shape == written.shape, (got.shape, written.shape, kw)
+    if render_kwargs_to_params(sw, sh, **kw).eye_h + render_kwargs_to_params(sw, sh, **kw).eye_w <= 128:
+        pytest.skip("eyes of H + W <= 128: ATen's other bilinear kernel (test_aten_restatements.py)")
+    for i in range(len(got)):
+        d = np.abs(got[i].astype(np.int16) - written[i].astype(np.int16))
+        if i in blank:
+            assert not d.any(), (seed, i, u8_diff_stats(got[i], written[i]), kw)
+        else:
+            assert np.count_nonzero(d) <= 4 and d.max() <= 2, (seed, i, u8_diff_stats(got[i], written[i]), kw)
