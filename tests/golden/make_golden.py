@@ -581,6 +581,31 @@ def gen_real1080():
 # 11. the other output formats at REAL size: Full-SBS with preserve_original_aspect (eye = the 1920x1080 frame
 #     itself, identity resize: the most noise-sensitive case), Passive Interlaced, Red-Cyan Anaglyph.  Same storage as real1080.npz.
 # ------------------------------------------------------------------------------------------
+# 10b. BASELINE configs[2] at REAL size (round 4): one 3840x2160 clip (3 decoded frames -> 2 rendered), CLI defaults + DOF 2.0, Half-SBS at the
+#      source size.  24.9 MB per muxed frame: row bands, an 8x decimated copy, per-row / per-column sums and the SHA-256 of the whole frame.
+#      (~50 s of reference time on 8 threads.)
+# ------------------------------------------------------------------------------------------
+REAL4K_KW = dict(REAL_KW, output_height=2160)
+REAL4K_BANDS = [(0, 8), (536, 544), (1076, 1084), (1616, 1624), (2152, 2160)]
+
+
+def gen_real4k():
+    sh, sw, n = 2160, 3840, 3
+    written, _ = run_loop_capturing(sh, sw, n, REAL4K_KW)
+    out = {"kw_json": np.frombuffer(json.dumps(REAL4K_KW).encode(), dtype=np.uint8),
+           "bands_json": np.frombuffer(json.dumps(REAL4K_BANDS).encode(), dtype=np.uint8)}
+    for i, fr in enumerate(written):
+        assert fr.shape == (2160, 3840, 3)
+        out[f"bands_{i}"] = np.concatenate([fr[a:b] for a, b in REAL4K_BANDS])
+        out[f"rowsum_{i}"] = fr.astype(np.int64).sum(axis=1)
+        out[f"colsum_{i}"] = fr.astype(np.int64).sum(axis=0)
+        out[f"sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+        out[f"dec8_{i}"] = fr[::8, ::8].copy()
+    print(f"  real4k: {len(written)} frames")
+    save("real4k.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------
 _REAL_COMMON = dict(output_height=1080, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
                     feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
 REAL_FORMAT_CASES = {
@@ -621,11 +646,13 @@ def gen_heal():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k"]
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:
         gen_real1080()
+    if "real4k" in which:
+        gen_real4k()
     if "real1080_formats" in which:
         gen_real1080_formats()
     if "heal" in which:

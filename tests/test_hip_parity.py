@@ -495,6 +495,17 @@ def test_configs0_real_size_1080p_hip_vs_reference_fixture_and_oracle(R, oracle)
     assert np.array_equal(outs[0], ro.render(frames[0], dbgr[0], 1))
 
 
+def test_configs2_real_size_4k_hip_vs_reference_fixture(R):
+    """BASELINE configs[2] at real size through the C ABI: both rendered frames of the 3840x2160 clip equal the live reference's frames
+    (tests/golden/real4k.npz: SHA-256 of the whole frame, bands, decimated copy, row / column sums)."""
+    from test_oracle_vs_golden import real4k_check
+
+    def render(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
+    real4k_check(render, 2)
+
+
 def test_real_size_other_formats_hip_vs_reference_fixture_and_oracle(R, oracle):
     """Full-SBS (preserve), Passive Interlaced and Red-Cyan Anaglyph at 1920x1080 through the C ABI: against the live reference's
     frames (real1080_formats.npz) under the measured per-format ceilings of conftest.PARITY_BARS, and the first frame of every
