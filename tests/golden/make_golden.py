@@ -645,14 +645,47 @@ def gen_heal():
     save("heal.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 11b. The other output formats at 3840x2160 (round 4): Full-SBS with preserve_original_aspect (eyes = the frame itself), Passive Interlaced,
+#      Red-Cyan Anaglyph, VR (fractional 8/3 INTER_AREA into the 1440x1600 canvas).  Per frame: SHA-256 of the whole frame, row / column sums
+#      (int32) and two 4-row bands -- 50 s of reference time per format.
+# ------------------------------------------------------------------------------------------
+_REAL4K_COMMON = dict(_REAL_COMMON, output_height=2160)
+REAL4K_FORMAT_CASES = {
+    "full_sbs_preserve": dict(_REAL4K_COMMON, output_format="Full-SBS", preserve_original_aspect=True, original_video_width=3840,
+                              original_video_height=2160),
+    "interlaced": dict(_REAL4K_COMMON, output_format="Passive Interlaced"),
+    "anaglyph": dict(_REAL4K_COMMON, output_format="Red-Cyan Anaglyph"),
+    "vr": dict(_REAL4K_COMMON, output_format="VR"),
+}
+REAL4K_FORMAT_BANDS = [(0, 4), (-4, None)]
+
+
+def gen_real4k_formats():
+    sh, sw, n = 2160, 3840, 3
+    out = {"cases_json": np.frombuffer(json.dumps(REAL4K_FORMAT_CASES).encode(), dtype=np.uint8)}
+    for name, kw in REAL4K_FORMAT_CASES.items():
+        written, _ = run_loop_capturing(sh, sw, n, kw)
+        out[f"{name}__shape"] = np.array(written[0].shape, dtype=np.int64)
+        for i, fr in enumerate(written):
+            out[f"{name}__bands_{i}"] = np.concatenate([fr[a:b] for a, b in REAL4K_FORMAT_BANDS])
+            out[f"{name}__rowsum_{i}"] = fr.astype(np.int64).sum(axis=1).astype(np.int32)
+            out[f"{name}__colsum_{i}"] = fr.astype(np.int64).sum(axis=0).astype(np.int32)
+            out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+        print(f"  real4k {name}: {len(written)} frames of {written[0].shape}")
+    save("real4k_formats.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats"]
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:
         gen_real1080()
     if "real4k" in which:
         gen_real4k()
+    if "real4k_formats" in which:
+        gen_real4k_formats()
     if "real1080_formats" in which:
         gen_real1080_formats()
     if "heal" in which:

@@ -506,6 +506,17 @@ def test_configs2_real_size_4k_hip_vs_reference_fixture(R):
     real4k_check(render, 2)
 
 
+def test_real_size_4k_other_formats_hip_vs_reference_fixture(R):
+    """Full-SBS (preserve), Passive Interlaced, Red-Cyan Anaglyph and VR at 3840x2160 through the C ABI: both rendered frames of each equal the
+    live reference's (tests/golden/real4k_formats.npz: SHA-256 of the whole frame, row / column sums, bands)."""
+    from test_oracle_vs_golden import real4k_formats_check
+
+    def render(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
+    real4k_formats_check(render, 2)
+
+
 def test_real_size_other_formats_hip_vs_reference_fixture_and_oracle(R, oracle):
     """Full-SBS (preserve), Passive Interlaced and Red-Cyan Anaglyph at 1920x1080 through the C ABI: against the live reference's
     frames (real1080_formats.npz) under the measured per-format ceilings of conftest.PARITY_BARS, and the first frame of every
