@@ -661,10 +661,18 @@ REAL4K_FORMAT_CASES = {
 REAL4K_FORMAT_BANDS = [(0, 4), (-4, None)]
 
 
-def gen_real4k_formats():
+# DOF strengths beyond the fused finishing kernel's 9 taps at 3840x2160: 3.0 (13 taps) Half-SBS and the slider's maximum 5.0 (21 taps) as anaglyph
+REAL4K_DOF_CASES = {
+    "half_sbs_dof3": dict(_REAL4K_COMMON, output_format="Half-SBS", dof_strength=3.0),
+    "anaglyph_dof5": dict(_REAL4K_COMMON, output_format="Red-Cyan Anaglyph", dof_strength=5.0),
+}
+
+
+def gen_real4k_formats(cases=None, fname="real4k_formats.npz"):
+    cases = REAL4K_FORMAT_CASES if cases is None else cases
     sh, sw, n = 2160, 3840, 3
-    out = {"cases_json": np.frombuffer(json.dumps(REAL4K_FORMAT_CASES).encode(), dtype=np.uint8)}
-    for name, kw in REAL4K_FORMAT_CASES.items():
+    out = {"cases_json": np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)}
+    for name, kw in cases.items():
         written, _ = run_loop_capturing(sh, sw, n, kw)
         out[f"{name}__shape"] = np.array(written[0].shape, dtype=np.int64)
         for i, fr in enumerate(written):
@@ -673,11 +681,11 @@ def gen_real4k_formats():
             out[f"{name}__colsum_{i}"] = fr.astype(np.int64).sum(axis=0).astype(np.int32)
             out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
         print(f"  real4k {name}: {len(written)} frames of {written[0].shape}")
-    save("real4k_formats.npz", **out)
+    save(fname, **out)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof"]
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:
@@ -686,6 +694,8 @@ if __name__ == "__main__":
         gen_real4k()
     if "real4k_formats" in which:
         gen_real4k_formats()
+    if "real4k_dof" in which:
+        gen_real4k_formats(REAL4K_DOF_CASES, "real4k_dof.npz")
     if "real1080_formats" in which:
         gen_real1080_formats()
     if "heal" in which:

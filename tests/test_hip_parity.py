@@ -515,6 +515,9 @@ def test_real_size_4k_other_formats_hip_vs_reference_fixture(R):
         R.reset_state(); R.new_clip()
         return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
     real4k_formats_check(render, 2)
+    # DOF strengths beyond the fused finishing kernel's 9 taps at real size: 3.0 (13 taps, Half-SBS) and the slider's maximum 5.0 (21 taps,
+    # anaglyph) -- k_dof_grade4's instantiations and k_sharp_fit against the reference's own 4K frames (tests/golden/real4k_dof.npz)
+    real4k_formats_check(render, 2, fixture="real4k_dof.npz")
 
 
 def test_real_size_other_formats_hip_vs_reference_fixture_and_oracle(R, oracle):
