@@ -684,8 +684,51 @@ def gen_real4k_formats(cases=None, fname="real4k_formats.npz"):
     save(fname, **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 12. Random render_sbs_3d configurations at 1920x1080 (round 4): every control the loop forwards drawn at random (the generator of
+#     tests/test_oracle_vs_live_reference.py::test_render_loop_every_control_exact_on_untailed_planes), 12 configurations, two rendered frames
+#     each.  Stored: the keyword set, SHA-256 and row sums of every frame (a few KB) -- the frames themselves are reproduced, not kept.
+# ------------------------------------------------------------------------------------------
+def random_controls(seed, sh, sw):
+    rng = np.random.default_rng(9500 + seed)
+    fmt = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph", "VR"][int(rng.integers(0, 5))]
+    rng.integers(0, 2)   # (the small-size sweep draws its frame size here)
+    kw = dict(output_format=fmt, output_height=sh, fg_shift=float(rng.uniform(0, 30)), mg_shift=float(rng.uniform(-10, 5)),
+              bg_shift=float(rng.uniform(-25, 0)), sharpness_factor=float(rng.uniform(0.0, 0.6)),
+              dof_strength=float([0.0, 1.0, 2.0, 2.0, 3.3][int(rng.integers(0, 5))]), feather_strength=float(rng.uniform(0, 20)),
+              blur_ksize=int(rng.integers(0, 7)) * 2 + 1, use_subject_tracking=bool(rng.integers(0, 2)),
+              use_floating_window=bool(rng.integers(0, 2)), max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)),
+              zero_parallax_strength=float(rng.uniform(0, 0.03)) if rng.integers(0, 2) else 0.0,
+              enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+              convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+              ipd_factor=float([1.0, 0.0, 1.2, 0.8][int(rng.integers(0, 4))]),
+              color_saturation=float(rng.uniform(0.8, 1.4)), color_contrast=float(rng.uniform(0.9, 1.2)),
+              color_brightness=float(rng.uniform(-0.05, 0.05)))
+    if fmt == "Full-SBS" or rng.integers(0, 3) == 0:
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    return kw
+
+
+def gen_real1080_random(seeds=range(12)):
+    sh, sw, n = 1080, 1920, 3
+    cases = {f"seed{sd}": random_controls(sd, sh, sw) for sd in seeds}
+    out = {"cases_json": np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)}
+    for name, kw in cases.items():
+        LOOP_CASES[name] = (sh, sw, n, kw)
+        try:
+            written = run_loop(name)
+        finally:
+            del LOOP_CASES[name]
+        out[f"{name}__shape"] = np.array(written[0].shape, dtype=np.int64)
+        for i, fr in enumerate(written):
+            out[f"{name}__rowsum_{i}"] = fr.astype(np.int64).sum(axis=1).astype(np.int32)
+            out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+        print(f"  real1080 random {name}: {kw['output_format']}, {len(written)} frames of {written[0].shape}")
+    save("real1080_random.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random"]
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:
@@ -696,6 +739,8 @@ if __name__ == "__main__":
         gen_real4k_formats()
     if "real4k_dof" in which:
         gen_real4k_formats(REAL4K_DOF_CASES, "real4k_dof.npz")
+    if "real1080_random" in which:
+        gen_real1080_random()
     if "real1080_formats" in which:
         gen_real1080_formats()
     if "heal" in which:

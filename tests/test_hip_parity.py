@@ -520,6 +520,17 @@ def test_real_size_4k_other_formats_hip_vs_reference_fixture(R):
     real4k_formats_check(render, 2, fixture="real4k_dof.npz")
 
 
+def test_real_size_1080p_random_configurations_hip_vs_reference_fixture(R):
+    """Twelve random configurations of the render loop at 1920x1080 through the C ABI: every frame equals the live reference's
+    (tests/golden/real1080_random.npz: SHA-256 of the whole frame, row sums)."""
+    from test_oracle_vs_golden import real1080_random_check
+
+    def render(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
+    real1080_random_check(render)
+
+
 def test_real_size_other_formats_hip_vs_reference_fixture_and_oracle(R, oracle):
     """Full-SBS (preserve), Passive Interlaced and Red-Cyan Anaglyph at 1920x1080 through the C ABI: against the live reference's
     frames (real1080_formats.npz) under the measured per-format ceilings of conftest.PARITY_BARS, and the first frame of every
