@@ -709,8 +709,8 @@ def random_controls(seed, sh, sw):
     return kw
 
 
-def gen_real1080_random(seeds=range(12)):
-    sh, sw, n = 1080, 1920, 3
+def gen_real1080_random(seeds=range(12), sh=1080, sw=1920, fname="real1080_random.npz"):
+    n = 3
     cases = {f"seed{sd}": random_controls(sd, sh, sw) for sd in seeds}
     out = {"cases_json": np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)}
     for name, kw in cases.items():
@@ -724,11 +724,11 @@ def gen_real1080_random(seeds=range(12)):
             out[f"{name}__rowsum_{i}"] = fr.astype(np.int64).sum(axis=1).astype(np.int32)
             out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
         print(f"  real1080 random {name}: {kw['output_format']}, {len(written)} frames of {written[0].shape}")
-    save("real1080_random.npz", **out)
+    save(fname, **out)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random"]
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:
@@ -741,6 +741,8 @@ if __name__ == "__main__":
         gen_real4k_formats(REAL4K_DOF_CASES, "real4k_dof.npz")
     if "real1080_random" in which:
         gen_real1080_random()
+    if "real4k_random" in which:   # the same generator at 3840x2160: shifts up to 6 % of the width = 230 pixels, blur sizes up to 13
+        gen_real1080_random(seeds=(0, 2, 3, 8, 13), sh=2160, sw=3840, fname="real4k_random.npz")
     if "real1080_formats" in which:
         gen_real1080_formats()
     if "heal" in which:

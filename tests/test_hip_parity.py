@@ -529,6 +529,9 @@ def test_real_size_1080p_random_configurations_hip_vs_reference_fixture(R):
         R.reset_state(); R.new_clip()
         return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
     real1080_random_check(render)
+    # five more of the same generator at 3840x2160 (tests/golden/real4k_random.npz): layer shifts up to 127 pixels, blur sizes up to 13, a 15-tap DOF,
+    # VR, masking / feathering off -- the fused warp's chunk rule and the unfused fallbacks at real size against the reference's own 4K frames
+    real1080_random_check(render, fixture="real4k_random.npz", sh=2160, sw=3840)
 
 
 def test_real_size_other_formats_hip_vs_reference_fixture_and_oracle(R, oracle):
