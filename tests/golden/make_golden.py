@@ -727,8 +727,48 @@ def gen_real1080_random(seeds=range(12), sh=1080, sw=1920, fname="real1080_rando
     save(fname, **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 13. Black-bar auto crop at 1920x1080 (round 4): letterboxed clips (synth.letterbox_clip: dark bars with a little noise, one frame with a dark
+#     first content row) through render_sbs_3d with auto_crop_black_bars -- detection per frame, crop, re-fit.  SHA-256 + row sums per frame.
+# ------------------------------------------------------------------------------------------
+_LB_BASE = dict(output_height=1080, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0, feather_strength=10.0,
+                blur_ksize=9, use_subject_tracking=True, use_floating_window=True, auto_crop_black_bars=True)
+LETTERBOX_CASES = {
+    "half_sbs_140_140": (140, 140, dict(_LB_BASE, output_format="Half-SBS")),
+    "half_sbs_131_137": (131, 137, dict(_LB_BASE, output_format="Half-SBS")),
+    "full_sbs_138_138": (138, 138, dict(_LB_BASE, output_format="Full-SBS", preserve_original_aspect=True, original_video_width=1920,
+                                        original_video_height=1080)),
+    "anaglyph_100_60": (100, 60, dict(_LB_BASE, output_format="Red-Cyan Anaglyph")),
+}
+
+
+def gen_real1080_letterbox():
+    sh, sw, n = 1080, 1920, 3
+    out = {"cases_json": np.frombuffer(json.dumps(LETTERBOX_CASES).encode(), dtype=np.uint8)}
+    for name, (top, bottom, kw) in LETTERBOX_CASES.items():
+        frames, depth_bgr = synth.letterbox_clip(n, sh, sw, top, bottom)
+        ref_stubs._Clip.clips["in.mp4"] = frames
+        ref_stubs._Clip.clips["depth.mp4"] = depth_bgr
+        rl.reset_state()
+        args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0,
+                    output_width=sw, selected_aspect_ratio=_Aspect("Default (16:9)"), aspect_ratios=r.aspect_ratios,
+                    suspend_flag=threading.Event(), cancel_flag=threading.Event())
+        args.update(kw)
+        with contextlib.redirect_stdout(io.StringIO()) as so:
+            r.render_sbs_3d(**args)
+        if "crashed" in so.getvalue():
+            raise RuntimeError(so.getvalue())
+        written = ref_stubs._Clip.written["out.avi"]
+        out[f"{name}__shape"] = np.array(written[0].shape, dtype=np.int64)
+        for i, fr in enumerate(written):
+            out[f"{name}__rowsum_{i}"] = fr.astype(np.int64).sum(axis=1).astype(np.int32)
+            out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+        print(f"  letterbox {name}: {len(written)} frames of {written[0].shape}")
+    save("real1080_letterbox.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random", "real1080_letterbox"]
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:
@@ -741,6 +781,8 @@ if __name__ == "__main__":
         gen_real4k_formats(REAL4K_DOF_CASES, "real4k_dof.npz")
     if "real1080_random" in which:
         gen_real1080_random()
+    if "real1080_letterbox" in which:
+        gen_real1080_letterbox()
     if "real4k_random" in which:   # the same generator at 3840x2160: shifts up to 6 % of the width = 230 pixels, blur sizes up to 13
         gen_real1080_random(seeds=(0, 2, 3, 8, 13), sh=2160, sw=3840, fname="real4k_random.npz")
     if "real1080_formats" in which:

@@ -534,6 +534,17 @@ def test_real_size_1080p_random_configurations_hip_vs_reference_fixture(R):
     real1080_random_check(render, fixture="real4k_random.npz", sh=2160, sw=3840)
 
 
+def test_real_size_1080p_letterbox_auto_crop_hip_vs_reference_fixture(R):
+    """Black-bar auto crop at 1920x1080 through the C ABI (K0 k_autocrop per frame, crop, re-fit): four letterboxed clips, every frame equals
+    the live reference's (tests/golden/real1080_letterbox.npz: SHA-256 of the whole frame, row sums)."""
+    from test_oracle_vs_golden import real1080_letterbox_check
+
+    def render(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
+    real1080_letterbox_check(render)
+
+
 def test_real_size_other_formats_hip_vs_reference_fixture_and_oracle(R, oracle):
     """Full-SBS (preserve), Passive Interlaced and Red-Cyan Anaglyph at 1920x1080 through the C ABI: against the live reference's
     frames (real1080_formats.npz) under the measured per-format ceilings of conftest.PARITY_BARS, and the first frame of every
