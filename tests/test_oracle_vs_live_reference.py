@@ -519,3 +519,35 @@ def test_blank_frame_loops_exact_on_untailed_planes(ref, oracle, seed):
             assert not d.any(), (seed, i, u8_diff_stats(got[i], written[i]), kw)
         else:
             assert np.count_nonzero(d) <= 4 and d.max() <= 2, (seed, i, u8_diff_stats(got[i], written[i]), kw)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pixel_shift_random_parameters_exact_at_1080p(ref, oracle, seed):
+    """``pixel_shift_cuda`` (B1) at REAL size -- a 1920x1080 warp from a 960x540 eye (Half-SBS geometry) or from a same-size plane -- with every
+    keyword drawn at random (blur sizes 1 ... 13, shift bound 0.5 ... 6 % of the width, arbitrary ``depth_pop_gamma`` / ``depth_pop_mid`` /
+    ``parallax_balance``: SLEEF ``pow`` with exponents no fixture has, convergence modes, masking / feathering on and off): the float32 shift
+    map AND both eyes equal the live reference's EXACTLY, and so does the floating-window tracker's state.  (6 seeds with the suite; seeds
+    0 ... 323 offline at the end of round 4.)"""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    same = bool(rng.integers(0, 2))
+    H, W = 1080, 1920
+    ih, iw = (H, W) if same else (540, 960)
+    kw = dict(blur_ksize=int(rng.integers(0, 7)) * 2 + 1, feather_strength=float(rng.uniform(0, 20)),
+              use_subject_tracking=bool(rng.integers(0, 2)), enable_floating_window=bool(rng.integers(0, 2)),
+              max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)), zero_parallax_strength=float(rng.uniform(0, 0.03)),
+              enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+              convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+              depth_pop_gamma=float(rng.uniform(0.6, 1.3)), depth_pop_mid=float(rng.uniform(0.35, 0.65)),
+              parallax_balance=float(rng.uniform(0.5, 1.0)))
+    fg, mg, bg = float(rng.uniform(0, 30)), float(rng.uniform(-10, 5)), float(rng.uniform(-25, 0))
+    bgr, d = synth.synth_frame(seed, ih, iw)
+    ft = oracle.frame_to_tensor(bgr)
+    ref_loader.reset_state(ref)
+    with torch.no_grad():
+        rl, rr, rs = ref.pixel_shift_cuda(torch.from_numpy(ft), torch.from_numpy(d[None].copy()), W, H, fg, mg, bg, return_shift_map=True, **kw)
+    st = State()
+    o = oracle.pixel_shift(ft, d[None], W, H, ShiftParams.defaults(fg, mg, bg, **kw), st, want_shift=True)
+    assert st.fw_prev_offset == ref.floating_window_tracker.prev_offset, (seed, kw)
+    assert np.array_equal(o["shift"], rs.numpy()), (seed, int(np.count_nonzero(o["shift"] != rs.numpy())), kw)
+    assert np.array_equal(o["left"], np.asarray(rl)) and np.array_equal(o["right"], np.asarray(rr)), (seed, kw)
