@@ -69,6 +69,36 @@ def test_bilinear_interpolate_small_outputs_take_atens_other_kernel(oracle):
             assert np.array_equal(got, exp), (oh, ow)
 
 
+def test_bilinear_interpolate_small_output_kernel_general_downscale():
+    """The premultiplied form of ATen's small-output kernel for an arbitrary down-scale, for whoever restates it next (oracle + K1): taps and
+    lambdas as in the nested form (area_pixel_compute_source_index in float32), four weights w_ab = fl(h_a * w_b), and ONE chain
+    t = p01 * w01; t = fma(p00, w00, t); t = fma(p10, w10, t); t = fma(p11, w11, t) -- note the order: the second tap of the top row first."""
+    f32 = np.float32
+
+    def fma(a, b, c):   # exact products in float64; the double rounding of the sum is below 2^-29 per operation
+        return (np.float64(a) * np.float64(b) + np.float64(c)).astype(f32)
+
+    def taps(isz, osz):
+        scale = f32(isz) / f32(osz)
+        src = np.maximum((scale * (np.arange(osz, dtype=f32) + f32(0.5)) - f32(0.5)).astype(f32), f32(0))
+        i0 = src.astype(np.int64)
+        l1 = (src - i0.astype(f32)).astype(f32)
+        return i0, np.minimum(i0 + 1, isz - 1), (f32(1) - l1).astype(f32), l1
+    rng = np.random.default_rng(1)
+    for (ih, iw, oh, ow) in ((50, 70, 36, 64), (33, 47, 20, 31), (90, 160, 45, 80)):
+        x = rng.random((ih, iw)).astype(f32)
+        exp = F.interpolate(torch.from_numpy(x)[None, None], size=(oh, ow), mode="bilinear", align_corners=False)[0, 0].numpy()
+        y0, y1, h0, h1 = taps(ih, oh)
+        x0, x1, w0, w1 = taps(iw, ow)
+        p = {"00": x[y0][:, x0], "01": x[y0][:, x1], "10": x[y1][:, x0], "11": x[y1][:, x1]}
+        w = {"00": (h0[:, None] * w0[None, :]).astype(f32), "01": (h0[:, None] * w1[None, :]).astype(f32),
+             "10": (h1[:, None] * w0[None, :]).astype(f32), "11": (h1[:, None] * w1[None, :]).astype(f32)}
+        t = (p["01"] * w["01"]).astype(f32)
+        for k in ("00", "10", "11"):
+            t = fma(p[k], w[k], t)
+        assert np.array_equal(t, exp), (ih, iw, oh, ow, int(np.count_nonzero(t != exp)))
+
+
 @pytest.mark.parametrize("shape", [(72, 128), (108, 192), (270, 480)])
 def test_grid_sample_bilinear_border_align_corners(oracle, shape):
     """core/render_3d.py:697-701: the warp.  Grids built like the reference's (linspace mesh + a horizontal shift)."""
