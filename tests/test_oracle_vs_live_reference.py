@@ -19,6 +19,15 @@ import ref_loader  # noqa: E402
 pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
 
 
+def _sweep(n):
+    """Seeds of the exact live sweeps: n with the suite; VD3D_SWEEP_SEEDS="a:b" runs seeds a .. b-1 instead (offline runs, e.g. with -n 8)."""
+    e = os.environ.get("VD3D_SWEEP_SEEDS")
+    if e:
+        a, b = (int(v) for v in e.split(":"))
+        return range(a, b)
+    return range(n)
+
+
 @pytest.fixture(scope="module")
 def ref():
     import torch
@@ -393,7 +402,7 @@ def test_even_blur_ksize_window(ref, oracle, k):
             assert mx <= 1 and frac < 8e-3, (k, H, W, mx, frac)
 
 
-@pytest.mark.parametrize("seed", range(25))
+@pytest.mark.parametrize("seed", _sweep(25))
 def test_render_loop_dof_slider_and_formats_exact_on_untailed_planes(ref, oracle, seed):
     """Round 4: the live reference's ``render_sbs_3d`` loop vs the oracle over the WHOLE DOF slider (0.1 ... 5.0: Gaussians of 3 to 21 taps, the
     strengths where MKL's vsExp is not the rounded exponential among them) in every output format incl. VR, on 16:9 frame sizes whose planes
@@ -431,7 +440,7 @@ def test_render_loop_dof_slider_and_formats_exact_on_untailed_planes(ref, oracle
     assert np.array_equal(got, written), (seed, fmt, (sh, sw), dof, u8_diff_stats(got, written))
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", _sweep(20))
 def test_render_loop_every_control_exact_on_untailed_planes(ref, oracle, seed):
     """The live reference's ``render_sbs_3d`` loop vs the oracle with EVERY control the loop forwards drawn at random -- layer shifts, shift
     bound, zero-parallax strength, static / dynamic convergence, IPD factor, edge masking / feathering on and off, blur sizes 1 ... 13, feather
@@ -521,7 +530,7 @@ def test_blank_frame_loops_exact_on_untailed_planes(ref, oracle, seed):
             assert np.count_nonzero(d) <= 4 and d.max() <= 2, (seed, i, u8_diff_stats(got[i], written[i]), kw)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _sweep(6))
 def test_pixel_shift_random_parameters_exact_at_1080p(ref, oracle, seed):
     """``pixel_shift_cuda`` (B1) at REAL size -- a 1920x1080 warp from a 960x540 eye (Half-SBS geometry) or from a same-size plane -- with every
     keyword drawn at random (blur sizes 1 ... 13, shift bound 0.5 ... 6 % of the width, arbitrary ``depth_pop_gamma`` / ``depth_pop_mid`` /
