@@ -446,8 +446,8 @@ def test_render_loop_every_control_exact_on_untailed_planes(ref, oracle, seed):
     bound, zero-parallax strength, static / dynamic convergence, IPD factor, edge masking / feathering on and off, blur sizes 1 ... 13, feather
     strength, subject tracking, floating window, DOF, sharpening, colour grade, original-aspect preservation -- on 16:9 frames whose planes are
     multiples of 32 elements and whose eyes have H + W > 128 (the two ATen code paths the oracle does not restate: see the sweeps above), four
-    rendered frames each (trackers, EMAs and the floating bar evolve).  Bar: EXACT.  (20 seeds run with the suite; an offline run of seeds
-    0 ... 299 at the end of round 4: 300 of 300 exact.)"""
+    rendered frames each (trackers, EMAs and the floating bar evolve).  Bar: EXACT.  (20 seeds run with the suite; offline runs of seeds
+    0 ... 899 at the end of round 4: 900 of 900 exact.)"""
     import make_golden as mg
     from visiondepth3d_amd.params import render_kwargs_to_params
     rng = np.random.default_rng(9500 + seed)
