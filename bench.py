@@ -47,10 +47,19 @@ WORKLOADS = {
     "4k-dibr-anaglyph": (2160, 3840, None, "4K DIBR only, Red-Cyan Anaglyph output (fused finishing kernel since round 4)"),
     "4k-dibr-vr": (2160, 3840, None, "4K DIBR only, VR output (1440x1600 canvas per eye: a fractional 8/3 INTER_AREA fit + letterbox, which the fused "
                    "finishing kernel does not take: the unfused DOF + sharpen / fit / mux kernels run)"),
+    "1080p-gui-defaults": (1080, 1920, None, "1080p DIBR only with the GUI's OWN default configuration (VisionDepth3D.py:1405-1453: Full-SBS, fg 4.5 / mg -1.5 / "
+                           "bg -6, blur_ksize 1, feather_strength 0.0, sharpness 0.2, zero_parallax 0.01): feather_shift_edges is an exact no-op there, so W1 "
+                           "runs without the mask kernel, the window sums and the blend (round 5)"),
+    "4k-dibr-gui": (2160, 3840, None, "4K DIBR only with the GUI's default configuration (Full-SBS 7680x2160 output, feather_strength 0.0: the exact "
+                    "no-feather W1) -- the configuration in which north_star's HBM question about the warp kernel is meaningful"),
+    "4k-dibr-gui-hsbs": (2160, 3840, None, "4K DIBR only, GUI default controls with Half-SBS output (the 2:1 eye resize inside W1, no feathering)"),
 }
+GUI_KW = dict(output_format="Full-SBS", fg_shift=4.5, mg_shift=-1.5, bg_shift=-6.0, sharpness_factor=0.2, dof_strength=2.0, feather_strength=0.0,
+              blur_ksize=1, use_subject_tracking=True, use_floating_window=True, zero_parallax_strength=0.01)   # VisionDepth3D.py:1405-1453
 # render keyword overrides of the variants above (everything else: RENDER_KW)
 WORKLOAD_KW = {"4k-dibr-dof3": dict(dof_strength=3.0), "4k-dibr-anaglyph": dict(output_format="Red-Cyan Anaglyph"),
-               "4k-dibr-vr": dict(output_format="VR")}
+               "4k-dibr-vr": dict(output_format="VR"), "1080p-gui-defaults": GUI_KW, "4k-dibr-gui": GUI_KW,
+               "4k-dibr-gui-hsbs": dict(GUI_KW, output_format="Half-SBS")}
 HEADLINE = "4k-dav2b-dibr"
 RENDER_KW = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
                  feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)  # render_cli.py:24-33
@@ -145,7 +154,9 @@ def cpu_depth_net(model_name, sh, sw):
 class Env:
     """torch / distributed context shared by the workloads of one invocation"""
 
-    def __init__(self, args):
+    def __init__(self, args, cpu_only=False):
+        """cpu_only: gloo ranks on CPU tensors -- set only by the launcher / protocol test driver under tests/ (tests/bench_oracle_gloo.py), which
+        re-uses this class, `self_launch` and the record helpers; nothing in this file can select it."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -154,12 +165,12 @@ class Env:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != max(args.gpus, 1):
             raise SystemExit(f"WORLD_SIZE={self.world} but --gpus {args.gpus}")
-        self.oracle_gloo = args.backend == "oracle-gloo"
-        have_gpu = torch.cuda.is_available() and not self.oracle_gloo
+        self.cpu_only = bool(cpu_only)
+        have_gpu = torch.cuda.is_available() and not self.cpu_only
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl" if have_gpu else "gloo", rank=self.rank, world_size=self.world)
-        if not have_gpu and not self.oracle_gloo:
+        if not have_gpu and not self.cpu_only:
             if self.world > 1:
                 # no GPU here: prove that the launcher started every rank and that they can talk, then stop cleanly (exit code 0 so
                 # that "does `bench.py --gpus N` start N ranks" can be checked without hardware; there is still no CPU fallback)
@@ -176,13 +187,18 @@ class Env:
             if self.local_rank >= torch.cuda.device_count():
                 raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {torch.cuda.device_count()} GPUs are visible")
             torch.cuda.set_device(self.local_rank)
+        self.rank_pids = [os.getpid()]           # one process per rank: the record names them (config.rank_pids)
+        if self.world > 1:
+            seen = [None] * self.world
+            dist.all_gather_object(seen, (self.rank, os.getpid(), self.local_rank))
+            self.rank_pids = [p for _, p, _ in sorted(seen)]
 
     def fence(self):
-        if not self.oracle_gloo:
+        if not self.cpu_only:
             self.torch.cuda.synchronize()
         if self.world > 1:
             self.dist.barrier()
-        if not self.oracle_gloo:
+        if not self.cpu_only:
             self.torch.cuda.synchronize()
 
 
@@ -197,14 +213,18 @@ def _synth_cached(synth, t, sh, sw):
     return _CLIP_CACHE[k]
 
 
+_P1_WAIT_MIN = [None]
+
+
 def _p1_wait(env, sharders):
     """P1-chain wait per step (sharded.ChunkSharder.p1_wait_ms), the maximum over slot sets and ranks (rank 0 never waits inside a step)."""
     if not sharders or env.world == 1:
         return None
     v = max([s.p1_wait_ms() or 0.0 for s in sharders])
-    t = env.torch.tensor([v], dtype=env.torch.float64, device="cpu" if env.oracle_gloo else "cuda")
+    t = env.torch.tensor([v, -v], dtype=env.torch.float64, device="cpu" if env.cpu_only else "cuda")
     env.dist.all_reduce(t, op=env.dist.ReduceOp.MAX)
-    return round(float(t.item()), 4)
+    _P1_WAIT_MIN[0] = round(-float(t[1].item()), 4)     # the smallest per-rank figure (rank 0 never waits inside a step)
+    return round(float(t[0].item()), 4)
 
 
 def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_dtype: str = "f32", profile: bool = True,
@@ -497,10 +517,11 @@ def run_upscale_chain(env, args, steps=4, warmup=2, B=8):
                                      "avg_forward_ms": round(net_ms, 3), "library_only_forward_ms": round(lib_ms, 3)}}
 
 
-def self_launch(n):
+def self_launch(n, script=None):
     """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run, one rank per GPU of this
     node (rendezvous on 127.0.0.1, a free port; HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only does dmabuf IPC).  Rank 0 prints the
-    JSON line on the inherited stdout; the exit code is the launcher's."""
+    JSON line on the inherited stdout; the exit code is the launcher's.  `script`: the file to re-execute (default: this one; the protocol
+    test driver under tests/ launches itself through the same code)."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -508,65 +529,8 @@ def self_launch(n):
         port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(script or __file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
-
-
-def run_oracle_gloo(env, args, sh=72, sw=128):
-    """TEST MODE (--backend oracle-gloo; tests/test_bench_launcher.py): the launcher, the clip layout, the chunked step protocol
-    (visiondepth3d_amd.sharded.ChunkSharder: point-to-point plane hand-off + two record all-gathers) and the barrier / max-over-ranks timing
-    of the GPU benchmark, with tests/oracle_chunk.OracleChunkBackend (the CPU oracle) as the sharder's backend over gloo on a tiny clip.
-    Proves without hardware that `bench.py --gpus N` runs N cooperating ranks; NOT a benchmark result and labelled as such."""
-    torch, dist = env.torch, env.dist
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_chunk import OracleChunkBackend          # test infrastructure (imports oracle/)
-    from visiondepth3d_amd import synth
-    from visiondepth3d_amd.params import render_kwargs_to_params
-    from visiondepth3d_amd.sharded import ChunkSharder
-    torch.set_num_threads(1)
-    B, world, rank = min(args.batch, 2), env.world, env.rank
-    p = render_kwargs_to_params(sw, sh, output_height=sh, **RENDER_KW)
-    be = OracleChunkBackend(p)
-    shr = ChunkSharder(be, rank, world, B)
-    be.new_clip()
-    nsteps = args.warmup + args.steps
-    clip = {}
-    for k in range(nsteps):
-        for j in range(B):
-            t = k * world * B + rank * B + j
-            f, d = synth.synth_frame(t, sh, sw)
-            clip[(k, j)] = (torch.from_numpy(f), torch.from_numpy(synth.depth_to_u8_bgr(d)[..., 0].copy()))
-    sums = {}
-
-    def step(k):
-        fl = [clip[(k, j)][0] for j in range(B)]
-        dl = [clip[(k, j)][1] for j in range(B)]
-        return shr.render_step(fl, dl, first_step=(k == 0), more_steps=(k + 1 < nsteps))
-    for k in range(args.warmup):
-        step(k)
-    env.fence()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, nsteps):
-        for j, o in enumerate(step(k)):   # a checksum per muxed frame, keyed by the frame's index in the clip
-            sums[k * world * B + rank * B + j] = int(o.numpy().astype(np.uint64).sum()) * 31 + int(o.numpy()[::3, ::5].astype(np.uint64).sum())
-    env.fence()
-    dt = time.perf_counter() - t0
-    parts = [sums]
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        parts = [None] * world
-        dist.all_gather_object(parts, sums)
-    sums = {str(t): v for part in parts for t, v in part.items()}
-    return {"metric": "stereo-pairs/sec end-to-end (depth+warp+fill+mux)", "value": round(world * args.steps * B / dt, 3), "unit": "stereo-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "TEST MODE: CPU oracle backend over gloo on a tiny synthetic clip -- launcher / protocol check, not a benchmark result",
-            "config": {"workload": f"oracle-gloo-{sw}x{sh}", "frames_per_step": B, "rccl_ranks": None, "gloo_ranks": world,
-                       "comm_per_step_per_rank": shr.bytes_per_step(), "clip_layout": "one clip, contiguous chunks of frames_per_step per rank and step",
-                       "p1_chain_wait_ms_per_step": _p1_wait(env, [shr])},
-            "frame_checksums": dict(sorted(sums.items(), key=lambda kv: int(kv[0])))}
 
 
 def copy_yardstick(env):
@@ -722,22 +686,11 @@ def main():
     ap.add_argument("--upscale-only", action="store_true", help="measure only the configs[4] sub-record (1080p depth + DIBR + Real-ESRGAN x4)")
     ap.add_argument("--chain-serial", action="store_true", help="configs[4] sub-record: depth, DIBR and the up-scale net on ONE stream (default: the up-scale "
                     "net of a batch on a second stream behind depth + DIBR of the next)")
-    ap.add_argument("--backend", default="hip", choices=("hip", "oracle-gloo"),
-                    help="hip: the product (libvd3d_hip.so, nccl = RCCL for --gpus > 1).  oracle-gloo: TEST MODE for tests/test_bench_launcher.py -- "
-                    "the same rank launcher, clip layout, step protocol and record assembly with the CPU oracle as the sharder's backend over gloo on a "
-                    "tiny clip; its line is labelled and is never a benchmark result")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))   # `python bench.py --gpus N` starts its own N ranks (one per GPU)
     env = Env(args)
-    if env.oracle_gloo:
-        rec = run_oracle_gloo(env, args)
-        if env.rank == 0:
-            print(json.dumps(rec), flush=True)
-        if env.world > 1:
-            env.dist.destroy_process_group()
-        return
     if args.upscale_only:
         print(json.dumps(run_upscale_chain(env, args)), flush=True)
         return
@@ -800,6 +753,8 @@ def main():
                        "distinct_frames_per_rank": head.get("clip"), "clip_frames_all_ranks": head.get("clip_frames_global"),
                        "clip_layout": "one clip, contiguous chunks of frames_per_step per rank and step" if env.world > 1 else None,
                        "p1_chain_wait_ms_per_step": head.get("p1_wait_ms") if env.world > 1 else None,
+                       "p1_chain_wait_ms_per_step_min_max": ([_P1_WAIT_MIN[0], head.get("p1_wait_ms")] if env.world > 1 else None),
+                       "rank_pids": env.rank_pids if env.world > 1 else None,
                        "params": "render_cli.py defaults + dof_strength 2.0; DOF levels in the reference's dense convolution order (parity mode)"},
         }
         hr = rooflines(head, copy_gbs)

@@ -270,6 +270,50 @@ def test_render_frame_f32_depth_and_collapse(R, oracle):
         assert np.array_equal(got, exp), (i, u8_diff_stats(got, exp))
 
 
+KW_GUI = dict(output_format="Full-SBS", fg_shift=4.5, mg_shift=-1.5, bg_shift=-6.0, sharpness_factor=0.2, dof_strength=2.0, feather_strength=0.0,
+              blur_ksize=1, use_subject_tracking=True, use_floating_window=True, zero_parallax_strength=0.01)   # VisionDepth3D.py:1405-1453
+
+
+@pytest.mark.parametrize("fmt,size,fs,k", [("Full-SBS", (108, 192), 0.0, 1), ("Full-SBS", (270, 480), 0.0, 9), ("Half-SBS", (216, 384), 0.0, 1),
+                                           ("Passive Interlaced", (108, 192), -3.0, 5), ("Red-Cyan Anaglyph", (144, 256), 0.0, 3),
+                                           ("Half-SBS", (1080, 1920), 0.0, 1), ("Full-SBS", (1080, 1920), 0.0, 1)])
+def test_feather_strength_zero_takes_the_exact_no_feather_warp(R, oracle, fmt, size, fs, k):
+    """Round 5: with feather_strength <= 0 feather_shift_edges (core/render_3d.py:328-374) is an exact no-op, so the library warps without the
+    mask kernel, the window sums and the blend (vd3d_api.hip::warp_stage_params) -- the GUI's own default configuration (VisionDepth3D.py:1405-1453).
+    The oracle still goes the long way (and equals the live reference there: tests/test_oracle_vs_live_reference.py::
+    test_render_loop_feather_strength_zero_exact); vd3d_debug_tune(4, 1) makes the library go the long way too.  All three: identical bytes, on
+    the per-frame entry point and on the batched step path."""
+    from visiondepth3d_amd import _lib
+    sh, sw = size
+    kw = dict(KW_GUI, output_format=fmt, output_height=sh, feather_strength=fs, blur_ksize=k)
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    n = 3 if sh >= 1080 else 5
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    exp = [ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in zip(frames, depths)]
+    outs = {}
+    try:
+        for long_way in (0, 1):
+            _lib.check(_lib.lib().vd3d_debug_tune(4, long_way))
+            R.reset_state(); R.new_clip()
+            outs[long_way] = [R.render_frame(T(f), T(synth.depth_to_u8_bgr(d)), p).cpu().numpy() for f, d in zip(frames, depths)]
+    finally:
+        _lib.check(_lib.lib().vd3d_debug_tune(4, 0))
+    for i in range(n):
+        assert np.array_equal(outs[0][i], exp[i]), (i, u8_diff_stats(outs[0][i], exp[i]))
+        assert np.array_equal(outs[1][i], exp[i]), (i, "long way", u8_diff_stats(outs[1][i], exp[i]))
+    # the batched step path (render_pairs -> ChunkSharder at world 1 -> vd3d_shard_pixels) takes the same decision
+    from visiondepth3d_amd.render_3d import render_pairs
+    R.reset_state()
+    kw_pairs = {k_: v for k_, v in kw.items()}
+    got = list(render_pairs(zip(frames, [synth.depth_to_u8_bgr(d) for d in depths]), renderer=R, skip_first=False, batch=2, **kw_pairs))
+    assert len(got) == n
+    for i in range(n):
+        assert np.array_equal(got[i], exp[i]), (i, "step path", u8_diff_stats(got[i], exp[i]))
+
+
 KW_CLI = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
               feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
 

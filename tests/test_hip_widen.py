@@ -371,6 +371,17 @@ def test_format_3d_output_and_linear_resize(R, oracle):
         exp = oracle.format_output(L, Rr, code)
         assert got.shape == exp.shape and np.array_equal(got, exp), name
     assert np.array_equal(R.format_3d_output(T(L), T(Rr), "no such format").cpu().numpy(), np.hstack((L, Rr)))   # :860 fallback
+    # eye sizes at which the render loop's pad_to_aspect_ratio would truncate int(w / h * h) to w - 1 (about one size in twenty): format_3d_output has
+    # no such step -- np.hstack / row interleave / the anaglyph mix of the eyes as they are (the last column came out black)
+    for (eh, ew) in ((7, 61), (7, 115), (804, 1920), (800, 854)):
+        assert int((ew / eh) * eh) == ew - 1, (eh, ew)
+        Lt = rng.integers(1, 256, (eh, ew, 3), dtype=np.uint8)
+        Rt = rng.integers(1, 256, (eh, ew, 3), dtype=np.uint8)
+        for name, code in (("Half-SBS", 0), ("Full-SBS", 1), ("Red-Cyan Anaglyph", 3), ("Passive Interlaced", 4)):
+            got = R.format_3d_output(T(Lt), T(Rt), name).cpu().numpy()
+            exp = oracle.format_output(Lt, Rt, code)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (name, eh, ew)
+        assert np.array_equal(R.format_3d_output(T(Lt), T(Rt), "Full-SBS").cpu().numpy(), np.hstack((Lt, Rt)))
     Lv = rng.integers(0, 256, (1600, 1440, 3), dtype=np.uint8)
     assert np.array_equal(R.format_3d_output(T(Lv), T(Lv[::-1].copy()), "VR").cpu().numpy(), np.hstack((Lv, Lv[::-1])))   # identity resize
     for (sh, sw), (dh, dw) in (((90, 160), (1600, 1440)), ((270, 480), (135, 240)), ((37, 53), (80, 31)), ((64, 64), (64, 64)), ((5, 7), (11, 3))):

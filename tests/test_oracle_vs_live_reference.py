@@ -560,3 +560,39 @@ def test_pixel_shift_random_parameters_exact_at_1080p(ref, oracle, seed):
     assert st.fw_prev_offset == ref.floating_window_tracker.prev_offset, (seed, kw)
     assert np.array_equal(o["shift"], rs.numpy()), (seed, int(np.count_nonzero(o["shift"] != rs.numpy())), kw)
     assert np.array_equal(o["left"], np.asarray(rl)) and np.array_equal(o["right"], np.asarray(rr)), (seed, kw)
+
+
+GUI_DEFAULTS = dict(output_format="Full-SBS", fg_shift=4.5, mg_shift=-1.5, bg_shift=-6.0, sharpness_factor=0.2, dof_strength=2.0,
+                    feather_strength=0.0, blur_ksize=1, use_subject_tracking=True, use_floating_window=True, max_pixel_shift_percent=0.02,
+                    auto_crop_black_bars=True, parallax_balance=0.8, zero_parallax_strength=0.01, enable_edge_masking=True,
+                    enable_feathering=True, convergence_strength=0.0, enable_dynamic_convergence=True)   # VisionDepth3D.py:1405-1453
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_render_loop_feather_strength_zero_exact(ref, oracle, case):
+    """Round 5: the GUI's own default configuration (VisionDepth3D.py:1405-1453: feather_strength 0.0, blur_ksize 1, Full-SBS) and its neighbours
+    (feather 0 behind a 9 x 9 window, a NEGATIVE strength, other formats) against the live reference's ``render_sbs_3d`` loop.  With a strength
+    <= 0 ``feather_shift_edges`` (core/render_3d.py:328-374) is an exact no-op -- clamp(grad * fs, 0, 1) = 0, its window average 0, shifted * 1 +
+    original * 0 -- which the HIP library exploits by not running the mask, window-sum and blend kernels at all (vd3d_api.hip::warp_stage_params;
+    tests/test_hip_parity.py::test_feather_strength_zero_takes_the_exact_no_feather_warp compares that path with THIS oracle, which still goes the
+    long way).  Bar: EXACT."""
+    import make_golden as mg
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    fmt, (sh, sw), fs, k = [("Full-SBS", (108, 192), 0.0, 1), ("Full-SBS", (144, 256), 0.0, 9), ("Half-SBS", (108, 192), 0.0, 1),
+                            ("Passive Interlaced", (108, 192), -3.0, 5), ("Red-Cyan Anaglyph", (144, 256), 0.0, 3), ("VR", (108, 192), 0.0, 1)][case]
+    kw = dict(GUI_DEFAULTS, output_format=fmt, output_height=sh, feather_strength=fs, blur_ksize=k)
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    n = 4
+    name = f"_live_feather0_{case}"
+    mg.LOOP_CASES[name] = (sh, sw, n, kw)
+    try:
+        written = np.stack(mg.run_loop(name))
+    finally:
+        del mg.LOOP_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ro = oracle.RenderOracle(render_kwargs_to_params(sw, sh, **kw))
+    ro.new_clip()
+    got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
+    assert got.shape == written.shape, (got.shape, written.shape, kw)
+    assert np.array_equal(got, written), (case, fmt, (sh, sw), u8_diff_stats(got, written))

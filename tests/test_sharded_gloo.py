@@ -1,9 +1,11 @@
-"""Multi-process CPU tests (gloo, world_size 2 and 3) of the chunked frame-sharding protocol (visiondepth3d_amd.sharded.ChunkSharder)
+"""Multi-process CPU tests (gloo, world_size 2, 3 and -- round 5 -- 8) of the chunked frame-sharding protocol (visiondepth3d_amd.sharded.ChunkSharder)
 with the CPU ORACLE as backend (tests/oracle_chunk.py): the real point-to-point plane hand-off, the two all-gathers and the final
 broadcast run over gloo, every stage computes real numbers, and the sharded clip must equal the sequential oracle render BIT FOR
 BIT -- muxed frames, final tracker state and final plane state on every rank.  The clip has a partial last step
 (one rank with a short chunk, with world 3 also ranks that only forward the plane) and a skip_blank_frames hit.  The same
-orchestrator drives the HIP backend over RCCL on the GPU box (bench.py --gpus N)."""
+orchestrator drives the HIP backend over RCCL on the GPU box (bench.py --gpus N).  World 8 (the size of the driver's SCALE run): 19 frames in
+chunks of 2 (one full step of 16 + a last step in which rank 0 owns two frames, rank 1 one and ranks 2 .. 7 only forward the plane) and 11
+frames in chunks of 1, each with blank frames and collapsing depth frames in BOTH steps."""
 import os
 import socket
 
@@ -25,10 +27,16 @@ STATE_FIELDS = ("fw_prev_offset", "fw_frame_counter", "ema_valid", "ema_lo", "em
                 "focal_valid", "smooth_valid", "focal", "sm_fg", "sm_mg", "sm_bg", "tdf_valid", "prev_depth_valid")
 
 
-def _clip():
-    frames, depths = synth.synth_clip(NF, SH, SW)
+def _blank(nf):
+    return BLANK | ({nf - 2} if nf > 8 else set())                     # longer clips: a blank frame in the last (partial) step too
+
+
+def _clip(nf=NF):
+    frames, depths = synth.synth_clip(nf, SH, SW)
     gray = [synth.depth_to_u8_bgr(d)[..., 0].copy() for d in depths]   # uint8 [h,w] depth planes
     gray[4][:] = 90                                                    # a collapsing depth frame (DepthPercentileEMA guard)
+    if nf > 8:
+        gray[nf - 1][:] = 31                                           # ... and one as the clip's last frame (a short chunk of the last step)
     return frames, gray
 
 
@@ -36,16 +44,17 @@ def _state_vec(st):
     return np.array([float(getattr(st, k)) for k in STATE_FIELDS], np.float64)
 
 
-def _sequential(oracle):
-    frames, gray = _clip()
+def _sequential(oracle, nf=NF):
+    frames, gray = _clip(nf)
     p = render_kwargs_to_params(SW, SH, **KW)
     ro = oracle.RenderOracle(p)
     ro.new_clip()
-    seq = [ro.render(f, g, 2, blank=(t in BLANK)) for t, (f, g) in enumerate(zip(frames, gray))]
+    blank = _blank(nf)
+    seq = [ro.render(f, g, 2, blank=(t in blank)) for t, (f, g) in enumerate(zip(frames, gray))]
     return seq, _state_vec(ro.state), ro.tdf_prev.copy()
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, nf=NF, b=B):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -55,12 +64,12 @@ def _worker(rank, world, port, outdir):
         from oracle_chunk import OracleChunkBackend
         from visiondepth3d_amd.sharded import ChunkSharder
         torch.set_num_threads(1)
-        frames, gray = _clip()
+        frames, gray = _clip(nf)
         p = render_kwargs_to_params(SW, SH, **KW)
         be = OracleChunkBackend(p)
-        sr = ChunkSharder(be, rank, world, B)
+        sr = ChunkSharder(be, rank, world, b)
         got = {}
-        for t, out in sr.render_clip(NF, lambda t: torch.from_numpy(frames[t]), lambda t: torch.from_numpy(gray[t]), blank_frames=BLANK):
+        for t, out in sr.render_clip(nf, lambda t: torch.from_numpy(frames[t]), lambda t: torch.from_numpy(gray[t]), blank_frames=_blank(nf)):
             got[t] = out.numpy()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **{str(k): v for k, v in got.items()})
         np.save(os.path.join(outdir, f"state{rank}.npy"), _state_vec(be.state))
@@ -77,19 +86,22 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_chunk_sharding_over_gloo_equals_sequential(tmp_path, oracle, world):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    seq, st_seq, plane_seq = _sequential(oracle)
+@pytest.mark.parametrize("world,nf,b", [(2, NF, B), (3, NF, B), (8, 19, 2), (8, 11, 1)])
+def test_chunk_sharding_over_gloo_equals_sequential(tmp_path, oracle, world, nf, b):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nf, b), nprocs=world, join=True)
+    seq, st_seq, plane_seq = _sequential(oracle, nf)
     owned = {}
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")
         for k in z.files:
             t = int(k)
-            assert (t % (world * B)) // B == r          # contiguous chunks: frame t of a step belongs to rank t // B
+            assert (t % (world * b)) // b == r          # contiguous chunks: frame t of a step belongs to rank t // B
             owned[t] = z[k]
-    assert sorted(owned) == list(range(NF))
-    for t in range(NF):
+    if world == 8:   # the last step is partial: ranks that own nothing in it only forward the plane, and still end in the sequential state (below)
+        last = {(t % (world * b)) // b for t in range((nf // (world * b)) * world * b, nf)}
+        assert 0 < len(last) < world
+    assert sorted(owned) == list(range(nf))
+    for t in range(nf):
         assert np.array_equal(owned[t], seq[t]), t
     for r in range(world):   # every rank ends in the sequential render's tracker AND plane state
         assert np.array_equal(np.load(tmp_path / f"state{r}.npy"), st_seq), r

@@ -55,6 +55,7 @@ struct vd3d_ctx {
   uint32_t* mm = nullptr; int mm_cap = 0;
   uint32_t* rowflag = nullptr; int rowflag_cap = 0;   // k_autocrop: one flag per source row
   uint8_t* blank_eye = nullptr; size_t blank_cap = 0; // skip_blank_frames: the side-masked source frame (source size)
+  uint8_t* fmt_eyes = nullptr; size_t fmt_cap = 0;    // vd3d_format_3d_output's own pair of resized VR eyes (never the shared warp-res planes: ADVICE r4)
   bool crop_scalars_dirty = false;                    // fs.crop_top/bottom hold a previous auto-crop result
   // frame sharding (three-phase protocol): per-slot planes of the frames this rank owns inside the current step
   int n_slots = 0, slot_eh = 0, slot_ew = 0, slot_H = 0, slot_W = 0;
@@ -244,7 +245,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->fmt_eyes};
   for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
   for (auto& t : c->wk_tabs) (void)hipFree(t.dev);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -355,6 +356,19 @@ static int check_shift_params(const vd3d_shift_params* p, int H, int W) {
   return 0;
 }
 
+// The shift parameters as the WARP stage sees them.  feather_shift_edges (core/render_3d.py:328-374) with feather_strength <= 0 is an exact no-op:
+// edge_mask = clamp(grad * fs, 0, 1) = 0 everywhere (the gradient magnitude is a finite non-negative number), its k x k average is 0, and
+// shifted * (1 - 0) + original * 0 = shifted (the samples are non-negative, so no signed zero survives; the final clamp(0, 1) only touches values the
+// uint8 conversion of tensor_to_frame maps to the same byte) -- so the mask kernel (k_e2w), the window sums and the blend are not run at all.  This is
+// the GUI's own default configuration (VisionDepth3D.py:1405-1453: feather_strength 0.0, blur_ksize 1).  k_shift keeps the caller's feather_strength:
+// suppress_artifacts_with_edge_mask uses it on its own (:204-216).  vd3d_debug_tune(4, 1) keeps the long way (A/B, tests).
+static int g_feather0_long = 0;
+static vd3d_shift_params warp_stage_params(const vd3d_shift_params& sp) {
+  vd3d_shift_params w = sp;
+  if (w.enable_feathering && w.feather_strength <= 0.0 && !g_feather0_long) w.enable_feathering = 0;
+  return w;
+}
+
 // the context's own planes and control block as a batch of one frame (sequential entry points)
 static vd_batch batch_of_one(vd3d_ctx* c) {
   vd_batch b;
@@ -378,18 +392,19 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     vd_launch_chain_work(s, b, a.have_eye, ih, iw, H, W, (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, a);
   }
   if (!skip_pixels) { StageTimer t(c, "warp");
-    const bool pre = sp.enable_feathering && vd_warp_fused_ok(ih, iw, H, W, sp);   // k_e2w -> W1 (see shard_pixels_impl)
+    const vd3d_shift_params spw = warp_stage_params(sp);   // feather_strength <= 0: the exact no-feather kernels
+    const bool pre = spw.enable_feathering && vd_warp_fused_ok(ih, iw, H, W, spw);   // k_e2w -> W1 (see shard_pixels_impl)
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
     bool fused = false;
     { StageTimer t2(c, "w1");
-      if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->D, c->S, H, W, (float)sp.feather_strength, c->E2); }
-      fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, sp, c->L, c->R, pre ? c->E2 : nullptr); }
+      if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->D, c->S, H, W, (float)spw.feather_strength, c->E2); }
+      fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, spw, c->L, c->R, pre ? c->E2 : nullptr); }
     if (!fused) {   // blur sizes / frame sizes the fused kernel refuses (its LDS tile would not fit): one stage per kernel
-    if (sp.enable_feathering) {
-      vd_launch_e2(s, c->D, c->S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
-      vd_launch_pool(s, c->e2L, c->e2R, H, W, sp.blur_ksize, c->bL, c->bR);
+    if (spw.enable_feathering) {
+      vd_launch_e2(s, c->D, c->S, H, W, (float)spw.feather_strength, c->e2L, c->e2R);
+      vd_launch_pool(s, c->e2L, c->e2R, H, W, spw.blur_ksize, c->bL, c->bR);
     }
-    vd_launch_warp(s, rgb, ih, iw, c->S, c->bL, c->bR, H, W, sp.enable_feathering ? 1 : 0, c->L, c->R);
+    vd_launch_warp(s, rgb, ih, iw, c->S, c->bL, c->bR, H, W, spw.enable_feathering ? 1 : 0, c->L, c->R);
     }
   }
   HIPCHK(hipGetLastError());
@@ -458,16 +473,18 @@ static float host_sum_aten(const float* v, int n) {
 // library's fused multiply-add rounds toward zero onto a positive shifter), r = x - t ln 2 in two fused steps, a degree-3 polynomial tail.
 static float host_exp_torch(float x) {
   if (!(fabsf(x) < 87.0f)) return (float)exp((double)x);   // the library's special-case path is not restated (never reached: x in [-8.5, 0])
-  static float th[32], tl[32];
-  static bool init = false;
-  if (!init) {
-    for (int j = 0; j < 32; ++j) {
-      const long double v = exp2l((long double)j / 32.0L);
-      th[j] = (float)v;
-      tl[j] = (float)((v - (long double)th[j]) / (long double)th[j]);
+  struct exp_tabs {   // function-local static of class type: C++11 initialises it once, thread-safely (one context per thread is a supported pattern)
+    float th[32], tl[32];
+    exp_tabs() {
+      for (int j = 0; j < 32; ++j) {
+        const long double v = exp2l((long double)j / 32.0L);
+        th[j] = (float)v;
+        tl[j] = (float)((v - (long double)th[j]) / (long double)th[j]);
+      }
     }
-    init = true;
-  }
+  };
+  static const exp_tabs tabs;
+  const float* th = tabs.th; const float* tl = tabs.tl;
   union { uint32_t u; float f; } c;
   c.u = 0x3fb8aa3bu; const float l2e = c.f;            // log2(e) as the library rounds it
   c.u = 0x3f317218u; const float ln2_hi = c.f;         // ln 2 = ln2_hi - 1.9046542e-09
@@ -802,6 +819,15 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
   vd_finish_consts fc;
   if ((rc = make_finish_consts(p, &fc))) return rc;
   HIPCHK(hipSetDevice(c->device));
+  if (p->warp_h != c->slot_H || p->warp_w != c->slot_W || p->eye_h != c->slot_eh || p->eye_w != c->slot_ew)
+    return set_err(VD3D_E_INVALID, "vd3d_shard_pixels: %dx%d (eye %dx%d) is not the size of vd3d_shard_begin (%dx%d, eye %dx%d)", p->warp_w, p->warp_h,
+                   p->eye_w, p->eye_h, c->slot_W, c->slot_H, c->slot_ew, c->slot_eh);
+  if (c->H != p->warp_h || c->W != p->warp_w) {
+    // another entry point (vd3d_pixel_shift / vd3d_render_frame at another size) re-sized the context's shared warp-res planes since
+    // vd3d_shard_begin: bring them back before a pixel pass writes H x W planes into them (hipFree synchronises the device)
+    if ((rc = join_pixels(c))) return rc;
+    if ((rc = ensure_work(c, p->warp_h, p->warp_w))) return rc;
+  }
   // overlapped mode: this pass runs on pix_stream behind everything enqueued on the main stream so far (the slot's measurements and
   // the replay that patched its constants); the main stream is free to start the next step's measurement chain meanwhile
   struct StreamSwap {
@@ -857,19 +883,20 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
   } else {
   { StageTimer t(c, "warp");
     // fused path with feathering: k_e2w writes the gradient mask of both eyes, W1 starts at its window sums
-    const bool pre = sp.enable_feathering && vd_warp_fused_ok(p->eye_h, p->eye_w, H, W, sp);
+    const vd3d_shift_params spw = warp_stage_params(sp);   // feather_strength <= 0 (the GUI's default): W1 without mask, window sums and blend -- exact
+    const bool pre = spw.enable_feathering && vd_warp_fused_ok(p->eye_h, p->eye_w, H, W, spw);
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
     bool fused;
     { StageTimer t2(c, "w1");
-      if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->slot_D[slot], S, H, W, (float)sp.feather_strength, E2); }
-      fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], S, H, W, sp, L, R, pre ? E2 : nullptr); }
+      if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->slot_D[slot], S, H, W, (float)spw.feather_strength, E2); }
+      fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], S, H, W, spw, L, R, pre ? E2 : nullptr); }
     if (!fused) {
       if ((rc = pix_exclusive(c))) return rc;
-      if (sp.enable_feathering) {
-        vd_launch_e2(s, c->slot_D[slot], S, H, W, (float)sp.feather_strength, c->e2L, c->e2R);
-        vd_launch_pool(s, c->e2L, c->e2R, H, W, sp.blur_ksize, c->bL, c->bR);
+      if (spw.enable_feathering) {
+        vd_launch_e2(s, c->slot_D[slot], S, H, W, (float)spw.feather_strength, c->e2L, c->e2R);
+        vd_launch_pool(s, c->e2L, c->e2R, H, W, spw.blur_ksize, c->bL, c->bR);
       }
-      vd_launch_warp(s, c->slot_rgb[slot], p->eye_h, p->eye_w, S, c->bL, c->bR, H, W, sp.enable_feathering ? 1 : 0, L, R);
+      vd_launch_warp(s, c->slot_rgb[slot], p->eye_h, p->eye_w, S, c->bL, c->bR, H, W, spw.enable_feathering ? 1 : 0, L, R);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1221,10 +1248,13 @@ VD3D_EXPORT int vd3d_format_3d_output(vd3d_ctx* c, const uint8_t* left_bgr, cons
   const uint8_t *L = left_bgr, *R = right_bgr;
   int eh = h, ew = w;
   if (format == VD3D_FMT_VR && (h != 1600 || w != 1440)) {
-    if ((rc = ensure_work(c, 1600, 1440))) return rc;   // gL / gR: two 1440 x 1600 eyes
-    vd_launch_resize_linear_u8(c->stream, left_bgr, h, w, c->gL, 1600, 1440);
-    vd_launch_resize_linear_u8(c->stream, right_bgr, h, w, c->gR, 1600, 1440);
-    L = c->gL; R = c->gR; eh = 1600; ew = 1440;
+    // two 1440 x 1600 eyes in a scratch of this entry point's own (grow-only): the context's warp-res planes belong to the render path, whose
+    // slots may be in flight at another size (an ensure_work() here would shrink them under a queued pixel pass)
+    const size_t ne = (size_t)1600 * 1440 * 3;
+    if (c->fmt_cap < 2 * ne) { HIPCHK(re_alloc(&c->fmt_eyes, 2 * ne)); c->fmt_cap = 2 * ne; }
+    vd_launch_resize_linear_u8(c->stream, left_bgr, h, w, c->fmt_eyes, 1600, 1440);
+    vd_launch_resize_linear_u8(c->stream, right_bgr, h, w, c->fmt_eyes + ne, 1600, 1440);
+    L = c->fmt_eyes; R = c->fmt_eyes + ne; eh = 1600; ew = 1440;
   }
   vd3d_render_params p;
   vd3d_render_params_default(&p);
@@ -1233,7 +1263,9 @@ VD3D_EXPORT int vd3d_format_3d_output(vd3d_ctx* c, const uint8_t* left_bgr, cons
   vd_finish_consts fc;
   memset(&fc, 0, sizeof fc);
   fc.sharp_kn = 0.f; fc.sharp_kc = 1.f;
-  vd_launch_sharp_mux(c->stream, L, R, p, fc, out_bgr);
+  // identity fit: format_3d_output stacks / interleaves / mixes the eyes as they are (np.hstack, row slices, the anaglyph matrix) -- NOT the
+  // render loop's pad_to_aspect_ratio, whose int(aspect * h) truncates to w - 1 for about one eye size in twenty (61x7, 1920x804, ...)
+  vd_launch_sharp_mux(c->stream, L, R, p, fc, out_bgr, 0, true);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1479,6 +1511,7 @@ VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
   else if (which == 1) g_chain_group = value;
   else if (which == 2) vd_set_warp_pre_th(value);
   else if (which == 3) g_fused_fit = value;
+  else if (which == 4) g_feather0_long = value;
   else return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
   return 0;
 }

@@ -161,8 +161,9 @@ void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, 
 // sharpen + fit + mux of two graded eyes with the fused finishing kernel's epilogue (vd3d_finish.hip); false: not its fit (k_sharp_mux then)
 bool vd_launch_sharp_fit(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p, const vd_finish_consts& fc, uint8_t* out);
 // presharp_pitch > 0: gL / gR hold sharpened eyes already (row pitch in pixels): fit + mux only
+// identity_fit: the eyes fill the fit rectangle 1:1 (warp == fit; vd3d_format_3d_output) -- no pad_to_aspect_ratio geometry
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
-                         const vd_finish_consts& fc, uint8_t* out, int presharp_pitch = 0);
+                         const vd_finish_consts& fc, uint8_t* out, int presharp_pitch = 0, bool identity_fit = false);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
 void vd_launch_torch_math(hipStream_t s, int op, const float* x, float p, float* out, long long n);
 void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const vd_dev_work* wk, uint8_t* dst);

@@ -598,12 +598,12 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
   }
 }
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
-                         const vd_finish_consts& fc, uint8_t* out, int presharp_pitch) {
+                         const vd_finish_consts& fc, uint8_t* out, int presharp_pitch, bool identity_fit) {
   vd_mux_geom m;
   m.pre = presharp_pitch;
   m.H = p.warp_h; m.W = p.warp_w; m.fit_w = p.fit_w; m.fit_h = p.fit_h;
   m.out_w = p.out_w; m.out_h = p.out_h; m.format = p.format;
-  if (p.format == VD3D_FMT_HALF_SBS) {  // cv2.resize straight to (per_eye_w, per_eye_h) :1413
+  if (p.format == VD3D_FMT_HALF_SBS || (identity_fit && p.warp_w == p.fit_w && p.warp_h == p.fit_h)) {  // cv2.resize straight to (per_eye_w, per_eye_h) :1413
     m.in_w = p.fit_w; m.in_h = p.fit_h; m.xo = 0; m.yo = 0;
   } else {  // pad_to_aspect_ratio :101-131
     const double ta = (double)p.fit_w / p.fit_h, ca = (double)p.warp_w / p.warp_h;

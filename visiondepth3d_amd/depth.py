@@ -183,7 +183,9 @@ class DepthPipe:
                 return
             tn.enable(True)
             tn.tuning_enable(False)
-            tn.set_filename(os.path.join(tempfile.gettempdir(), "vd3d_tunableop_%d.csv" % os.getpid()))   # never write into the package
+            # never write into the package; ONE fixed scratch name (TunableOp rewrites its results file when the process exits and this
+            # build has no switch for that: a per-pid name left one file per process behind)
+            tn.set_filename(os.path.join(tempfile.gettempdir(), "vd3d_tunableop_results.csv"))
             self.tuned_gemm = bool(tn.read_file(table))
             if not self.tuned_gemm:   # other hipBLASLt / rocBLAS / PyTorch build: the solution indices mean nothing there
                 tn.enable(False)
@@ -300,8 +302,18 @@ class DepthPipe:
         tail = None
         if (f32 and isinstance(head.activation2, torch.nn.ReLU) and head.conv2.out_channels in (16, 32, 64) and head.conv3.kernel_size == (1, 1)
                 and head.conv2.bias is not None and head.conv3.bias is not None and head.conv1.bias is not None):
-            # conv3's operands never change after construction / from_pretrained: read its scalar bias ONCE (no per-call host sync)
-            tail = (head.conv3.weight.detach().reshape(-1).contiguous(), float(head.conv3.bias.detach().float().item()), float(head.max_depth))
+            # conv3's scalar bias is read on the host ONCE per parameter version (no per-call sync); an in-place update of the parameters
+            # (load_state_dict, .copy_) bumps their version counters and is picked up at the next call
+            tail = {"key": None, "w3": None, "b3": 0.0}
+
+            def tail_operands():
+                w, b = head.conv3.weight, head.conv3.bias
+                key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+                if tail["key"] != key:
+                    tail["w3"] = w.detach().reshape(-1).contiguous()
+                    tail["b3"] = float(b.detach().float().item())
+                    tail["key"] = key
+                return tail["w3"], tail["b3"], float(head.max_depth)
 
         def head_fwd(hidden_states, patch_height, patch_width):
             x = hidden_states[head.head_in_index]
@@ -311,7 +323,8 @@ class DepthPipe:
                 y = conv_nb(head.conv2, h)
                 if self._flop_count is not None:
                     self._flop_count[0] += 2.0 * y.numel() / y.shape[0]   # the 1x1 convolution to one channel inside the tail kernel
-                return R.dpt_head_tail(y, head.conv2.bias, tail[0], tail[1], tail[2])
+                w3, b3, scale = tail_operands()
+                return R.dpt_head_tail(y, head.conv2.bias, w3, b3, scale)
             h = up(head.conv1(x), size)
             h = head.conv3(head.activation1(head.conv2(h)))
             return (head.activation2(h) * head.max_depth).squeeze(dim=1)

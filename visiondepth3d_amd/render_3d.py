@@ -735,7 +735,9 @@ def render_pairs(pairs, *, renderer: Renderer | None = None, target_ratio=16 / 9
     ``batch`` > 1 (default 8): frames go through the renderer in STEPS of ``batch`` frames (``sharded.ChunkSharder`` at world 1: the
     select chain of a step in a dozen launches instead of eight per frame, its pixel kernels on two streams behind the next step's
     chain) -- bit-identical to the frame-by-frame loop (``batch=1``: one ``vd3d_render_frame`` per pair), frames are yielded in order,
-    up to two steps late."""
+    up to two steps (``2 * batch`` frames) late.  Cost of the default: ``2 * batch`` slots of seven float32 planes each stay allocated
+    on the device (about 4 GB at 3840x2160 with ``batch=8``).  The generator puts the renderer into overlapped mode; ``close()`` it
+    (or exhaust it) to return the renderer to sequential mode -- a consumer that stops early should not wait for garbage collection."""
     r = renderer or default_renderer()
     blank = set(blank_frames or ()) if kw.get("skip_blank_frames") else set()
     it = iter(pairs)

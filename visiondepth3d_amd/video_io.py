@@ -183,7 +183,7 @@ def render_sbs_3d(
     cap, dcap = cv.VideoCapture(input_path), cv.VideoCapture(depth_path)
     if not cap.isOpened() or not dcap.isOpened():
         return
-    sink, cancelled = None, (lambda: cancel_flag is not None and cancel_flag.is_set())
+    sink, clip, cancelled = None, None, (lambda: cancel_flag is not None and cancel_flag.is_set())
     try:
         n_total = int(cap.get(cv.CAP_PROP_FRAME_COUNT))
         fps = cap.get(cv.CAP_PROP_FPS) or fps or 30.0
@@ -288,6 +288,8 @@ def render_sbs_3d(
     except Exception as e:   # the reference reports a crash and still closes its files (:1476-1499)
         print(f"Render crashed: {e}")
     finally:
+        if clip is not None and hasattr(clip, "close"):
+            clip.close()          # an early break (end_s, sink failure, cancel) must not leave the renderer in overlapped mode until the GC runs
         cap.release()
         dcap.release()
         if sink is not None:
