@@ -380,7 +380,12 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
         r.set_profiling(False)
 
     flops = pipe.flops_per_frame(sh, sw) if (pipe is not None and rank == 0) else None
+    feather_on = bool(p.shift.enable_feathering) and float(p.shift.feather_strength) > 0.0
+    # W1's algorithmic bytes per stereo pair: the eye-resolution RGB planes (3 x float32) + one warp-resolution float32 plane (the
+    # shift / depth the samples are steered by) + two uint8 eyes out: 3 N + 4 N + 6 N = 13 N when the eyes are half the warp size each way
+    w1_alg = 12 * p.eye_h * p.eye_w + 4 * p.warp_h * p.warp_w + 6 * p.warp_h * p.warp_w
     res = dict(workload=workload, desc=desc, sh=sh, sw=sw, model=model_name, B=B, steps=steps, warmup=warmup, dt=dt,
+               w1_alg_bytes=w1_alg, e1_alg_bytes=6 * p.warp_h * p.warp_w + 4 * p.eye_h * p.eye_w + 3 * p.out_h * p.out_w, feather_on=feather_on, eye=(p.eye_h, p.eye_w), warp=(p.warp_h, p.warp_w), out=(p.out_h, p.out_w),
                frames_total=world * steps * B, stage_ms=stage_ms, iso_ms=iso_ms, net_ms=net_ms, flops_per_frame=flops,
                N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), pix_streams=(1 if host_io else max(1, int(args.pix_streams))) if pix_ov else 0,
                depth_dtype=depth_dtype if model_name else None,
@@ -575,13 +580,16 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
         return (seq, instep, "sequential pass after the timed region") if seq > 0 else (instep, instep, "inside the timed region (no sequential pass in this run)")
     w1_ms, w1_instep, w1_src = pick("w1")
     if w1_ms > 0:
-        alg = 13 * N  # W1 = read RGB 3N + read depth 4N + write two u8 eyes 6N per stereo pair
+        alg = res.get("w1_alg_bytes", 13 * N)  # W1 = read RGB 3N + read depth 4N + write two u8 eyes 6N per stereo pair (13 N with half-size eyes)
         ach = alg / (w1_ms * 1e-3) / 1e9
         e2w_ms = (iso.get("e2w") if w1_src.startswith("sequential") else st.get("e2w")) or -1
         w1 = pm.get("k_warp_fused", pm if "corrected_bytes_per_launch" in pm else {})
         lane = w1.get("valu_lane_instr_per_launch")
-        rf = {"bound": "valu" if lane else "hbm", "kernel": "W1 = k_e2w (warped-depth gradient mask of both eyes) + k_warp_fused (window sums + warp + "
-                                                           "blend): the same work as round 3's single launch, two launches since round 4",
+        w1_kernel = ("W1 = k_e2w (warped-depth gradient mask of both eyes) + k_warp_fused (window sums + warp + blend): the same work as round 3's "
+                     "single launch, two launches since round 4") if res.get("feather_on", True) else \
+                    ("W1 = k_warp_fused<FEATHER = false> alone: feather_strength <= 0 makes feather_shift_edges an exact no-op (round 5), no mask "
+                     "kernel, no window sums, no blend -- nested-bilinear warp of both eyes + truncation")
+        rf = {"bound": "valu" if lane else "hbm", "kernel": w1_kernel,
               "k_e2w_avg_launch_ms": (e2w_ms if e2w_ms > 0 else None), "k_warp_fused_avg_launch_ms": (round(w1_ms - e2w_ms, 5) if e2w_ms > 0 else None),
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
               "traffic": w1.get("corrected_bytes_per_launch"), "traffic_source": w1.get("source"),
@@ -603,10 +611,13 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
             rf["valu"] = {"lane_instr_per_pixel": round(lane / N, 1), "measured_v_fma_rate_lane_ops_per_s": VALU_PEAK_LANE_OPS,
                           "spec_lane_ops_per_s": VALU_SPEC_LANE_OPS, "frac_of_measured_rate": round(lane / t / VALU_PEAK_LANE_OPS, 4),
                           "frac_of_spec_rate": round(lane / t / VALU_SPEC_LANE_OPS, 4), "source": w1.get("source")}
+            rf["valu_frac_of_spec"] = rf["valu"]["frac_of_spec_rate"]   # beside `frac` (HBM yardstick) in the same object: the bound that actually binds
+        if alg and rf.get("traffic"):
+            rf["traffic_over_algorithmic"] = round(rf["traffic"] / alg, 3)
         out["roofline"] = rf
     fin_ms, fin_instep, fin_src = pick("finish")
-    if fin_ms > 0:  # E1: 6N eyes in + N eye-res depth + 3N Half-SBS out
-        alg = 10 * N
+    if fin_ms > 0:  # E1: 6N eyes in + N eye-res depth + 3N Half-SBS out (10 N at 4K Half-SBS; per geometry: two u8 eyes + the eye-res float32 depth + the muxed frame)
+        alg = res.get("e1_alg_bytes", 10 * N)
         ach = alg / (fin_ms * 1e-3) / 1e9
         e1 = pm.get("k_finish_fused", {})
         lane = e1.get("valu_lane_instr_per_launch")
@@ -713,12 +724,15 @@ def main():
         except Exception as e:   # a sub-record must never take the headline down
             rvr = None
             print(f"[bench] 4k-dibr-vr failed: {str(e)[:200]}", file=sys.stderr)
+        rg1 = run_workload(env, args, "1080p-gui-defaults", 10, 3, profile=prof)
+        rg4 = run_workload(env, args, "4k-dibr-gui", 6, 2, profile=prof)
         rhi = run_workload(env, args, "4k-dibr", 6, 2, profile=False, isolated_pass=False, host_io=True)   # host-I/O-included figure
         rhi["workload"] = "4k-dibr-hostio"
         rhi["desc"] = ("4K DIBR only with the frames starting in pinned host memory and the muxed frames copied back to pinned host memory "
                        "(frame_io.PinnedRing, three slots: H2D, render and D2H of consecutive steps overlap): the PCIe-inclusive rate, never `value`")
         subs = {"4k-dibr": (r4, None), "1080p-dav2s-dibr": (r1e, None), "1080p-dibr": (r1d, None), "4k-dav2b-dibr-bf16": (rbf, None),
-                "4k-dibr-sepdof": (rdn, None), "4k-dibr-dof3": (rd3, None), "4k-dibr-anaglyph": (ran, None), "4k-dibr-hostio": (rhi, None)}
+                "4k-dibr-sepdof": (rdn, None), "4k-dibr-dof3": (rd3, None), "4k-dibr-anaglyph": (ran, None), "4k-dibr-hostio": (rhi, None),
+                "1080p-gui-defaults": (rg1, None), "4k-dibr-gui": (rg4, None)}
         if rvr is not None:
             subs["4k-dibr-vr"] = (rvr, None)
         roof_src = r4
@@ -778,6 +792,12 @@ def main():
                 rf = rooflines(rs, copy_gbs, pmc_workload=None)
                 if "roofline_depthnet" in rf:
                     extra["roofline_depthnet"] = rf["roofline_depthnet"]
+                if name in ("1080p-gui-defaults", "4k-dibr-gui"):   # W1 where north_star's HBM question is meaningful: no feathering (round 5)
+                    rg = rooflines(rs, copy_gbs, pmc_workload=name)
+                    for k in ("roofline", "roofline_e1"):
+                        if k in rg:
+                            extra[k] = rg[k]
+                    extra["geometry"] = {"warp": rs["warp"], "eye": rs["eye"], "out": rs["out"]}
                 if name == "4k-dibr-sepdof":
                     extra["note"] = ("opt-in fast mode of the finishing stage (DESIGN.md section 2); every other record, the headline included, "
                                      "runs the dense association that matches the reference's CPU result exactly")

@@ -1512,6 +1512,8 @@ VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
   else if (which == 2) vd_set_warp_pre_th(value);
   else if (which == 3) g_fused_fit = value;
   else if (which == 4) g_feather0_long = value;
+  else if (which == 5) vd_set_conv_mode(value);
+  else if (which == 6) vd_set_finish_persist(value);
   else return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
   return 0;
 }

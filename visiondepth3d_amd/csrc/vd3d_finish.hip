@@ -631,6 +631,309 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   VD_OCC_OUT(ff_occ);
 }
 
+// ================================================================================================================================
+// Round 5: E1 as a PERSISTENT kernel (k_finish_fused_p; dense levels, 64x26 geometry: the default route; k_finish_fused above stays for the
+// separable levels, fit factor 4 and as the A/B reference, vd3d_debug_tune(6, 0)).  What round 4's stamps showed: 28 % of a workgroup's life is the
+// tile load -- a global round trip nothing overlaps, three workgroups per CU notwithstanding -- and the launch span is set by the CUs that drew
+// 45 tiles while others drew 33.  Here:
+//   * one workgroup per CU slot (3 x CUs workgroups) walks its tiles -- virtual block ids b, b + grid, b + 2 grid ... through the same XCD
+//     row-group order as before (a multiple of 8 apart: every workgroup stays on its XCD's tile rows), so every slot gets the same number of
+//     tiles (+- 1) spread over the whole picture;
+//   * the NEXT tile's raw bytes travel by LDS-DMA (global_load_lds_dwordx3: 12 bytes = 4 BGR pixels per lane, no registers) into a staging
+//     buffer that aliases the halo-window buffer -- dead between the levels and the next tile's windows -- while the current tile's epilogue
+//     (sharpen + fit + mux + stores) runs; the next iteration converts them LDS -> planar float tile without a global round trip.  A tile at
+//     the image border (reflect padding per pixel) is loaded the old way at the top of its iteration.
+// Arithmetic: the same device functions in the same order as k_finish_fused<true, 26>: identical bytes.
+// ================================================================================================================================
+VD_STAMP_DECL(ffp_stamps);
+template <int TH_>
+__global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
+                                                          const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
+                                                          const vd_dev_work* __restrict__ w, const float* __restrict__ w2g_,
+                                                          uint8_t* __restrict__ out, int nvb) {
+  static_assert(ff_geo<TH_>::WIDE, "persistent kernel: wide geometry only");
+  constexpr int FF_TH = ff_geo<TH_>::TH, FF_GH = ff_geo<TH_>::GH, FF_IH = ff_geo<TH_>::IH, FF_NT = ff_geo<TH_>::NT;
+  constexpr int FF_HS = ff_geo<TH_>::HS, FF_HC = ff_geo<TH_>::HC, FF_NSW = ff_geo<TH_>::NSW;
+  constexpr int NTASK = FF_IH * FF_IS;                     // 12-byte groups of the input tile: 36 x 20 = 720
+  constexpr int STAGE_F = (NTASK * 3 > 3 * FF_HC ? NTASK * 3 : 3 * FF_HC);   // floats: the raw tile (8 640 B) and the halo windows (8 064 B) share this buffer
+  static_assert(NTASK <= 2 * FF_NT, "two tile-load tasks per thread");
+  __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
+  __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
+  __shared__ __attribute__((aligned(16))) float hal[STAGE_F];
+  __shared__ __attribute__((aligned(16))) int lvl_mask[4];   // [0]: levels any pixel of this tile needs (16 bytes: keeps the arrays 16-byte aligned)
+  uint32_t* stage = reinterpret_cast<uint32_t*>(hal);
+  const int H0 = a.H, W0 = a.W;
+  const float w_focal = a.use_override ? a.focal : w->focal;
+  const int w_bar_w = a.use_override ? a.bar_w : w->bar_width, w_bar_s = a.use_override ? a.bar_s : w->bar_side;
+  const bool src_ok = (W0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(eyeL) | reinterpret_cast<uintptr_t>(eyeR)) & 3) == 0;
+
+  // tile of virtual block vb (-1: a padding block of the XCD order); interior = 12-byte-group loads / LDS-DMA possible
+  auto decode = [&](int vb, int* eye, int* x0, int* y0) -> bool {
+    int trow, tbx;
+    vd_xcd_tile_rows(vb, a.ntx, FF_XG, a.xcd, &trow, &tbx);
+    if (trow >= 2 * a.nty) return false;
+    *eye = trow >= a.nty ? 1 : 0;
+    *x0 = tbx * FF_TW; *y0 = (trow - *eye * a.nty) * FF_TH;
+    return true;
+  };
+  auto interior = [&](int x0, int y0) -> bool {
+    const int ix0 = x0 - 4 - FF_R, iy0 = y0 - 1 - FF_R;
+    return src_ok && ix0 >= 0 && ix0 + FF_IW <= W0 && iy0 >= 0 && iy0 + FF_IH <= H0;
+  };
+
+  int vb = blockIdx.x;
+  int eye = 0, x0 = 0, y0 = 0;
+  while (vb < nvb && !decode(vb, &eye, &x0, &y0)) vb += gridDim.x;
+  if (vb >= nvb) return;                                   // workgroup-uniform, before any barrier
+  bool staged = false;                                     // this tile's raw bytes are in `stage` (put there by the previous iteration)
+  VD_STAMP(ffp_stamps, 0, false);
+  while (true) {
+    // The thread mapping (see k_finish_fused) is tile-invariant, and so is everything derived from it -- LDS addresses of the tile-load tasks, of the
+    // strips, of the epilogue's tasks: left alone, the optimiser hoists all of it out of the tile loop into ~40 registers that the dense levels
+    // need (122 VGPRs instead of 80 = two workgroups per CU instead of three).  An opaque per-iteration copy of the thread index makes it
+    // recompute them per tile: a few dozen integer operations.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    tid &= 1023;
+    // ... and the same for the frame geometry: the scalar expressions derived from it (tap scales, border tests, 64-bit row pitches) otherwise pile
+    // up in SGPRs that spill into VGPR lanes
+    int H = H0, W = W0;
+    vd_ff_args ai = a;
+    asm volatile("" : "+s"(H), "+s"(W), "+s"(ai.eh), "+s"(ai.ew));
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
+    bool strip = true, halo_px = false;
+    int sy, ss, hq = 0;
+    if (wv < FF_NSW) { sy = 4 * wv + (lane & 3); ss = 2 + (lane >> 2); }
+    else {
+      sy = min(lane >> 1, FF_GH - 1); halo_px = true; ss = (lane & 1) ? FF_IS - 2 : 1; hq = (lane & 1) ? 0 : 3;
+      strip = (lane >> 1) < FF_GH;
+    }
+    const uint8_t* __restrict__ src = eye == 0 ? eyeL : eyeR;
+    const int gx0 = x0 - 4, gy0 = y0 - 1;
+    const int ix0 = gx0 - FF_R, iy0 = gy0 - FF_R;
+    const int gy = gy0 + sy, gxs = ix0 + 4 * ss;
+    int zoff = 0;
+    asm volatile("" : "+s"(zoff));                         // per-iteration opaque zero: the weight table's scalar loads are not hoisted out of the tile loop
+    const float* w2g = w2g_ + zoff;
+    // depth samples of the blur weight: requested now, consumed after the first barrier
+    const int yc = min(max(gy, 0), H - 1);
+    const bool fast21 = strip && fc.nlev && 2 * ai.eh == H && 2 * ai.ew == W && gxs >= 4 && gxs + 6 <= W;
+    vd_tap ay21 = {0, 0, 0.f, 0.f};
+    float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fast21) {
+      ay21 = vd_tap21(ai.eh, yc);
+      const int c0 = (gxs >> 1) - 1;
+      const float* r0 = dn + (size_t)ay21.i0 * ai.ew + c0;
+      const float* r1 = dn + (size_t)ay21.i1 * ai.ew + c0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { p0[j] = r0[j]; p1[j] = r1[j]; }
+    }
+    if (tid == 0) lvl_mask[0] = 0;
+    const bool in_interior = interior(x0, y0);
+    if (staged || in_interior) {
+      uint32_t ld[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = tid + k * FF_NT;
+        if (t < NTASK) {
+          if (staged) { ld[k][0] = stage[3 * t]; ld[k][1] = stage[3 * t + 1]; ld[k][2] = stage[3 * t + 2]; }
+          else {
+            const int ty = t / FF_IS, g = t - ty * FF_IS;
+            const uint32_t* pp = reinterpret_cast<const uint32_t*>(src + ((size_t)(iy0 + ty) * W + ix0 + 4 * g) * 3);
+            ld[k][0] = pp[0]; ld[k][1] = pp[1]; ld[k][2] = pp[2];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = tid + k * FF_NT;
+        if (t < NTASK) {
+          const int ty = t / FF_IS, g = t - ty * FF_IS;
+          const uint32_t a0 = ld[k][0], a1 = ld[k][1], a2 = ld[k][2];
+#define FF_B(k) ff_byte((k) < 4 ? a0 : ((k) < 8 ? a1 : a2), 8 * ((k) & 3))
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int bo = 2 - c;
+            const vd_f4 v4 = {vd_u8_unit(FF_B(0 + bo)), vd_u8_unit(FF_B(3 + bo)), vd_u8_unit(FF_B(6 + bo)), vd_u8_unit(FF_B(9 + bo))};
+            *reinterpret_cast<vd_f4*>(&tile[c][ty][4 * g]) = v4;
+          }
+#undef FF_B
+        }
+      }
+    } else {
+      for (int t = tid; t < FF_IH * FF_IW; t += FF_NT) {
+        const int ty = t / FF_IW, tx = t - ty * FF_IW;
+        const int y = vd_reflect(iy0 + ty, H), x = vd_reflect(ix0 + tx, W);
+        const uint8_t* px = src + ((size_t)y * W + x) * 3;
+        tile[0][ty][tx] = vd_u8_unit((float)px[2]);
+        tile[1][ty][tx] = vd_u8_unit((float)px[1]);
+        tile[2][ty][tx] = vd_u8_unit((float)px[0]);
+      }
+    }
+    int lo[4] = {0, 0, 0, 0};
+    vd_f4 alpha = {0.f, 0.f, 0.f, 0.f};
+    int lmin = 9, lmax = -1;
+    __syncthreads();   // lvl_mask = 0 visible; tile complete; the staging buffer has been consumed (it becomes the halo-window buffer now)
+    VD_STAMP(ffp_stamps, 1, false);
+    for (int t = tid; t < 3 * 2 * FF_IH; t += FF_NT) {   // halo-column windows (consumed after the next barrier)
+      const int c = t / (2 * FF_IH), rem = t - c * (2 * FF_IH), side = rem / FF_IH, row = rem - side * FF_IH;
+      const float* srcp = &tile[c][row][side ? (4 * (FF_IS - 2)) - FF_R : (4 + 3) - FF_R];
+      float* dstp = &hal[c * FF_HC + side * FF_HS + row * 9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) dstp[j] = srcp[j];
+    }
+    int my_mask = 0;
+    if (strip && fc.nlev) {
+      const float focal = w_focal;
+      float dd[4];
+      if (fast21) {
+        const vd_tap ay = ay21;
+        const float a0 = vd_fma(p0[0], 0.25f, 0.75f * p0[1]), b0 = vd_fma(p1[0], 0.25f, 0.75f * p1[1]);
+        const float a1 = vd_fma(p0[1], 0.75f, 0.25f * p0[2]), b1 = vd_fma(p1[1], 0.75f, 0.25f * p1[2]);
+        const float a2 = vd_fma(p0[1], 0.25f, 0.75f * p0[2]), b2 = vd_fma(p1[1], 0.25f, 0.75f * p1[2]);
+        const float a3 = vd_fma(p0[2], 0.75f, 0.25f * p0[3]), b3 = vd_fma(p1[2], 0.75f, 0.25f * p1[3]);
+        dd[0] = vd_fma(a0, ay.w0, ay.w1 * b0); dd[1] = vd_fma(a1, ay.w0, ay.w1 * b1);
+        dd[2] = vd_fma(a2, ay.w0, ay.w1 * b2); dd[3] = vd_fma(a3, ay.w0, ay.w1 * b3);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int x = min(max(gxs + q, 0), W - 1);
+          if (ai.eh == H && ai.ew == W) dd[q] = dn[(size_t)yc * W + x];
+          else if (2 * ai.eh == H && 2 * ai.ew == W) {
+            const vd_tap ay = vd_tap21(ai.eh, yc), ax = vd_tap21(ai.ew, x);
+            const float* r0 = dn + (size_t)ay.i0 * ai.ew;
+            const float* r1 = dn + (size_t)ay.i1 * ai.ew;
+            dd[q] = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
+          } else {
+            const vd_tap ay = vd_interp_tap(ai.eh, H, yc), ax = vd_interp_tap(ai.ew, W, x);
+            const float* r0 = dn + (size_t)ay.i0 * ai.ew;
+            const float* r1 = dn + (size_t)ay.i1 * ai.ew;
+            dd[q] = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
+          }
+        }
+      }
+      const bool fastfw = fc.fw == FF_FW_STD;
+      const float rcfw = 1.0f / FF_FW_STD;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ad = fabsf(dd[q] - focal);
+        float qv;
+        if (fastfw && (ad >= 1e-30f || ad == 0.f)) {
+          const float q0 = ad * rcfw;
+          qv = vd_fma(vd_fma(-q0, FF_FW_STD, ad), rcfw, q0);
+        } else qv = ad / fc.fw;
+        const float bw = vd_clamp_fin(qv, 0.f, 1.f);
+        const float bi = vd_clamp_fin(bw * (float)fc.nlev, 0.f, fc.imax);
+        int l = (int)floorf(bi);
+        l = l > fc.nlev - 1 ? fc.nlev - 1 : (l < 0 ? 0 : l);
+        lo[q] = l; alpha[q] = bi - (float)l;
+        if (!halo_px || q == hq) { lmin = min(lmin, l); lmax = max(lmax, l + 1); }
+      }
+      if (halo_px && hq == 3) { lo[0] = lo[3]; alpha[0] = alpha[3]; }
+      for (int l = max(lmin, 1); l <= lmax; ++l) my_mask |= 1 << l;
+    }
+    {
+      int wmask = 0;
+#pragma unroll
+      for (int l = 1; l <= 4; ++l)
+        if (__ballot((my_mask >> l) & 1)) wmask |= 1 << l;
+      if ((tid & 63) == 0 && wmask) atomicOr(&lvl_mask[0], wmask);
+    }
+    vd_f4 vres[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      vres[c] = *reinterpret_cast<const vd_f4*>(&tile[c][sy + FF_R][4 * ss]);
+      if (halo_px && hq == 3) vres[c][0] = vres[c][3];
+    }
+    __syncthreads();
+    VD_STAMP(ffp_stamps, 2, false);
+    const int need_mask = lvl_mask[0];
+    for (int l = 0; l < fc.nlev; ++l) {
+      if (!(need_mask >> (l + 1) & 1)) continue;
+      const int off = FF_R - fc.ksz[l] / 2;
+      const bool mine = (my_mask >> (l + 1)) & 1;
+      if (wv == FF_NSW) {   // wave-uniform: the halo-pixel wave
+        const int side = lane & 1;
+        switch (off) {
+          case 0: ff_level_dense_px<0, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
+          case 1: ff_level_dense_px<1, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
+          case 2: ff_level_dense_px<2, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
+          default: ff_level_dense_px<3, FF_HS>(hal, w2g + 81 * l, mine, sy, side, l + 1, lo[0], alpha[0], vres); break;
+        }
+        continue;
+      }
+      switch (off) {
+        case 0: ff_level_dense<0, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
+        case 1: ff_level_dense<1, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
+        case 2: ff_level_dense<2, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
+        default: ff_level_dense<3, FF_IH>(tile, w2g + 81 * l, mine, sy, ss, l + 1, lo, alpha, vres); break;
+      }
+    }
+    VD_STAMP(ffp_stamps, 3, false);
+    if (strip) {
+      const int bar_w = w_bar_w, bar_s = w_bar_s;
+      vd_f4 rgbv[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        vd_f4 v = vres[c];
+        if (fc.nlev) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = vd_clamp_fin(v[q], 0.f, 1.f);
+        }
+        rgbv[c] = v;
+      }
+      const vd_f4 luma = ((float)0.2126 * rgbv[0] + (float)0.7152 * rgbv[1]) + (float)0.0722 * rgbv[2];
+      uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        vd_f4 v = luma + (rgbv[c] - luma) * fc.sat;
+        v = 0.5f + (v - 0.5f) * fc.con;
+        v = v + fc.bri;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float vc = vd_clamp_fin(v[q], 0.f, 1.f);
+          pk[q] |= (uint32_t)(uint8_t)(vc * 255.0f) << (8 * (2 - c));
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = gxs + (halo_px ? hq : q);
+        const bool masked = bar_w > 0 && ((bar_s == 2 && x < bar_w) || (bar_s == 1 && x >= W - bar_w));
+        if (masked) pk[q] = 0u;
+      }
+      if (halo_px) gb[sy][4 * (ss - 1) + hq] = pk[0];
+      else *reinterpret_cast<uint4*>(&gb[sy][4 * (ss - 1)]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    __syncthreads();   // graded tile complete; the levels are done: the halo-window buffer is dead and takes the next tile's raw bytes
+    VD_STAMP(ffp_stamps, 4, false);
+    // next tile of this workgroup; its raw bytes by LDS-DMA while the epilogue below runs
+    int nvb_ = vb + gridDim.x, neye = 0, nx0 = 0, ny0 = 0;
+    while (nvb_ < nvb && !decode(nvb_, &neye, &nx0, &ny0)) nvb_ += gridDim.x;
+    const bool more = nvb_ < nvb;
+    const bool nstaged = more && interior(nx0, ny0);       // workgroup-uniform
+    if (nstaged) {
+      const uint8_t* __restrict__ nsrc = neye == 0 ? eyeL : eyeR;
+      const int nix0 = nx0 - 4 - FF_R, niy0 = ny0 - 1 - FF_R;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = tid + k * FF_NT;
+        if (t < NTASK) {   // lanes past the last group stay inactive: the DMA writes LDS at M0 + 12 * lane for ACTIVE lanes only
+          const int ty = t / FF_IS, g = t - ty * FF_IS;
+          const uint8_t* gp = nsrc + ((size_t)(niy0 + ty) * W + nix0 + 4 * g) * 3;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                           (__attribute__((address_space(3))) void*)(stage + 3 * (k * FF_NT + wv_u * 64)), 12, 0, 0);
+        }
+      }
+    }
+    ff_epilogue<FF_TH, FF_NT>(gb, ai, fc, eye, x0, y0, gx0, gy0, tid, out);
+    VD_STAMP(ffp_stamps, 5, true);
+    if (!more) break;
+    vb = nvb_; eye = neye; x0 = nx0; y0 = ny0; staged = nstaged;
+    __syncthreads();   // epilogue done with gb / every wave past its levels; the DMA has landed (the compiler drains vmcnt before the barrier)
+  }
+}
+
 // The epilogue alone, for eyes that are graded already (k_dof_grade4's planes: Gaussians beyond the fused kernel's 9 taps): tile of graded dwords
 // straight from the u8 planes, then sharpen + fit + mux as above.  Replaces k_sharp_mux (one thread per output pixel, 120 byte loads each: 236 us
 // per 4K frame pair) wherever the fused kernel's fit conditions hold.
@@ -699,6 +1002,12 @@ bool vd_launch_sharp_fit(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
   return true;
 }
 
+// 0: one tile per workgroup (rounds 2 - 4); k > 0: the persistent kernel with k workgroups per CU (vd3d_debug_tune(6, k))
+#ifndef FF_PERSIST
+#define FF_PERSIST 3
+#endif
+static int g_ff_persist = FF_PERSIST;
+void vd_set_finish_persist(int k) { g_ff_persist = k < 0 ? 0 : (k > 8 ? 8 : k); }
 bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, const float* dn, int eh, int ew,
                             const vd3d_render_params& p, const vd_finish_consts& fc, const vd_dev_work* w, float focal,
                             int use_override, int bar_w, int bar_s, uint8_t* out, int dense, const float* w2_dev) {
@@ -718,6 +1027,22 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
   dim3 g;
   ff_grid(p, th, &a, &g);
   if (dense && !w2_dev) return false;
+  if (wide && g_ff_persist && a.xcd) {
+    // persistent route: one workgroup per CU slot; three 51.7 KB workgroups of 512 threads fit a CU (80 VGPRs).  The grid is a multiple of 8, so a
+    // workgroup's virtual blocks b, b + grid, ... stay on its XCD's tile rows.
+    static int n_cu[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !n_cu[dev] && hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu[dev] = 256;
+    const int ncu = (dev >= 0 && dev < 64 && n_cu[dev] > 0) ? n_cu[dev] : 256;
+    const int nvb = (int)g.x;
+    int slots = g_ff_persist * ncu;                 // vd3d_debug_tune(6, k): k workgroups per CU (default 3)
+    slots -= slots % 8;
+    if (slots >= 8 && nvb > slots) {
+      hipLaunchKernelGGL((k_finish_fused_p<FF_WIDE_TH>), dim3(slots), dim3(ff_geo<FF_WIDE_TH>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out, nvb);
+      return true;
+    }
+  }
   if (wide) hipLaunchKernelGGL((k_finish_fused<true, FF_WIDE_TH>), g, dim3(ff_geo<FF_WIDE_TH>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   else if (dense) hipLaunchKernelGGL((k_finish_fused<true, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   else hipLaunchKernelGGL((k_finish_fused<false, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
