@@ -430,7 +430,7 @@ int vd3d_torch_math(vd3d_ctx* ctx, int op, const float* x, float param, float* o
  * "select_s1", "warp" (= "shift" + "w1", the fused warp kernel alone), "finish", "handoff", "advance", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
  * profiling was enabled (-1 if never seen); both getters synchronise. */
 int vd3d_set_profiling(vd3d_ctx* ctx, int enable);
-/* development probe: launch-shape knobs of the batched select chain (0: workgroup divisor per frame, 1: frames per P3 group, 2: W1 tile height 16 | 32, 3: routes of the finishing stage, bit 0 = fused kernel in front of a fit it does not take, bit 1 = its epilogue as the sharpen / fit / mux kernel behind the unfused DOF kernels; default 3, 4: 1 = feather_strength <= 0 still runs the mask / window-sum / blend kernels instead of the exact no-feather warp; default 0, 5: up-scale body convolution, < 0 = one tile per workgroup (the kernel of rounds 2 - 4), 0 .. 99 = persistent 32 x 16 kernel whose second workgroup per CU starts that many microseconds late, >= 100 = the 32 x 8 kernel with (value - 100) workgroups per CU; default -2 = by size); results never depend on them */
+/* development probe: launch-shape knobs of the batched select chain (0: workgroup divisor per frame, 1: frames per P3 group, 2: W1 tile height 16 | 32, 3: routes of the finishing stage, bit 0 = fused kernel in front of a fit it does not take, bit 1 = its epilogue as the sharpen / fit / mux kernel behind the unfused DOF kernels; default 3, 4: 1 = feather_strength <= 0 still runs the mask / window-sum / blend kernels instead of the exact no-feather warp; default 0, 5: up-scale body convolution, < 0 = one tile per workgroup (the kernel of rounds 2 - 4), 0 .. 99 = persistent 32 x 16 kernel whose second workgroup per CU starts that many microseconds late, >= 100 = the 32 x 8 kernel with (value - 100) workgroups per CU; default -2 = by size, 6: fused finishing kernel, 0 = one tile per workgroup (default), k > 0 = the persistent kernel with k workgroups per CU); results never depend on them */
 int vd3d_debug_tune(int which, int value);
 float vd3d_last_stage_ms(vd3d_ctx* ctx, const char* stage);
 long vd3d_stage_calls(vd3d_ctx* ctx, const char* stage);

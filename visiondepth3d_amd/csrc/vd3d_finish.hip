@@ -243,13 +243,12 @@ VD_DEV void ff_anaglyph_store(uint8_t* o, int eye, const int fv[3][4], int nvali
 // integer-ratio INTER_AREA (:1413), mux (SBS halves / interlaced rows / anaglyph bytes).  Called by k_finish_fused behind its grade phase and by
 // k_sharp_fit on planes that are graded already.
 template <int FF_TH, int FF_NT>
-VD_DEV void ff_epilogue(const uint32_t (*gb)[FF_GP], const vd_ff_args& a, const vd_finish_consts& fc, int eye, int x0, int y0, int gx0, int gy0,
-                        int tid, uint8_t* __restrict__ out) {
+VD_DEV void ff_epilogue_k(const uint32_t (*gb)[FF_GP], const vd_ff_args& a, float kn, float kc, int eye, int x0, int y0, int gx0, int gy0,
+                          int tid, uint8_t* __restrict__ out) {
   const int H = a.H, W = a.W;
   // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux
   const int ow = FF_TW / a.fx, oh = FF_TH / a.fy;      // output pixels produced by this tile
   const int ox0 = x0 / a.fx, oy0 = y0 / a.fy;
-  const float kn = fc.sharp_kn, kc = fc.sharp_kc;
   const bool out_interior = x0 >= 1 && x0 + FF_TW <= W - 1 && y0 >= 1 && y0 + FF_TH <= H - 1 && a.fy == 1 &&
                             (a.fx == 1 || a.fx == 2) && ox0 + ow <= a.in_w && oy0 + oh <= a.in_h;
   if (out_interior) {
@@ -347,6 +346,12 @@ VD_DEV void ff_epilogue(const uint32_t (*gb)[FF_GP], const vd_ff_args& a, const 
       for (int bi = 0; bi < 3 * nvalid; ++bi) o[bi] = (uint8_t)(pack[bi >> 2] >> (8 * (bi & 3)));
     }
   }
+}
+
+template <int FF_TH, int FF_NT>
+VD_DEV void ff_epilogue(const uint32_t (*gb)[FF_GP], const vd_ff_args& a, const vd_finish_consts& fc, int eye, int x0, int y0, int gx0, int gy0,
+                        int tid, uint8_t* __restrict__ out) {
+  ff_epilogue_k<FF_TH, FF_NT>(gb, a, fc.sharp_kn, fc.sharp_kc, eye, x0, y0, gx0, gy0, tid, out);
 }
 
 #ifndef FF_OCC_ATTR
@@ -647,15 +652,20 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
 // ================================================================================================================================
 VD_STAMP_DECL(ffp_stamps);
 template <int TH_>
-__global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
+__global__ __launch_bounds__(ff_geo<TH_>::NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_finish_fused_p(const uint8_t* __restrict__ eyeL, const uint8_t* __restrict__ eyeR,
                                                           const float* __restrict__ dn, vd_finish_consts fc, vd_ff_args a,
                                                           const vd_dev_work* __restrict__ w, const float* __restrict__ w2g_,
-                                                          uint8_t* __restrict__ out, int nvb) {
+                                                          uint8_t* __restrict__ out, int nvb, int* __restrict__ ctr) {
   static_assert(ff_geo<TH_>::WIDE, "persistent kernel: wide geometry only");
   constexpr int FF_TH = ff_geo<TH_>::TH, FF_GH = ff_geo<TH_>::GH, FF_IH = ff_geo<TH_>::IH, FF_NT = ff_geo<TH_>::NT;
   constexpr int FF_HS = ff_geo<TH_>::HS, FF_HC = ff_geo<TH_>::HC, FF_NSW = ff_geo<TH_>::NSW;
   constexpr int NTASK = FF_IH * FF_IS;                     // 12-byte groups of the input tile: 36 x 20 = 720
-  constexpr int STAGE_F = (NTASK * 3 > 3 * FF_HC ? NTASK * 3 : 3 * FF_HC);   // floats: the raw tile (8 640 B) and the halo windows (8 064 B) share this buffer
+#ifndef FF_DMA12
+#define FF_DMA12 0   // 0 (default; measured correct): three dword DMAs per group into three planes.  1: one 12-byte DMA per group -- its LDS image is NOT 12 bytes per lane on gfx950 (byte compare fails from the first staged tile on)   // (global_load_lds_dwordx3, LDS image = 12 bytes per lane); 0: three dword DMAs per group into three planes
+#endif
+  constexpr int STG_P = ((NTASK + 63) / 64) * 64;          // plane pitch of the dword-plane layout
+  constexpr int STAGE_RAW = FF_DMA12 ? NTASK * 3 : 3 * STG_P;
+  constexpr int STAGE_F = (STAGE_RAW > 3 * FF_HC ? STAGE_RAW : 3 * FF_HC);   // floats: the raw tile (8 640 B) and the halo windows (8 064 B) share this buffer
   static_assert(NTASK <= 2 * FF_NT, "two tile-load tasks per thread");
   __shared__ __attribute__((aligned(16))) float tile[3][FF_IH][FF_IW];
   __shared__ __attribute__((aligned(16))) uint32_t gb[FF_GH][FF_GP];
@@ -681,10 +691,26 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
     return src_ok && ix0 >= 0 && ix0 + FF_IW <= W0 && iy0 >= 0 && iy0 + FF_IH <= H0;
   };
 
+  // DYNAMIC tile queue: the first tile of a workgroup is its own block index, every further one comes from a launch-wide counter (ctr[0], starts at
+  // 0; virtual block = gridDim.x + ticket).  A static interleave was measured 20 % SLOWER than the one-tile kernel: tiles cost 16 k .. 53 k cycles
+  // depending on the DOF levels they need, and the launch ends with the unluckiest of 768 slots.  ctr[1] counts finished workgroups; the last one
+  // zeroes both words for the launch that gets this counter pair next (the host hands out pairs round-robin, so concurrent launches on other
+  // streams never share one).
+  auto next_ticket = [&](int* eye_, int* x0_, int* y0_) -> int {   // called by ONE lane
+    int v;
+    do { v = (int)gridDim.x + atomicAdd(ctr, 1); } while (v < nvb && !decode(v, eye_, x0_, y0_));
+    return v;
+  };
+  auto leave = [&]() { if (threadIdx.x == 0 && atomicAdd(ctr + 1, 1) == (int)gridDim.x - 1) { atomicExch(ctr, 0); atomicExch(ctr + 1, 0); } };
   int vb = blockIdx.x;
   int eye = 0, x0 = 0, y0 = 0;
-  while (vb < nvb && !decode(vb, &eye, &x0, &y0)) vb += gridDim.x;
-  if (vb >= nvb) return;                                   // workgroup-uniform, before any barrier
+  if (!decode(vb, &eye, &x0, &y0)) {                       // a padding block of the XCD order: take a ticket (workgroup-uniform branch)
+    if (threadIdx.x == 0) { int e_, x_, y_; lvl_mask[1] = next_ticket(&e_, &x_, &y_); }
+    __syncthreads();
+    vb = lvl_mask[1];
+    __syncthreads();
+    if (vb >= nvb || !decode(vb, &eye, &x0, &y0)) { leave(); return; }
+  }
   bool staged = false;                                     // this tile's raw bytes are in `stage` (put there by the previous iteration)
   VD_STAMP(ffp_stamps, 0, false);
   while (true) {
@@ -700,6 +726,18 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
     int H = H0, W = W0;
     vd_ff_args ai = a;
     asm volatile("" : "+s"(H), "+s"(W), "+s"(ai.eh), "+s"(ai.ew));
+    asm volatile("" : "+s"(ai.fit_w), "+s"(ai.fit_h), "+s"(ai.in_w), "+s"(ai.in_h), "+s"(ai.xo), "+s"(ai.yo), "+s"(ai.fx), "+s"(ai.fy), "+s"(ai.out_w), "+s"(ai.format));
+    ai.H = H; ai.W = W;
+    // (uniform values that need VALU instructions -- 1 / (fx fy), the blur weight's division by fc.fw, integer divisions by run-time constants -- are
+    // hoisted as whole VGPRs otherwise: a register per scalar)
+    float f_fw = fc.fw, f_imax = fc.imax, f_sat = fc.sat, f_con = fc.con, f_bri = fc.bri, f_kn = fc.sharp_kn, f_kc = fc.sharp_kc;
+    int f_nlev = fc.nlev;
+    asm volatile("" : "+s"(f_fw), "+s"(f_imax), "+s"(f_sat), "+s"(f_con), "+s"(f_bri), "+s"(f_kn), "+s"(f_kc), "+s"(f_nlev));
+    uint8_t* outp = out;
+    const uint8_t* eL = eyeL; const uint8_t* eR = eyeR; const float* dnp = dn;
+    int zo2 = 0;
+    asm volatile("" : "+s"(zo2));
+    outp += zo2; eL += zo2; eR += zo2; dnp += zo2;
     const int lane = tid & 63, wv = tid >> 6;
     const int wv_u = __builtin_amdgcn_readfirstlane(wv);
     bool strip = true, halo_px = false;
@@ -709,7 +747,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
       sy = min(lane >> 1, FF_GH - 1); halo_px = true; ss = (lane & 1) ? FF_IS - 2 : 1; hq = (lane & 1) ? 0 : 3;
       strip = (lane >> 1) < FF_GH;
     }
-    const uint8_t* __restrict__ src = eye == 0 ? eyeL : eyeR;
+    const uint8_t* __restrict__ src = eye == 0 ? eL : eR;
     const int gx0 = x0 - 4, gy0 = y0 - 1;
     const int ix0 = gx0 - FF_R, iy0 = gy0 - FF_R;
     const int gy = gy0 + sy, gxs = ix0 + 4 * ss;
@@ -718,14 +756,14 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
     const float* w2g = w2g_ + zoff;
     // depth samples of the blur weight: requested now, consumed after the first barrier
     const int yc = min(max(gy, 0), H - 1);
-    const bool fast21 = strip && fc.nlev && 2 * ai.eh == H && 2 * ai.ew == W && gxs >= 4 && gxs + 6 <= W;
+    const bool fast21 = strip && f_nlev && 2 * ai.eh == H && 2 * ai.ew == W && gxs >= 4 && gxs + 6 <= W;
     vd_tap ay21 = {0, 0, 0.f, 0.f};
     float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
     if (fast21) {
       ay21 = vd_tap21(ai.eh, yc);
       const int c0 = (gxs >> 1) - 1;
-      const float* r0 = dn + (size_t)ay21.i0 * ai.ew + c0;
-      const float* r1 = dn + (size_t)ay21.i1 * ai.ew + c0;
+      const float* r0 = dnp + (size_t)ay21.i0 * ai.ew + c0;
+      const float* r1 = dnp + (size_t)ay21.i1 * ai.ew + c0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { p0[j] = r0[j]; p1[j] = r1[j]; }
     }
@@ -737,7 +775,10 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
       for (int k = 0; k < 2; ++k) {
         const int t = tid + k * FF_NT;
         if (t < NTASK) {
-          if (staged) { ld[k][0] = stage[3 * t]; ld[k][1] = stage[3 * t + 1]; ld[k][2] = stage[3 * t + 2]; }
+          if (staged) {
+            if (FF_DMA12) { ld[k][0] = stage[3 * t]; ld[k][1] = stage[3 * t + 1]; ld[k][2] = stage[3 * t + 2]; }
+            else { ld[k][0] = stage[t]; ld[k][1] = stage[STG_P + t]; ld[k][2] = stage[2 * STG_P + t]; }
+          }
           else {
             const int ty = t / FF_IS, g = t - ty * FF_IS;
             const uint32_t* pp = reinterpret_cast<const uint32_t*>(src + ((size_t)(iy0 + ty) * W + ix0 + 4 * g) * 3);
@@ -771,6 +812,9 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
         tile[2][ty][tx] = vd_u8_unit((float)px[0]);
       }
     }
+    // this workgroup's NEXT tile: the ticket is requested here (a device-scope atomic: ~2 us) and looked at only before the third barrier
+    int ticket = nvb;
+    if (tid == 0) ticket = (int)gridDim.x + atomicAdd(ctr, 1);
     int lo[4] = {0, 0, 0, 0};
     vd_f4 alpha = {0.f, 0.f, 0.f, 0.f};
     int lmin = 9, lmax = -1;
@@ -784,7 +828,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
       for (int j = 0; j < 9; ++j) dstp[j] = srcp[j];
     }
     int my_mask = 0;
-    if (strip && fc.nlev) {
+    if (strip && f_nlev) {
       const float focal = w_focal;
       float dd[4];
       if (fast21) {
@@ -799,21 +843,21 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int x = min(max(gxs + q, 0), W - 1);
-          if (ai.eh == H && ai.ew == W) dd[q] = dn[(size_t)yc * W + x];
+          if (ai.eh == H && ai.ew == W) dd[q] = dnp[(size_t)yc * W + x];
           else if (2 * ai.eh == H && 2 * ai.ew == W) {
             const vd_tap ay = vd_tap21(ai.eh, yc), ax = vd_tap21(ai.ew, x);
-            const float* r0 = dn + (size_t)ay.i0 * ai.ew;
-            const float* r1 = dn + (size_t)ay.i1 * ai.ew;
+            const float* r0 = dnp + (size_t)ay.i0 * ai.ew;
+            const float* r1 = dnp + (size_t)ay.i1 * ai.ew;
             dd[q] = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
           } else {
             const vd_tap ay = vd_interp_tap(ai.eh, H, yc), ax = vd_interp_tap(ai.ew, W, x);
-            const float* r0 = dn + (size_t)ay.i0 * ai.ew;
-            const float* r1 = dn + (size_t)ay.i1 * ai.ew;
+            const float* r0 = dnp + (size_t)ay.i0 * ai.ew;
+            const float* r1 = dnp + (size_t)ay.i1 * ai.ew;
             dd[q] = vd_bilerp(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ax.w0, ax.w1, ay.w0, ay.w1);
           }
         }
       }
-      const bool fastfw = fc.fw == FF_FW_STD;
+      const bool fastfw = f_fw == FF_FW_STD;
       const float rcfw = 1.0f / FF_FW_STD;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -822,11 +866,11 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
         if (fastfw && (ad >= 1e-30f || ad == 0.f)) {
           const float q0 = ad * rcfw;
           qv = vd_fma(vd_fma(-q0, FF_FW_STD, ad), rcfw, q0);
-        } else qv = ad / fc.fw;
+        } else qv = ad / f_fw;
         const float bw = vd_clamp_fin(qv, 0.f, 1.f);
-        const float bi = vd_clamp_fin(bw * (float)fc.nlev, 0.f, fc.imax);
+        const float bi = vd_clamp_fin(bw * (float)f_nlev, 0.f, f_imax);
         int l = (int)floorf(bi);
-        l = l > fc.nlev - 1 ? fc.nlev - 1 : (l < 0 ? 0 : l);
+        l = l > f_nlev - 1 ? f_nlev - 1 : (l < 0 ? 0 : l);
         lo[q] = l; alpha[q] = bi - (float)l;
         if (!halo_px || q == hq) { lmin = min(lmin, l); lmax = max(lmax, l + 1); }
       }
@@ -849,7 +893,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
     __syncthreads();
     VD_STAMP(ffp_stamps, 2, false);
     const int need_mask = lvl_mask[0];
-    for (int l = 0; l < fc.nlev; ++l) {
+    for (int l = 0; l < f_nlev; ++l) {
       if (!(need_mask >> (l + 1) & 1)) continue;
       const int off = FF_R - fc.ksz[l] / 2;
       const bool mine = (my_mask >> (l + 1)) & 1;
@@ -877,7 +921,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         vd_f4 v = vres[c];
-        if (fc.nlev) {
+        if (f_nlev) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = vd_clamp_fin(v[q], 0.f, 1.f);
         }
@@ -887,9 +931,9 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
       uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        vd_f4 v = luma + (rgbv[c] - luma) * fc.sat;
-        v = 0.5f + (v - 0.5f) * fc.con;
-        v = v + fc.bri;
+        vd_f4 v = luma + (rgbv[c] - luma) * f_sat;
+        v = 0.5f + (v - 0.5f) * f_con;
+        v = v + f_bri;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float vc = vd_clamp_fin(v[q], 0.f, 1.f);
@@ -905,15 +949,20 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
       if (halo_px) gb[sy][4 * (ss - 1) + hq] = pk[0];
       else *reinterpret_cast<uint4*>(&gb[sy][4 * (ss - 1)]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
+    if (tid == 0) {
+      int e_, x_, y_;
+      while (ticket < nvb && !decode(ticket, &e_, &x_, &y_)) ticket = (int)gridDim.x + atomicAdd(ctr, 1);   // padding blocks of the XCD order (rare)
+      lvl_mask[1] = ticket;
+    }
     __syncthreads();   // graded tile complete; the levels are done: the halo-window buffer is dead and takes the next tile's raw bytes
     VD_STAMP(ffp_stamps, 4, false);
     // next tile of this workgroup; its raw bytes by LDS-DMA while the epilogue below runs
-    int nvb_ = vb + gridDim.x, neye = 0, nx0 = 0, ny0 = 0;
-    while (nvb_ < nvb && !decode(nvb_, &neye, &nx0, &ny0)) nvb_ += gridDim.x;
-    const bool more = nvb_ < nvb;
+    int nvb_ = lvl_mask[1], neye = 0, nx0 = 0, ny0 = 0;
+    nvb_ = __builtin_amdgcn_readfirstlane(nvb_);
+    const bool more = nvb_ < nvb && decode(nvb_, &neye, &nx0, &ny0);
     const bool nstaged = more && interior(nx0, ny0);       // workgroup-uniform
     if (nstaged) {
-      const uint8_t* __restrict__ nsrc = neye == 0 ? eyeL : eyeR;
+      const uint8_t* __restrict__ nsrc = neye == 0 ? eL : eR;
       const int nix0 = nx0 - 4 - FF_R, niy0 = ny0 - 1 - FF_R;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -921,14 +970,21 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused_p(
         if (t < NTASK) {   // lanes past the last group stay inactive: the DMA writes LDS at M0 + 12 * lane for ACTIVE lanes only
           const int ty = t / FF_IS, g = t - ty * FF_IS;
           const uint8_t* gp = nsrc + ((size_t)(niy0 + ty) * W + nix0 + 4 * g) * 3;
+#if FF_DMA12
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                            (__attribute__((address_space(3))) void*)(stage + 3 * (k * FF_NT + wv_u * 64)), 12, 0, 0);
+#else
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + 4 * j),
+                                             (__attribute__((address_space(3))) void*)(stage + j * STG_P + k * FF_NT + wv_u * 64), 4, 0, 0);
+#endif
         }
       }
     }
-    ff_epilogue<FF_TH, FF_NT>(gb, ai, fc, eye, x0, y0, gx0, gy0, tid, out);
+    ff_epilogue_k<FF_TH, FF_NT>(gb, ai, f_kn, f_kc, eye, x0, y0, gx0, gy0, tid, outp);
     VD_STAMP(ffp_stamps, 5, true);
-    if (!more) break;
+    if (!more) { leave(); break; }
     vb = nvb_; eye = neye; x0 = nx0; y0 = ny0; staged = nstaged;
     __syncthreads();   // epilogue done with gb / every wave past its levels; the DMA has landed (the compiler drains vmcnt before the barrier)
   }
@@ -1003,8 +1059,11 @@ bool vd_launch_sharp_fit(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
 }
 
 // 0: one tile per workgroup (rounds 2 - 4); k > 0: the persistent kernel with k workgroups per CU (vd3d_debug_tune(6, k))
+// Default 0: measured (profiles/r05_e1_persistent.md) the persistent kernel is 7 % SLOWER than the one-tile kernel at three workgroups per CU (299.7 vs 280.3 us
+// per 4K frame pair, byte-identical) -- the hardware's own dispatcher already balances the 16 k .. 53 k-cycle tiles dynamically, and keeping the tile loop
+// inside 80 VGPRs costs re-materialised constants, per-tile recomputation of the thread mapping and 8 spilled dwords.  Kept as an opt-in for the evidence.
 #ifndef FF_PERSIST
-#define FF_PERSIST 3
+#define FF_PERSIST 0
 #endif
 static int g_ff_persist = FF_PERSIST;
 void vd_set_finish_persist(int k) { g_ff_persist = k < 0 ? 0 : (k > 8 ? 8 : k); }
@@ -1038,8 +1097,14 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
     const int nvb = (int)g.x;
     int slots = g_ff_persist * ncu;                 // vd3d_debug_tune(6, k): k workgroups per CU (default 3)
     slots -= slots % 8;
-    if (slots >= 8 && nvb > slots) {
-      hipLaunchKernelGGL((k_finish_fused_p<FF_WIDE_TH>), dim3(slots), dim3(ff_geo<FF_WIDE_TH>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out, nvb);
+    static int* ctr_ring[64] = {};   // per device: 256 counter pairs, all zero; a launch takes the next pair and leaves it zeroed (see the kernel)
+    static unsigned ctr_next[64] = {};
+    if (dev >= 0 && dev < 64 && !ctr_ring[dev]) {
+      if (hipMalloc((void**)&ctr_ring[dev], 256 * 2 * sizeof(int)) != hipSuccess || hipMemset(ctr_ring[dev], 0, 256 * 2 * sizeof(int)) != hipSuccess) ctr_ring[dev] = nullptr;
+    }
+    if (slots >= 8 && nvb > slots && dev >= 0 && dev < 64 && ctr_ring[dev]) {
+      int* ctr = ctr_ring[dev] + 2 * (__atomic_fetch_add(&ctr_next[dev], 1u, __ATOMIC_RELAXED) & 255u);
+      hipLaunchKernelGGL((k_finish_fused_p<FF_WIDE_TH>), dim3(slots), dim3(ff_geo<FF_WIDE_TH>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out, nvb, ctr);
       return true;
     }
   }
