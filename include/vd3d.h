@@ -115,7 +115,12 @@ typedef struct vd3d_render_params {
    * 0: separable columns-then-rows sums -- 4x less arithmetic, identical to <= 6e-7 in float, which the reference's own uint8
    * truncation turns into +-1 LSB on ~0.5 % of samples before the sharpen stage (gain ~4.5): an opt-in fast mode. */
   int32_t dof_dense_conv;
-  int32_t reserved0;
+  /* Float32 summation order of the two `torch.mean` calls on the path (compute_dynamic_parallax_scale :418, compute_motion_metric :928; round 5).
+   * The reference's values are those of ATen's float32 cascade sum, which depends on the number of intra-op threads torch runs with
+   * (TensorIterator splits reductions of >= 32 768 elements across them).  N >= 1: reproduce torch with N threads bit for bit
+   * (torch.get_num_threads() of the reference process; its default is the machine's core count).  0 (what vd3d_render_params_default sets):
+   * the correctly rounded mean of the exact sum -- independent of any thread count, within one float32 ULP of every N. */
+  int32_t aten_sum_threads;
 } vd3d_render_params;
 
 /*

@@ -175,18 +175,37 @@ def subject_depth(d):
     return float(lib().vo_subject_depth(pd, H, W))
 
 
-def dynamic_parallax_scale(d, min_scale=0.6, max_scale=1.0):
+def dynamic_parallax_scale(d, min_scale=0.6, max_scale=1.0, aten_threads=0):
+    """aten_threads > 0: torch.mean of the centre crop as torch computes it with that many intra-op threads (ATen's float32 cascade sum)."""
     d, pd = _f(d)
     H, W = d.shape[-2:]
     m, v = C.c_float(), C.c_float()
-    return float(lib().vo_dynamic_parallax_scale(pd, H, W, min_scale, max_scale, C.byref(m), C.byref(v)))
+    lib().vo_set_aten_threads(int(aten_threads))
+    try:
+        return float(lib().vo_dynamic_parallax_scale(pd, H, W, min_scale, max_scale, C.byref(m), C.byref(v)))
+    finally:
+        lib().vo_set_aten_threads(0)
 
 
-def motion_metric(prev, cur):
+def motion_metric(prev, cur, aten_threads=0):
     prev, pp = _f(prev)
     cur, pc = _f(cur)
     mad = C.c_float()
-    return float(lib().vo_motion_metric(pp, pc, cur.size, C.byref(mad)))
+    lib().vo_set_aten_threads(int(aten_threads))
+    try:
+        return float(lib().vo_motion_metric(pp, pc, cur.size, C.byref(mad)))
+    finally:
+        lib().vo_set_aten_threads(0)
+
+
+def sum_aten_2d(view, threads=1):
+    """torch.sum of a float32 2-D view (rows may be strided, columns contiguous) as ATen's CPU kernel adds it with `threads` intra-op threads."""
+    v = np.asarray(view)
+    assert v.dtype == np.float32 and v.ndim == 2 and v.strides[1] == 4 and v.strides[0] % 4 == 0
+    L = lib()
+    L.vo_sum_aten_2d.restype = C.c_float
+    L.vo_sum_aten_2d.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int]
+    return np.float32(L.vo_sum_aten_2d(v.ctypes.data, v.shape[0], v.shape[1], v.strides[0] // 4, int(threads)))
 
 
 def curvature_clamp(d, strength=0.08):

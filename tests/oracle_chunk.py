@@ -140,10 +140,10 @@ class OracleChunkBackend:
         row, prow = self.etab[step_idx + 1], self.etab[step_idx]
         dn = _normalise(sl["filt"], row)
         sl["dn"] = dn
-        scale = O.dynamic_parallax_scale(dn.reshape(p.eye_h, p.eye_w), 0.90, 1.15)
+        scale = O.dynamic_parallax_scale(dn.reshape(p.eye_h, p.eye_w), 0.90, 1.15, aten_threads=p.aten_sum_threads)
         motion = 0.0
         if prow[3]:
-            motion = O.motion_metric(_normalise(sl["prev_plane"], prow), dn)
+            motion = O.motion_metric(_normalise(sl["prev_plane"], prow), dn, aten_threads=p.aten_sum_threads)
         s_norm = O.subject_depth(dn.reshape(p.eye_h, p.eye_w))
         sp = self._literal_shift_params(0.0, 0.0, 0.0)
         s1 = O.pixel_shift(sl["fe"], dn.reshape(1, p.eye_h, p.eye_w), p.warp_w, p.warp_h, sp, State())["dbg"]["s1"]

@@ -162,6 +162,39 @@ def test_sum_order_of_torch_sum(oracle):
             assert oracle.sum_aten(v) == np.float32(torch.from_numpy(v).sum().item()), n
 
 
+@pytest.mark.parametrize("threads", [1, 2, 3, 4, 5, 7, 8, 16, 64])
+def test_cascade_sum_of_torch_mean_at_any_size_and_thread_count(oracle, threads):
+    """Round 5: core/render_3d.py:418 (torch.mean of the strided centre crop) and :928 (torch.mean of a contiguous plane).  ATen's float32 cascade sum --
+    8 lanes x 4 interleaved accumulators, a 4-level cascade with 16-step level-0 blocks, the serial_for_each walk of a thread's range row piece by row
+    piece, TensorIterator's two-pass reduction over min(T, ceil(numel / 32768)) ranges and the final reduction of the T partials by the same loop -- restated
+    in oracle/vd3d_oracle.c::vo_sum_aten_2d: identical to torch.sum / torch.mean for every size from a thumbnail to 3840 x 2160 at this thread count.
+    (The device counterpart, vd3d_atensum.hip, is compared with this restatement by tests/test_hip_parity.py::test_aten_sum_order_of_the_two_torch_means.)"""
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        if torch.get_num_threads() != threads:
+            pytest.skip("this torch build cannot run that many intra-op threads")
+        rng = np.random.default_rng(threads)
+        for (H, W) in ((18, 30), (36, 64), (108, 192), (270, 480), (540, 960), (1080, 1920), (1079, 1917), (2160, 3840)):
+            x = rng.random((H, W), dtype=np.float32)
+            t = torch.from_numpy(x)
+            crop_t = t[H // 4:H * 3 // 4, W // 4:W * 3 // 4]
+            crop = x[H // 4:H * 3 // 4, W // 4:W * 3 // 4]
+            assert oracle.sum_aten_2d(crop, threads) == np.float32(crop_t.sum().item()), (H, W, "crop")
+            assert np.float32(oracle.sum_aten_2d(crop, threads) / np.float32(crop.size)) == np.float32(torch.mean(crop_t).item()), (H, W, "mean")
+            assert oracle.sum_aten_2d(x.reshape(1, -1), threads) == np.float32(t.sum().item()), (H, W, "plane")
+            # the functions of the path, with that thread count
+            d = torch.from_numpy(x)[None]
+            mean_t, var_t = torch.mean(d[:, H // 4:H * 3 // 4, W // 4:W * 3 // 4]), torch.var(d[:, H // 4:H * 3 // 4, W // 4:W * 3 // 4])
+            exp = (0.90 + (var_t / (mean_t + 1e-5)).clamp(0.0, 1.0) * (1.15 - 0.90)).item()
+            assert oracle.dynamic_parallax_scale(x, 0.90, 1.15, aten_threads=threads) == exp, (H, W)
+            y = rng.random((H, W), dtype=np.float32)
+            mad = torch.mean(torch.abs(torch.from_numpy(y)[None] - d)).item()
+            assert oracle.motion_metric(x, y, aten_threads=threads) == max(0.0, min(1.0, mad * 4.0)), (H, W)
+    finally:
+        torch.set_num_threads(prev)
+
+
 def _torch_kernel1d(k, sigma):
     half = (k - 1) * 0.5
     lin = torch.linspace(-half, half, steps=k)

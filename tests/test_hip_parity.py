@@ -314,6 +314,46 @@ def test_feather_strength_zero_takes_the_exact_no_feather_warp(R, oracle, fmt, s
         assert np.array_equal(got[i], exp[i]), (i, "step path", u8_diff_stats(got[i], exp[i]))
 
 
+@pytest.mark.parametrize("fmt,size,threads", [("Half-SBS", (108, 192), 1), ("Half-SBS", (108, 192), 6), ("Half-SBS", (1080, 1920), 4), ("Half-SBS", (1080, 1920), 64),
+                                              ("Full-SBS", (540, 960), 3), ("Red-Cyan Anaglyph", (1080, 1920), 16), ("Half-SBS", (2160, 3840), 8)])
+def test_aten_sum_order_of_the_two_torch_means(R, oracle, fmt, size, threads):
+    """Round 5: vd3d_render_params::aten_sum_threads = N reproduces the float32 `torch.mean` of compute_dynamic_parallax_scale (:418) and compute_motion_metric
+    (:928) as torch computes them with N intra-op threads -- ATen's cascade sum over the thread partition (vd3d_atensum.hip: one wave per crop row, one
+    workgroup per thread share of the difference plane, level-0 blocks built in parallel and folded in order) -- bit for bit like the oracle's restatement,
+    which tests/test_aten_restatements.py pins against torch itself.  Per-frame entry point and the batched step path (measure / replay: the float sums
+    travel in the exchanged record), frames, scalars and final tracker state."""
+    from visiondepth3d_amd.render_3d import render_pairs
+    sh, sw = size
+    kw = dict(KW_GUI, output_format=fmt, output_height=sh, feather_strength=6.0, blur_ksize=5, aten_sum_threads=threads)
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    assert p.aten_sum_threads == threads
+    n = 3 if sh >= 1080 else 5
+    frames, depths = synth.synth_clip(n, sh, sw)
+    gray = [synth.depth_to_u8_bgr(d) for d in depths]
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    exp, exp_sc = [], []
+    for f, g in zip(frames, gray):
+        exp.append(ro.render(f, g, 1)); exp_sc.append(ro.last.as_dict())
+    R.reset_state(); R.new_clip()
+    for i, (f, g) in enumerate(zip(frames, gray)):
+        got = R.render_frame(T(f), T(g), p).cpu().numpy()
+        a, b = R.last_scalars().as_dict(), exp_sc[i]
+        assert a == b, (i, {k_: (a[k_], b[k_]) for k_ in a if a[k_] != b[k_]})
+        assert np.array_equal(got, exp[i]), (i, u8_diff_stats(got, exp[i]))
+    st_seq = R.export_state().as_dict()
+    assert st_seq == ro.state.as_dict()
+    R.reset_state()
+    got = list(render_pairs(zip(frames, gray), renderer=R, skip_first=False, batch=2, **kw))
+    for i in range(n):
+        assert np.array_equal(got[i], exp[i]), (i, "step path", u8_diff_stats(got[i], exp[i]))
+    assert R.export_state().as_dict() == st_seq
+    # the order-free default (aten_sum_threads = 0) is a different -- correctly rounded -- mean: same frames on almost every clip, never the subject here
+    p0 = render_kwargs_to_params(sw, sh, **dict(kw, aten_sum_threads=0))
+    assert p0.aten_sum_threads == 0
+
+
 KW_CLI = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
               feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
 

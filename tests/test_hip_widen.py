@@ -109,6 +109,29 @@ def test_fractional_fit_finish_vs_oracle(R, oracle):
         assert np.array_equal(got, exp), (fmt, fw, fh, u8_diff_stats(got, exp))
 
 
+def test_two_by_two_fit_vector_epilogue_vs_oracle(R, oracle):
+    """Round 5: the fused finishing kernel's vector epilogue also takes the 2 x 2 fit -- the GUI's own default on a 4K source (Full-SBS = 1920 x 1080
+    eyes from a 3840 x 2160 warp, VisionDepth3D.py:1405-1453; OpenCV's ResizeAreaFastVec (sum + 2) >> 2).  Interior tiles take the vector path, border
+    tiles the per-pixel one: both against the oracle, every format that reaches this fit, ragged sizes included."""
+    rng = np.random.default_rng(31)
+    for (H, W), fmt in [((156, 256), "Full-SBS"), ((208, 320), "Passive Interlaced"), ((156, 384), "Red-Cyan Anaglyph"), ((210, 300), "Full-SBS"),
+                        ((2160, 3840), "Full-SBS")]:
+        L = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        Rr = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        dn = rng.random((H // 2, W // 2)).astype(np.float32) if H > 1000 else rng.random((H, W)).astype(np.float32)
+        p = render_kwargs_to_params(W, H, output_format=fmt, output_height=H, fg_shift=8.0, mg_shift=-2.0, bg_shift=-5.0,
+                                    sharpness_factor=0.2, dof_strength=2.0, preserve_original_aspect=True,
+                                    original_video_width=W, original_video_height=H)
+        p.fit_w, p.fit_h = W // 2, H // 2
+        p.out_w = W if fmt == "Full-SBS" else W // 2
+        p.out_h = H // 2
+        if H > 1000:
+            p.eye_w, p.eye_h = W // 2, H // 2
+        got = R.finish_frame(T(L), T(Rr), T(dn), p, 0.4, bar_width=7, bar_side=2).cpu().numpy()
+        exp = oracle.finish_frame(L, Rr, dn, p, 0.4, 7, 2)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (fmt, H, W, u8_diff_stats(got, exp))
+
+
 def test_fused_finish_in_front_of_any_fit_equals_the_unfused_kernels(R, oracle):
     """Round 4: a fit the fused finishing kernel does not take (fractional / up-scaling INTER_AREA, the VR canvas) no longer sends the frame to
     the unfused DOF + grade kernels: E1 runs 1:1 into a side-by-side scratch of sharpened eyes and k_sharp_mux does fit + mux only.  Both

@@ -22,7 +22,7 @@ SH, SW, NF, B = 72, 128, 7, 2
 BLANK = {2}
 KW = dict(output_format="Half-SBS", output_height=72, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15,
           dof_strength=2.0, feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True,
-          skip_blank_frames=True, ipd_factor=1.1)
+          skip_blank_frames=True, ipd_factor=1.1, aten_sum_threads=3)   # torch.mean in ATen's summation order with 3 threads (round 5): part of the replayed record
 STATE_FIELDS = ("fw_prev_offset", "fw_frame_counter", "ema_valid", "ema_lo", "ema_hi", "conv_valid", "bar_prev_width", "conv_val",
                 "focal_valid", "smooth_valid", "focal", "sm_fg", "sm_mg", "sm_bg", "tdf_valid", "prev_depth_valid")
 

@@ -75,7 +75,7 @@ class RenderParams(C.Structure):
         ("sharpness_factor", C.c_double),
         ("color_saturation", C.c_double), ("color_contrast", C.c_double), ("color_brightness", C.c_double),
         ("target_ratio", C.c_double),
-        ("dof_dense_conv", C.c_int32), ("reserved0", C.c_int32),
+        ("dof_dense_conv", C.c_int32), ("aten_sum_threads", C.c_int32),
     ]
 
 

@@ -55,6 +55,11 @@ struct vd3d_ctx {
   uint32_t* mm = nullptr; int mm_cap = 0;
   uint32_t* rowflag = nullptr; int rowflag_cap = 0;   // k_autocrop: one flag per source row
   uint8_t* blank_eye = nullptr; size_t blank_cap = 0; // skip_blank_frames: the side-masked source frame (source size)
+  // vd3d_render_params::aten_sum_threads > 0: piece plan of the two torch.mean sums (vd3d_atensum.hip) for the current eye size / thread count, and the
+  // per-frame piece sums of a batch.  Plans are never overwritten (a queued kernel may still read one): a new key gets new buffers.
+  int aten_eh = 0, aten_ew = 0, aten_T = 0, aten_n_small = 0, aten_n_big = 0, aten_nr_crop = 0, aten_nr_mad = 0;
+  int* aten_plan = nullptr; float* aten_scratch = nullptr;
+  std::vector<void*> aten_retired;
   uint8_t* fmt_eyes = nullptr; size_t fmt_cap = 0;    // vd3d_format_3d_output's own pair of resized VR eyes (never the shared warp-res planes: ADVICE r4)
   bool crop_scalars_dirty = false;                    // fs.crop_top/bottom hold a previous auto-crop result
   // frame sharding (three-phase protocol): per-slot planes of the frames this rank owns inside the current step
@@ -245,7 +250,8 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->fmt_eyes};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->fmt_eyes, c->aten_plan, c->aten_scratch};
+  for (void* q : c->aten_retired) (void)hipFree(q);
   for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
   for (auto& t : c->wk_tabs) (void)hipFree(t.dev);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -345,6 +351,30 @@ VD3D_EXPORT int vd3d_state_planes(vd3d_ctx* c, float** tdf_prev, float** norm_pr
 VD3D_EXPORT int vd3d_last_scalars(vd3d_ctx* c, vd3d_frame_scalars* out) {
   HIPCHK(hipMemcpyAsync(out, &c->work->fs, sizeof(vd3d_frame_scalars), hipMemcpyDeviceToHost, c->stream));
   return vd3d_sync(c);
+}
+
+// vd3d_render_params::aten_sum_threads > 0: the two torch.mean calls of the loop body in ATen's float32 summation order (vd3d_atensum.hip)
+static int aten_setup(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args* a) {
+  a->aten_threads = 0;
+  const int T = p->aten_sum_threads;
+  if (T <= 0) return 0;
+  if (c->aten_eh != p->eye_h || c->aten_ew != p->eye_w || c->aten_T != T) {
+    std::vector<int> flat;
+    int ns = 0, nb = 0, nrc = 0, nrm = 0;
+    if (!vd_aten_plan_build(p->eye_h, p->eye_w, T, flat, &ns, &nb, &nrc, &nrm))
+      return set_err(VD3D_E_UNSUPPORTED, "aten_sum_threads %d with %dx%d eyes: outside the restated range (1 .. 256 threads)", T, p->eye_w, p->eye_h);
+    if (c->aten_plan) c->aten_retired.push_back(c->aten_plan);
+    if (c->aten_scratch) c->aten_retired.push_back(c->aten_scratch);
+    c->aten_plan = nullptr; c->aten_scratch = nullptr;
+    HIPCHK(hipMalloc((void**)&c->aten_plan, flat.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(c->aten_plan, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));   // a fresh buffer: nothing queued reads it yet
+    HIPCHK(hipMalloc((void**)&c->aten_scratch, (size_t)VD_MAX_BATCH * (size_t)(ns + nb) * sizeof(float)));
+    c->aten_eh = p->eye_h; c->aten_ew = p->eye_w; c->aten_T = T;
+    c->aten_n_small = ns; c->aten_n_big = nb; c->aten_nr_crop = nrc; c->aten_nr_mad = nrm;
+  }
+  a->aten_threads = T; a->aten_n_small = c->aten_n_small; a->aten_n_big = c->aten_n_big; a->aten_nr_crop = c->aten_nr_crop; a->aten_nr_mad = c->aten_nr_mad;
+  a->aten_plan = c->aten_plan; a->aten_scratch = c->aten_scratch;
+  return 0;
 }
 
 // ---- shared middle section: shaped depth, s1, shift, feather, warp --------------------------------
@@ -712,6 +742,7 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   a.blank = blank ? 1 : 0;
   a.n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a.ipd_factor = p->ipd_factor; a.shift = sp;
+  if ((rc = aten_setup(c, p, &a))) return rc;
   float* dn_cur = c->dn[c->dn_cur];
   if (p->auto_crop_black_bars) {   // :1230-1248 decided on device, no host round trip
     if (p->src_h > c->rowflag_cap) { HIPCHK(re_alloc(&c->rowflag, (size_t)p->src_h)); c->rowflag_cap = p->src_h; }
@@ -966,7 +997,7 @@ VD3D_EXPORT int vd3d_wait_pixels(vd3d_ctx* c, int slot) {
 // ---- frame sharding, measure / replay protocol (visiondepth3d_amd/sharded.py: MeasureReplaySharder) ----------
 // Replicated work per foreign frame = ONE small kernel (the TemporalDepthFilter plane EMA); everything else is measured by the
 // owner, exchanged as a few numbers per frame and replayed as scalar recurrences on every rank.
-static void shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args* a, vd3d_shift_params* sp) {
+static int shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args* a, vd3d_shift_params* sp) {
   *sp = p->shift;
   sp->parallax_balance = 0.8; sp->depth_pop_gamma = 0.85; sp->depth_pop_mid = 0.50; sp->depth_stretch_lo = 0.05;
   sp->depth_stretch_hi = 0.95; sp->fg_pop_multiplier = 1.20; sp->bg_push_multiplier = 1.10; sp->subject_lock_strength = 1.00;
@@ -975,6 +1006,7 @@ static void shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args*
   a->n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
   a->ipd_factor = p->ipd_factor; a->shift = *sp; a->etab = c->etab;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VD3D_DBG"); dbg = e ? atoi(e) : 0; } a->dbg = dbg; }   // timing probes only (vd3d_kernels.h)
+  return aten_setup(c, p, a);
 }
 // P1, for every OWN frame of the step in frame order (a rank owns a contiguous chunk of the step): ingest (RGB kept in the slot),
 // TemporalDepthFilter plane EMA, exact q.02 / q.98 of the filtered plane written to q_out_dev[0..1]; the filtered planes of this
@@ -995,7 +1027,7 @@ static int shard2_p1_impl(vd3d_ctx* c, const uint8_t* const* frames_bgr, const v
   for (int j = 0; j < n; ++j) { int rcw = wait_slot(c, slot0 + j); if (rcw) return rcw; }
   hipStream_t s = c->stream;
   vd_stage_args a; vd3d_shift_params sp;
-  shard2_args(c, p, &a, &sp);
+  { int rca = shard2_args(c, p, &a, &sp); if (rca) return rca; }
   a.crop_tab = p->auto_crop_black_bars ? c->crop_tab : nullptr;
   const size_t ne = (size_t)p->eye_h * p->eye_w;
   StageTimer t(c, "p1_own");
@@ -1087,8 +1119,8 @@ static int shard2_p3_impl(vd3d_ctx* c, int slot0, int step_idx0, int n, const vd
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   vd_stage_args a; vd3d_shift_params sp;
-  shard2_args(c, p, &a, &sp);
   int rc;
+  if ((rc = shard2_args(c, p, &a, &sp))) return rc;
   if ((rc = check_shift_params(&sp, p->warp_h, p->warp_w))) return rc;
   a.shard = 3;
   for (int j = 0; j < n; ++j) if ((rc = wait_slot(c, slot0 + j))) return rc;
@@ -1131,7 +1163,7 @@ VD3D_EXPORT int vd3d_shard2_r2(vd3d_ctx* c, const long long* m_all_dev, const in
   if (!c || !m_all_dev || !own_slot_host || !p || n < 1 || n > VD_MAX_STEP) return set_err(VD3D_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   vd_stage_args a; vd3d_shift_params sp;
-  shard2_args(c, p, &a, &sp);
+  { int rca = shard2_args(c, p, &a, &sp); if (rca) return rca; }
   for (int t = 0; t < n; ++t) { int rc = wait_slot(c, own_slot_host[t]); if (rc) return rc; }
   StageTimer t(c, "replay");
   vd_launch_shard2_r2(c->stream, c->work, m_all_dev, c->etab, own_slot_host, blank_host_or_null, n, c->slot_work, a);

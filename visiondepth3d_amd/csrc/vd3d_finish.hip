@@ -249,12 +249,13 @@ VD_DEV void ff_epilogue_k(const uint32_t (*gb)[FF_GP], const vd_ff_args& a, floa
   // epilogue: sharpen (:717-732) + integer-ratio INTER_AREA (:1413) + mux
   const int ow = FF_TW / a.fx, oh = FF_TH / a.fy;      // output pixels produced by this tile
   const int ox0 = x0 / a.fx, oy0 = y0 / a.fy;
-  const bool out_interior = x0 >= 1 && x0 + FF_TW <= W - 1 && y0 >= 1 && y0 + FF_TH <= H - 1 && a.fy == 1 &&
-                            (a.fx == 1 || a.fx == 2) && ox0 + ow <= a.in_w && oy0 + oh <= a.in_h;
+  // vector path: fits (1, 1), (2, 1) and -- round 5 -- (2, 2): the GUI's own default on a 4K source (Full-SBS = 1920 x 1080 eyes, VisionDepth3D.py:1405-1453)
+  const bool out_interior = x0 >= 1 && x0 + FF_TW <= W - 1 && y0 >= 1 && y0 + FF_TH <= H - 1 &&
+                            ((a.fy == 1 && (a.fx == 1 || a.fx == 2)) || (a.fy == 2 && a.fx == 2 && (FF_TH & 1) == 0)) && ox0 + ow <= a.in_w && oy0 + oh <= a.in_h;
   if (out_interior) {
-    // one task = 4 consecutive OUTPUT pixels of one row = fx groups of 4 sharpened pixels; 12-byte packed store
+    // one task = 4 consecutive OUTPUT pixels of one row = fx groups of 4 sharpened pixels (x fy rows); 12-byte packed store
     const int ngrp = ow / 4;                          // 16 (fx = 1) or 8 (fx = 2)
-    for (int t = tid; t < FF_TH * ngrp; t += FF_NT) {
+    for (int t = tid; t < oh * ngrp; t += FF_NT) {
       const int ty = t / ngrp, m = t - ty * ngrp;
       const int oy = oy0 + ty;
       if (a.format == VD3D_FMT_INTERLACED && (((oy + a.yo) & 1) != eye)) continue;
@@ -262,6 +263,20 @@ VD_DEV void ff_epilogue_k(const uint32_t (*gb)[FF_GP], const vd_ff_args& a, floa
       int fv[3][4];
       if (a.fx == 1) {
         ff_sharp4(gb, ty + 1, 4 + 4 * m, kn, kc, fv);
+      } else if (a.fy == 2) {   // 2 x 2 box of sharpened bytes: OpenCV's ResizeAreaFastVec, (sum + 2) >> 2 (same as the per-pixel path below)
+        // left half of the four output pixels, then the right half: two tiles of sharpened values live at a time, not four (the kernel's 80-VGPR
+        // budget = three workgroups per CU is set by the dense levels; all four at once took 96)
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+          int sa[3][4], sb[3][4];
+          ff_sharp4(gb, 2 * ty + 1, 4 + 8 * m + 4 * hx, kn, kc, sa);
+          ff_sharp4(gb, 2 * ty + 2, 4 + 8 * m + 4 * hx, kn, kc, sb);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fv[c][2 * hx + q] = ((sa[c][2 * q] + sa[c][2 * q + 1]) + (sb[c][2 * q] + sb[c][2 * q + 1]) + 2) >> 2;
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
         int s0[3][4], s1[3][4];
         ff_sharp4(gb, ty + 1, 4 + 8 * m, kn, kc, s0);

@@ -28,6 +28,10 @@ struct vd_stage_args {
   int dbg;             // development probes (timing only, results are garbage): bit0 = skip the last-workgroup scalar stage, bit1 = skip ticket +
                        // fences, bit2 = skip the LDS -> global histogram flush, bit3 = skip the LDS histogram adds
   int blank;           // skip_blank_frames hit (core/render_3d.py:1278-1281): no ipd scaling, no FloatingWindowTracker / focal update
+  // vd3d_render_params::aten_sum_threads > 0 (vd3d_atensum.hip): torch.mean's float32 summation order for the dynamic parallax scale and the motion metric
+  int aten_threads, aten_n_small, aten_n_big, aten_nr_crop, aten_nr_mad;
+  const int* aten_plan;   // device: [pieces][4] = {plane offset, length, range, job}
+  float* aten_scratch;    // device: [frames of the batch][pieces] piece sums
   vd3d_shift_params shift;
 };
 
@@ -154,6 +158,12 @@ bool vd_warp_fused_ok(int ih, int iw, int H, int W, const vd3d_shift_params& p);
 // k_e2w (vd3d_warp.hip): gradient mask plane E2[H][W][2] (left, right eye) of feather_shift_edges from the shaped depth and the shift plane
 void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, float feather_strength, float* E2);
 void vd_set_warp_pre_th(int th);
+#ifdef __cplusplus
+#include <vector>
+// vd3d_atensum.hip: piece plan of the two torch.mean sums for one eye size and torch thread count (host vectors; the caller uploads them)
+bool vd_aten_plan_build(int eh, int ew, int T, std::vector<int>& pieces_flat, int* n_small, int* n_big, int* nr_crop, int* nr_mad);
+#endif
+void vd_launch_aten_sums(hipStream_t s, const vd_batch& b, const vd_stage_args& a);
 void vd_set_finish_persist(int k);   // vd3d_finish.hip: 0 = one tile per workgroup, k > 0 = persistent fused finishing kernel, k workgroups per CU
 void vd_set_conv_mode(int v);   // vd3d_conv.hip: < 0 one tile per workgroup (rounds 2 - 4), >= 0 persistent kernel with a phase skew of v microseconds
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,

@@ -446,6 +446,9 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
         if (a.have_eye && a.shard == 3) {   // measurements only: the recurrences run in k_shard2_r2
           w->fs.s_norm = subject_from_job(&lcs[VD_J_EYE_SUBJ]);
           a.m_out[0] = w->sum1; a.m_out[1] = w->sum2; a.m_out[2] = w->sum_mad;
+          if (a.aten_threads > 0) {   // torch-order float32 sums travel instead of the exact |difference| sum (which the mean of :928 then does not use)
+            reinterpret_cast<float*>(&a.m_out[2])[0] = w->aten_sum_mean; reinterpret_cast<float*>(&a.m_out[2])[1] = w->aten_sum_mad;
+          }
           reinterpret_cast<float*>(&a.m_out[3])[0] = w->fs.s_norm;
           w->sum1 = 0; w->sum2 = 0; w->sum_mad = 0;
         } else
@@ -455,7 +458,8 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           // compute_dynamic_parallax_scale :412-427 from the exact fixed-point sums
           const double n = (double)a.n_crop;
           const double s1d = (double)w->sum1 / VD_FX, s2d = (double)w->sum2 / VD_FX;
-          const float mean = (float)(s1d / n);
+          float mean = (float)(s1d / n);
+          if (a.aten_threads > 0 && a.n_crop > 0) mean = w->aten_sum_mean / (float)a.n_crop;   // torch.mean = ATen's float32 cascade sum / float(n)
           const float var = (float)((s2d - s1d * s1d / n) / (a.n_crop > 1 ? n - 1.0 : 1.0));
           const float nv = vd_clamp(var / (mean + 1e-5f), 0.f, 1.f);
           const float scale = (float)0.90 + nv * (float)(1.15 - 0.90);
@@ -477,7 +481,8 @@ VD_DEV void run_scalar_stage(vd_dev_work* w, const uint32_t* histA, const uint32
           w->fs.mad = 0.f;
           double motion = 0.0;
           if (st->prev_depth_valid && !a.blank) {
-            const float mad = (float)(((double)w->sum_mad / VD_FX) / (double)a.n_eye);
+            float mad = (float)(((double)w->sum_mad / VD_FX) / (double)a.n_eye);
+            if (a.aten_threads > 0 && a.n_eye > 0) mad = w->aten_sum_mad / (float)a.n_eye;
             w->fs.mad = mad;
             double m = (double)mad * 4.0;
             motion = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
@@ -1246,6 +1251,7 @@ void vd_launch_chain_work(hipStream_t s, const vd_batch& b, int have_eye, int ih
   const int work_wg_b = batch_grid(n, 4096, 512, b.n);   // K4: streams the stored curved-depth plane (one release fence per workgroup)
   // K3a normalises the eye-res plane (its own launch: K3b then samples plain values -- no per-tap division, taps shared by four pixels)
   if (have_eye) hipLaunchKernelGGL(k_chain_norm, dim3(eye_wg, nf), dim3(1024), 0, s, b, ih, iw, a);
+  if (have_eye && a.aten_threads > 0) vd_launch_aten_sums(s, b, a);   // torch.mean's summation order (vd3d_atensum.hip): read by K4's scalar stage
   hipLaunchKernelGGL(k_chain_stage1, dim3(work_wg, nf), dim3(1024), 0, s, b, f, a);
   hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b, nf), dim3(1024), 0, s, b, ih, iw, eye_wg_b, f, a);
   hipLaunchKernelGGL(k_chain_shape, dim3(batch_grid(n, 4096, 512, b.n), nf), dim3(1024), 0, s, b, f, mid, gamma, a);
@@ -1299,7 +1305,8 @@ __global__ void k_shard2_r2(vd_dev_work* w, const long long* __restrict__ m_all,
     w->fs.s_norm = s_norm;
     const double nn = (double)a.n_crop;
     const double s1d = (double)sum1 / VD_FX, s2d = (double)sum2 / VD_FX;
-    const float mean = (float)(s1d / nn);
+    float mean = (float)(s1d / nn);
+    if (a.aten_threads > 0 && a.n_crop > 0) mean = reinterpret_cast<const float*>(&m_all[4 * t + 2])[0] / (float)a.n_crop;
     const float var = (float)((s2d - s1d * s1d / nn) / (a.n_crop > 1 ? nn - 1.0 : 1.0));
     const float nv = vd_clamp(var / (mean + 1e-5f), 0.f, 1.f);
     const float scale = (float)0.90 + nv * (float)(1.15 - 0.90);
@@ -1320,7 +1327,8 @@ __global__ void k_shard2_r2(vd_dev_work* w, const long long* __restrict__ m_all,
     w->fs.mad = 0.f;
     double motion = 0.0;
     if (have_prev && !blank) {
-      const float mad = (float)(((double)sum_mad / VD_FX) / (double)a.n_eye);
+      float mad = (float)(((double)sum_mad / VD_FX) / (double)a.n_eye);
+      if (a.aten_threads > 0 && a.n_eye > 0) mad = reinterpret_cast<const float*>(&m_all[4 * t + 2])[1] / (float)a.n_eye;
       w->fs.mad = mad;
       const double m = (double)mad * 4.0;
       motion = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);

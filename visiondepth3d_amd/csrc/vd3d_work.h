@@ -55,4 +55,5 @@ struct vd_dev_work {
   float focal;
   int32_t bar_width, bar_side;
   int32_t acrop[4];        // crop_x, crop_y, crop_w, crop_h of THIS frame when auto_crop_black_bars is on (k_autocrop)
+  float aten_sum_mean, aten_sum_mad;   // vd3d_render_params::aten_sum_threads > 0: torch.sum's float32 value of the centre crop / of |d_t - d_{t-1}| (vd3d_atensum.hip)
 };

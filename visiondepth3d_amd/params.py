@@ -36,11 +36,13 @@ def shift_params_from_kwargs(fg_shift, mg_shift, bg_shift, **kw) -> ShiftParams:
 
 def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, mg_shift, bg_shift,
                             sharpness_factor, output_format, dof_strength, target_ratio=16 / 9, dof_dense_conv=True,
-                            **kw) -> RenderParams:
+                            aten_sum_threads=0, **kw) -> RenderParams:
     """``dof_dense_conv`` (extension, not a render_sbs_3d parameter; default on): the DOF Gaussian levels in the reference's dense k x k
     association -- the mode that reproduces the reference's finishing stage bit for bit.  ``False`` selects the separable form
     (about 25 % less time in the finishing kernel, differs from the reference on ~0.5 % of samples; include/vd3d.h
-    vd3d_render_params::dof_dense_conv)."""
+    vd3d_render_params::dof_dense_conv).  ``aten_sum_threads`` (extension): N >= 1 reproduces the float32 ``torch.mean`` of the dynamic parallax scale
+    and of the motion metric as torch computes them with N intra-op threads (``torch.get_num_threads()`` of the reference process); 0 = the correctly
+    rounded exact mean (include/vd3d.h vd3d_render_params::aten_sum_threads)."""
     unknown = set(kw) - set(RENDER_DEFAULTS) - {"output_width", "input_path", "depth_path", "output_path",
                                                 "selected_codec", "fps", "selected_aspect_ratio", "aspect_ratios"}
     if unknown:
@@ -64,4 +66,5 @@ def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, 
     p.auto_crop_black_bars = 1 if o["auto_crop_black_bars"] else 0   # :1230-1234, crop decided per frame on device
     p.target_ratio = float(target_ratio)
     p.dof_dense_conv = 1 if dof_dense_conv else 0
+    p.aten_sum_threads = int(aten_sum_threads)
     return p
