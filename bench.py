@@ -238,7 +238,8 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     from visiondepth3d_amd.render_3d import Renderer
 
     sh, sw, model_name, desc = WORKLOADS[workload]
-    host_io = bool(args.host_io) if host_io is None else bool(host_io)
+    if host_io is None:
+        host_io = "nv12" if args.host_io_nv12 else bool(args.host_io)
     p = render_kwargs_to_params(sw, sh, output_height=sh, dof_dense_conv=not workload.endswith("-sepdof"),
                                 **dict(RENDER_KW, **WORKLOAD_KW.get(workload, {})))
     overlap = (not args.no_overlap) and model_name is not None
@@ -257,13 +258,25 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     depths = torch.stack([torch.from_numpy(d) for d in depths_np]).cuda()          # [C,h,w] f32
     outs = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
     ring = h_clip = None
+    nv12 = host_io == "nv12"    # NV12 wire format both ways (video_io.PIPE_PIX_FMT = "nv12"): 1.5 bytes per pixel cross PCIe instead of 3
+    fb_bgr = outs_bgr = None
     if host_io:   # the clip lives in pinned host memory, results return to pinned host memory
         from visiondepth3d_amd.frame_io import PinnedRing
-        h_clip = frames.cpu().pin_memory()
-        ring = PinnedRing(B, (sh, sw, 3), (p.out_h, p.out_w, 3), torch.device("cuda", local_rank), depth=3)
+        if nv12:
+            conv = Renderer(local_rank)
+            h_clip = torch.stack([conv.bgr_to_nv12(frames[j]) for j in range(frames.shape[0])]).cpu().pin_memory()   # [C, h*3/2, w]
+            conv.close()
+            ring = PinnedRing(B, (sh * 3 // 2, sw), (p.out_h * 3 // 2, p.out_w), torch.device("cuda", local_rank), depth=int(args.ring_depth))
+            fb_bgr = torch.empty((B, sh, sw, 3), dtype=torch.uint8, device="cuda")
+            outs_bgr = torch.empty((B, p.out_h, p.out_w, 3), dtype=torch.uint8, device="cuda")
+        else:
+            h_clip = frames.cpu().pin_memory()
+            ring = PinnedRing(B, (sh, sw, 3), (p.out_h, p.out_w, 3), torch.device("cuda", local_rank), depth=int(args.ring_depth))
 
     # host-io: measured slower with the overlapped passes (the copy engines then compete with two compute streams)
     pix_ov = (not host_io) if args.pixel_overlap is None else bool(args.pixel_overlap)
+    if nv12:
+        pix_ov = False    # the colour conversions run on the renderer's one stream, in front of and behind the step
     shr2 = None
     if world > 1 or args.sharded or pix_ov or not args.per_frame:   # the step protocol (batched select chain) is the default DIBR path at any world size
         from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
@@ -298,6 +311,10 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
             kr = i % ring.n
             ring.upload(kr, h_clip[idx[0]:idx[0] + B] if contiguous else h_clip[idx])
             fb, outs_k = ring.d_in[kr], ring.d_out[kr]
+            if nv12:   # NV12 -> BGR on the device (vd3d_nv12_to_bgr), the step renders into a BGR buffer, BGR -> NV12 below
+                for j in range(B):
+                    r.nv12_to_bgr(ring.d_in[kr][j], out=fb_bgr[j])
+                fb, outs_k = fb_bgr, outs_bgr
         if overlap:
             torch.cuda.current_stream().wait_event(done[k])  # hand-off buffer k is free again (no-op until first recorded)
         dloc = None
@@ -339,6 +356,9 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
         if overlap:
             done[k].record(dibr_stream)
         if ring is not None:   # D2H behind the stream that produced the muxed frames
+            if nv12:
+                for j in range(B):
+                    r.bgr_to_nv12(outs_bgr[j], out=ring.d_out[kr][j])
             ring.download(kr, compute_stream=r.pixel_stream if pix_ov else dibr_stream)
 
     for i in range(warmup):
@@ -387,10 +407,10 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     res = dict(workload=workload, desc=desc, sh=sh, sw=sw, model=model_name, B=B, steps=steps, warmup=warmup, dt=dt,
                w1_alg_bytes=w1_alg, e1_alg_bytes=6 * p.warp_h * p.warp_w + 4 * p.eye_h * p.eye_w + 3 * p.out_h * p.out_w, feather_on=feather_on, eye=(p.eye_h, p.eye_w), warp=(p.warp_h, p.warp_w), out=(p.out_h, p.out_w),
                frames_total=world * steps * B, stage_ms=stage_ms, iso_ms=iso_ms, net_ms=net_ms, flops_per_frame=flops,
-               N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), pix_streams=(1 if host_io else max(1, int(args.pix_streams))) if pix_ov else 0,
+               N=p.warp_h * p.warp_w, pix_ov=bool(pix_ov), pix_streams=(1 if host_io else max(1, int(args.pix_streams))) if pix_ov else 0, ring_depth=(int(args.ring_depth) if host_io else None),
                depth_dtype=depth_dtype if model_name else None,
                lib_sel=({"hipblaslt_solution_table": bool(pipe.tuned_gemm), "miopen_find_mode": bool(pipe.miopen_find)} if pipe is not None else None),
-               host_io=host_io, clip=args.clip, clip_frames_global=world * args.clip,
+               host_io=bool(host_io), clip=args.clip, clip_frames_global=world * args.clip,
                p1_wait_ms=_p1_wait(env, shr2),
                shard_bytes=(shr2[0].bytes_per_step() if (shr2 and hasattr(shr2[0], "bytes_per_step")) else None))
     del pipe
@@ -595,13 +615,16 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
               "traffic": w1.get("corrected_bytes_per_launch"), "traffic_source": w1.get("source"),
               "traffic_taken_at_commit": (_pmc("commit") or None),
               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": w1_ms, "avg_launch_measured": w1_src,
+              "rocprof_avg_launch_ms": (round(w1["rocprof_avg_launch_us"] / 1e3, 5) if w1.get("rocprof_avg_launch_us") else None),
               "in_step_avg_launch_ms": w1_instep if w1_instep > 0 else None,
               "in_step_frac": round(alg / (w1_instep * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if w1_instep > 0 else None,
               "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
               "note": "frac prices SURVEY 8(d)'s 13 N algorithmic bytes against the 8 TB/s HBM spec (north_star's yardstick); the kernel is "
                       "VALU-issue-bound, not HBM-bound (the reference's nested-bilinear arithmetic is kept bit-exact): `valu` prices the "
                       "PMC-counted VALU lane-instructions of one launch against the chip's MEASURED v_fma_f32 issue rate (50.2 T lane-ops/s) and the data sheet's. "
-                      "avg_launch_ms / achieved / frac: HIP events of the sequential pass over the same frames that follows the timed region (one kernel on "
+                      "ONE source prices the kernel: avg_launch_ms / achieved / frac = HIP events of the sequential pass of THIS run; rocprof_avg_launch_ms is the "
+                      "committed rocprofv3 --kernel-trace figure of the same command (profiles/pmc_latest.json, taken at traffic_taken_at_commit), printed for "
+                      "cross-checking only. avg_launch_ms / achieved / frac: HIP events of the sequential pass over the same frames that follows the timed region (one kernel on "
                       "the GPU at a time: the kernel's cost, what rocprofv3 --kernel-trace of the --no-pixel-overlap run reports); in_step_*: HIP events "
                       "inside the timed region, where the launch shares the CUs with the chain and the other pixel stream (grows with the concurrency "
                       "while the frame rate rises). traffic is that of BOTH launches: the E2 plane's round trip (8 N written, 8 N + halo read) is the "
@@ -625,6 +648,7 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
               "traffic": e1.get("corrected_bytes_per_launch"), "algorithmic_bytes_per_launch": alg, "avg_launch_ms": fin_ms,
               "avg_launch_measured": fin_src, "in_step_avg_launch_ms": fin_instep if fin_instep > 0 else None,
+              "rocprof_avg_launch_ms": (round(e1["rocprof_avg_launch_us"] / 1e3, 5) if e1.get("rocprof_avg_launch_us") else None),
               "in_step_frac": round(alg / (fin_instep * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if fin_instep > 0 else None}
         if lane:   # E1 against BOTH bounds (HBM above, fp32 ALU here)
             t = fin_ms * 1e-3
@@ -686,6 +710,9 @@ def main():
     ap.add_argument("--per-frame", action="store_true", help="one vd3d_render_frame call per frame instead of the batched step protocol (N = 1, no pixel overlap)")
     ap.add_argument("--host-io", action="store_true", help="frames start in (pinned) host memory and muxed frames end there: "
                     "PCIe-inclusive rate through visiondepth3d_amd.frame_io.PinnedRing (not the contract's `value`)")
+    ap.add_argument("--host-io-nv12", action="store_true", help="like --host-io with NV12 frames on the wire both ways (half the PCIe bytes; the colour "
+                    "conversions run on the device: vd3d_nv12_to_bgr / vd3d_bgr_to_nv12)")
+    ap.add_argument("--ring-depth", type=int, default=4, help="slots of the pinned staging ring of --host-io (H2D, render and D2H of consecutive steps overlap)")
     ap.add_argument("--pixel-overlap", dest="pixel_overlap", action="store_true", default=None,
                     help="two slot sets + vd3d_set_pixel_overlap: the pixel kernels of step i run on a second stream of the renderer while "
                     "the (latency-bound) measurement chain of step i+1 runs on the first (the default)")
@@ -727,6 +754,14 @@ def main():
         rg1 = run_workload(env, args, "1080p-gui-defaults", 10, 3, profile=prof)
         rg4 = run_workload(env, args, "4k-dibr-gui", 6, 2, profile=prof)
         rhi = run_workload(env, args, "4k-dibr", 6, 2, profile=False, isolated_pass=False, host_io=True)   # host-I/O-included figure
+        rhn = None
+        try:
+            rhn = run_workload(env, args, "4k-dibr", 6, 2, profile=False, isolated_pass=False, host_io="nv12")
+            rhn["workload"] = "4k-dibr-hostio-nv12"
+            rhn["desc"] = ("like 4k-dibr-hostio with NV12 frames on the wire both ways (12.4 MB up, 12.4 MB down per pair instead of 24.9 each): "
+                           "vd3d_nv12_to_bgr in front of the step, vd3d_bgr_to_nv12 behind it, both on the device; never `value`")
+        except Exception as e:
+            print(f"[bench] 4k-dibr-hostio-nv12 failed: {str(e)[:200]}", file=sys.stderr)
         rhi["workload"] = "4k-dibr-hostio"
         rhi["desc"] = ("4K DIBR only with the frames starting in pinned host memory and the muxed frames copied back to pinned host memory "
                        "(frame_io.PinnedRing, three slots: H2D, render and D2H of consecutive steps overlap): the PCIe-inclusive rate, never `value`")
@@ -735,6 +770,8 @@ def main():
                 "1080p-gui-defaults": (rg1, None), "4k-dibr-gui": (rg4, None)}
         if rvr is not None:
             subs["4k-dibr-vr"] = (rvr, None)
+        if rhn is not None:
+            subs["4k-dibr-hostio-nv12"] = (rhn, None)
         roof_src = r4
         try:
             up_rec = run_upscale_chain(env, args)
@@ -801,6 +838,11 @@ def main():
                 if name == "4k-dibr-sepdof":
                     extra["note"] = ("opt-in fast mode of the finishing stage (DESIGN.md section 2); every other record, the headline included, "
                                      "runs the dense association that matches the reference's CPU result exactly")
+                if name == "4k-dibr-hostio-nv12":
+                    bpf = rs["sh"] * rs["sw"] * 3   # 1.5 bytes per pixel each way
+                    extra["pcie_bytes_per_frame"] = bpf
+                    extra["pcie_GBs_each_way"] = round(bpf / 2 * rs["frames_total"] / rs["dt"] / 1e9, 2)
+                    extra["note"] = "host-I/O-inclusive with NV12 on the wire (BT.601 limited range, 4:2:0: NOT the reference's bgr24 bytes -- an opt-in wire format)"
                 if name == "4k-dibr-hostio":
                     bpf = rs["sh"] * rs["sw"] * 3 * 2   # one source frame up, one muxed Half-SBS frame (same size) down; the float32 depth planes stay in HBM
                     extra["pcie_bytes_per_frame"] = bpf
