@@ -354,6 +354,43 @@ def test_aten_sum_order_of_the_two_torch_means(R, oracle, fmt, size, threads):
     assert p0.aten_sum_threads == 0
 
 
+def test_other_entry_points_between_the_frames_of_a_step_path_clip(R, oracle):
+    """`format_3d_output(..., "VR")` and `pixel_shift_cuda` at ANOTHER size re-size the context's shared warp-resolution planes; a module-level
+    call of either on the renderer that is in the middle of a batched `render_pairs` clip (frames arrive up to two steps late, so a consumer does exactly
+    that between yields) used to leave the next pixel pass writing H x W planes into the smaller buffers.  Now format_3d_output has a scratch of its own and the
+    pixel pass re-establishes its planes: the clip's frames stay the oracle's, and the interleaved calls return their own right answers."""
+    from visiondepth3d_amd.render_3d import render_pairs
+    sh, sw = 270, 480
+    kw = dict(KW_GUI, output_format="Full-SBS", output_height=sh, feather_strength=8.0, blur_ksize=5, preserve_original_aspect=True,
+              original_video_width=sw, original_video_height=sh)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    n = 9
+    frames, depths = synth.synth_clip(n, sh, sw)
+    gray = [synth.depth_to_u8_bgr(d) for d in depths]
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    exp = [ro.render(f, g, 1) for f, g in zip(frames, gray)]
+    rng = np.random.default_rng(3)
+    eyeL = rng.integers(0, 256, (90, 160, 3), dtype=np.uint8)
+    eyeR = rng.integers(0, 256, (90, 160, 3), dtype=np.uint8)
+    small = synth.synth_frame(3, 54, 96)
+    # (no tracker in the interleaved call: pixel_shift_cuda's FloatingWindowTracker is shared state in the reference too, and this test is about memory)
+    sp = ShiftParams.defaults(6.0, -1.5, -4.0, blur_ksize=5, feather_strength=8.0, use_subject_tracking=False, enable_floating_window=False)
+    ft = torch.from_numpy(oracle.frame_to_tensor(small[0])).cuda()
+    dt = torch.from_numpy(small[1])[None].cuda()
+    R.reset_state()
+    got = []
+    for i, fr in enumerate(render_pairs(zip(frames, gray), renderer=R, skip_first=False, batch=2, **kw)):
+        got.append(fr)
+        vr = R.format_3d_output(T(eyeL), T(eyeR), "VR").cpu().numpy()            # 1440 x 1600 eyes: a different plane size
+        assert np.array_equal(vr, oracle.format_output(eyeL, eyeR, 2)), i
+        if i % 2 == 0:
+            L_, R_ = R.pixel_shift(ft, dt, 96, 54, sp)                           # ... and a smaller one, through the shared planes themselves
+            assert L_.shape == (54, 96, 3) and R_.shape == (54, 96, 3)
+    assert len(got) == n
+    for i in range(n):
+        assert np.array_equal(got[i], exp[i]), (i, u8_diff_stats(got[i], exp[i]))
+
+
 KW_CLI = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
               feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
 
