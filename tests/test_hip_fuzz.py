@@ -51,12 +51,23 @@ def _random_render_kw(rng):
     return h, w, kw
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", list(range(40)) + list(range(200, 230)))
 def test_render_loop_fuzz(R, oracle, seed):
     rng = np.random.default_rng(seed)
     sh, sw, kw = _random_render_kw(rng)
+    extra = {}
+    if seed >= 200:   # round 5: the two new decisions of the loop body, on top of the same random configurations --
+        # feather_strength <= 0 (the exact no-feather warp) and torch.mean's summation order for a random torch thread count; larger frames every
+        # third seed so that the thread partition (>= 32 768 elements) and the big-piece kernel are reached
+        if seed % 2 == 0:
+            kw["feather_strength"] = float([0.0, 0.0, -1.5][seed % 3])
+        extra["aten_sum_threads"] = int([1, 2, 3, 5, 8, 16, 64, 0][int(rng.integers(0, 8))])
+        if seed % 3 == 0:
+            sh, sw = sh * 4, sw * 4
+            if "original_video_width" in kw:
+                kw.update(original_video_width=sw, original_video_height=sh)
     try:
-        p = render_kwargs_to_params(sw, sh, dof_dense_conv=bool(seed & 1), **kw)   # odd seeds: the reference's dense DOF association
+        p = render_kwargs_to_params(sw, sh, dof_dense_conv=bool(seed & 1), **extra, **kw)   # odd seeds: the reference's dense DOF association
     except NotImplementedError:
         pytest.skip("feature outside the built scope")
     depth_as = ["bgr_u8", "gray_u8", "f32"][int(rng.integers(0, 3))]
