@@ -767,8 +767,47 @@ def gen_real1080_letterbox():
     save("real1080_letterbox.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# 14. The GUI's OWN default configuration (round 5; VisionDepth3D.py:1405-1453: Full-SBS, fg 4.5 / mg -1.5 / bg -6, blur_ksize 1, feather_strength 0.0,
+#     sharpness 0.2, zero_parallax 0.01, auto crop on) at real sizes: 1920x1080 (eyes at warp resolution), 3840x2160 (the 2 x 2 fit into 1920x1080 eyes) and
+#     the Half-SBS variant.  feather_strength 0 is where the library skips the mask / window-sum / blend kernels (an exact no-op of feather_shift_edges),
+#     so these frames pin that decision against the reference on the GPU box.  SHA-256 + row sums per frame; the fixture records torch's thread count
+#     (torch.mean's summation order depends on it: vd3d_render_params::aten_sum_threads).
+# ------------------------------------------------------------------------------------------
+GUI_DEFAULTS = dict(output_format="Full-SBS", fg_shift=4.5, mg_shift=-1.5, bg_shift=-6.0, sharpness_factor=0.2, dof_strength=2.0, feather_strength=0.0,
+                    blur_ksize=1, use_subject_tracking=True, use_floating_window=True, max_pixel_shift_percent=0.02, auto_crop_black_bars=True,
+                    parallax_balance=0.8, zero_parallax_strength=0.01, enable_edge_masking=True, enable_feathering=True,
+                    convergence_strength=0.0, enable_dynamic_convergence=True)
+GUI_CASES = {
+    "gui_1080_full": (1080, 1920, dict(GUI_DEFAULTS, output_height=1080)),
+    "gui_1080_half": (1080, 1920, dict(GUI_DEFAULTS, output_height=1080, output_format="Half-SBS")),
+    "gui_4k_full": (2160, 3840, dict(GUI_DEFAULTS, output_height=2160)),
+    "gui_1080_blur9_feather0": (1080, 1920, dict(GUI_DEFAULTS, output_height=1080, blur_ksize=9, output_format="Half-SBS")),
+}
+
+
+def gen_gui_defaults():
+    n = 4
+    out = {"cases_json": np.frombuffer(json.dumps({k: [v[0], v[1], v[2]] for k, v in GUI_CASES.items()}).encode(), dtype=np.uint8),
+           "torch_threads": np.array([torch.get_num_threads()], dtype=np.int64)}
+    for name, (sh, sw, kw) in GUI_CASES.items():
+        LOOP_CASES[name] = (sh, sw, n, kw)
+        try:
+            written = run_loop(name)
+        finally:
+            del LOOP_CASES[name]
+        out[f"{name}__shape"] = np.array(written[0].shape, dtype=np.int64)
+        for i, fr in enumerate(written):
+            out[f"{name}__rowsum_{i}"] = fr.astype(np.int64).sum(axis=1).astype(np.int32)
+            out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+        print(f"  gui defaults {name}: {kw['output_format']}, {len(written)} frames of {written[0].shape}")
+    save("gui_defaults.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random", "real1080_letterbox"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random", "real1080_letterbox", "gui_defaults"]
+    if "gui_defaults" in which:
+        gen_gui_defaults()
     if "attrib" in which:
         gen_attrib()
     if "real1080" in which:

@@ -655,6 +655,26 @@ def test_real_size_1080p_random_configurations_hip_vs_reference_fixture(R):
     real1080_random_check(render, fixture="real4k_random.npz", sh=2160, sw=3840)
 
 
+def test_gui_default_configuration_hip_vs_reference_fixture(R):
+    """The GUI's own defaults (feather_strength 0.0: the exact no-feather warp; Full-SBS at 1920x1080 and -- through the 2 x 2 fit of the fused finishing
+    kernel's vector epilogue -- at 3840x2160; Half-SBS; feather 0 behind a 9 x 9 window) through the C ABI: every frame equals the live reference's
+    (tests/golden/gui_defaults.npz: SHA-256 of the whole frame, row sums), per-frame entry point and batched step path."""
+    from test_oracle_vs_golden import gui_defaults_check
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
+
+    def render(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
+    gui_defaults_check(render)
+
+    def render_steps(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        sh = ChunkSharder(HipChunkBackend(R, p), 0, 1, len(frames))
+        outs = sh.render_step([T(f) for f in frames], [T(d) for d in dbgr], first_step=True)
+        return [o.cpu().numpy() for o in outs]
+    gui_defaults_check(render_steps, names=("gui_4k_full", "gui_1080_half"))
+
+
 def test_real_size_1080p_letterbox_auto_crop_hip_vs_reference_fixture(R):
     """Black-bar auto crop at 1920x1080 through the C ABI (K0 k_autocrop per frame, crop, re-fit): four letterboxed clips, every frame equals
     the live reference's (tests/golden/real1080_letterbox.npz: SHA-256 of the whole frame, row sums)."""
