@@ -122,6 +122,11 @@ def lib():
     L.vd3d_render_params_default.argtypes = [C.POINTER(RenderParams)]
     if L.vd3d_abi_version() != _abi.ABI_VERSION:
         raise ImportError("libvd3d_hip.so ABI version mismatch")
+    # development probes: VD3D_TUNE="knob:value,knob:value" applies vd3d_debug_tune at load time (launch policies only: results never depend on them)
+    for kv in filter(None, os.environ.get("VD3D_TUNE", "").split(",")):
+        k, v = kv.split(":")
+        if L.vd3d_debug_tune(int(k), int(v)) != 0:
+            raise ImportError(f"VD3D_TUNE: unknown knob {k}")
     _lib = L
     return L
 

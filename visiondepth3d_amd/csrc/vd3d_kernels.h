@@ -158,6 +158,7 @@ bool vd_warp_fused_ok(int ih, int iw, int H, int W, const vd3d_shift_params& p);
 // k_e2w (vd3d_warp.hip): gradient mask plane E2[H][W][2] (left, right eye) of feather_shift_edges from the shaped depth and the shift plane
 void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, float feather_strength, float* E2);
 void vd_set_warp_pre_th(int th);
+void vd_set_warp_nofeather_th(int th);
 #ifdef __cplusplus
 #include <vector>
 // vd3d_atensum.hip: piece plan of the two torch.mean sums for one eye size and torch thread count (host vectors; the caller uploads them)

@@ -674,6 +674,12 @@ static bool wf_fastdiv_ok(int k) {   // every float in [0, k*k] checked; inexact
 // multiplies their arithmetic, so flatter tiles (less LDS per workgroup, more workgroups per CU) become an option
 static int g_wf_pre_th = 32;
 void vd_set_warp_pre_th(int th) { g_wf_pre_th = th == 16 ? 16 : 32; }
+// ... and of W1 without feathering (round 5: no mask halo at all, vd3d_debug_tune(7, 16 | 32))
+#ifndef WF_NOFEATHER_TH
+#define WF_NOFEATHER_TH 32
+#endif
+static int g_wf_nf_th = WF_NOFEATHER_TH;
+void vd_set_warp_nofeather_th(int th) { g_wf_nf_th = th == 16 ? 16 : 32; }
 
 // returns false when the fused kernel cannot be used (tiles would not fit the 160 KB LDS): caller falls back to v0.
 // E2 != NULL: the gradient mask was computed by k_e2w (PRE variants); plan_only: decide, do not launch.
@@ -778,6 +784,8 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
                           const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2) {
   if (E2 && p.enable_feathering && g_wf_pre_th == 16 && warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, true))
     return warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, false);
+  if (!p.enable_feathering && g_wf_nf_th == 16 && warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, nullptr, true))
+    return warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, nullptr, false);
   return warp_fused_impl<32>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, false);
 }
 // would vd_launch_warp_fused take this frame?  (the caller then runs k_e2w for the mask plane first)
