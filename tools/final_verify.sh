@@ -1,6 +1,5 @@
 #!/bin/bash
-# Round-end verification on one GPU box: full GPU test suite, smoke(), the default bench line (saved for profiles/rNN_bench_default.json),
-# VR on both finishing routes.
+# Round-end verification on one GPU box: full GPU test suite, smoke(), the default bench line (saved for profiles/rNN_bench_default.json).
 #   gpurun --timeout 1500 -- 'bash tools/final_verify.sh'
 export TMPDIR=/tmp
 O=gpurun_out/final; mkdir -p $O
@@ -11,11 +10,7 @@ python - <<'PY'
 import json
 d = json.load(open("gpurun_out/final/bench_default.json"))
 print("default:", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("in_step_frac"), d["cpu_baseline"]["value"])
+print("roofline:", {k: d["roofline"].get(k) for k in ("avg_launch_ms", "rocprof_avg_launch_ms", "traffic", "traffic_over_algorithmic", "valu_frac_of_spec", "traffic_taken_at_commit")})
 for k, s in d.get("sub_records", {}).items():
-    print("  ", k, s.get("value"), s.get("error"))
+    print("  ", k, s.get("value"), s.get("error"), (s.get("roofline") or {}).get("frac"), (s.get("roofline") or {}).get("traffic_over_algorithmic"))
 PY
-for f in 1 0; do
-  VD3D_FUSED_FIT=$f python bench.py --workload 4k-dibr-vr --steps 4 --warmup 2 --no-cpu-baseline --no-pixel-overlap 2>/dev/null | tail -1 > $O/vr_fused$f.json
-  python -c "
-import json; d=json.load(open('$O/vr_fused$f.json')); print('4k-dibr-vr sequential, VD3D_FUSED_FIT=$f', d['value'], d.get('stage_ms'))"
-done
