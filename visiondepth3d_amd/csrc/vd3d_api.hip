@@ -1547,6 +1547,8 @@ VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
   else if (which == 5) vd_set_conv_mode(value);
   else if (which == 6) vd_set_finish_persist(value);
   else if (which == 7) vd_set_warp_nofeather_th(value);
+  else if (which == 8) vd_set_finish_xcd(value);
+  else if (which == 9) vd_set_warp_order(value);
   else return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
   return 0;
 }

@@ -37,7 +37,13 @@
 #define FF_IW (FF_GW + 2 * FF_R)    // input tile width  = 80
 #define FF_IS (FF_IW / 4)           // strips per tile row = 20 (strip 0 and 19 are input halo, 1 and 18 the graded halo columns)
 #define FF_GP 76                    // pitch of the graded dword tile (multiple of 4: b128 rows)
-#define FF_XG 2                     // tile rows per XCD group (vd_xcd_tile_rows)
+// tile rows per XCD group (vd_xcd_tile_rows).  Round 5: ONE row per group -- a tile costs 16 k .. 53 k cycles depending on the DOF levels its pixels need, every XCD
+// gets exactly an eighth of the tiles, and the launch ends with the XCD whose rows were the most expensive: with two rows per group E1 took 250 us per 4K frame
+// pair, with one 231 (plain row-major order, neighbouring tiles on different XCDs: 235; four rows: 310 on the harness scene).  The vertical halo rows are then
+// fetched once per XCD -- bytes this kernel has to spare (0.04 of HBM).  profiles/r05_e1_persistent.md
+#ifndef FF_XG
+#define FF_XG 1
+#endif
 #ifndef FF_WIDE_TH
 #define FF_WIDE_TH 26               // tile height of the wide geometry (A/B builds: -DFF_WIDE_TH=30 / 22 / 14, tools/build_ab.sh)
 #endif
@@ -1051,9 +1057,11 @@ static bool ff_geometry(const vd3d_render_params& p, int eh, int ew, vd_ff_args*
   a.use_override = 0; a.bar_w = 0; a.bar_s = 0; a.focal = 0.f;
   return true;
 }
+static int g_ff_xcd = 1;   // vd3d_debug_tune(8, 0): plain row-major tile order (workgroup b on XCD b % 8: neighbouring tiles on different XCDs)
+void vd_set_finish_xcd(int on) { g_ff_xcd = on ? 1 : 0; }
 static void ff_grid(const vd3d_render_params& p, int th, vd_ff_args* a, dim3* g) {
   a->ntx = (p.warp_w + FF_TW - 1) / FF_TW; a->nty = (p.warp_h + th - 1) / th;
-  a->xcd = 1;
+  a->xcd = g_ff_xcd;
   const int ngrp = (2 * a->nty + FF_XG - 1) / FF_XG;
   *g = dim3(a->xcd ? 8 * ((ngrp + 7) / 8) * FF_XG * a->ntx : 2 * a->ntx * a->nty);
 }

@@ -158,6 +158,7 @@ bool vd_warp_fused_ok(int ih, int iw, int H, int W, const vd3d_shift_params& p);
 // k_e2w (vd3d_warp.hip): gradient mask plane E2[H][W][2] (left, right eye) of feather_shift_edges from the shaped depth and the shift plane
 void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, float feather_strength, float* E2);
 void vd_set_warp_pre_th(int th);
+void vd_set_warp_order(int v);
 void vd_set_warp_nofeather_th(int th);
 #ifdef __cplusplus
 #include <vector>
@@ -165,7 +166,8 @@ void vd_set_warp_nofeather_th(int th);
 bool vd_aten_plan_build(int eh, int ew, int T, std::vector<int>& pieces_flat, int* n_small, int* n_big, int* nr_crop, int* nr_mad);
 #endif
 void vd_launch_aten_sums(hipStream_t s, const vd_batch& b, const vd_stage_args& a);
-void vd_set_finish_persist(int k);   // vd3d_finish.hip: 0 = one tile per workgroup, k > 0 = persistent fused finishing kernel, k workgroups per CU
+void vd_set_finish_persist(int k);
+void vd_set_finish_xcd(int on);   // vd3d_finish.hip: 0 = one tile per workgroup, k > 0 = persistent fused finishing kernel, k workgroups per CU
 void vd_set_conv_mode(int v);   // vd3d_conv.hip: < 0 one tile per workgroup (rounds 2 - 4), >= 0 persistent kernel with a phase skew of v microseconds
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,

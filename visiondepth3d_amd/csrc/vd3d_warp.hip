@@ -266,9 +266,15 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int2 rs14[64];                          // VRSQRT14 table of vd_sqrt_torch (phase B)
   const int H = a.H, W = a.W, k = a.k, r = k / 2;
-  const int tile = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
-  if (tile >= a.ntiles) return;                      // padding workgroup of the last band (workgroup-uniform, before any barrier)
-  const int tby = tile / a.ntx, tbx = tile - tby * a.ntx;
+  int tby, tbx;
+  if (a.xcd == 2) {   // round 5 (vd3d_debug_tune(9, 2)): tile rows dealt to the XCDs round-robin (vd_xcd_tile_rows, one row per group) instead of one contiguous band each
+    vd_xcd_tile_rows(blockIdx.x, a.ntx, 1, 1, &tby, &tbx);
+    if (tby * a.ntx >= a.ntiles) return;
+  } else {
+    const int tile = vd_xcd_tile(blockIdx.x, a.per, a.xcd);
+    if (tile >= a.ntiles) return;                      // padding workgroup of the last band (workgroup-uniform, before any barrier)
+    tby = tile / a.ntx; tbx = tile - tby * a.ntx;
+  }
   const int x0 = tbx * WF_TW, y0 = tby * WF_TH;
   const int ww = WF_TW + k, wh = WF_TH + k;          // wd region
   const int ew = WF_TW + k - 1, eh = WF_TH + k - 1;  // e2 region
@@ -672,6 +678,11 @@ static bool wf_fastdiv_ok(int k) {   // every float in [0, k*k] checked; inexact
 
 // tile height of W1 with a precomputed mask (tuning probe: vd3d_debug_tune(2, 16 | 32)); without the mask phases in the tile the halo no longer
 // multiplies their arithmetic, so flatter tiles (less LDS per workgroup, more workgroups per CU) become an option
+// Tile order of W1 (vd3d_debug_tune(9, v)): 0 plain row-major, 1 one contiguous band of tiles per XCD (round 3), 2 tile rows round-robin over the XCDs, -1 (default) by path:
+// the feathered path keeps the bands (its 9 x 9 halo re-reads stay in one L2: fabric traffic 3.3x -> 1.3x, same time in all three orders, 152 .. 155 us), the no-feather path of
+// round 5 has no halo worth keeping and runs plain (4K: 66.9 us against 74 .. 75.5 in bands and 69.8 round-robin, gpurun_out/r05c21).
+static int g_wf_order = -1;
+void vd_set_warp_order(int v) { g_wf_order = v < -1 ? -1 : (v > 2 ? 2 : v); }
 static int g_wf_pre_th = 32;
 void vd_set_warp_pre_th(int th) { g_wf_pre_th = th == 16 ? 16 : 32; }
 // ... and of W1 without feathering (round 5: no mask halo at all, vd3d_debug_tune(7, 16 | 32))
@@ -745,9 +756,10 @@ static bool warp_fused_impl(hipStream_t s, const float* rgb, int ih, int iw, con
   if (plan_only) return true;
   a.ntx = (W + WF_TW - 1) / WF_TW;
   a.ntiles = a.ntx * ((H + WF_TH - 1) / WF_TH);
-  a.xcd = 1;
+  a.xcd = g_wf_order >= 0 ? g_wf_order : (a.feather ? 1 : 0);
   a.per = (a.ntiles + 7) / 8;
-  dim3 g(a.xcd ? 8 * a.per : a.ntiles);
+  const int nrows = a.ntiles / a.ntx;
+  dim3 g(a.xcd == 2 ? 8 * ((nrows + 7) / 8) * a.ntx : (a.xcd ? 8 * a.per : a.ntiles));
   static bool attr[64] = {false};   // per device: the attribute belongs to the device's copy of the code object
   int dev = 0;
   (void)hipGetDevice(&dev);
