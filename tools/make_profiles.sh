@@ -34,7 +34,7 @@ for WL in 4k-dibr 4k-dibr-gui 1080p-gui-defaults; do
   SPECS="$SPECS $WL=${DBS}$TR"
 done
 VD3D_COMMIT=${VD3D_COMMIT:-unknown} python $R/tools/pmc_to_json.py $TAG $SPECS > $O/pmc_latest.json
-run_steady 4k_dav2b_f32 "python $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-sub-records --no-profile" 4
-run_steady 1080p_esrgan4k "python $R/bench.py --upscale-only" 3
+[ -n "$SKIP_STEADY" ] || run_steady 4k_dav2b_f32 "python $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-sub-records --no-profile" 4
+[ -n "$SKIP_STEADY" ] || run_steady 1080p_esrgan4k "python $R/bench.py --upscale-only" 3
 rm -rf $O/p_* $O/t_*
 ls -la $O
