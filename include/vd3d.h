@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VD3D_ABI_VERSION 4
+#define VD3D_ABI_VERSION 5
 
 typedef enum vd3d_status {
   VD3D_OK = 0,
@@ -81,6 +81,14 @@ typedef struct vd3d_shift_params {
   double fg_pop_multiplier;                /* 1.20 */
   double bg_push_multiplier;               /* 1.10 */
   double subject_lock_strength;            /* 1.00 */
+  /* Extension, not a pixel_shift_cuda keyword (round 5).  N >= 1: reproduce ATen's SCALAR TAILS for a reference process that runs torch with N
+   * intra-op threads (torch.get_num_threads()): torch.pow / torch.sigmoid on a float32 CPU plane split its n elements over min(N, ceil(n / 32768))
+   * threads and send the last (chunk length mod 32) elements of every chunk through libm (std::pow in double with the unrounded Python exponent,
+   * glibc's expf) instead of the SLEEF vector bodies (core/render_3d.py:209,517,620).  No plane a video produces has such a tail (1920x1080 and
+   * 3840x2160 split evenly over 1 .. 96 threads); odd sizes do.  0 (the default): SLEEF values everywhere.  Inside vd3d_render_frame and the sharded entry
+   * points vd3d_render_params::aten_sum_threads is used instead of this field. */
+  int32_t aten_threads;                    /* 0 */
+  int32_t reserved0;
 } vd3d_shift_params;
 
 /*
@@ -120,7 +128,7 @@ typedef struct vd3d_render_params {
    * (TensorIterator splits reductions of >= 32 768 elements across them).  N >= 1: reproduce torch with N threads bit for bit
    * (torch.get_num_threads() of the reference process; its default is the machine's core count).  0 (what vd3d_render_params_default sets):
    * the correctly rounded mean of the exact sum -- independent of any thread count, within one float32 ULP of every N. */
-  int32_t aten_sum_threads;
+  int32_t aten_sum_threads;                /* also the N of vd3d_shift_params::aten_threads for the frames of this clip */
 } vd3d_render_params;
 
 /*
@@ -431,6 +439,11 @@ int vd3d_stream_copy(vd3d_ctx* ctx, const void* src, void* dst, size_t bytes);
  * op 2 = torch.sqrt(x) (:206, :349, :440; MKL VML vsSqrt -- one ULP low on 0.6 % of the inputs).  The kernels of the chain call the
  * same device functions; this entry exists so that they can be compared against the oracle / torch on arbitrary inputs. */
 int vd3d_torch_math(vd3d_ctx* ctx, int op, const float* x, float param, float* out, long long n);
+/* Ops 0 and 1 of the above as a torch process with `aten_threads` intra-op threads computes them on a contiguous n-element float32 CPU tensor: the SLEEF
+ * values, and on the scalar tails of every thread's chunk (vd3d_shift_params::aten_threads) libm's -- (float) pow((double) x, param) with the unrounded
+ * Python exponent, 1 / (1 + expf(-x)) with glibc's expf.  aten_threads 0: no tails; < 0: every element takes the tail arithmetic (diagnostic).  The shaping and
+ * shift kernels call the same device functions.  n < 2^32. */
+int vd3d_torch_math_aten(vd3d_ctx* ctx, int op, const float* x, double param, float* out, long long n, int aten_threads);
 /* HIP-event profiling of the stages on the ctx stream ("frame", "ingest", "select_eye", "select_dc", "shape",
  * "select_s1", "warp" (= "shift" + "w1", the fused warp kernel alone), "finish", "handoff", "advance", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
  * profiling was enabled (-1 if never seen); both getters synchronise. */

@@ -58,6 +58,12 @@ def lib():
         _lib.vo_sharpen.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, _u8p]
         _lib.vo_shape_depth_for_pop.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                                 C.c_float, _f32p, _f32p, _f32p]
+        _lib.vo_shape_depth_for_pop_aten.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                     C.c_double, C.c_int, _f32p, _f32p, _f32p]
+        _lib.vo_interp_bilinear_aten.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]
+        _lib.vo_torch_math_aten.argtypes = [C.c_int, _f32p, C.c_double, _f32p, C.c_longlong, C.c_int]
+        _lib.vo_expf_glibc.restype = C.c_float
+        _lib.vo_expf_glibc.argtypes = [C.c_float]
         _lib.vo_curvature_clamp.argtypes = [_f32p, C.c_int, C.c_int, C.c_float]
         _lib.vo_gaussian_kernel1d.argtypes = [C.c_int, C.c_float, _f32p]
         _lib.vo_finish_frame.argtypes = [_u8p, _u8p, _f32p, C.c_int, C.c_int, C.POINTER(RenderParams), C.c_double,
@@ -102,12 +108,27 @@ def tensor_to_frame(t):
     return out
 
 
-def interp_bilinear(t, oh, ow):
+def interp_bilinear(t, oh, ow, aten_threads=0):
+    """F.interpolate(bilinear, align_corners=False).  ``aten_threads`` >= 1: the kernel ATen picks for a process with that many intra-op threads (its
+    premultiplied channels_last kernel for outputs with oh + ow <= 128, and for 3-channel inputs with one thread); 0: the nested form at every size."""
     t, pt = _f(t)
     c, ih, iw = t.shape
     out = np.empty((c, oh, ow), np.float32)
-    lib().vo_interp_bilinear(pt, c, ih, iw, out.ctypes.data_as(_f32p), oh, ow)
+    lib().vo_interp_bilinear_aten(pt, c, ih, iw, out.ctypes.data_as(_f32p), oh, ow, int(aten_threads))
     return out
+
+
+def torch_math_aten(op, x, param=0.0, aten_threads=0):
+    """torch.pow(x, param) (op 0) / torch.sigmoid(x) (op 1) of a contiguous float32 tensor as a torch process with ``aten_threads`` intra-op threads
+    computes them: SLEEF vector bodies, libm on the scalar tails of every thread's chunk (vd3d_oracle.c, "ATen's SCALAR TAILS")."""
+    x, px = _f(x)
+    out = np.empty_like(x)
+    lib().vo_torch_math_aten(int(op), px, float(param), out.ctypes.data_as(_f32p), x.size, int(aten_threads))
+    return out
+
+
+def expf_glibc(x):
+    return float(lib().vo_expf_glibc(C.c_float(np.float32(x))))
 
 
 def torch_math(op, x, param=0.0):
@@ -215,13 +236,13 @@ def curvature_clamp(d, strength=0.08):
     return d
 
 
-def shape_depth_for_pop(d, subject, stretch_lo=0.05, stretch_hi=0.95, depth_mid=0.5, gamma=0.85):
+def shape_depth_for_pop(d, subject, stretch_lo=0.05, stretch_hi=0.95, depth_mid=0.5, gamma=0.85, aten_threads=0):
     d, pd = _f(d)
     out = np.empty_like(d)
     lo, hi = C.c_float(), C.c_float()
     f = lambda x: C.c_float(np.float32(x))
-    lib().vo_shape_depth_for_pop(pd, d.size, f(subject), f(stretch_lo), f(stretch_hi), f(depth_mid), f(gamma),
-                                 out.ctypes.data_as(_f32p), C.byref(lo), C.byref(hi))
+    lib().vo_shape_depth_for_pop_aten(pd, d.size, f(subject), f(stretch_lo), f(stretch_hi), f(depth_mid), float(gamma), int(aten_threads),
+                                      out.ctypes.data_as(_f32p), C.byref(lo), C.byref(hi))
     return out, lo.value, hi.value
 
 

@@ -85,8 +85,8 @@ class OracleChunkBackend:
         d = depth.numpy()
         dt = (d.astype(F32) / F32(255.0)).astype(F32) if d.dtype == np.uint8 else d.astype(F32)
         cy, cx, ch, cw = p.crop_y, p.crop_x, p.crop_h, p.crop_w
-        fe = O.interp_bilinear(ft[:, cy:cy + ch, cx:cx + cw], p.eye_h, p.eye_w)
-        de = O.interp_bilinear(dt[None, cy:cy + ch, cx:cx + cw], p.eye_h, p.eye_w)[0]
+        fe = O.interp_bilinear(ft[:, cy:cy + ch, cx:cx + cw], p.eye_h, p.eye_w, aten_threads=p.aten_sum_threads)
+        de = O.interp_bilinear(dt[None, cy:cy + ch, cx:cx + cw], p.eye_h, p.eye_w, aten_threads=p.aten_sum_threads)[0]
         prev_plane = self.tdf.copy()
         de_flat = np.ascontiguousarray(de.reshape(-1))
         self.L.vo_temporal_filter(C.byref(self.state), self.tdf.ctypes.data_as(O._f32p), de_flat.ctypes.data_as(O._f32p), self.ne)
@@ -160,6 +160,7 @@ class OracleChunkBackend:
         sp.parallax_balance, sp.depth_pop_gamma, sp.depth_pop_mid = 0.8, 0.85, 0.50
         sp.depth_stretch_lo, sp.depth_stretch_hi = 0.05, 0.95
         sp.fg_pop_multiplier, sp.bg_push_multiplier, sp.subject_lock_strength = 1.20, 1.10, 1.00
+        sp.aten_threads = self.p.aten_sum_threads   # the N-thread ATen mode covers the scalar tails and the small-output bilinear kernel too
         return sp
 
     # ---- R2: every remaining recurrence, in frame order (the scalar half of vo_render_frame_impl)

@@ -95,7 +95,7 @@ def test_render_loop_fuzz(R, oracle, seed):
     assert R.export_state().as_dict() == ro.state.as_dict(), (seed, kw)
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(42))
 def test_pixel_shift_fuzz(R, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     ih, iw = int(rng.integers(16, 90)), int(rng.integers(24, 150))
@@ -112,6 +112,8 @@ def test_pixel_shift_fuzz(R, oracle, seed):
               parallax_balance=float(rng.uniform(0.5, 1.0)))
     bgr, d = synth.synth_frame(seed, ih, iw)
     ft = oracle.frame_to_tensor(bgr)
+    if seed >= 12:   # round 5, the N-thread ATen mode at these odd sizes: scalar tails of pow / sigmoid (libm) and, for H + W <= 128 or one thread, ATen's other bilinear kernel
+        kw["aten_threads"] = int([1, 2, 4, 8, 3, 16][seed % 6])
     p = ShiftParams.defaults(float(rng.uniform(0, 30)), float(rng.uniform(-10, 5)), float(rng.uniform(-25, 0)), **kw)
     st = State()
     o = oracle.pixel_shift(ft, d[None], W, H, p, st, want_shift=True)

@@ -354,6 +354,53 @@ def test_aten_sum_order_of_the_two_torch_means(R, oracle, fmt, size, threads):
     assert p0.aten_sum_threads == 0
 
 
+@pytest.mark.parametrize("fmt,size,oh,threads", [("Half-SBS", (72, 128), 72, 4), ("Half-SBS", (90, 150), 60, 8), ("Full-SBS", (54, 70), 54, 2), ("Red-Cyan Anaglyph", (75, 133), 50, 1),
+                                                  ("Half-SBS", (270, 480), 270, 1), ("Passive Interlaced", (101, 203), 101, 3)])
+def test_aten_mode_at_sizes_with_scalar_tails_and_small_eyes(R, oracle, fmt, size, oh, threads):
+    """Round 5, the N-thread ATen mode beyond the two means: planes whose element count is not a multiple of 32 send the last elements of every thread's chunk
+    through libm in torch.pow / torch.sigmoid (k_chain_shape<true>, k_shift<true>: fp64 pow and glibc's expf), and eyes / warp planes with H + W <= 128 -- or the
+    3-channel frame whenever the reference ran ONE torch thread, at any size -- are resized by ATen's premultiplied-weight bilinear kernel (ingest and chain
+    kernels by flag; W1 and the finishing kernels get the plane resized ahead of them and run with identity geometry).  The oracle's restatement of both is pinned
+    against the live reference at arbitrary sizes (tests/test_oracle_vs_live_reference.py::test_render_loop_any_size_exact_in_aten_mode); here device == oracle:
+    frames, scalars, state -- per-frame entry point, the batched step path, and the stand-alone finishing entry."""
+    from visiondepth3d_amd.render_3d import render_pairs
+    sh, sw = size
+    kw = dict(KW_GUI, output_format=fmt, output_height=oh, feather_strength=7.0, blur_ksize=5, dof_strength=2.0, aten_sum_threads=threads)
+    if fmt == "Full-SBS":
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    p = render_kwargs_to_params(sw, sh, **kw)
+    n = 4
+    frames, depths = synth.synth_clip(n, sh, sw)
+    gray = [synth.depth_to_u8_bgr(d) for d in depths]
+    ro = oracle.RenderOracle(p); ro.new_clip()
+    exp, exp_sc = [], []
+    for f, g in zip(frames, gray):
+        exp.append(ro.render(f, g, 1)); exp_sc.append(ro.last.as_dict())
+    R.reset_state(); R.new_clip()
+    for i, (f, g) in enumerate(zip(frames, gray)):
+        got = R.render_frame(T(f), T(g), p).cpu().numpy()
+        a, b = R.last_scalars().as_dict(), exp_sc[i]
+        assert a == b, (i, {k_: (a[k_], b[k_]) for k_ in a if a[k_] != b[k_]})
+        assert np.array_equal(got, exp[i]), (i, u8_diff_stats(got, exp[i]))
+    assert R.export_state().as_dict() == ro.state.as_dict()
+    R.reset_state()
+    got = list(render_pairs(zip(frames, gray), renderer=R, skip_first=False, batch=2, **kw))
+    for i in range(n):
+        assert np.array_equal(got[i], exp[i]), (i, "step path", u8_diff_stats(got[i], exp[i]))
+    # the default mode is a different (thread-independent) arithmetic on exactly these corners: it must NOT be what the ATen mode computes everywhere
+    p0 = render_kwargs_to_params(sw, sh, **dict(kw, aten_sum_threads=0))
+    ro0 = oracle.RenderOracle(p0); ro0.new_clip()
+    R.reset_state(); R.new_clip()
+    for f, g in zip(frames, gray):
+        assert np.array_equal(R.render_frame(T(f), T(g), p0).cpu().numpy(), ro0.render(f, g, 1))
+    # stand-alone finishing entry: depth_for_dof resized by the kernel ATen picks
+    rng = np.random.default_rng(sh)
+    Lh = rng.integers(0, 256, (p.warp_h, p.warp_w, 3), dtype=np.uint8); Rh = rng.integers(0, 256, (p.warp_h, p.warp_w, 3), dtype=np.uint8)
+    dn = rng.random((p.eye_h, p.eye_w), dtype=np.float32)
+    got_f = R.finish_frame(T(Lh), T(Rh), T(dn), p, 0.4).cpu().numpy()
+    assert np.array_equal(got_f, oracle.finish_frame(Lh, Rh, dn, p, 0.4, 0, 0))
+
+
 def test_other_entry_points_between_the_frames_of_a_step_path_clip(R, oracle):
     """`format_3d_output(..., "VR")` and `pixel_shift_cuda` at ANOTHER size re-size the context's shared warp-resolution planes; a module-level
     call of either on the renderer that is in the middle of a batched `render_pairs` clip (frames arrive up to two steps late, so a consumer does exactly

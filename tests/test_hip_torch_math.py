@@ -62,6 +62,51 @@ def test_sqrt_device_equals_oracle(R, oracle):
         _same(R, oracle, "sqrt", np.arange(lo, lo + (1 << 23), dtype=np.uint32).view(np.float32).copy())
 
 
+def _same_aten(R, oracle, op, x, param, threads, allow=0):
+    got = R.torch_math_aten(op, torch.from_numpy(x).cuda(), param, threads).cpu().numpy()
+    exp = oracle.torch_math_aten({"pow": 0, "sigmoid": 1}[op], x, param, threads)
+    bad = np.nonzero((got.view(np.uint32) != exp.view(np.uint32)) & ~(np.isnan(got) & np.isnan(exp)))[0]
+    assert bad.size <= allow, (op, param, threads, bad.size, [(float(x[i]).hex(), float(got[i]).hex(), float(exp[i]).hex()) for i in bad[:4]])
+    return bad.size
+
+
+def test_glibc_expf_tail_of_sigmoid_device_equals_oracle(R, oracle):
+    """Round 5, ATen's scalar tails: torch.sigmoid on the last (chunk length mod 32) elements of a thread's chunk is 1 / (1 + expf(-x)) with GLIBC's expf,
+    restated in double arithmetic on the device (vd_expf_glibc) and in the oracle (checked there against libm on all 2^32 inputs).  Every element through
+    the tail arithmetic (aten_threads < 0): exact, incl. the overflow / underflow branches and subnormal results."""
+    rng = np.random.default_rng(13)
+    x = np.concatenate([rng.uniform(-30, 30, N), rng.uniform(-120, 120, N), rng.normal(0, 1e-3, N), _bits(1e-30, 100.0, N, rng), -_bits(1e-30, 110.0, N, rng),
+                        [0.0, -0.0, 88.0, -88.0, 88.72, 88.73, -103.9, -104.0, 104.5, -104.5, 1e-40, np.inf, -np.inf, 32.5647, -63.0994]]).astype(np.float32)
+    _same_aten(R, oracle, "sigmoid", x, 0.0, -1)
+    for lo in (0x42000000, 0xc2700000):     # every float of the binades holding the two inputs on which glibc's SSE2 and FMA builds differ (0x4202422f, 0xc27c65d9)
+        _same_aten(R, oracle, "sigmoid", np.arange(lo, lo + (1 << 23), dtype=np.uint32).view(np.float32).copy(), 0.0, -1)
+
+
+@pytest.mark.parametrize("gamma", [0.85, 1.5, 0.7, 1.17, 0.6123, 1.3])
+def test_libm_pow_tail_device_equals_oracle(R, oracle, gamma):
+    """torch.pow on a scalar tail is (float) std::pow((double) x, gamma): the oracle calls glibc's pow, the device ocml's.  Both are within an ULP of a DOUBLE, so
+    the float32 results agree unless x^gamma lies within ~2^-52 of a float32 rounding boundary -- expected on about one element in 2^28; none of these 8.4 M."""
+    rng = np.random.default_rng(int(gamma * 1000))
+    x = np.concatenate([rng.uniform(0, 1, N).astype(np.float32), _bits(2.0 ** -126, 4.0, N, rng), np.array([0.0, 1.0, 0.5, 2.0 ** -24, 1 - 2.0 ** -24, 1e-45], np.float32)])
+    _same_aten(R, oracle, "pow", x, gamma, -1, allow=1)
+
+
+@pytest.mark.parametrize("n,threads", [(31, 4), (3500, 8), (32768, 8), (32769, 8), (100003, 3), (123 * 457, 5), (333 * 777, 16), (1000003, 64), (1920 * 1080, 8), (250 * 333, 1)])
+def test_tail_positions_device_equals_oracle(R, oracle, n, threads):
+    """WHERE the tails are: min(threads, ceil(n / 32768)) chunks of ceil(n / that), the last (length mod 32) elements of each (vd_tails_of == the oracle's
+    at_tails_of, which tests/test_aten_restatements.py pins against torch).  1920 x 1080 at 8 threads has none."""
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0, 1, n).astype(np.float32)
+    _same_aten(R, oracle, "pow", x, 0.85, threads)
+    _same_aten(R, oracle, "sigmoid", (x * 24 - 12).astype(np.float32), 0.0, threads)
+    got = R.torch_math_aten("pow", torch.from_numpy(x).cuda(), 0.85, threads).cpu().numpy()
+    plain = R.torch_math("pow", torch.from_numpy(x).cuda(), 0.85).cpu().numpy()
+    if n == 1920 * 1080:
+        assert np.array_equal(got, plain)
+    elif n == 3500:
+        assert 0 < np.count_nonzero(got != plain) <= 12 and np.array_equal(got[:3488], plain[:3488])      # one chunk: the last 3500 mod 32 = 12 elements (~28 % of them differ)
+
+
 def test_torch_math_rejects_bad_arguments(R):
     with pytest.raises(KeyError):
         R.torch_math("exp", torch.zeros(4))

@@ -57,6 +57,15 @@ def test_pixel_shift_random_parameters(ref, oracle, seed):
     ref_loader.reset_state(ref)
     with torch.no_grad():
         rl, rr, rs = ref.pixel_shift_cuda(torch.from_numpy(ft), torch.from_numpy(d[None].copy()), W, H, fg, mg, bg, return_shift_map=True, **kw)
+    # Round 5: the N-thread ATen mode (aten_threads = the reference process's torch.get_num_threads()) restates the two size-dependent ATen code paths these odd
+    # sizes hit -- libm on the scalar tails of pow / sigmoid, the premultiplied-weight bilinear kernel for outputs with H + W <= 128 -- and is EXACT here: tracker,
+    # shift map, both eyes (offline: 400 of 400 seeds at 1, 3, 4 and 8 threads).
+    st_a = State()
+    oa = oracle.pixel_shift(ft, d[None], W, H, ShiftParams.defaults(fg, mg, bg, aten_threads=torch.get_num_threads(), **kw), st_a, want_shift=True)
+    assert st_a.fw_prev_offset == ref.floating_window_tracker.prev_offset, (seed, kw)
+    assert np.array_equal(oa["shift"].view(np.uint32), rs.numpy().view(np.uint32)), (seed, (ih, iw, H, W), kw)
+    assert np.array_equal(oa["left"], np.asarray(rl)) and np.array_equal(oa["right"], np.asarray(rr)), (seed, (ih, iw, H, W), kw)
+    # ... and the default, thread-independent mode (aten_threads = 0: SLEEF values and the nested bilinear form everywhere) stays within the bounds below
     st = State()
     o = oracle.pixel_shift(ft, d[None], W, H, ShiftParams.defaults(fg, mg, bg, **kw), st, want_shift=True)
     assert st.fw_prev_offset == ref.floating_window_tracker.prev_offset, (seed, kw)
@@ -259,8 +268,8 @@ def test_blank_frame_loops_random_configurations(ref, oracle, seed):
 @pytest.mark.parametrize("seed", range(10))
 def test_helpers_random_inputs(ref, oracle, seed):
     """Leaf functions of the path on random planes / parameters against the live reference: order statistics, subject depth,
-    dynamic parallax scale and motion metric exact; shaping within 1 ULP (random plane sizes: ATen's scalar tail loop calls libm's pow on
-    the last n mod 32 elements), DOF and grade within 1 LSB (separable vs dense summation)."""
+    dynamic parallax scale and motion metric exact; shaping exact in the N-thread ATen mode (random plane sizes: ATen's scalar tail loop calls libm's pow on
+    the last n mod 32 elements; within 1 ULP in the default mode), DOF and grade within 1 LSB (separable vs dense summation)."""
     import torch
     rng = np.random.default_rng(9000 + seed)
     h, w = int(rng.integers(20, 70)), int(rng.integers(30, 110))
@@ -292,6 +301,8 @@ def test_helpers_random_inputs(ref, oracle, seed):
     sh_ref = ref.shape_depth_for_pop(torch.from_numpy(c_ref.copy())[None], s0, stretch_lo=0.05, stretch_hi=0.95, depth_mid=mid, gamma=gamma)[0].numpy()
     sh = oracle.shape_depth_for_pop(c_ref, float(s0), 0.05, 0.95, mid, gamma)[0]
     assert np.max(np.abs(sh - sh_ref)) <= 1.2e-7, (seed, float(np.max(np.abs(sh - sh_ref))))
+    sh_a = oracle.shape_depth_for_pop(c_ref, float(s0), 0.05, 0.95, mid, gamma, aten_threads=thr)[0]      # round 5: with ATen's scalar tails restated -- exact
+    assert np.array_equal(sh_a.view(np.uint32), sh_ref.view(np.uint32)), (seed, int(np.count_nonzero(sh_a != sh_ref)))
     # DOF + grade on a small eye: <= 1 LSB after truncation
     bgr = synth.synth_frame(seed + 7, h, w)[0]
     t = ref.frame_to_tensor(bgr)
@@ -488,8 +499,8 @@ def test_render_loop_every_control_exact_on_untailed_planes(ref, oracle, seed):
 @pytest.mark.parametrize("seed", range(12))
 def test_blank_frame_loops_exact_on_untailed_planes(ref, oracle, seed):
     """skip_blank_frames in the live reference's loop (blackdetect list injected: blank frames keep the SOURCE frame through sharpen / fit / mux
-    and freeze nothing -- the trackers still advance on them) on 16:9 frames with untailed planes and eyes of H + W > 128, every format incl.
-    output heights that differ from the source.  Bar: EXACT on every frame since round 5.  (Until round 4 rendered frames were allowed 4 samples /
+    and freeze nothing -- the trackers still advance on them) on 16:9 frames, every format incl. output heights that differ from the source (72: eyes of
+    64 x 36 that ATen resizes with its premultiplied-weight kernel -- restated since round 5, no size is skipped any more).  Bar: EXACT on every frame since round 5.  (Until round 4 rendered frames were allowed 4 samples /
     2 levels for ONE cause: the dynamic parallax scale rests on a float32 `torch.mean`, whose value is that of ATen's cascade sum -- and above
     32 K elements of its thread partition -- while the oracle used the correctly rounded exact sum; about one frame in 300 got a scale one ULP apart
     (seed 6, frame 1: 0.92083001 / 0.92083007).  The cascade sum is restated now (oracle vo_sum_aten_2d, vd3d_render_params::aten_sum_threads = the
@@ -525,11 +536,50 @@ def test_blank_frame_loops_exact_on_untailed_planes(ref, oracle, seed):
     except NotImplementedError:
         pytest.skip("a fit the oracle does not restate")
     assert got.shape == written.shape, (got.shape, written.shape, kw)
-    if render_kwargs_to_params(sw, sh, **kw).eye_h + render_kwargs_to_params(sw, sh, **kw).eye_w <= 128:
-        pytest.skip("eyes of H + W <= 128: ATen's other bilinear kernel (test_aten_restatements.py)")
     for i in range(len(got)):
         d = np.abs(got[i].astype(np.int16) - written[i].astype(np.int16))
         assert not d.any(), (seed, i, i in blank, u8_diff_stats(got[i], written[i]), kw)
+
+
+@pytest.mark.parametrize("seed", _sweep(10))
+def test_render_loop_any_size_exact_in_aten_mode(ref, oracle, seed):
+    """Round 5: NO SIZE RULE.  The live reference's ``render_sbs_3d`` loop vs the oracle in the N-thread ATen mode (``aten_sum_threads`` = the
+    reference process's torch.get_num_threads()) on source frames of ANY size and aspect -- odd widths and heights, 2:1 and 4:3 sources that the loop crops to
+    16:9, thumbnails whose eyes ATen resizes with its premultiplied-weight kernel, planes whose pow / sigmoid tails go through libm -- with every control drawn at
+    random, four rendered frames each.  Bar: EXACT.  (10 seeds with the suite; offline at the end of round 5: 470 of 470 at 1, 3, 4 and 8 torch threads,
+    tools/sweep_live_reference.py-style runs of this body.)"""
+    import torch
+    import make_golden as mg
+    from visiondepth3d_amd.params import render_kwargs_to_params
+    rng = np.random.default_rng(9700 + seed)
+    fmt = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph", "VR"][int(rng.integers(0, 5))]
+    sh, sw = (int(rng.integers(20, 76)) * 2, int(rng.integers(30, 131)) * 2) if seed % 2 == 0 else (int(rng.integers(40, 150)), int(rng.integers(60, 260)))
+    kw = dict(output_format=fmt, output_height=sh, fg_shift=float(rng.uniform(0, 30)), mg_shift=float(rng.uniform(-10, 5)),
+              bg_shift=float(rng.uniform(-25, 0)), sharpness_factor=float(rng.uniform(0.0, 0.6)),
+              dof_strength=float([0.0, 1.0, 2.0, 2.0, 3.3][int(rng.integers(0, 5))]), feather_strength=float(rng.uniform(0, 20)),
+              blur_ksize=int(rng.integers(0, 7)) * 2 + 1, use_subject_tracking=bool(rng.integers(0, 2)),
+              use_floating_window=bool(rng.integers(0, 2)), max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)),
+              enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+              convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+              ipd_factor=float([1.0, 0.0, 1.2, 0.8][int(rng.integers(0, 4))]),
+              color_saturation=float(rng.uniform(0.8, 1.4)), color_contrast=float(rng.uniform(0.9, 1.2)),
+              color_brightness=float(rng.uniform(-0.05, 0.05)))
+    if rng.integers(0, 3) == 0:
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    n = 4
+    name = f"_live_any_{seed}"
+    mg.LOOP_CASES[name] = (sh, sw, n, kw)
+    try:
+        written = np.stack(mg.run_loop(name))
+    finally:
+        del mg.LOOP_CASES[name]
+    frames, depths = synth.synth_clip(n, sh, sw)
+    p = render_kwargs_to_params(sw, sh, aten_sum_threads=torch.get_num_threads(), **kw)
+    ro = oracle.RenderOracle(p)
+    ro.new_clip()
+    got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
+    assert got.shape == written.shape, (got.shape, written.shape, kw)
+    assert np.array_equal(got, written), (seed, fmt, (sh, sw), (p.eye_h, p.eye_w), (p.warp_h, p.warp_w), u8_diff_stats(got, written))
 
 
 @pytest.mark.parametrize("seed", _sweep(4))

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 FMT_HALF_SBS, FMT_FULL_SBS, FMT_VR, FMT_ANAGLYPH, FMT_INTERLACED = range(5)
 FORMAT_IDS = {
@@ -41,6 +41,8 @@ class ShiftParams(C.Structure):
         ("fg_pop_multiplier", C.c_double),
         ("bg_push_multiplier", C.c_double),
         ("subject_lock_strength", C.c_double),
+        ("aten_threads", C.c_int32),    # extension: ATen's scalar tails for a reference running N torch threads (include/vd3d.h); 0 = none
+        ("reserved0", C.c_int32),
     ]
 
     @classmethod
@@ -51,7 +53,7 @@ class ShiftParams(C.Structure):
                 max_pixel_shift_percent=0.02, parallax_balance=0.8, zero_parallax_strength=0.0,
                 convergence_strength=0.0, depth_pop_gamma=0.85, depth_pop_mid=0.50, depth_stretch_lo=0.05,
                 depth_stretch_hi=0.95, fg_pop_multiplier=1.20, bg_push_multiplier=1.10,
-                subject_lock_strength=1.00)
+                subject_lock_strength=1.00, aten_threads=0, reserved0=0)
         for k, v in kw.items():
             if k not in dict(cls._fields_):
                 raise TypeError(f"unknown pixel_shift_cuda parameter {k!r}")

@@ -60,6 +60,9 @@ struct vd3d_ctx {
   int aten_eh = 0, aten_ew = 0, aten_T = 0, aten_n_small = 0, aten_n_big = 0, aten_nr_crop = 0, aten_nr_mad = 0;
   int* aten_plan = nullptr; float* aten_scratch = nullptr;
   std::vector<void*> aten_retired;
+  // the N-thread ATen mode (round 5): planes resized by ATen's premultiplied-weight kernel ahead of W1 (RGB, [3][H][W]) and of the finishing kernels (depth, [H][W])
+  float* pm_rgb = nullptr; size_t pm_rgb_cap = 0;
+  float* pm_dd = nullptr; size_t pm_dd_cap = 0;
   uint8_t* fmt_eyes = nullptr; size_t fmt_cap = 0;    // vd3d_format_3d_output's own pair of resized VR eyes (never the shared warp-res planes: ADVICE r4)
   bool crop_scalars_dirty = false;                    // fs.crop_top/bottom hold a previous auto-crop result
   // frame sharding (three-phase protocol): per-slot planes of the frames this rank owns inside the current step
@@ -213,6 +216,7 @@ VD3D_EXPORT void vd3d_shift_params_default(vd3d_shift_params* p) {
   p->max_pixel_shift_percent = 0.02; p->parallax_balance = 0.8; p->zero_parallax_strength = 0.0;
   p->convergence_strength = 0.0; p->depth_pop_gamma = 0.85; p->depth_pop_mid = 0.50; p->depth_stretch_lo = 0.05;
   p->depth_stretch_hi = 0.95; p->fg_pop_multiplier = 1.20; p->bg_push_multiplier = 1.10; p->subject_lock_strength = 1.00;
+  p->aten_threads = 0; p->reserved0 = 0;
 }
 VD3D_EXPORT void vd3d_render_params_default(vd3d_render_params* p) {
   memset(p, 0, sizeof *p);
@@ -250,7 +254,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->fmt_eyes, c->aten_plan, c->aten_scratch};
+  void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->fmt_eyes, c->aten_plan, c->aten_scratch, c->pm_rgb, c->pm_dd};
   for (void* q : c->aten_retired) (void)hipFree(q);
   for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
   for (auto& t : c->wk_tabs) (void)hipFree(t.dev);
@@ -411,6 +415,18 @@ static vd_batch batch_of_one(vd3d_ctx* c) {
   return b;
 }
 
+// N-thread ATen mode: a resize ATen runs with its premultiplied-weight kernel (vd_interp_premult) is done here, into a scratch plane of the context, and the
+// consumer (W1, the finishing kernels) is then called with identity geometry.  The scratch is shared by the context's pixel streams: callers on one of them go through
+// pix_exclusive first.
+static int premult_resize(vd3d_ctx* c, int C, const float** plane, int* ih, int* iw, int H, int W, int aten_threads, float** scratch, size_t* cap) {
+  if ((*ih == H && *iw == W) || !vd_interp_premult(C, H, W, aten_threads)) return 0;
+  const size_t need = (size_t)C * H * W;
+  if (*cap < need) { HIPCHK(hipDeviceSynchronize()); HIPCHK(re_alloc(scratch, need)); *cap = need; }
+  vd_launch_interp_planes(c->stream, *plane, C, *ih, *iw, *scratch, H, W, 1);
+  *plane = *scratch; *ih = H; *iw = W;
+  return 0;
+}
+
 static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_plane, int ih, int iw, int W, int H,
                               const vd3d_shift_params& sp, vd_stage_args a, bool skip_pixels = false) {
   hipStream_t s = c->stream;
@@ -422,6 +438,7 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     vd_launch_chain_work(s, b, a.have_eye, ih, iw, H, W, (float)sp.depth_pop_mid, (float)sp.depth_pop_gamma, a);
   }
   if (!skip_pixels) { StageTimer t(c, "warp");
+    { int rcp = premult_resize(c, 3, &rgb, &ih, &iw, H, W, sp.aten_threads, &c->pm_rgb, &c->pm_rgb_cap); if (rcp) return rcp; }
     const vd3d_shift_params spw = warp_stage_params(sp);   // feather_strength <= 0: the exact no-feather kernels
     const bool pre = spw.enable_feathering && vd_warp_fused_ok(ih, iw, H, W, spw);   // k_e2w -> W1 (see shard_pixels_impl)
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
@@ -609,6 +626,10 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
                       uint8_t* out, const vd_dev_work* wk = nullptr) {
   StageTimer t(c, "finish");
   if (!wk) wk = c->work;
+  if (fc.nlev && !(eh == p->warp_h && ew == p->warp_w) && vd_interp_premult(1, p->warp_h, p->warp_w, p->aten_sum_threads)) {   // depth_for_dof (:1347-1350) by ATen's other kernel
+    int rcx = pix_exclusive(c); if (rcx) return rcx;
+    if ((rcx = premult_resize(c, 1, &dn, &eh, &ew, p->warp_h, p->warp_w, p->aten_sum_threads, &c->pm_dd, &c->pm_dd_cap))) return rcx;
+  }
   const int dense = (p->dof_dense_conv && fc.nlev) ? 1 : 0;   // the reference's dense k x k conv order
   const float* d_w2 = nullptr;
   if (dense) {
@@ -725,6 +746,7 @@ static int render_frame_impl(vd3d_ctx* c, const uint8_t* frame_bgr, const void* 
   vd3d_shift_params sp = p->shift;
   sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
   sp.depth_stretch_hi = 0.95; sp.fg_pop_multiplier = 1.20; sp.bg_push_multiplier = 1.10; sp.subject_lock_strength = 1.00;
+  sp.aten_threads = p->aten_sum_threads;   // ATen's scalar tails for the same reference process (include/vd3d.h)
   if ((rc = check_shift_params(&sp, p->warp_h, p->warp_w))) return rc;
   vd_finish_consts fc;
   if ((rc = make_finish_consts(p, &fc))) return rc;
@@ -847,6 +869,7 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
   vd3d_shift_params sp = p->shift;
   sp.parallax_balance = 0.8; sp.depth_pop_gamma = 0.85; sp.depth_pop_mid = 0.50; sp.depth_stretch_lo = 0.05;
   sp.depth_stretch_hi = 0.95; sp.fg_pop_multiplier = 1.20; sp.bg_push_multiplier = 1.10; sp.subject_lock_strength = 1.00;
+  sp.aten_threads = p->aten_sum_threads;   // ATen's scalar tails for the same reference process (include/vd3d.h)
   vd_finish_consts fc;
   if ((rc = make_finish_consts(p, &fc))) return rc;
   HIPCHK(hipSetDevice(c->device));
@@ -915,19 +938,25 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
   { StageTimer t(c, "warp");
     // fused path with feathering: k_e2w writes the gradient mask of both eyes, W1 starts at its window sums
     const vd3d_shift_params spw = warp_stage_params(sp);   // feather_strength <= 0 (the GUI's default): W1 without mask, window sums and blend -- exact
-    const bool pre = spw.enable_feathering && vd_warp_fused_ok(p->eye_h, p->eye_w, H, W, spw);
+    const float* rgb = c->slot_rgb[slot];
+    int rih = p->eye_h, riw = p->eye_w;
+    if (!(rih == H && riw == W) && vd_interp_premult(3, H, W, sp.aten_threads)) {   // N-thread ATen mode: the eye -> warp resize of :595 by ATen's other kernel
+      if ((rc = pix_exclusive(c))) return rc;
+      if ((rc = premult_resize(c, 3, &rgb, &rih, &riw, H, W, sp.aten_threads, &c->pm_rgb, &c->pm_rgb_cap))) return rc;
+    }
+    const bool pre = spw.enable_feathering && vd_warp_fused_ok(rih, riw, H, W, spw);
     { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
     bool fused;
     { StageTimer t2(c, "w1");
       if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->slot_D[slot], S, H, W, (float)spw.feather_strength, E2); }
-      fused = vd_launch_warp_fused(s, c->slot_rgb[slot], p->eye_h, p->eye_w, c->slot_D[slot], S, H, W, spw, L, R, pre ? E2 : nullptr); }
+      fused = vd_launch_warp_fused(s, rgb, rih, riw, c->slot_D[slot], S, H, W, spw, L, R, pre ? E2 : nullptr); }
     if (!fused) {
       if ((rc = pix_exclusive(c))) return rc;
       if (spw.enable_feathering) {
         vd_launch_e2(s, c->slot_D[slot], S, H, W, (float)spw.feather_strength, c->e2L, c->e2R);
         vd_launch_pool(s, c->e2L, c->e2R, H, W, spw.blur_ksize, c->bL, c->bR);
       }
-      vd_launch_warp(s, c->slot_rgb[slot], p->eye_h, p->eye_w, S, c->bL, c->bR, H, W, spw.enable_feathering ? 1 : 0, L, R);
+      vd_launch_warp(s, rgb, rih, riw, S, c->bL, c->bR, H, W, spw.enable_feathering ? 1 : 0, L, R);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1001,6 +1030,7 @@ static int shard2_args(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args* 
   *sp = p->shift;
   sp->parallax_balance = 0.8; sp->depth_pop_gamma = 0.85; sp->depth_pop_mid = 0.50; sp->depth_stretch_lo = 0.05;
   sp->depth_stretch_hi = 0.95; sp->fg_pop_multiplier = 1.20; sp->bg_push_multiplier = 1.10; sp->subject_lock_strength = 1.00;
+  sp->aten_threads = p->aten_sum_threads;
   memset(a, 0, sizeof *a);
   a->have_eye = 1; a->W = p->warp_w; a->H = p->warp_h; a->n_eye = (long long)p->eye_h * p->eye_w;
   a->n_crop = (long long)(p->eye_h * 3 / 4 - p->eye_h / 4) * (long long)(p->eye_w * 3 / 4 - p->eye_w / 4);
@@ -1533,6 +1563,16 @@ VD3D_EXPORT int vd3d_torch_math(vd3d_ctx* c, int op, const float* x, float param
   if (op < 0 || op > 2 || n < 0 || (n > 0 && (!x || !out))) return set_err(VD3D_E_INVALID, "vd3d_torch_math: op 0..2, n >= 0, device pointers");
   HIPCHK(hipSetDevice(c->device));
   if (n) vd_launch_torch_math(c->stream, op, x, param, out, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_torch_math_aten(vd3d_ctx* c, int op, const float* x, double param, float* out, long long n, int aten_threads) {
+  if (!c) return set_err(VD3D_E_INVALID, "NULL context");
+  if (op < 0 || op > 1 || n < 0 || n >= (1ll << 32) || (n > 0 && (!x || !out)))
+    return set_err(VD3D_E_INVALID, "vd3d_torch_math_aten: op 0..1, 0 <= n < 2^32, device pointers");
+  HIPCHK(hipSetDevice(c->device));
+  if (n) vd_launch_torch_math_aten(c->stream, op, x, param, out, n, aten_threads);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -213,6 +213,65 @@ VD_DEV float vd_sleef_expf(float d) {
 }
 VD_DEV float vd_sigmoid_torch(float x) { return 1.0f / (1.0f + vd_sleef_expf(0.0f - x)); }
 
+// ---- ATen's scalar tails (round 5; oracle/vd3d_oracle.c "ATen's SCALAR TAILS" has the derivation) --------------------------------------------
+// torch.pow / torch.sigmoid on a contiguous n-element float32 CPU plane: min(threads, ceil(n / 32768)) chunks of ceil(n / that) elements (one chunk
+// below 32768 elements or with one thread), and the last (chunk length mod 32) elements of every chunk go through libm instead of SLEEF.
+// vd_tails_of runs on the host; kernels that evaluate pow / sigmoid are instantiated with and without the tail test, so planes without
+// tails (every video size) run the code they always ran.
+struct vd_tails { unsigned chunk, n; int on; };
+static inline vd_tails vd_tails_of(unsigned long long n, int threads) {
+  vd_tails t; t.chunk = n ? (unsigned)n : 1u; t.n = (unsigned)n; t.on = 0;
+  if (threads <= 0 || n == 0 || n >= (1ull << 32)) return t;
+  unsigned long long nt = (n + 32767) / 32768;
+  if (nt > (unsigned long long)threads) nt = (unsigned long long)threads;
+  if (n < 32768 || nt < 1) nt = 1;
+  const unsigned long long chunk = (n + nt - 1) / nt, last = n - (n - 1) / chunk * chunk;
+  t.chunk = (unsigned)chunk;
+  t.on = ((n > chunk) && (chunk & 31)) || (last & 31) ? 1 : 0;
+  return t;
+}
+static inline vd_tails vd_tails_all(unsigned long long n) { vd_tails t; t.chunk = 1u; t.n = (unsigned)n; t.on = 2; return t; }   // diagnostic: every element (vd3d_torch_math_aten)
+VD_DEV bool vd_in_tail(const vd_tails& t, unsigned i) {
+  if (t.on == 2) return true;
+  const unsigned start = i / t.chunk * t.chunk, rem = t.n - start, len = rem < t.chunk ? rem : t.chunk;
+  return i - start >= (len & ~31u);
+}
+// glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, the FMA-contracted x86-64 build): N = 32 table of 2^(i/32) as double bit patterns minus i << 47,
+// a cubic in double, one rounding to float32 at the end.  Checked on the CPU against libm on all 2^32 inputs (oracle), here against the oracle.
+static __constant__ const unsigned long long c_vd_exp2f_t[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+VD_DEV float vd_expf_glibc(float x) {
+  const unsigned ux = __float_as_uint(x), abstop = (ux >> 20) & 0x7ffu;
+  if (abstop >= 0x42bu) {                                         // |x| >= 88, inf, nan
+    if (ux == 0xff800000u) return 0.0f;
+    if (abstop >= 0x7f8u) return x + x;
+    if (x > 0x1.62e42ep6f) return __builtin_inff();
+    if (x < -0x1.9fe368p6f) return 0.0f;
+  }
+  const double xd = (double)x, invln2n = 0x1.71547652b82fep+0 * 32, shift = 0x1.8p+52;
+  const double c0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, c1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, c2 = 0x1.62e42ff0c52d6p-1 / 32;
+  const double z = invln2n * xd;                                   // (the library is built with -ffp-contract=off: every operation below is one rounding)
+  double kd = z + shift;
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd = kd - shift;
+  const double r = __builtin_fma(invln2n, xd, -kd);
+  const double sc = __longlong_as_double((long long)(c_vd_exp2f_t[ki & 31] + (ki << 47)));
+  const double q = __builtin_fma(c0, r, c1), r2 = r * r;
+  double y = __builtin_fma(c2, r, 1.0);
+  y = __builtin_fma(q, r2, y);
+  return (float)(y * sc);
+}
+VD_DEV float vd_sigmoid_tail(float x) { return 1.0f / (1.0f + vd_expf_glibc(-x)); }
+// (float) std::pow((double) x, e): ocml's double pow is within an ULP of a double like glibc's, so the two agree on the float32 rounding except
+// when x^e lies within ~2^-52 (relative) of a float32 rounding boundary
+VD_DEV float vd_pow_tail(float x, double e) { return (float)pow((double)x, e); }
+static inline __host__ __device__ bool vd_pow_is_special(float e) { return e == 0.0f || e == 1.0f || e == 0.5f || e == 2.0f || e == 3.0f || e == -0.5f || e == -1.0f || e == -2.0f; }
+
 // packed-f32 vector types: hipcc lowers arithmetic on these to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (2 lanes-worth of
 // IEEE float32 work per VALU issue slot on gfx950); each element is rounded exactly like the scalar operator.
 typedef float vd_f2 __attribute__((ext_vector_type(2)));
@@ -291,6 +350,23 @@ VD_DEV float vd_bilerp(float p00, float p01, float p10, float p11, float wx0, fl
   float a = vd_fma(p00, wx0, wx1 * p01);
   float b = vd_fma(p10, wx0, wx1 * p11);
   return vd_fma(a, wy0, wy1 * b);
+}
+
+// ATen's OTHER float32 bilinear kernel (cpu_upsample_linear_channels_last, taken for outputs with oh + ow <= 128 and for 3-channel inputs when torch runs one
+// intra-op thread; round 5, oracle/vd3d_oracle.c vo_interp_bilinear_aten): row and column weights multiplied first, then ONE chain starting at the second tap of the
+// top row.  Part of the N-thread ATen mode (vd3d_shift_params::aten_threads >= 1); without it the nested form above is used at every size.
+VD_DEV float vd_bilerp_pm(float p00, float p01, float p10, float p11, float wx0, float wx1, float wy0, float wy1) {
+  const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+  float t = p01 * w01;
+  t = vd_fma(p00, w00, t);
+  t = vd_fma(p10, w10, t);
+  return vd_fma(p11, w11, t);
+}
+VD_DEV float vd_bilerp_sel(bool pm, float p00, float p01, float p10, float p11, float wx0, float wx1, float wy0, float wy1) {
+  return pm ? vd_bilerp_pm(p00, p01, p10, p11, wx0, wx1, wy0, wy1) : vd_bilerp(p00, p01, p10, p11, wx0, wx1, wy0, wy1);
+}
+static inline __host__ __device__ bool vd_interp_premult(int C, int oh, int ow, int aten_threads) {
+  return aten_threads >= 1 && (oh + ow <= 128 || (aten_threads == 1 && C == 3));
 }
 
 // grid_sample(bilinear, border, align_corners=True) parameters for a normalised coordinate pair

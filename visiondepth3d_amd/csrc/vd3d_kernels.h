@@ -99,17 +99,19 @@ VD_DEV float vd_ingest_pixel(const uint8_t* __restrict__ frame, const void* __re
   const size_t i10 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i0 + p.crop_x);
   const size_t i11 = (size_t)(ty.i1 + p.crop_y) * p.src_w + (tx.i1 + p.crop_x);
   const size_t ne = (size_t)p.eye_h * p.eye_w, o = (size_t)ey * p.eye_w + ex;
+  // the N-thread ATen mode (round 5): which of ATen's two bilinear kernels resizes the 3-channel frame / the 1-channel depth at this eye size
+  const bool pm_c = vd_interp_premult(3, p.eye_h, p.eye_w, p.aten_sum_threads), pm_d = vd_interp_premult(1, p.eye_h, p.eye_w, p.aten_sum_threads);
   if (frame) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {  // output plane c = R,G,B ; source byte 2-c
       const int sc = 2 - c;
       float p00 = vd_u8_unit((float)frame[i00 * 3 + sc]), p01 = vd_u8_unit((float)frame[i01 * 3 + sc]);
       float p10 = vd_u8_unit((float)frame[i10 * 3 + sc]), p11 = vd_u8_unit((float)frame[i11 * 3 + sc]);
-      rgb_eye[c * ne + o] = vd_bilerp(p00, p01, p10, p11, tx.w0, tx.w1, ty.w0, ty.w1);
+      rgb_eye[c * ne + o] = vd_bilerp_sel(pm_c, p00, p01, p10, p11, tx.w0, tx.w1, ty.w0, ty.w1);
     }
   }
-  const float cur = vd_bilerp(vd_depth_at(depth, fmt, i00), vd_depth_at(depth, fmt, i01), vd_depth_at(depth, fmt, i10),
-                              vd_depth_at(depth, fmt, i11), tx.w0, tx.w1, ty.w0, ty.w1);
+  const float cur = vd_bilerp_sel(pm_d, vd_depth_at(depth, fmt, i00), vd_depth_at(depth, fmt, i01), vd_depth_at(depth, fmt, i10),
+                                  vd_depth_at(depth, fmt, i11), tx.w0, tx.w1, ty.w0, ty.w1);
   const float prev = tdf_valid ? tdf_prev[o] : cur;   // tdf_prev may be tdf itself (in-place) or the plane this thread wrote one frame ago
   const float nv = 0.5f * prev + (float)(1 - 0.5) * cur;
   tdf[o] = nv;
@@ -180,6 +182,9 @@ bool vd_launch_sharp_fit(hipStream_t s, const uint8_t* gL, const uint8_t* gR, co
 void vd_launch_sharp_mux(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p,
                          const vd_finish_consts& fc, uint8_t* out, int presharp_pitch = 0, bool identity_fit = false);
 void vd_launch_stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
+// F.interpolate(bilinear, align_corners=False) of C float32 planes; premult: ATen's premultiplied-weight kernel (vd_bilerp_pm) instead of the nested form
+void vd_launch_interp_planes(hipStream_t s, const float* src, int C, int ih, int iw, float* dst, int oh, int ow, int premult);
+void vd_launch_torch_math_aten(hipStream_t s, int op, const float* x, double p, float* out, long long n, int threads);
 void vd_launch_torch_math(hipStream_t s, int op, const float* x, float p, float* out, long long n);
 void vd_launch_blank_eye(hipStream_t s, const uint8_t* src, int h, int w, const vd_dev_work* wk, uint8_t* dst);
 

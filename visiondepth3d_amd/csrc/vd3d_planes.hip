@@ -18,8 +18,9 @@ struct vd_shift_consts {
   float mid, fg, mg, bg, fgm, bgm, pb, half_width, fs, ma, mb;
   int edge;
 };
+template <bool TAILS>   // round 5: ATen's scalar tails (vd_tails_of) -- those pixels take glibc's expf in the sigmoid and libm's pow in the layer weight
 __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int H, int W, const vd_dev_work* __restrict__ w,
-                                               vd_shift_consts c, float* __restrict__ S) {
+                                               vd_shift_consts c, float* __restrict__ S, vd_tails tl) {
   __shared__ __attribute__((aligned(16))) float em[SH_TH + 4][SH_TW + 4];
   __shared__ int2 rs14[64];
   const int x0 = blockIdx.x * SH_TW, y0 = blockIdx.y * SH_TH;
@@ -36,7 +37,10 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
         const float dy = y > 0 ? fabsf(cc - D[(size_t)(y - 1) * W + x]) : 0.f;
         const float g = vd_sqrt_torch(dx * dx + dy * dy, rs14);      // torch.sqrt / torch.sigmoid: the CPU libraries' values
         const float z = ((g - (float)0.02) * c.fs) * 5.f;
-        e = 1.f - vd_sigmoid_torch(z);
+        float sg;
+        if (TAILS && vd_in_tail(tl, (unsigned)y * (unsigned)W + (unsigned)x)) sg = vd_sigmoid_tail(z);
+        else sg = vd_sigmoid_torch(z);
+        e = 1.f - sg;
       }
       em[ty][tx] = e;
     }
@@ -66,7 +70,10 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
     const int x = x0 + tx + q;
     if (x >= W) break;
     const float Dv = D[(size_t)y * W + x];
-    const float fgw = vd_clamp(vd_pow15_torch(1.0f - Dv), 0.f, 1.f);
+    float p15;
+    if (TAILS && vd_in_tail(tl, (unsigned)y * (unsigned)W + (unsigned)x)) p15 = vd_pow_tail(1.0f - Dv, 1.5);
+    else p15 = vd_pow15_torch(1.0f - Dv);
+    const float fgw = vd_clamp(p15, 0.f, 1.f);
     const float mgw = vd_clamp(1.0f - fabsf(Dv - c.mid) * 3.0f, 0.f, 1.f);
     const float bgw = vd_clamp(Dv, 0.f, 1.f);
     const float raw = ((fgw * fgf) * c.fgm + mgw * mgf) + (bgw * bgf) * c.bgm;
@@ -92,7 +99,9 @@ void vd_launch_shift(hipStream_t s, const float* D, int H, int W, const vd_dev_w
   c.ma = (float)(1.0 - ms); c.mb = (float)ms;
   c.edge = p.enable_edge_masking ? 1 : 0;
   c.fg = c.mg = c.bg = 0.f;
-  hipLaunchKernelGGL(k_shift, dim3((W + SH_TW - 1) / SH_TW, (H + SH_TH - 1) / SH_TH), dim3(256), 0, s, D, H, W, w, c, S);
+  const vd_tails tl = vd_tails_of((unsigned long long)H * W, p.aten_threads);
+  if (tl.on) hipLaunchKernelGGL(k_shift<true>, dim3((W + SH_TW - 1) / SH_TW, (H + SH_TH - 1) / SH_TH), dim3(256), 0, s, D, H, W, w, c, S, tl);
+  else hipLaunchKernelGGL(k_shift<false>, dim3((W + SH_TW - 1) / SH_TW, (H + SH_TH - 1) / SH_TH), dim3(256), 0, s, D, H, W, w, c, S, tl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,6 +658,40 @@ __global__ __launch_bounds__(256) void k_torch_math(int op, const float* __restr
     const float v = x[i];
     out[i] = op == 0 ? vd_pow_torch(v, p, rs14) : op == 1 ? vd_sigmoid_torch(v) : vd_sqrt_torch(v, rs14);
   }
+}
+// F.interpolate(bilinear, align_corners=False) of C planes into HBM (round 5).  The render kernels resize inside themselves; this one exists for the N-thread
+// ATen mode, where small outputs (and 3-channel inputs of a one-thread torch) take ATen's premultiplied-weight kernel: the plane is resized here and the consumer
+// is called with identity geometry.
+__global__ __launch_bounds__(256) void k_interp_planes(const float* __restrict__ src, int ih, int iw, float* __restrict__ dst, int oh, int ow, int pm) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ow || y >= oh) return;
+  const float* pl = src + (size_t)blockIdx.z * ih * iw;
+  const vd_tap ty = vd_interp_tap(ih, oh, y), tx = vd_interp_tap(iw, ow, x);
+  const float* r0 = pl + (size_t)ty.i0 * iw;
+  const float* r1 = pl + (size_t)ty.i1 * iw;
+  dst[((size_t)blockIdx.z * oh + y) * ow + x] = vd_bilerp_sel(pm != 0, r0[tx.i0], r0[tx.i1], r1[tx.i0], r1[tx.i1], tx.w0, tx.w1, ty.w0, ty.w1);
+}
+void vd_launch_interp_planes(hipStream_t s, const float* src, int C, int ih, int iw, float* dst, int oh, int ow, int premult) {
+  hipLaunchKernelGGL(k_interp_planes, dim3((ow + 63) / 64, (oh + 3) / 4, C), dim3(256), 0, s, src, ih, iw, dst, oh, ow, premult);
+}
+
+// the same with ATen's scalar tails for `threads` intra-op threads (threads < 0: every element takes the tail arithmetic -- diagnostic)
+__global__ __launch_bounds__(256) void k_torch_math_aten(int op, const float* __restrict__ x, double p, float* __restrict__ out, long long n, vd_tails tl) {
+  __shared__ int2 rs14[64];
+  vd_stage_rs14(rs14, threadIdx.x, 256);
+  __syncthreads();
+  const float pf = (float)p;
+  const bool special = vd_pow_is_special(pf);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    const bool tail = tl.on && vd_in_tail(tl, (unsigned)i);
+    out[i] = op == 0 ? (tail && !special ? vd_pow_tail(v, p) : vd_pow_torch(v, pf, rs14)) : (tail ? vd_sigmoid_tail(v) : vd_sigmoid_torch(v));
+  }
+}
+void vd_launch_torch_math_aten(hipStream_t s, int op, const float* x, double p, float* out, long long n, int threads) {
+  const long long nb = (n + 255) / 256;
+  const vd_tails tl = threads < 0 ? vd_tails_all((unsigned long long)n) : vd_tails_of((unsigned long long)n, threads);
+  hipLaunchKernelGGL(k_torch_math_aten, dim3((unsigned)(nb < 16384 ? (nb > 0 ? nb : 1) : 16384)), dim3(256), 0, s, op, x, p, out, n, tl);
 }
 void vd_launch_torch_math(hipStream_t s, int op, const float* x, float p, float* out, long long n) {
   const long long nb = (n + 255) / 256;

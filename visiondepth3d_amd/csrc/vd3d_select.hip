@@ -927,6 +927,7 @@ __global__ __launch_bounds__(1024) void k_chain_b0(vd_batch b, long long n, int 
 // does not depend on the dn plane another workgroup of the same launch is writing) or from a given plane (B1 API)
 struct FWorkSrc {
   const float* src; int ih, iw, H, W, norm, collapse; float lo, den;
+  int pm;   // round 5: ATen's premultiplied-weight bilinear kernel (N-thread ATen mode, warp planes with H + W <= 128)
   float scale_h, scale_w, step_x, step_y;   // hoisted loop invariants (same float32 expressions as vd_interp_tap / vd_lin11)
   VD_DEV float tap(size_t idx) const {
     float d = src[idx];
@@ -938,11 +939,11 @@ struct FWorkSrc {
     float d;
     if (ih == H && iw == W) d = tap((size_t)y * W + x);
     else {
-      const bool two = 2 * ih == H && 2 * iw == W;   // exact 2:1 (Half-SBS): closed-form taps, same values
+      const bool two = !pm && 2 * ih == H && 2 * iw == W;   // exact 2:1 (Half-SBS): closed-form taps, same values
       const vd_tap ty = two ? vd_tap21(ih, y) : vd_interp_tap_s(ih, H, scale_h, y);
       const vd_tap tx = two ? vd_tap21(iw, x) : vd_interp_tap_s(iw, W, scale_w, x);
-      d = vd_bilerp(tap((size_t)ty.i0 * iw + tx.i0), tap((size_t)ty.i0 * iw + tx.i1), tap((size_t)ty.i1 * iw + tx.i0),
-                    tap((size_t)ty.i1 * iw + tx.i1), tx.w0, tx.w1, ty.w0, ty.w1);
+      d = vd_bilerp_sel(pm != 0, tap((size_t)ty.i0 * iw + tx.i0), tap((size_t)ty.i0 * iw + tx.i1), tap((size_t)ty.i1 * iw + tx.i0),
+                        tap((size_t)ty.i1 * iw + tx.i1), tx.w0, tx.w1, ty.w0, ty.w1);
     }
     const float xx = vd_lin11_step(step_x, W, x), yy = vd_lin11_step(step_y, H, y);
     const float curv = 1.f - (xx * xx + yy * yy);
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(1024) void k_chain_stage1(vd_batch b, FWorkSrc f, v
   const long long n = (long long)f.H * f.W;
   const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
   if ((f.W & 3) == 0 && (reinterpret_cast<uintptr_t>(dc) & 15) == 0) {
-    const bool two = !f.norm && 2 * f.ih == f.H && 2 * f.iw == f.W;
+    const bool two = !f.pm && !f.norm && 2 * f.ih == f.H && 2 * f.iw == f.W;
     const long long n4 = n >> 2;
     for (long long b4 = (long long)wg * 1024; b4 < n4; b4 += (long long)nwg * 1024) {
       const long long i4 = b4 + threadIdx.x;
@@ -1124,7 +1125,9 @@ __global__ __launch_bounds__(1024) void k_chain_b1(vd_batch b, int eh, int ew, i
 }
 
 // K5: shape_depth_for_pop -> D plane + pass A of J4 ; last workgroup: scan A2
-__global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, float mid, float gamma, vd_stage_args a) {
+// TAILS (round 5): the plane has ATen scalar tails for the reference's thread count (vd_tails_of; no video size does) -- those pixels take libm's pow
+template <bool TAILS>
+__global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, float mid, float gamma, vd_stage_args a, vd_tails tl) {
   __shared__ uint32_t h1[NBL];
   __shared__ uint32_t sm[128];
   const vd_batch_frame& F = b.f[blockIdx.y];
@@ -1135,11 +1138,13 @@ __global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, fl
   const long long n = (long long)f.H * f.W;
   const int stretch = w->shp_stretch;
   const float lo = w->shp_lo, den = w->shp_den, subj_s = w->shp_subj_s;
-  auto shape1 = [&](float d) {   // shape_depth_for_pop :519-558 for one pixel
+  const double gamma_d = a.shift.depth_pop_gamma;   // the Python float: ATen's scalar lambda takes it unrounded
+  auto shape1 = [&](float d, unsigned i) {   // shape_depth_for_pop :519-558 for one pixel
     const float ds = stretch ? vd_clamp((d - lo) / den, 0.f, 1.f) : d;
     const float centered = (ds - subj_s) + mid;
     const float t = centered - mid;
     const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+    if (TAILS) { if (vd_in_tail(tl, i)) return vd_clamp(sgn * vd_pow_tail(fabsf(t), gamma_d) + mid, 0.f, 1.f); }
     return vd_clamp(sgn * vd_pow_torch(fabsf(t), gamma, c_vd_rs14) + mid, 0.f, 1.f);   // torch.pow: SLEEF's value
   };
   if ((f.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(dc) | reinterpret_cast<uintptr_t>(D)) & 15) == 0) {
@@ -1151,7 +1156,8 @@ __global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, fl
       int y = 0, x = 0;
       if (ok) {
         const vd_f4 d = reinterpret_cast<const vd_f4*>(dc)[i4];
-        v.x = shape1(d.x); v.y = shape1(d.y); v.z = shape1(d.z); v.w = shape1(d.w);
+        const unsigned i0 = (unsigned)i4 * 4u;
+        v.x = shape1(d.x, i0); v.y = shape1(d.y, i0 + 1u); v.z = shape1(d.z, i0 + 2u); v.w = shape1(d.w, i0 + 3u);
         reinterpret_cast<vd_f4*>(D)[i4] = v;
         const unsigned i = (unsigned)i4 * 4u;
         y = (int)(i / (unsigned)f.W); x = (int)(i - (unsigned)y * (unsigned)f.W);
@@ -1167,7 +1173,7 @@ __global__ __launch_bounds__(1024) void k_chain_shape(vd_batch b, FWorkSrc f, fl
       float v = 0.f; bool in_crop = false;
       if (i < n) {
         const int y = (int)((unsigned)i / (unsigned)f.W), x = (int)((unsigned)i - (unsigned)y * (unsigned)f.W);
-        v = shape1(dc[i]);
+        v = shape1(dc[i], (unsigned)i);
         D[i] = v;
         in_crop = vd_in_subject_crop(y, x, f.H, f.W, v);
       }
@@ -1218,7 +1224,8 @@ static inline int batch_grid(long long n, int per_wg, int cap, int nframes) {
 void vd_launch_chain_eye(hipStream_t s, const vd_batch& b, int fmt, const vd3d_render_params& p, const vd_stage_args& a) {
   const long long ne = (long long)p.eye_h * p.eye_w;
   // K1 fast path: exact 2:1 eye resize of a fixed crop window, 4 eye pixels per thread through 8- / 16-byte loads
-  int fast = !p.auto_crop_black_bars && p.crop_w == 2 * p.eye_w && p.crop_h == 2 * p.eye_h && (p.eye_w & 3) == 0 &&
+  int fast = !vd_interp_premult(3, p.eye_h, p.eye_w, p.aten_sum_threads) &&   // the N-thread ATen mode resizes such eyes with its premultiplied-weight kernel: generic path
+             !p.auto_crop_black_bars && p.crop_w == 2 * p.eye_w && p.crop_h == 2 * p.eye_h && (p.eye_w & 3) == 0 &&
              (fmt == VD3D_DEPTH_F32 || fmt == VD3D_DEPTH_GRAY_U8) && ((3 * (long long)p.src_w) & 7) == 0 &&
              ((3 * ((long long)p.crop_y * p.src_w + p.crop_x)) & 7) == 0;
   const long long dsz = fmt == VD3D_DEPTH_F32 ? 4 : 1;
@@ -1239,6 +1246,7 @@ void vd_launch_chain_work(hipStream_t s, const vd_batch& b, int have_eye, int ih
                           const vd_stage_args& a) {
   FWorkSrc f;
   f.src = nullptr; f.ih = ih; f.iw = iw; f.H = H; f.W = W; f.norm = 0; f.collapse = 0; f.lo = 0.f; f.den = 1.f;
+  f.pm = vd_interp_premult(1, H, W, a.shift.aten_threads) ? 1 : 0;
   f.scale_h = (float)ih / (float)H; f.scale_w = (float)iw / (float)W;
   f.step_x = W > 1 ? (1.f - (-1.f)) / (float)(W - 1) : 0.f; f.step_y = H > 1 ? (1.f - (-1.f)) / (float)(H - 1) : 0.f;
   const long long ne = (long long)ih * iw, n = (long long)H * W;
@@ -1254,7 +1262,9 @@ void vd_launch_chain_work(hipStream_t s, const vd_batch& b, int have_eye, int ih
   if (have_eye && a.aten_threads > 0) vd_launch_aten_sums(s, b, a);   // torch.mean's summation order (vd3d_atensum.hip): read by K4's scalar stage
   hipLaunchKernelGGL(k_chain_stage1, dim3(work_wg, nf), dim3(1024), 0, s, b, f, a);
   hipLaunchKernelGGL(k_chain_b1, dim3(eye_wg_b + work_wg_b, nf), dim3(1024), 0, s, b, ih, iw, eye_wg_b, f, a);
-  hipLaunchKernelGGL(k_chain_shape, dim3(batch_grid(n, 4096, 512, b.n), nf), dim3(1024), 0, s, b, f, mid, gamma, a);
+  const vd_tails tl = vd_tails_of((unsigned long long)n, vd_pow_is_special(gamma) ? 0 : a.shift.aten_threads);
+  if (tl.on) hipLaunchKernelGGL(k_chain_shape<true>, dim3(batch_grid(n, 4096, 512, b.n), nf), dim3(1024), 0, s, b, f, mid, gamma, a, tl);
+  else hipLaunchKernelGGL(k_chain_shape<false>, dim3(batch_grid(n, 4096, 512, b.n), nf), dim3(1024), 0, s, b, f, mid, gamma, a, tl);
   hipLaunchKernelGGL(k_chain_b2, dim3(batch_grid(n, 4096, 512, b.n), nf), dim3(1024), 0, s, b, H, W, a);
 }
 

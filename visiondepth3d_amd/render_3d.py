@@ -547,6 +547,15 @@ class Renderer:
         _lib.check(self._L.vd3d_torch_math(self._ctx, {"pow": 0, "sigmoid": 1, "sqrt": 2}[op], _ptr(t), float(param), _ptr(o), t.numel()))
         return o
 
+    def torch_math_aten(self, op: str, x: torch.Tensor, param: float = 0.0, aten_threads: int = 0) -> torch.Tensor:
+        """``torch_math`` for "pow" / "sigmoid" with ATen's scalar tails for a torch process of ``aten_threads`` intra-op threads (libm on the last
+        ``len mod 32`` elements of every thread's chunk; < 0: on every element) -- include/vd3d.h vd3d_torch_math_aten."""
+        t = x.to(self.device, torch.float32).contiguous()
+        o = torch.empty_like(t)
+        self._enter(t, o)
+        _lib.check(self._L.vd3d_torch_math_aten(self._ctx, {"pow": 0, "sigmoid": 1}[op], _ptr(t), float(param), _ptr(o), t.numel(), int(aten_threads)))
+        return o
+
     def quantiles(self, plane: torch.Tensor, qs):
         p = plane.to(self.device, torch.float32).contiguous()
         q = (C.c_float * len(qs))(*[float(np.float32(v)) for v in qs])
