@@ -421,9 +421,9 @@ def test_even_blur_ksize_window(ref, oracle, k):
 def test_render_loop_dof_slider_and_formats_exact_on_untailed_planes(ref, oracle, seed):
     """Round 4: the live reference's ``render_sbs_3d`` loop vs the oracle over the WHOLE DOF slider (0.1 ... 5.0: Gaussians of 3 to 21 taps, the
     strengths where MKL's vsExp is not the rounded exponential among them) in every output format incl. VR, on 16:9 frame sizes whose planes
-    are multiples of 32 elements (no ATen scalar tail: every float32 operator is the SLEEF / MKL vector path the oracle restates; a 2:1 or 3:2
-    source would be cropped to 113-pixel rows whose last elements go through libm -- 3 to 11 samples of such a frame then differ by up to 2
-    levels, the limitation DESIGN.md section 2 names).  Bar: EXACT."""
+    are multiples of 32 elements (no ATen scalar tail: every float32 operator is the SLEEF / MKL vector path the DEFAULT mode computes with; on other sizes 3 to 11
+    samples of a frame differ by up to 2 levels in that mode -- the N-thread ATen mode of round 5 restates the tails and is exact at any size,
+    test_render_loop_any_size_exact_in_aten_mode).  Bar: EXACT."""
     import make_golden as mg
     from visiondepth3d_amd.params import render_kwargs_to_params
     rng = np.random.default_rng(9100 + seed)
@@ -460,7 +460,8 @@ def test_render_loop_every_control_exact_on_untailed_planes(ref, oracle, seed):
     """The live reference's ``render_sbs_3d`` loop vs the oracle with EVERY control the loop forwards drawn at random -- layer shifts, shift
     bound, zero-parallax strength, static / dynamic convergence, IPD factor, edge masking / feathering on and off, blur sizes 1 ... 13, feather
     strength, subject tracking, floating window, DOF, sharpening, colour grade, original-aspect preservation -- on 16:9 frames whose planes are
-    multiples of 32 elements and whose eyes have H + W > 128 (the two ATen code paths the oracle does not restate: see the sweeps above), four
+    multiples of 32 elements and whose eyes have H + W > 128 (where the DEFAULT mode, aten_sum_threads = 0, already is the reference's arithmetic; the two size-dependent
+    ATen code paths outside that rule are restated in the N-thread ATen mode: test_render_loop_any_size_exact_in_aten_mode below), four
     rendered frames each (trackers, EMAs and the floating bar evolve).  Bar: EXACT.  (12 seeds run with the suite; offline runs of seeds
     0 ... 899 at the end of round 4: 900 of 900 exact.)"""
     import make_golden as mg
