@@ -804,8 +804,63 @@ def gen_gui_defaults():
     save("gui_defaults.npz", **out)
 
 
+def any_size_case(seed):
+    """One random configuration of the live any-size sweep (tests/test_oracle_vs_live_reference.py::test_render_loop_any_size_exact_in_aten_mode draws the same)."""
+    rng = np.random.default_rng(9700 + seed)
+    fmt = ["Half-SBS", "Full-SBS", "Passive Interlaced", "Red-Cyan Anaglyph", "VR"][int(rng.integers(0, 5))]
+    sh, sw = (int(rng.integers(20, 76)) * 2, int(rng.integers(30, 131)) * 2) if seed % 2 == 0 else (int(rng.integers(40, 150)), int(rng.integers(60, 260)))
+    kw = dict(output_format=fmt, output_height=sh, fg_shift=float(rng.uniform(0, 30)), mg_shift=float(rng.uniform(-10, 5)),
+              bg_shift=float(rng.uniform(-25, 0)), sharpness_factor=float(rng.uniform(0.0, 0.6)),
+              dof_strength=float([0.0, 1.0, 2.0, 2.0, 3.3][int(rng.integers(0, 5))]), feather_strength=float(rng.uniform(0, 20)),
+              blur_ksize=int(rng.integers(0, 7)) * 2 + 1, use_subject_tracking=bool(rng.integers(0, 2)),
+              use_floating_window=bool(rng.integers(0, 2)), max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)),
+              enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+              convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+              ipd_factor=float([1.0, 0.0, 1.2, 0.8][int(rng.integers(0, 4))]),
+              color_saturation=float(rng.uniform(0.8, 1.4)), color_contrast=float(rng.uniform(0.9, 1.2)),
+              color_brightness=float(rng.uniform(-0.05, 0.05)))
+    if rng.integers(0, 3) == 0:
+        kw.update(preserve_original_aspect=True, original_video_width=sw, original_video_height=sh)
+    return sh, sw, kw
+
+
+# round 5: the reference's render loop at frame sizes NO size rule covers (odd widths / heights, sources the loop crops to 16:9, eyes of H + W <= 128), run with a
+# FIXED number of torch threads per case -- the N-thread ATen mode (aten_sum_threads) must reproduce these frames on the oracle and through the C ABI
+ANY_SIZE_SEEDS = {1: 4, 2: 1, 3: 8, 4: 3, 5: 1, 6: 4, 9: 2, 11: 8, 12: 4, 15: 1}   # seed -> torch threads
+
+
+def gen_aten_any_size():
+    n = 4
+    prev = torch.get_num_threads()
+    cases = {}
+    out = {}
+    try:
+        for seed, threads in ANY_SIZE_SEEDS.items():
+            sh, sw, kw = any_size_case(seed)
+            name = f"any{seed}_t{threads}"
+            torch.set_num_threads(threads)
+            assert torch.get_num_threads() == threads
+            LOOP_CASES[name] = (sh, sw, n, kw)
+            try:
+                written = run_loop(name)
+            finally:
+                del LOOP_CASES[name]
+            cases[name] = [sh, sw, kw, threads]
+            out[f"{name}__shape"] = np.array(written[0].shape, dtype=np.int64)
+            for i, fr in enumerate(written):
+                out[f"{name}__rowsum_{i}"] = fr.astype(np.int64).sum(axis=1).astype(np.int32)
+                out[f"{name}__sha_{i}"] = np.frombuffer(sha(fr).encode(), dtype=np.uint8)
+            print(f"  any size {name}: {sw}x{sh} {kw['output_format']}, {threads} torch threads, {len(written)} frames of {written[0].shape}")
+    finally:
+        torch.set_num_threads(prev)
+    out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save("aten_any_size.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random", "real1080_letterbox", "gui_defaults"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random", "real1080_letterbox", "gui_defaults", "aten_any_size"]
+    if "aten_any_size" in which:
+        gen_aten_any_size()
     if "gui_defaults" in which:
         gen_gui_defaults()
     if "attrib" in which:

@@ -722,6 +722,26 @@ def test_gui_default_configuration_hip_vs_reference_fixture(R):
     gui_defaults_check(render_steps, names=("gui_4k_full", "gui_1080_half"))
 
 
+def test_aten_mode_any_size_hip_vs_reference_fixture(R):
+    """Round 5: ten frame sizes no size rule covers (odd sizes, cropped sources, thumbnails), each rendered by the live reference with a fixed torch thread count
+    (tests/golden/aten_any_size.npz), through the C ABI in the N-thread ATen mode -- libm on ATen's scalar tails, ATen's premultiplied-weight bilinear kernel for the
+    small planes and for the frame of a one-thread reference, the cascade sums: every frame equals the reference's, per-frame entry point and batched step path."""
+    from test_oracle_vs_golden import aten_any_size_check
+    from visiondepth3d_amd.sharded import ChunkSharder, HipChunkBackend
+
+    def render(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        return [R.render_frame(T(f), T(d), p).cpu().numpy() for f, d in zip(frames, dbgr)]
+    assert aten_any_size_check(render) == 10
+
+    def render_steps(p, frames, dbgr):
+        R.reset_state(); R.new_clip()
+        sh = ChunkSharder(HipChunkBackend(R, p), 0, 1, len(frames))
+        outs = sh.render_step([T(f) for f in frames], [T(d) for d in dbgr], first_step=True)
+        return [o.cpu().numpy() for o in outs]
+    aten_any_size_check(render_steps)
+
+
 def test_real_size_1080p_letterbox_auto_crop_hip_vs_reference_fixture(R):
     """Black-bar auto crop at 1920x1080 through the C ABI (K0 k_autocrop per frame, crop, re-fit): four letterboxed clips, every frame equals
     the live reference's (tests/golden/real1080_letterbox.npz: SHA-256 of the whole frame, row sums)."""
