@@ -195,6 +195,12 @@ def test_quantile(oracle, q):
         if n == 20736:
             v = (np.floor(v * 255) / 255).astype(np.float32)       # an 8-bit depth plane: many ties
         assert np.float32(oracle.quantile(v, q)) == np.float32(torch.quantile(torch.from_numpy(v), q).item()), (q, n)
+    # round 5: ATen's lerp is ONE fused multiply-add per branch.  On short vectors the neighbouring order statistics are far enough apart for that to show (the
+    # two-rounding form of rounds 1 - 4 differs on 0.25 % of these; found by a live sweep on a 39 x 27 plane), on video-sized planes it never did.
+    for _ in range(1500):
+        n = int(rng.integers(50, 3000))
+        v = rng.random(n, dtype=np.float32)
+        assert np.float32(oracle.quantile(v, q)) == np.float32(torch.quantile(torch.from_numpy(v), q).item()), (q, n)
 
 
 @pytest.mark.parametrize("k,sigma", [(3, 0.5), (5, 1.0), (7, 1.5), (9, 2.0), (13, 3.0), (21, 5.0)])

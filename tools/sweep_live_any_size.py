@@ -1,0 +1,94 @@
+"""Offline sweeps behind DESIGN.md section 2 "N-thread ATen mode" (development container only: imports /root/reference through tests/golden/ref_loader.py).
+
+    python tools/sweep_live_any_size.py loop  A B [threads] [odd]   # render_sbs_3d at random frame sizes / aspects, seeds A .. B-1, oracle in the N-thread mode
+    python tools/sweep_live_any_size.py shift A B [threads]         # pixel_shift_cuda at odd sizes (the body of test_pixel_shift_random_parameters), exact comparison
+
+Prints one line per configuration that differs and the count at the end.  Round 5: loop 0-40 (4 threads), 0-30 odd (4), 40-240 (8), 240-340 odd (1), 340-440 odd (3):
+470 of 470 exact; shift 0-120 (4), 0-60 (1), 60-120 (8), 120-400 (3): 400 of 400 exact (profiles/r05_parity_sweeps.md)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), ROOT]
+import make_golden as mg  # noqa: E402
+import ref_loader  # noqa: E402
+from oracle import oracle  # noqa: E402
+from visiondepth3d_amd import synth  # noqa: E402
+from visiondepth3d_amd._abi import ShiftParams, State  # noqa: E402
+from visiondepth3d_amd.params import render_kwargs_to_params  # noqa: E402
+
+
+def loop_case(seed, odd):
+    sh, sw, kw = mg.any_size_case(seed)
+    if odd:   # the odd-size branch for every seed (any_size_case alternates by seed parity); VD3D_SWEEP_SCALE=k: k times larger frames (planes above 32 768 elements:
+        # several chunks per plane, each with its own tail)
+        rng = np.random.default_rng(97000 + seed)
+        k = int(os.environ.get("VD3D_SWEEP_SCALE", "1"))
+        sh, sw = int(rng.integers(40 * k, 150 * k)), int(rng.integers(60 * k, 260 * k))
+        kw["output_height"] = sh
+        if "original_video_width" in kw:
+            kw.update(original_video_width=sw, original_video_height=sh)
+    return sh, sw, kw
+
+
+def sweep_loop(a, b, threads, odd):
+    bad = 0
+    for seed in range(a, b):
+        sh, sw, kw = loop_case(seed, odd)
+        name = f"_sweep_any_{seed}"
+        mg.LOOP_CASES[name] = (sh, sw, 4, kw)
+        try:
+            written = np.stack(mg.run_loop(name))
+        finally:
+            del mg.LOOP_CASES[name]
+        frames, depths = synth.synth_clip(4, sh, sw)
+        p = render_kwargs_to_params(sw, sh, aten_sum_threads=threads, **kw)
+        ro = oracle.RenderOracle(p)
+        ro.new_clip()
+        got = np.stack([ro.render(f, synth.depth_to_u8_bgr(d), 1) for f, d in list(zip(frames, depths))[1:]])
+        d = -1 if got.shape != written.shape else int((got != written).sum())
+        if d:
+            bad += 1
+            print("seed", seed, (sh, sw), kw["output_format"], "eye", (p.eye_h, p.eye_w), "warp", (p.warp_h, p.warp_w), "differing samples", d)
+    return bad
+
+
+def sweep_shift(a, b, threads, ref):
+    bad = 0
+    for seed in range(a, b):
+        rng = np.random.default_rng(5000 + seed)
+        ih, iw = int(rng.integers(24, 80)), int(rng.integers(32, 130))
+        H, W = (ih, iw) if rng.integers(0, 3) == 0 else (int(rng.integers(24, 120)), int(rng.integers(32, 200)))
+        kw = dict(blur_ksize=int(rng.integers(0, 6)) * 2 + 1, feather_strength=float(rng.uniform(0, 20)),
+                  use_subject_tracking=bool(rng.integers(0, 2)), enable_floating_window=bool(rng.integers(0, 2)),
+                  max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)), zero_parallax_strength=float(rng.uniform(0, 0.03)),
+                  enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+                  convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+                  depth_pop_gamma=float(rng.uniform(0.6, 1.3)), depth_pop_mid=float(rng.uniform(0.35, 0.65)),
+                  parallax_balance=float(rng.uniform(0.5, 1.0)))
+        fg, mgs, bg = float(rng.uniform(0, 30)), float(rng.uniform(-10, 5)), float(rng.uniform(-25, 0))
+        bgr, d = synth.synth_frame(seed, ih, iw)
+        ft = oracle.frame_to_tensor(bgr)
+        ref_loader.reset_state(ref)
+        with torch.no_grad():
+            rl, rr, rs = ref.pixel_shift_cuda(torch.from_numpy(ft), torch.from_numpy(d[None].copy()), W, H, fg, mgs, bg, return_shift_map=True, **kw)
+        o = oracle.pixel_shift(ft, d[None], W, H, ShiftParams.defaults(fg, mgs, bg, aten_threads=threads, **kw), State(), want_shift=True)
+        ds = int((o["shift"].view(np.uint32) != rs.numpy().view(np.uint32)).sum())
+        dl, dr = int((o["left"] != np.asarray(rl)).sum()), int((o["right"] != np.asarray(rr)).sum())
+        if ds or dl or dr:
+            bad += 1
+            print("seed", seed, (ih, iw, H, W), "shift", ds, "left", dl, "right", dr)
+    return bad
+
+
+if __name__ == "__main__":
+    mode, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    threads = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+    ref = ref_loader.load()
+    torch.set_num_threads(threads)
+    assert torch.get_num_threads() == threads
+    n_bad = sweep_loop(a, b, threads, len(sys.argv) > 5) if mode == "loop" else sweep_shift(a, b, threads, ref)
+    print(f"{mode} seeds {a}..{b - 1} at {threads} torch threads: {b - a - n_bad} of {b - a} exact")

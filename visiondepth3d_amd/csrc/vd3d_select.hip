@@ -285,9 +285,9 @@ VD_DEV void scan_b_job(vd_sel_ctl* c, const uint32_t* __restrict__ histB_job, co
   __syncthreads();
 }
 
-VD_DEV float quantile_lerp(float va, float vb, float w) {  // ATen lerp: two-branch form
+VD_DEV float quantile_lerp(float va, float vb, float w) {  // ATen lerp: two-branch form, each branch ONE fused multiply-add (round 5: oracle quantile_from_ranks)
   float diff = vb - va;
-  return (w < 0.5f) ? va + w * diff : vb - diff * (1.f - w);
+  return (w < 0.5f) ? vd_fma(w, diff, va) : vd_fma(-diff, 1.f - w, vb);
 }
 VD_DEV float subject_from_job(const vd_sel_ctl* c) {  // core/render_3d.py:159-172
   if (c->fallback) return 0.5f;
