@@ -547,8 +547,8 @@ def test_render_loop_any_size_exact_in_aten_mode(ref, oracle, seed):
     """Round 5: NO SIZE RULE.  The live reference's ``render_sbs_3d`` loop vs the oracle in the N-thread ATen mode (``aten_sum_threads`` = the
     reference process's torch.get_num_threads()) on source frames of ANY size and aspect -- odd widths and heights, 2:1 and 4:3 sources that the loop crops to
     16:9, thumbnails whose eyes ATen resizes with its premultiplied-weight kernel, planes whose pow / sigmoid tails go through libm -- with every control drawn at
-    random, four rendered frames each.  Bar: EXACT.  (10 seeds with the suite; offline at the end of round 5: 470 of 470 at 1, 3, 4 and 8 torch threads,
-    tools/sweep_live_reference.py-style runs of this body.)"""
+    random, four rendered frames each.  Bar: EXACT.  (10 seeds with the suite; offline at the end of round 5: 1 760 of 1 760 at 1 .. 8 torch threads (tools/sweep_live_any_size.py,
+    profiles/r05_parity_sweeps.md).)"""
     import torch
     import make_golden as mg
     from visiondepth3d_amd.params import render_kwargs_to_params

@@ -1,10 +1,10 @@
 """Offline sweeps behind DESIGN.md section 2 "N-thread ATen mode" (development container only: imports /root/reference through tests/golden/ref_loader.py).
 
     python tools/sweep_live_any_size.py loop  A B [threads] [odd]   # render_sbs_3d at random frame sizes / aspects, seeds A .. B-1, oracle in the N-thread mode
+    python tools/sweep_live_any_size.py wide  A B [threads]         # the same with other output heights (fits), skip_blank_frames, black-bar auto crop on top
     python tools/sweep_live_any_size.py shift A B [threads]         # pixel_shift_cuda at odd sizes (the body of test_pixel_shift_random_parameters), exact comparison
 
-Prints one line per configuration that differs and the count at the end.  Round 5: loop 0-40 (4 threads), 0-30 odd (4), 40-240 (8), 240-340 odd (1), 340-440 odd (3):
-470 of 470 exact; shift 0-120 (4), 0-60 (1), 60-120 (8), 120-400 (3): 400 of 400 exact (profiles/r05_parity_sweeps.md)."""
+Prints one line per configuration that differs and the count at the end.  The runs of round 5 and their results: profiles/r05_parity_sweeps.md."""
 import os
 import sys
 
@@ -56,6 +56,64 @@ def sweep_loop(a, b, threads, odd):
     return bad
 
 
+def sweep_wide(a, b, threads):
+    """render_sbs_3d at random sizes with the loop-level variants on top: output heights that differ from the source (INTER_AREA / INTER_LINEAR fits), skip_blank_frames
+    with a random blank list, auto_crop_black_bars on letterboxed clips.  Configurations whose fit the oracle does not restate are counted as skipped."""
+    import contextlib
+    import io
+    import threading
+    bad = skipped = 0
+    for seed in range(a, b):
+        sh, sw, kw = loop_case(seed, True)
+        rng = np.random.default_rng(555000 + seed)
+        variant = int(rng.integers(0, 4))
+        n = 6
+        blank = []
+        frames = dbgr = None
+        if variant in (0, 3):
+            kw["output_height"] = max(24, int(sh * float(rng.uniform(0.5, 2.0))))
+        if variant in (1, 3):
+            kw["skip_blank_frames"] = True
+            blank = sorted(set(int(v) for v in rng.integers(0, n - 1, size=int(rng.integers(1, 4)))))
+        if variant == 2 and sh >= 60:
+            kw["auto_crop_black_bars"] = True
+            frames, dbgr = synth.letterbox_clip(n, sh, sw, int(rng.integers(2, sh // 6)), int(rng.integers(2, sh // 6)))
+        if frames is None:
+            frames, depths = synth.synth_clip(n, sh, sw)
+            dbgr = [synth.depth_to_u8_bgr(d) for d in depths]
+        mg.ref_stubs._Clip.clips["in.mp4"] = frames
+        mg.ref_stubs._Clip.clips["depth.mp4"] = dbgr
+        mg.rl.reset_state()
+        args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0, output_width=sw,
+                    selected_aspect_ratio=mg._Aspect("Default (16:9)"), aspect_ratios=mg.r.aspect_ratios, suspend_flag=threading.Event(), cancel_flag=threading.Event())
+        args.update(kw)
+        saved = mg.r.detect_black_white_frames
+        mg.r.detect_black_white_frames = lambda *a_, **k_: list(blank)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()) as so:
+                mg.r.render_sbs_3d(**args)
+        finally:
+            mg.r.detect_black_white_frames = saved
+        if "crashed" in so.getvalue():
+            print("seed", seed, "reference crashed:", so.getvalue()[-200:].replace("\n", " | ")); skipped += 1; continue
+        written = np.stack(mg.ref_stubs._Clip.written["out.avi"])
+        try:
+            p = render_kwargs_to_params(sw, sh, aten_sum_threads=threads, **kw)
+            ro = oracle.RenderOracle(p)
+            ro.new_clip()
+            got = np.stack([ro.render(f, d, 1, blank=(i in blank)) for i, (f, d) in enumerate(list(zip(frames, dbgr))[1:])])
+        except NotImplementedError as e:
+            skipped += 1
+            continue
+        d = -1 if got.shape != written.shape else int((got != written).sum())
+        if d:
+            bad += 1
+            print("seed", seed, "variant", variant, (sh, sw), kw["output_format"], "out_h", kw["output_height"], "blank", blank, "eye", (p.eye_h, p.eye_w), "warp", (p.warp_h, p.warp_w),
+                  "differing samples", d, "max", int(np.abs(got.astype(int) - written).max()) if d > 0 else None, "frames", [int((got[i] != written[i]).sum()) for i in range(len(got))] if d > 0 else None)
+    print("skipped (fits the oracle does not restate / reference errors):", skipped)
+    return bad
+
+
 def sweep_shift(a, b, threads, ref):
     bad = 0
     for seed in range(a, b):
@@ -90,5 +148,5 @@ if __name__ == "__main__":
     ref = ref_loader.load()
     torch.set_num_threads(threads)
     assert torch.get_num_threads() == threads
-    n_bad = sweep_loop(a, b, threads, len(sys.argv) > 5) if mode == "loop" else sweep_shift(a, b, threads, ref)
+    n_bad = sweep_loop(a, b, threads, len(sys.argv) > 5) if mode == "loop" else sweep_wide(a, b, threads) if mode == "wide" else sweep_shift(a, b, threads, ref)
     print(f"{mode} seeds {a}..{b - 1} at {threads} torch threads: {b - a - n_bad} of {b - a} exact")
