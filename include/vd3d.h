@@ -30,6 +30,8 @@
 extern "C" {
 #endif
 
+/* 5 (round 5): vd3d_shift_params gained aten_threads / reserved0 at its end (vd3d_render_params embeds it: its later fields moved by 8 bytes); vd3d_torch_math_aten.
+ * 4 (round 5): vd3d_render_params::reserved0 became aten_sum_threads (same layout). */
 #define VD3D_ABI_VERSION 5
 
 typedef enum vd3d_status {
