@@ -20,7 +20,9 @@ run_steady() {  # name, cmd, steps
     python $R/tools/steady_state.py $DB $3 60; echo '```'; } > $O/${TAG}_$1_steady.md; rm -rf $O/t_$1
 }
 SPECS=""
-for WL in 4k-dibr 4k-dibr-gui 1080p-gui-defaults; do
+WLS="4k-dibr 4k-dibr-gui 1080p-gui-defaults"
+[ -n "$ONLY_STEADY" ] && WLS=""   # ONLY_STEADY=1: just the two steady-state cuts
+for WL in $WLS; do
   N=$(echo $WL | tr '-' '_')
   run_stats $N "python $R/bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-pixel-overlap"
   TR=$DB
@@ -33,7 +35,7 @@ for WL in 4k-dibr 4k-dibr-gui 1080p-gui-defaults; do
   python $R/tools/pmc_summary.py $(echo $DBS | tr ',' ' ') > $O/${TAG}_pmc_${N}.md
   SPECS="$SPECS $WL=${DBS}$TR"
 done
-VD3D_COMMIT=${VD3D_COMMIT:-unknown} python $R/tools/pmc_to_json.py $TAG $SPECS > $O/pmc_latest.json
+[ -n "$ONLY_STEADY" ] || VD3D_COMMIT=${VD3D_COMMIT:-unknown} python $R/tools/pmc_to_json.py $TAG $SPECS > $O/pmc_latest.json
 [ -n "$SKIP_STEADY" ] || run_steady 4k_dav2b_f32 "python $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-sub-records --no-profile" 4
 [ -n "$SKIP_STEADY" ] || run_steady 1080p_esrgan4k "python $R/bench.py --upscale-only" 3
 rm -rf $O/p_* $O/t_*
