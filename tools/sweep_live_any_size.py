@@ -118,8 +118,9 @@ def sweep_shift(a, b, threads, ref):
     bad = 0
     for seed in range(a, b):
         rng = np.random.default_rng(5000 + seed)
-        ih, iw = int(rng.integers(24, 80)), int(rng.integers(32, 130))
-        H, W = (ih, iw) if rng.integers(0, 3) == 0 else (int(rng.integers(24, 120)), int(rng.integers(32, 200)))
+        k = int(os.environ.get("VD3D_SWEEP_SCALE", "1"))   # k times larger planes (several chunks per plane)
+        ih, iw = int(rng.integers(24 * k, 80 * k)), int(rng.integers(32 * k, 130 * k))
+        H, W = (ih, iw) if rng.integers(0, 3) == 0 else (int(rng.integers(24 * k, 120 * k)), int(rng.integers(32 * k, 200 * k)))
         kw = dict(blur_ksize=int(rng.integers(0, 6)) * 2 + 1, feather_strength=float(rng.uniform(0, 20)),
                   use_subject_tracking=bool(rng.integers(0, 2)), enable_floating_window=bool(rng.integers(0, 2)),
                   max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)), zero_parallax_strength=float(rng.uniform(0, 0.03)),
