@@ -51,7 +51,18 @@ def _random_render_kw(rng):
     return h, w, kw
 
 
-@pytest.mark.parametrize("seed", list(range(40)) + list(range(200, 230)))
+def _seeds(default):
+    """VD3D_FUZZ_SEEDS="a:b" runs seeds a .. b-1 instead of the suite's (offline widening on a GPU box; seeds >= 200 of the loop fuzz and >= 12 of the
+    pixel_shift fuzz carry a random torch thread count: the N-thread ATen mode)."""
+    import os
+    e = os.environ.get("VD3D_FUZZ_SEEDS")
+    if e:
+        a, b = (int(v) for v in e.split(":"))
+        return list(range(a, b))
+    return default
+
+
+@pytest.mark.parametrize("seed", _seeds(list(range(40)) + list(range(200, 230))))
 def test_render_loop_fuzz(R, oracle, seed):
     rng = np.random.default_rng(seed)
     sh, sw, kw = _random_render_kw(rng)
@@ -95,7 +106,7 @@ def test_render_loop_fuzz(R, oracle, seed):
     assert R.export_state().as_dict() == ro.state.as_dict(), (seed, kw)
 
 
-@pytest.mark.parametrize("seed", range(42))
+@pytest.mark.parametrize("seed", _seeds(list(range(42))))
 def test_pixel_shift_fuzz(R, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     ih, iw = int(rng.integers(16, 90)), int(rng.integers(24, 150))
