@@ -804,6 +804,52 @@ def gen_gui_defaults():
     save("gui_defaults.npz", **out)
 
 
+def shift_sweep_case(seed):
+    """One random `pixel_shift_cuda` configuration at an odd, small size (the body of tests/test_oracle_vs_live_reference.py::test_pixel_shift_random_parameters and of
+    tools/sweep_live_any_size.py shift)."""
+    rng = np.random.default_rng(5000 + seed)
+    ih, iw = int(rng.integers(24, 80)), int(rng.integers(32, 130))
+    H, W = (ih, iw) if rng.integers(0, 3) == 0 else (int(rng.integers(24, 120)), int(rng.integers(32, 200)))
+    kw = dict(blur_ksize=int(rng.integers(0, 6)) * 2 + 1, feather_strength=float(rng.uniform(0, 20)),
+              use_subject_tracking=bool(rng.integers(0, 2)), enable_floating_window=bool(rng.integers(0, 2)),
+              max_pixel_shift_percent=float(rng.uniform(0.005, 0.06)), zero_parallax_strength=float(rng.uniform(0, 0.03)),
+              enable_edge_masking=bool(rng.integers(0, 3) > 0), enable_feathering=bool(rng.integers(0, 3) > 0),
+              convergence_strength=float([0.0, 3.0, -2.0][int(rng.integers(0, 3))]), enable_dynamic_convergence=bool(rng.integers(0, 2)),
+              depth_pop_gamma=float(rng.uniform(0.6, 1.3)), depth_pop_mid=float(rng.uniform(0.35, 0.65)),
+              parallax_balance=float(rng.uniform(0.5, 1.0)))
+    fg, mg_, bg = float(rng.uniform(0, 30)), float(rng.uniform(-10, 5)), float(rng.uniform(-25, 0))
+    return ih, iw, H, W, fg, mg_, bg, kw
+
+
+# round 5: `pixel_shift_cuda` on SMALL, odd planes with a fixed torch thread count -- where ATen's scalar tails, its premultiplied-weight bilinear kernel and the fused
+# `lerp` of torch.quantile all show (seed 970 is the 39 x 27 plane on which a 600-configuration sweep found the last of them): float32 shift map, both eyes, tracker
+SMALL_PLANE_SEEDS = {970: 2, 3: 4, 7: 1, 12: 8, 21: 3, 101: 4, 159: 1, 594: 8}   # seed -> torch threads
+
+
+def gen_pixel_shift_small():
+    out, meta = {}, {}
+    prev = torch.get_num_threads()
+    try:
+        for seed, threads in SMALL_PLANE_SEEDS.items():
+            ih, iw, H, W, fg, mg_, bg, kw = shift_sweep_case(seed)
+            torch.set_num_threads(threads)
+            assert torch.get_num_threads() == threads
+            bgr, d = synth.synth_frame(seed, ih, iw)
+            rl.reset_state()
+            with torch.no_grad():
+                L, R, S = r.pixel_shift_cuda(r.frame_to_tensor(bgr), torch.from_numpy(d)[None], W, H, fg, mg_, bg, **kw)
+            key = f"small{seed}_t{threads}"
+            out[key + "__L"], out[key + "__R"] = np.asarray(L), np.asarray(R)
+            out[key + "__S"] = S.numpy().astype(np.float32)
+            out[key + "__prev_offset"] = np.float64(r.floating_window_tracker.prev_offset)
+            meta[key] = dict(ih=ih, iw=iw, H=H, W=W, fg=fg, mg=mg_, bg=bg, kw=dict(kw, aten_threads=threads), frame_idx=seed)
+            print(f"  small plane {key}: {iw}x{ih} -> {W}x{H}, {threads} torch threads")
+    finally:
+        torch.set_num_threads(prev)
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("pixel_shift_small_planes.npz", **out)
+
+
 def any_size_case(seed):
     """One random configuration of the live any-size sweep (tests/test_oracle_vs_live_reference.py::test_render_loop_any_size_exact_in_aten_mode draws the same)."""
     rng = np.random.default_rng(9700 + seed)
@@ -858,9 +904,11 @@ def gen_aten_any_size():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random", "real1080_letterbox", "gui_defaults", "aten_any_size"]
+    which = sys.argv[1:] or ["kat", "shift", "helpers", "loops", "widen", "previews", "blank", "heal", "attrib", "real1080", "real1080_formats", "real4k", "real4k_formats", "real4k_dof", "real1080_random", "real4k_random", "real1080_letterbox", "gui_defaults", "aten_any_size", "shift_small"]
     if "aten_any_size" in which:
         gen_aten_any_size()
+    if "shift_small" in which:
+        gen_pixel_shift_small()
     if "gui_defaults" in which:
         gen_gui_defaults()
     if "attrib" in which:

@@ -129,6 +129,19 @@ def test_pixel_shift_bit_exact_vs_oracle_and_golden(R, oracle):
             assert np.array_equal(arr.cpu().numpy(), g[f"{key}__{eye}"]), (key, eye, u8_diff_stats(arr.cpu().numpy(), g[f"{key}__{eye}"]))
 
 
+def test_pixel_shift_small_planes_hip_vs_reference_fixture(R, oracle):
+    """Round 5: eight small, odd planes rendered by the live reference with 1 .. 8 torch threads (tests/golden/pixel_shift_small_planes.npz) through the C ABI in the N-thread
+    ATen mode: float32 shift map, both eyes and the tracker equal the reference's -- scalar tails (k_chain_shape<true> / k_shift<true>), the premultiplied-weight bilinear
+    kernel ahead of W1, torch.quantile's fused lerp in the select chain's scalar stage."""
+    from test_oracle_vs_golden import small_planes_check
+
+    def run(bgr, d, W, H, p):
+        R.reset_state()
+        L, Rr, S = R.pixel_shift(T(oracle.frame_to_tensor(bgr)), T(d[None]), W, H, p, want_shift=True)
+        return S.cpu().numpy(), L.cpu().numpy(), Rr.cpu().numpy(), R.export_state().fw_prev_offset
+    assert small_planes_check(run) == 8
+
+
 def test_pixel_shift_cuda_signature_and_singleton(oracle):
     """Reference-shaped call: host arrays out, module-level tracker persists across calls."""
     from visiondepth3d_amd import render_3d as r3
