@@ -51,3 +51,19 @@ def test_w1_and_mask_kernel_budgets():
     assert w1["vgpr"] <= 80 and w1["lds"] % 16 == 0, w1       # static LDS in front of the dynamic array keeps it 16-byte aligned (ds_read_b128)
     e2w = next(v for n, v in k.items() if n.startswith("_Z5k_e2w"))
     assert e2w["vgpr"] <= 64 and e2w["lds"] <= 20 * 1024, e2w
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_scalar_tail_instantiations_leave_the_video_size_kernels_alone():
+    """Round 5: `k_shift` and `k_chain_shape` exist with and without ATen's scalar-tail arithmetic (fp64 `pow`, glibc's `expf` in double).  Every video-sized plane launches
+    the <false> instantiation, which must keep the registers it had before the mode existed (20 / 52); the <true> ones may be as fat as they like but must not spill."""
+    k = _census("vd3d_planes.hip")
+    sh_plain = next(v for n, v in k.items() if n.startswith("_Z7k_shiftILb0E"))
+    sh_tails = next(v for n, v in k.items() if n.startswith("_Z7k_shiftILb1E"))
+    assert sh_plain["vgpr"] <= 20 and sh_plain["spill"] == 0, sh_plain
+    assert sh_tails["spill"] == 0, sh_tails
+    k = _census("vd3d_select.hip")
+    cs_plain = next(v for n, v in k.items() if n.startswith("_Z13k_chain_shapeILb0E"))
+    cs_tails = next(v for n, v in k.items() if n.startswith("_Z13k_chain_shapeILb1E"))
+    assert cs_plain["vgpr"] <= 52 and cs_plain["spill"] == 0, cs_plain
+    assert cs_tails["spill"] == 0 and cs_tails["vgpr"] <= 128, cs_tails       # 1024 threads per workgroup: 4 waves per SIMD x 128 VGPRs
