@@ -88,7 +88,11 @@ typedef struct vd3d_shift_params {
    * threads and send the last (chunk length mod 32) elements of every chunk through libm (std::pow in double with the unrounded Python exponent,
    * glibc's expf) instead of the SLEEF vector bodies (core/render_3d.py:209,517,620).  No plane a video produces has such a tail (1920x1080 and
    * 3840x2160 split evenly over 1 .. 96 threads); odd sizes do.  0 (the default): SLEEF values everywhere.  Inside vd3d_render_frame and the sharded entry
-   * points vd3d_render_params::aten_sum_threads is used instead of this field. */
+   * points vd3d_render_params::aten_sum_threads is used instead of this field.
+   * HOST ISA ASSUMPTION of the mode (both fields): the reference's torch is an x86-64 build that dispatches to its AVX-512 kernels (elementwise loops step
+   * two 16-lane vectors: tail = chunk length mod 32; an AVX2-only host would have mod 16) on glibc >= 2.27 (expf = the FMA ifunc variant, restated and checked
+   * on all 2^32 inputs against glibc 2.35).  For a reference on another ISA the mode stays deterministic but is no longer that reference's bits at sizes with
+   * tails.  Range 0 .. 1024.  The Python shims (pixel_shift_cuda, render_sbs_3d) pass torch.get_num_threads() of the calling process by default (round 6). */
   int32_t aten_threads;                    /* 0 */
   int32_t reserved0;
 } vd3d_shift_params;

@@ -13,6 +13,29 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference_threads(n): run the test as a reference process with n torch intra-op threads (drop-in default mode)")
+
+
+@pytest.fixture(autouse=True)
+def _aten_thread_mode(request, monkeypatch):
+    """Round 6: the drop-in entries (pixel_shift_cuda, render_pairs / render_clip, video_io.render_sbs_3d) default the N of the N-thread ATen mode to
+    torch.get_num_threads() of the calling process -- a number that differs between this container (8) and the GPU box (its core count).  The suite
+    therefore pins it per test: by default VD3D_ATEN_THREADS=0 (the thread-independent arithmetic every test written before round 6 assumes: their oracle
+    parameters come from render_kwargs_to_params / ShiftParams.defaults, whose default is 0); a test marked ``reference_threads(n)`` runs as the reference
+    process its fixture was generated in -- no override, torch.set_num_threads(n) -- and so exercises the shims' real default."""
+    m = request.node.get_closest_marker("reference_threads")
+    if m is None:
+        monkeypatch.setenv("VD3D_ATEN_THREADS", "0")
+        yield
+        return
+    import torch
+    prev = torch.get_num_threads()
+    monkeypatch.delenv("VD3D_ATEN_THREADS", raising=False)
+    torch.set_num_threads(int(m.args[0]))
+    try:
+        yield
+    finally:
+        torch.set_num_threads(prev)
 
 
 def load_golden(name):

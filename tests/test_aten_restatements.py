@@ -234,7 +234,7 @@ def test_sum_order_of_torch_sum(oracle):
             assert oracle.sum_aten(v) == np.float32(torch.from_numpy(v).sum().item()), n
 
 
-@pytest.mark.parametrize("threads", [1, 2, 3, 4, 5, 7, 8, 16, 64])
+@pytest.mark.parametrize("threads", [1, 2, 3, 4, 5, 7, 8, 16, 64, 128, 300])
 def test_cascade_sum_of_torch_mean_at_any_size_and_thread_count(oracle, threads):
     """Round 5: core/render_3d.py:418 (torch.mean of the strided centre crop) and :928 (torch.mean of a contiguous plane).  ATen's float32 cascade sum --
     8 lanes x 4 interleaved accumulators, a 4-level cascade with 16-step level-0 blocks, the serial_for_each walk of a thread's range row piece by row

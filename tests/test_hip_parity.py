@@ -328,7 +328,8 @@ def test_feather_strength_zero_takes_the_exact_no_feather_warp(R, oracle, fmt, s
 
 
 @pytest.mark.parametrize("fmt,size,threads", [("Half-SBS", (108, 192), 1), ("Half-SBS", (108, 192), 6), ("Half-SBS", (1080, 1920), 4), ("Half-SBS", (1080, 1920), 64),
-                                              ("Full-SBS", (540, 960), 3), ("Red-Cyan Anaglyph", (1080, 1920), 16), ("Half-SBS", (2160, 3840), 8)])
+                                              ("Full-SBS", (540, 960), 3), ("Red-Cyan Anaglyph", (1080, 1920), 16), ("Half-SBS", (2160, 3840), 8),
+                                              ("Half-SBS", (2160, 3840), 128), ("Half-SBS", (1080, 1920), 300)])
 def test_aten_sum_order_of_the_two_torch_means(R, oracle, fmt, size, threads):
     """Round 5: vd3d_render_params::aten_sum_threads = N reproduces the float32 `torch.mean` of compute_dynamic_parallax_scale (:418) and compute_motion_metric
     (:928) as torch computes them with N intra-op threads -- ATen's cascade sum over the thread partition (vd3d_atensum.hip: one wave per crop row, one

@@ -421,6 +421,7 @@ def test_format_3d_output_and_linear_resize(R, oracle):
         r3._default = prev
 
 
+@pytest.mark.reference_threads(8)   # the fixtures' reference process ran torch with 8 threads: NO extension keyword, no override -- the shim's own default
 def test_render_sbs_3d_end_to_end_equals_the_reference_loop(R, monkeypatch):
     """B2's Python face on the GPU: visiondepth3d_amd.video_io.render_sbs_3d with the in-memory video backend (tests/golden/ref_stubs.py -- the
     same fake cv2 the reference's loop ran on when the fixtures were generated) and the real renderer, i.e. the batched step path of render_pairs
@@ -451,3 +452,84 @@ def test_render_sbs_3d_end_to_end_equals_the_reference_loop(R, monkeypatch):
                 got = np.stack(ref_stubs._Clip.written["out.avi"])
                 exp = g[f"{name}__frames"]
                 assert got.shape == exp.shape and np.array_equal(got, exp), (name, batch, u8_diff_stats(got, exp) if got.shape == exp.shape else got.shape)
+
+
+def _run_shell(video_io, ref_stubs, R, sh, sw, n, kw):
+    import threading
+    frames, depths = synth.synth_clip(n, sh, sw)
+    ref_stubs._Clip.clips["in.mp4"] = frames
+    ref_stubs._Clip.clips["depth.mp4"] = [synth.depth_to_u8_bgr(d) for d in depths]
+    ref_stubs._Clip.written.pop("out.avi", None)
+    R.reset_state()
+    args = dict(input_path="in.mp4", depth_path="depth.mp4", output_path="out.avi", selected_codec="XVID", fps=24.0, output_width=sw,
+                selected_aspect_ratio="Default (16:9)", aspect_ratios={"Default (16:9)": 16 / 9}, suspend_flag=threading.Event(), cancel_flag=threading.Event())
+    args.update(kw)
+    video_io.render_sbs_3d(**args, renderer=R)
+    return ref_stubs._Clip.written["out.avi"]
+
+
+def test_drop_in_default_is_the_reference_processes_thread_count(R, monkeypatch):
+    """Round 6.  The 51-parameter entry with NO extension keyword and no environment override reproduces the live reference's frames at sizes
+    where its arithmetic depends on torch.get_num_threads() (tests/golden/aten_any_size.npz: odd sizes, thumbnails, cropped sources, each rendered by the reference
+    with a fixed thread count) whenever the calling process runs torch with that many threads -- the shim IS running in the reference's process.  Then the same
+    through VD3D_ATEN_THREADS from a process with another thread count, and the proof that the default matters: with the thread-independent arithmetic
+    (VD3D_ATEN_THREADS=0) at least three of those frames differ."""
+    import hashlib, json, sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_stubs
+    from visiondepth3d_amd import video_io
+    monkeypatch.setattr(video_io, "video_backend", ref_stubs)
+    g = load_golden("aten_any_size.npz")
+    cases = json.loads(bytes(g["cases_json"]).decode())
+    prev = torch.get_num_threads()
+
+    def frames_match(name, outs):
+        ok = len(outs) == 3
+        for i, out in enumerate(outs):
+            ok = ok and tuple(out.shape) == tuple(int(v) for v in g[f"{name}__shape"])
+            ok = ok and hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest()[:16] == bytes(g[f"{name}__sha_{i}"]).decode()
+        return ok
+    try:
+        monkeypatch.delenv("VD3D_ATEN_THREADS", raising=False)
+        for name, (sh, sw, kw, threads) in cases.items():
+            torch.set_num_threads(threads)
+            for batch in (8, 1):
+                monkeypatch.setattr(video_io, "RENDER_BATCH", batch)
+                assert frames_match(name, _run_shell(video_io, ref_stubs, R, sh, sw, 4, kw)), (name, batch, "default = torch.get_num_threads()")
+        monkeypatch.setattr(video_io, "RENDER_BATCH", 8)
+        torch.set_num_threads(5)   # a host with another core count renders a clip the way a 1- / 4-thread reference did
+        for name in ("any1_t4", "any2_t1", "any15_t1"):
+            sh, sw, kw, threads = cases[name]
+            monkeypatch.setenv("VD3D_ATEN_THREADS", str(threads))
+            assert frames_match(name, _run_shell(video_io, ref_stubs, R, sh, sw, 4, kw)), (name, "VD3D_ATEN_THREADS")
+        monkeypatch.setenv("VD3D_ATEN_THREADS", "0")
+        differing = sum(not frames_match(name, _run_shell(video_io, ref_stubs, R, *cases[name][:2], 4, cases[name][2])) for name in ("any1_t4", "any2_t1", "any15_t1"))
+        assert differing >= 1
+    finally:
+        torch.set_num_threads(prev)
+
+
+def test_pixel_shift_cuda_shim_default_is_the_reference_processes_thread_count(monkeypatch):
+    """The B1 shim with the reference's own keywords only (core/render_3d.py:561-585): small odd planes rendered by the live reference with 1 .. 8 torch threads
+    (tests/golden/pixel_shift_small_planes.npz) -- float32 shift map, both eyes and the module-level tracker equal the reference's when this process runs torch with
+    the fixture's thread count."""
+    import torch
+    from visiondepth3d_amd import render_3d as r3
+    g = load_golden("pixel_shift_small_planes.npz")
+    meta = golden_json(g, "meta_json")
+    prev = torch.get_num_threads()
+    monkeypatch.delenv("VD3D_ATEN_THREADS", raising=False)
+    try:
+        for key, m in meta.items():
+            kw = dict(m["kw"])
+            threads = kw.pop("aten_threads")
+            torch.set_num_threads(threads)
+            bgr, d = synth.synth_frame(m["frame_idx"], m["ih"], m["iw"])
+            r3.default_renderer().reset_state()
+            L, Rr, S = r3.pixel_shift_cuda(r3.frame_to_tensor(bgr), T(d[None]), m["W"], m["H"], m["fg"], m["mg"], m["bg"], **kw)
+            assert r3.default_renderer().export_state().fw_prev_offset == float(g[key + "__prev_offset"]), key
+            assert np.array_equal(S.numpy().view(np.uint32), g[key + "__S"].view(np.uint32)), key
+            assert np.array_equal(L, g[key + "__L"]) and np.array_equal(Rr, g[key + "__R"]), (key, u8_diff_stats(L, g[key + "__L"]))
+    finally:
+        torch.set_num_threads(prev)

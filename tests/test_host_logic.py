@@ -57,6 +57,51 @@ def test_shift_kwargs():
         shift_params_from_kwargs(1, 2, 3, bogus=1)
 
 
+def test_drop_in_entries_default_to_the_calling_process_thread_count(monkeypatch):
+    """Round 6: the shims run inside the reference's process, so the N of the N-thread ATen mode defaults to that process's
+    torch.get_num_threads() (core/render_3d.py:418,928,209,517,595-596 depend on it); VD3D_ATEN_THREADS overrides (0 = thread-independent); the parameter
+    builders below the shims keep the C ABI's default 0."""
+    import torch
+    from visiondepth3d_amd import params as P
+    from visiondepth3d_amd.render_3d import render_pairs
+    prev = torch.get_num_threads()
+    monkeypatch.delenv("VD3D_ATEN_THREADS", raising=False)   # (the suite's autouse fixture pins 0 for every other test)
+    try:
+        for n in (1, 3, 5):
+            torch.set_num_threads(n)
+            assert P.reference_aten_threads() == n
+            assert shift_params_from_kwargs(1, 2, 3).aten_threads == n                      # pixel_shift_cuda(...) without the extension keyword
+            assert shift_params_from_kwargs(1, 2, 3, aten_threads=0).aten_threads == 0       # explicit: thread-independent
+            assert shift_params_from_kwargs(1, 2, 3, aten_threads=7).aten_threads == 7
+            seen = []
+
+            class Rec(_FakeRenderer):
+                def render_frame(self, frame, depth, params, blank=False):
+                    seen.append(params.aten_sum_threads)
+                    return super().render_frame(frame, depth, params, blank)
+            frames, depths = _fake_clip(3)
+            kw = dict(output_height=54, fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, output_format="Half-SBS", dof_strength=2.0)
+            list(render_pairs(zip(frames, depths), renderer=Rec(), **kw))
+            assert seen == [n, n]
+            seen.clear()
+            list(render_pairs(zip(frames, depths), renderer=Rec(), aten_sum_threads=0, **kw))
+            assert seen == [0, 0]
+        torch.set_num_threads(2)
+        monkeypatch.setenv("VD3D_ATEN_THREADS", "64")
+        assert P.reference_aten_threads() == 64 and shift_params_from_kwargs(1, 2, 3).aten_threads == 64
+        monkeypatch.setenv("VD3D_ATEN_THREADS", "0")
+        assert P.reference_aten_threads() == 0
+        monkeypatch.setenv("VD3D_ATEN_THREADS", "5000")
+        with pytest.raises(ValueError):
+            P.reference_aten_threads()
+    finally:
+        torch.set_num_threads(prev)
+    # the builders under the shims: the C ABI's default
+    assert render_kwargs_to_params(192, 108, output_height=108, fg_shift=1, mg_shift=1, bg_shift=1, sharpness_factor=0, output_format="Half-SBS",
+                                   dof_strength=0).aten_sum_threads == 0
+    assert ShiftParams.defaults(1, 2, 3).aten_threads == 0
+
+
 def test_synth_is_deterministic_and_well_conditioned():
     f1, d1 = synth.synth_frame(5, 108, 192)
     f2, d2 = synth.synth_frame(5, 108, 192)

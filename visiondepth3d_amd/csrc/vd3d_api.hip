@@ -366,7 +366,7 @@ static int aten_setup(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args* a
     std::vector<int> flat;
     int ns = 0, nb = 0, nrc = 0, nrm = 0;
     if (!vd_aten_plan_build(p->eye_h, p->eye_w, T, flat, &ns, &nb, &nrc, &nrm))
-      return set_err(VD3D_E_UNSUPPORTED, "aten_sum_threads %d with %dx%d eyes: outside the restated range (1 .. 256 threads)", T, p->eye_w, p->eye_h);
+      return set_err(VD3D_E_UNSUPPORTED, "aten_sum_threads %d with %dx%d eyes: outside the restated range (1 .. 1024 threads)", T, p->eye_w, p->eye_h);
     if (c->aten_plan) c->aten_retired.push_back(c->aten_plan);
     if (c->aten_scratch) c->aten_retired.push_back(c->aten_scratch);
     c->aten_plan = nullptr; c->aten_scratch = nullptr;

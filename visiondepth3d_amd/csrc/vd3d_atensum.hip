@@ -193,7 +193,7 @@ VD_DEV float as_serial_piece(const float* x, int n) {
   return fin;
 }
 
-#define AS_MAX_T 256
+#define AS_MAX_T 1024   // torch.get_num_threads() of the reference process: 8 KB of LDS for the two partial buffers (256 until round 5)
 __global__ __launch_bounds__(64) void k_aten_final(vd_batch b, vd_stage_args a, as_plan pl, const float* __restrict__ scratch, int nr_crop, int nr_mad) {
   __shared__ float buf[2][AS_MAX_T];
   const vd_batch_frame& F = b.f[blockIdx.x];

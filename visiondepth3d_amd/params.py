@@ -9,6 +9,7 @@ and IGNORED (the loop passes literals, :1299-1305), and ``parallax_balance`` is 
 from __future__ import annotations
 
 import inspect
+import os
 
 from ._abi import RenderParams, ShiftParams
 from .geometry import make_render_params, plan_geometry
@@ -26,11 +27,35 @@ RENDER_DEFAULTS = dict(
 )
 
 
+def reference_aten_threads() -> int:
+    """The N of the N-thread ATen mode for a DROP-IN caller (round 6): ``torch.get_num_threads()`` of the calling process.  The shims
+    (``pixel_shift_cuda``, ``render_sbs_3d``, ``render_clip`` / ``render_pairs``) run INSIDE the reference's process, where that number is what
+    the reference's own ``torch.mean`` (core/render_3d.py:418,928), ``torch.pow`` / ``torch.sigmoid`` (:209,517,620) and small-output bilinear
+    ``F.interpolate`` (:595-596,1262-1263) would have run with -- so by default they reproduce the reference's thread-dependent float32
+    arithmetic, not the thread-independent one.  ``VD3D_ATEN_THREADS`` overrides it (0 = the thread-independent arithmetic, the C-ABI default;
+    N = a reference run on an N-thread machine).  Restated range: 1 .. 1024 threads.
+
+    Assumption of the mode: the reference's torch is an x86-64 AVX-512 build on glibc >= 2.27 -- ATen's elementwise scalar
+    tails are ``chunk_len mod 32`` elements (two 16-lane vectors per step; an AVX2-only host has ``mod 16``), ``expf`` is glibc's FMA ifunc
+    variant.  On another ISA the mode is still deterministic but no longer the reference's bits at sizes with tails."""
+    v = os.environ.get("VD3D_ATEN_THREADS")
+    if v is not None and v.strip() != "":
+        n = int(v)
+    else:
+        import torch
+        n = int(torch.get_num_threads())
+    if n < 0 or n > 1024:
+        raise ValueError(f"ATen thread count {n} outside 0 .. 1024 (set VD3D_ATEN_THREADS)")
+    return n
+
+
 def shift_params_from_kwargs(fg_shift, mg_shift, bg_shift, **kw) -> ShiftParams:
     """pixel_shift_cuda(..., **kw) -> vd3d_shift_params (unknown keywords raise TypeError like Python would)."""
     kw = dict(kw)
     kw.pop("return_shift_map", None)
     kw.pop("dof_strength", None)  # accepted and unused by pixel_shift_cuda (:579)
+    if kw.get("aten_threads") is None:   # extension keyword absent: the calling (reference) process's torch thread count -- reference_aten_threads()
+        kw["aten_threads"] = reference_aten_threads()
     return ShiftParams.defaults(fg_shift, mg_shift, bg_shift, **kw)
 
 
@@ -42,7 +67,9 @@ def render_kwargs_to_params(src_w: int, src_h: int, *, output_height, fg_shift, 
     (about 25 % less time in the finishing kernel, differs from the reference on ~0.5 % of samples; include/vd3d.h
     vd3d_render_params::dof_dense_conv).  ``aten_sum_threads`` (extension): N >= 1 reproduces the float32 ``torch.mean`` of the dynamic parallax scale
     and of the motion metric as torch computes them with N intra-op threads (``torch.get_num_threads()`` of the reference process); 0 = the correctly
-    rounded exact mean (include/vd3d.h vd3d_render_params::aten_sum_threads)."""
+    rounded exact mean (include/vd3d.h vd3d_render_params::aten_sum_threads).  This function keeps the C ABI's default (0); the drop-in entries
+    (``render_pairs`` / ``render_clip`` / ``video_io.render_sbs_3d``) pass ``reference_aten_threads()`` unless told otherwise.  The mode assumes an
+    AVX-512 / glibc reference host (see ``reference_aten_threads``)."""
     unknown = set(kw) - set(RENDER_DEFAULTS) - {"output_width", "input_path", "depth_path", "output_path",
                                                 "selected_codec", "fps", "selected_aspect_ratio", "aspect_ratios"}
     if unknown:

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from ._abi import DEPTH_BGR_U8, DEPTH_F32, DEPTH_GRAY_U8, DT_BF16, DT_F16, DT_F32, FORMAT_IDS, FrameScalars, RenderParams, ShiftParams, State
 from .geometry import aspect_ratios  # noqa: F401  (re-exported like the reference module does)
-from .params import render_kwargs_to_params, shift_params_from_kwargs
+from .params import reference_aten_threads, render_kwargs_to_params, shift_params_from_kwargs
 
 torch_device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
@@ -698,7 +698,8 @@ def frame_to_tensor(frame):  # core/render_3d.py:135-138: BGR->RGB, /255.0 ON TH
 def pixel_shift_cuda(frame_tensor, depth_tensor, width, height, fg_shift, mg_shift, bg_shift, return_shift_map=True, **kw):
     """Same signature and returns as the reference (core/render_3d.py:561-712): host uint8 BGR arrays
     (+ the float32 shift map on CPU when ``return_shift_map``).  Mutates the default renderer's
-    FloatingWindowTracker exactly like the reference mutates its module global."""
+    FloatingWindowTracker exactly like the reference mutates its module global.  Extension keyword ``aten_threads`` (default: this process's
+    ``torch.get_num_threads()`` / ``VD3D_ATEN_THREADS``, ``params.reference_aten_threads``; 0 = thread-independent arithmetic)."""
     p = shift_params_from_kwargs(fg_shift, mg_shift, bg_shift, **kw)
     r = default_renderer()
     res = r.pixel_shift(frame_tensor, depth_tensor, width, height, p, want_shift=bool(return_shift_map))
@@ -733,7 +734,7 @@ def render_clip(frames, depths, **kw):
 
 
 def render_pairs(pairs, *, renderer: Renderer | None = None, target_ratio=16 / 9, keep_on_device=False,
-                 blank_frames=None, start_frame_idx=0, skip_first=True, batch=8, **kw):
+                 blank_frames=None, start_frame_idx=0, skip_first=True, batch=8, aten_sum_threads=None, **kw):
     """``render_clip`` over ONE iterable of (frame, depth) pairs.  ``skip_first=False``: the caller has already consumed the
     clip's first frame (render_sbs_3d's capture shell does, like the reference).
 
@@ -745,10 +746,17 @@ def render_pairs(pairs, *, renderer: Renderer | None = None, target_ratio=16 / 9
     select chain of a step in a dozen launches instead of eight per frame, its pixel kernels on two streams behind the next step's
     chain) -- bit-identical to the frame-by-frame loop (``batch=1``: one ``vd3d_render_frame`` per pair), frames are yielded in order,
     up to two steps (``2 * batch`` frames) late.  Cost of the default: ``2 * batch`` slots of seven float32 planes each stay allocated
-    on the device (about 4 GB at 3840x2160 with ``batch=8``).  The generator puts the renderer into overlapped mode; ``close()`` it
+    on the device (about 4 GB at 3840x2160 with ``batch=8``).
+
+    ``aten_sum_threads`` (extension; default ``None`` = ``params.reference_aten_threads()``: ``torch.get_num_threads()`` of this process, or
+    ``VD3D_ATEN_THREADS``): the N of the N-thread ATen mode -- the reference's two ``torch.mean`` sums, its ``pow`` / ``sigmoid`` scalar tails and its
+    small-output bilinear kernel as torch computes them with N intra-op threads (core/render_3d.py:418,928,209,517,595-596).  0 = the
+    thread-independent arithmetic (the C ABI's default).  The generator puts the renderer into overlapped mode; ``close()`` it
     (or exhaust it) to return the renderer to sequential mode -- a consumer that stops early should not wait for garbage collection."""
     r = renderer or default_renderer()
     blank = set(blank_frames or ()) if kw.get("skip_blank_frames") else set()
+    # the reference's thread-dependent float32 arithmetic by default (round 6): this loop stands in for the reference's own, in its process
+    kw["aten_sum_threads"] = reference_aten_threads() if aten_sum_threads is None else int(aten_sum_threads)
     it = iter(pairs)
     if skip_first and next(it, None) is None:
         return
