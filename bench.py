@@ -120,14 +120,35 @@ def _host_mem_available_bytes():
     return None
 
 
+def _physical_cores():
+    """Physical cores of the host (unique (package, core) pairs of /proc/cpuinfo restricted to this process's affinity mask); None if unreadable."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cpu, phys = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu, phys = int(v), None
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id" and cpu in allowed:
+                seen.add((phys, int(v)))
+        return len(seen) or None
+    except Exception:
+        return None
+
+
 def cpu_baseline_allcores(sh, sw, frames_per_core, max_cores=None, timeout_s=90.0):
     """The same oracle on every host thread at once (one independent clip per PROCESS, `bench.py --cpu-worker ...`): the CPU path's
-    whole-socket throughput.  Plain subprocesses with a hard timeout -- nothing here can hang the benchmark.  Every hardware thread
-    `os.cpu_count()` reports is used (round 6; rounds 4 - 5 stopped at 64), unless half of the host's available memory would not hold one
-    oracle process per thread (a 4K process peaks at ~1.03 GB, a 1080p one at ~0.3 GB: measured) -- then as many as fit, and the record says so."""
+    whole-socket throughput.  Plain subprocesses with a hard timeout -- nothing here can hang the benchmark.  One process per PHYSICAL core
+    (round 6; rounds 4 - 5 stopped at 64 of the box's 128): the oracle is float32 arithmetic, SMT siblings share the core's vector units -- one
+    process per hardware thread (256 on the MI355X box) was tried first and 103 of 256 workers had not finished one 4K frame after 120 s -- unless half
+    of the host's available memory would not hold one oracle process per core (a 4K process peaks at ~1.03 GB, a 1080p one at ~0.3 GB: measured)
+    -- then as many as fit; `cores` is what ran, `host_threads` what os.cpu_count() reports."""
     import subprocess
     host = os.cpu_count() or 1
-    cores = min(host, max_cores or host)
+    cores = min(_physical_cores() or host, max_cores or host)
     per_proc = 1.1e9 * (sh * sw) / (2160 * 3840) + 0.15e9
     avail = _host_mem_available_bytes()
     if avail:
@@ -304,12 +325,13 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
             r.set_pixel_overlap(1 if host_io else max(1, int(args.pix_streams)))   # frames' pixel passes round-robin over this many streams
 
     pipe = None
-    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}[depth_dtype]
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f32x3": torch.float32}[depth_dtype]
     if model_name:
         from visiondepth3d_amd.depth import DepthPipe
         # fused front end + fused backbone / neck glue; library selection: committed GEMM table + MIOpen find mode (runs during the warm-up)
         # (find mode only where the number is a parity-mode one: the bf16 sub-record keeps MIOpen's immediate mode and its shorter start)
-        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh, miopen_find=(not args.no_miopen_find) and depth_dtype == "f32")
+        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh, miopen_find=(not args.no_miopen_find) and depth_dtype in ("f32", "f32x3"),
+                         gemm="bf16x3" if depth_dtype == "f32x3" else "f32")
 
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
@@ -695,7 +717,7 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
                                  "isolated_avg_frame_ms": iso.get("frame")}
     if res.get("net_ms") and res.get("flops_per_frame"):
         tf = res["flops_per_frame"] * res["B"] / (res["net_ms"] * 1e-3) / 1e12
-        pk = MFMA_PEAK_TFLOPS[res["depth_dtype"]]
+        pk = MFMA_PEAK_TFLOPS[{"f32x3": "f32"}.get(res["depth_dtype"], res["depth_dtype"])]   # f32x3: float32-equivalent flops against the float32 MFMA peak (may exceed 1)
         out["roofline_depthnet"] = {"bound": "mfma", "kernel": f"{res['model']} forward + hand-off ({res['depth_dtype']}; hipBLASLt / AOTriton / "
                                     "MIOpen through PyTorch-ROCm, glue fused in HIP)", "achieved": round(tf, 2), "peak": pk,
                                     "unit": "TFLOP/s", "frac": round(tf / pk, 4), "flops_per_frame": res["flops_per_frame"],
@@ -709,7 +731,8 @@ def sub_record(res, extra=None):
     d = {"workload": res["workload"], "description": res["desc"], "value": round(res["frames_total"] / res["dt"], 3),
          "unit": "stereo-pairs/s", "steps": res["steps"], "warmup": res["warmup"], "frames_timed": res["frames_total"],
          "ms_per_step": round(res["dt"] / res["steps"] * 1e3, 4),
-         "dtype": "f32" if res["depth_dtype"] in (None, "f32") else "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)"}
+         "dtype": {None: "f32", "f32": "f32", "f32x3": "f32 (bf16x3 split MFMA, f32 accumulate)"}.get(
+             res["depth_dtype"], "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)")}
     if extra:
         d.update(extra)
     return d
@@ -821,7 +844,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="measure ONLY this workload (profiling runs); default: the headline + the sub-records described above")
-    ap.add_argument("--depth-dtype", default="f32", choices=("f32", "bf16"), help="depth-net precision of the measured workload "
+    ap.add_argument("--depth-dtype", default="f32", choices=("f32", "bf16", "f32x3"), help="depth-net precision of the measured workload (f32x3: float32 with the linears on the split-bf16 GEMM, opt-in) "
                     "(f32 = the reference's; bf16 is labelled reduced precision)")
     ap.add_argument("--batch", type=int, default=16, help="frames per step")
     ap.add_argument("--clip", type=int, default=32, help="distinct synthetic frames resident in HBM (cycled); default 2 x batch so that "
@@ -868,6 +891,11 @@ def main():
         r1e = run_workload(env, args, "1080p-dav2s-dibr", 10, 3, depth_dtype="f32", profile=prof)
         r1d = run_workload(env, args, "1080p-dibr", 10, 3, profile=prof)
         rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
+        try:   # round 6: the headline workload with the transformer linears on the library's split-bf16 GEMM (float32-faithful, opt-in; never `value`)
+            rx3 = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="f32x3", profile=prof, isolated_pass=False)
+        except Exception as e:
+            rx3 = None
+            print(f"[bench] 4k-dav2b-dibr-f32x3 failed: {str(e)[:200]}", file=sys.stderr)
         rdn = run_workload(env, args, "4k-dibr-sepdof", 4, 2, profile=prof, isolated_pass=False)
         rd3 = run_workload(env, args, "4k-dibr-dof3", 4, 2, profile=prof, isolated_pass=False)
         ran = run_workload(env, args, "4k-dibr-anaglyph", 4, 2, profile=prof, isolated_pass=False)
@@ -895,6 +923,8 @@ def main():
                 "1080p-gui-defaults": (rg1, None), "4k-dibr-gui": (rg4, None)}
         if rvr is not None:
             subs["4k-dibr-vr"] = (rvr, None)
+        if rx3 is not None:
+            subs["4k-dav2b-dibr-f32x3"] = (rx3, None)
         if rhn is not None:
             subs["4k-dibr-hostio-nv12"] = (rhn, None)
         roof_src = r4
@@ -907,17 +937,19 @@ def main():
         copy_gbs = copy_yardstick(env)
         sh, sw, model_name, desc = WORKLOADS[wl]
         value = head["frames_total"] / head["dt"]
-        reduced = model_name is not None and args.depth_dtype != "f32"
+        reduced = model_name is not None and args.depth_dtype == "bf16"
         res = {
             "metric": "stereo-pairs/sec end-to-end (depth+warp+fill+mux)",
             "value": round(value, 3), "unit": "stereo-pairs/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(head["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not reduced else "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)",
+            "dtype": ("f32 (bf16x3 split MFMA, f32 accumulate)" if (model_name and args.depth_dtype == "f32x3") else "f32") if not reduced
+                     else "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)",
             "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)" if not args.host_io else
                     "synthetic; frames start in pinned host memory and muxed frames are copied back to pinned host memory (PCIe-inclusive run)",
             "config": {"workload": wl, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
                        "frames_per_step": args.batch, "depth_model": model_name,
-                       "depth_net_dtype": ({"f32": "float32 (the reference's precision)", "bf16": "bfloat16"}[args.depth_dtype]
+                       "depth_net_dtype": ({"f32": "float32 (the reference's precision)", "bf16": "bfloat16",
+                                            "f32x3": "float32 via split-bf16 linears (opt-in)"}[args.depth_dtype]
                                            if model_name else None),
                        "arithmetic": "u8 in/out, float32 DIBR kernels, float64 scalar trackers",
                        "depth_net_library_selection": head.get("lib_sel"),
@@ -973,6 +1005,11 @@ def main():
                     extra["pcie_bytes_per_frame"] = bpf
                     extra["pcie_GBs_each_way"] = round(bpf / 2 * rs["frames_total"] / rs["dt"] / 1e9, 2)
                     extra["note"] = "host-I/O-inclusive (PCIe Gen5 x16, 63 GB/s spec each way); depth planes precomputed and resident, like `4k-dibr`"
+                if name == "4k-dav2b-dibr-f32x3":
+                    extra["note"] = ("same workload as the headline with the four linears of every transformer block on vd3d_gemm_x3: every float32 operand split "
+                                     "exactly into three bf16 terms, six bf16 MFMA products per MAC, float32 accumulation, exact GELU in fc1's epilogue -- "
+                                     "float32-faithful (tests/test_hip_gemm.py: vs float64, and the float32 leg's own bar against the stock graph), opt-in; the "
+                                     "headline stays pure float32 (hipBLASLt)")
                 if name == "4k-dav2b-dibr-bf16":
                     extra["note"] = ("same workload as the headline with the depth net in bfloat16: NOT like-for-like with the reference "
                                      "(float32); its uint8 depth-plane deviation is measured by tests/test_hip_depth_e2e.py")

@@ -387,6 +387,19 @@ int vd3d_depth_preprocess(vd3d_ctx* ctx, const uint8_t* frames_bgr, int B, int H
 int vd3d_add_layernorm(vd3d_ctx* ctx, int dtype, const void* x, const void* y_or_null, const void* gamma, const void* beta,
                        float eps, int64_t rows, int cols, void* out_sum, void* out_norm);
 
+/* The linear layers of the depth network's transformer blocks (a25; core/render_depth.py:1106-1119 runs them in float32 through the Hugging Face
+ * pipeline) as a split-bf16 GEMM -- an OPT-IN mode of DepthPipe (gemm="bf16x3"; the default stays hipBLASLt's float32 GEMM).
+ *   Y[M][N] = X[M][K] . W[N][K]^T + bias[N]   (row-major float32 device arrays, leading dimensions K / K / N; epilogue 1: + exact GELU)
+ * Every float32 operand is split EXACTLY into three bf16 terms (8 + 8 + 8 significant bits); six of the nine term products -- all but x2 w3, x3 w2,
+ * x3 w3, together <= 2^-23 |x w| -- go through v_mfma_f32_32x32x16_bf16 with float32 accumulation: float32-faithful results (the error of a float32
+ * GEMM in another summation order; tests/test_hip_gemm.py vs float64) at 6 bf16 MFMAs per MAC instead of the float32-input MFMA (1/16 of the bf16 rate
+ * on gfx950, which has no TF32).  The weights are split and packed once: vd3d_gemm_x3_weight_bytes(N, K) bytes (< 0: K is not a positive multiple of
+ * 16), filled by vd3d_gemm_x3_pack_weights; the image is opaque and only valid for this library version.  NaN / Inf inputs give NaN. */
+enum { VD3D_GEMM_EPI_NONE = 0, VD3D_GEMM_EPI_GELU = 1 };
+int64_t vd3d_gemm_x3_weight_bytes(int N, int K);
+int vd3d_gemm_x3_pack_weights(vd3d_ctx* ctx, const float* W, int N, int K, void* image);
+int vd3d_gemm_x3(vd3d_ctx* ctx, const float* X, int64_t M, int K, const void* w_image, int N, const float* bias_or_null, int epilogue, float* Y);
+
 /* F.interpolate(mode="bilinear", align_corners=True) of an NHWC (channels_last) tensor [B][ih][iw][C] -> [B][oh][ow][C] of
  * `dtype`, C a multiple of 8 (bf16) / 4 (f32): the up-samplings of the DPT neck / head (a25). */
 int vd3d_upsample_bilinear_nhwc(vd3d_ctx* ctx, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);

@@ -1,0 +1,125 @@
+"""GPU tests (-m gpu) of the split-bf16 GEMM (vd3d_gemm_x3, csrc/vd3d_gemm.hip): the opt-in `gemm="bf16x3"` mode of the depth leg (round 6).
+
+A floating-point kernel: the bar is stated against FLOAT64 and beside torch's own float32 GEMM (hipBLASLt) on the same operands --
+  |y - y64| <= 4 * 2^-24 * (sum_k |x||w| + |b|)   per element (a float32 dot product's own worst case grows with K; measured: ~0.2 of that),
+  relative RMS error within 3x of the float32 library GEMM's (six accumulations per MAC instead of one, the dropped cross terms <= 2^-23 per product).
+Then the depth leg in that mode against the STOCK float32 Hugging Face graph with the bar the float32 leg itself meets (tests/test_hip_depth_e2e.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+@pytest.fixture(scope="module")
+def R():
+    from visiondepth3d_amd.render_3d import Renderer
+    assert torch.cuda.is_available()
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def _err(y, x, w, b, gelu):
+    ref = F.linear(x.double(), w.double(), None if b is None else b.double())
+    scale = x.abs().double() @ w.abs().double().T
+    if b is not None:
+        scale = scale + b.abs().double()
+    if gelu:
+        ref = F.gelu(ref)   # |gelu'| <= 1.13: the same bar holds behind it (+ erff's own 1-2 ULP, inside the factor 4)
+        scale = scale * 1.13 + 1e-30
+    d = (y.double() - ref).abs()
+    return float((d / scale).max()), float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("M,K,N,bias,gelu", [(1000, 768, 2304, True, False), (257, 768, 768, True, False), (2443, 768, 3072, True, True),
+                                             (600, 3072, 768, True, False), (513, 384, 1152, True, False), (300, 1024, 4096, False, True),
+                                             (1, 16, 1, True, False), (255, 48, 100, False, False), (256, 32, 256, True, False)])
+def test_gemm_x3_is_float32_faithful(R, M, K, N, bias, gelu):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + K)
+    # operands with a wide dynamic range (LayerNorm outputs times a few outlier channels, like DINOv2's residual stream)
+    x = torch.randn(M, K, device="cuda", generator=g) * torch.exp(torch.randn(1, K, device="cuda", generator=g) * 1.5)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g) if bias else None
+    img = R.gemm_x3_pack(w)
+    y = R.linear_x3(x, img, N, b, gelu=gelu)
+    assert y.shape == (M, N) and y.dtype == torch.float32 and bool(torch.isfinite(y).all())
+    y32 = F.linear(x, w, b)
+    if gelu:
+        y32 = F.gelu(y32)
+    e3, r3 = _err(y, x, w, b, gelu)
+    e32, r32 = _err(y32, x, w, b, gelu)
+    assert e3 <= 4 * 2.0 ** -24, (e3, e32)
+    assert r3 <= 3 * r32 + 1e-8, (r3, r32)
+    # a batch dimension in front, and the same call again (no state between calls)
+    if M % 2 == 0:
+        y2 = R.linear_x3(x.view(2, M // 2, K), img, N, b, gelu=gelu)
+        assert y2.shape == (2, M // 2, N) and torch.equal(y2.view(M, N), y)
+    assert torch.equal(R.linear_x3(x, img, N, b, gelu=gelu), y)
+
+
+def test_gemm_x3_split_is_exact_and_layout_is_asymmetric(R):
+    """Known answers: (i) with W = I the GEMM returns x itself BIT FOR BIT (x = x1 + x2 + x3 exactly, each term times 1.0, small terms first) -- for values across
+    the exponent range, negative numbers and zeros; (ii) an asymmetric integer-valued problem, exact in every arithmetic: catches a transposed / permuted tile."""
+    K = N = 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(300, K, device="cuda", generator=g) * torch.exp(torch.randn(300, K, device="cuda", generator=g) * 8.0)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 1.0e30, 1.1754944e-38, 16777215.0], device="cuda")
+    img = R.gemm_x3_pack(torch.eye(K, device="cuda"))
+    y = R.linear_x3(x, img, N)
+    assert torch.equal(y, x)
+    M, K, N = 515, 64, 320
+    xi = (torch.arange(M * K, device="cuda").view(M, K) % 13 - 6).float()
+    wi = ((torch.arange(N * K, device="cuda").view(N, K) * 7) % 11 - 5).float()
+    bi = torch.arange(N, device="cuda").float()
+    y = R.linear_x3(xi, R.gemm_x3_pack(wi), N, bi)
+    assert torch.equal(y.double(), F.linear(xi.double(), wi.double(), bi.double()))
+
+
+def test_gemm_x3_argument_checks(R):
+    from visiondepth3d_amd._lib import Vd3dError
+    with pytest.raises(NotImplementedError):
+        R.gemm_x3_pack(torch.zeros(8, 20, device="cuda"))        # K not a multiple of 16
+    img = R.gemm_x3_pack(torch.zeros(8, 32, device="cuda"))
+    with pytest.raises(Vd3dError):
+        R.linear_x3(torch.zeros(4, 24, device="cuda"), img, 8)    # K mismatch shows as an unsupported K
+
+
+def test_depth_leg_bf16x3_meets_the_float32_legs_bar_1080p(R):
+    """The acceptance the float32 leg itself meets against the STOCK float32 graph (tests/test_hip_depth_e2e.py): raw prediction within 1e-4 of its range,
+    >= 99.5 % of the uint8 plane's bytes identical, no byte off by more than one level -- with every transformer linear on the split-bf16 GEMM."""
+    from test_hip_depth_e2e import _plane_stats, _record, _stock_u8_planes
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import DepthPipe
+    H, W = 1080, 1920
+    frames = torch.from_numpy(np.stack([synth.synth_frame(i, H, W)[0] for i in range(2)])).cuda()
+    exp_u8, exp_pred = _stock_u8_planes("depth-anything-v2-small", frames)
+    pipe = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.float32, renderer=R, gemm="bf16x3")
+    pred = pipe.infer_bgr_u8(frames, raw=True)
+    st = _plane_stats(R.depth_handoff(pred, H, W), exp_u8)
+    st["pred_max_err_of_range"] = float((pred - exp_pred).abs().max()) / float(exp_pred.max() - exp_pred.min())
+    # the float32 leg on the same frames, for the record: the two modes side by side
+    p32 = DepthPipe("depth-anything-v2-small", device="cuda", dtype=torch.float32, renderer=R).infer_bgr_u8(frames, raw=True)
+    st["f32_leg_pred_max_err_of_range"] = float((p32 - exp_pred).abs().max()) / float(exp_pred.max() - exp_pred.min())
+    st["x3_vs_f32_leg_u8"] = _plane_stats(R.depth_handoff(pred, H, W), R.depth_handoff(p32, H, W))
+    _record("bf16x3_1080p", st)
+    assert st["pred_max_err_of_range"] < 1e-4, st
+    assert st["exact"] >= 0.995 and st["max"] <= 1, st
+
+
+def test_depth_leg_bf16x3_4k_base_one_frame(R):
+    """configs[3]'s depth leg (DA-V2-Base at 3840x2160) in the split-bf16 mode, same bar."""
+    from test_hip_depth_e2e import _plane_stats, _record, _stock_u8_planes
+    from visiondepth3d_amd import synth
+    from visiondepth3d_amd.depth import DepthPipe
+    H, W = 2160, 3840
+    frames = torch.from_numpy(np.stack([synth.synth_frame(0, H, W)[0]])).cuda()
+    exp_u8, exp_pred = _stock_u8_planes("depth-anything-v2-base", frames)
+    pipe = DepthPipe("depth-anything-v2-base", device="cuda", dtype=torch.float32, renderer=R, gemm="bf16x3")
+    pred = pipe.infer_bgr_u8(frames, raw=True)
+    st = _plane_stats(R.depth_handoff(pred, H, W), exp_u8)
+    st["pred_max_err_of_range"] = float((pred - exp_pred).abs().max()) / float(exp_pred.max() - exp_pred.min())
+    _record("bf16x3_4k_base", st)
+    assert st["pred_max_err_of_range"] < 1e-4, st
+    assert st["exact"] >= 0.995 and st["max"] <= 1, st

@@ -59,7 +59,8 @@ struct vd3d_ctx {
   // per-frame piece sums of a batch.  Plans are never overwritten (a queued kernel may still read one): a new key gets new buffers.
   int aten_eh = 0, aten_ew = 0, aten_T = 0, aten_n_small = 0, aten_n_big = 0, aten_nr_crop = 0, aten_nr_mad = 0;
   int* aten_plan = nullptr; float* aten_scratch = nullptr;
-  std::vector<void*> aten_retired;
+  struct vd_aten_entry { int eh, ew, T, n_small, n_big, nr_crop, nr_mad; int* plan; float* scratch; };
+  std::vector<vd_aten_entry> aten_cache;   // plans of other (eye size, thread count) keys this context has used (re-used, bounded at 8)
   // the N-thread ATen mode (round 5): planes resized by ATen's premultiplied-weight kernel ahead of W1 (RGB, [3][H][W]) and of the finishing kernels (depth, [H][W])
   float* pm_rgb = nullptr; size_t pm_rgb_cap = 0;
   float* pm_dd = nullptr; size_t pm_dd_cap = 0;
@@ -255,7 +256,7 @@ VD3D_EXPORT int vd3d_ctx_destroy(vd3d_ctx* c) {
   prof_collect(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   void* ptrs[] = {c->work, c->histA, c->rgb_eye, c->tdf, c->dn[0], c->dn[1], c->D, c->S, c->e2L, c->e2R, c->E2, c->bL, c->bR, c->L, c->R, c->gL, c->gR, c->gLR, c->mm, c->dc, c->rowflag, c->etab, c->crop_tab, c->blank_eye, c->fmt_eyes, c->aten_plan, c->aten_scratch, c->pm_rgb, c->pm_dd};
-  for (void* q : c->aten_retired) (void)hipFree(q);
+  for (const auto& e : c->aten_cache) { (void)hipFree(e.plan); (void)hipFree(e.scratch); }
   for (auto& t : c->w2_tabs) (void)hipFree(t.dev);
   for (auto& t : c->wk_tabs) (void)hipFree(t.dev);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -357,24 +358,53 @@ VD3D_EXPORT int vd3d_last_scalars(vd3d_ctx* c, vd3d_frame_scalars* out) {
   return vd3d_sync(c);
 }
 
+// the current plan goes back into the context's cache / a cached plan becomes current
+static void aten_cache_put(vd3d_ctx* c) {
+  if (!c->aten_plan) return;
+  c->aten_cache.push_back(vd3d_ctx::vd_aten_entry{c->aten_eh, c->aten_ew, c->aten_T, c->aten_n_small, c->aten_n_big, c->aten_nr_crop, c->aten_nr_mad, c->aten_plan, c->aten_scratch});
+  c->aten_plan = nullptr; c->aten_scratch = nullptr; c->aten_eh = c->aten_ew = c->aten_T = -1;
+}
+static bool aten_cache_get(vd3d_ctx* c, int eh, int ew, int T) {
+  for (size_t i = 0; i < c->aten_cache.size(); ++i) {
+    const vd3d_ctx::vd_aten_entry e = c->aten_cache[i];
+    if (e.eh != eh || e.ew != ew || e.T != T) continue;
+    c->aten_cache.erase(c->aten_cache.begin() + (long)i);
+    c->aten_eh = eh; c->aten_ew = ew; c->aten_T = T;
+    c->aten_n_small = e.n_small; c->aten_n_big = e.n_big; c->aten_nr_crop = e.nr_crop; c->aten_nr_mad = e.nr_mad;
+    c->aten_plan = e.plan; c->aten_scratch = e.scratch;
+    return true;
+  }
+  return false;
+}
+
 // vd3d_render_params::aten_sum_threads > 0: the two torch.mean calls of the loop body in ATen's float32 summation order (vd3d_atensum.hip)
 static int aten_setup(vd3d_ctx* c, const vd3d_render_params* p, vd_stage_args* a) {
   a->aten_threads = 0;
   const int T = p->aten_sum_threads;
   if (T <= 0) return 0;
   if (c->aten_eh != p->eye_h || c->aten_ew != p->eye_w || c->aten_T != T) {
-    std::vector<int> flat;
-    int ns = 0, nb = 0, nrc = 0, nrm = 0;
-    if (!vd_aten_plan_build(p->eye_h, p->eye_w, T, flat, &ns, &nb, &nrc, &nrm))
-      return set_err(VD3D_E_UNSUPPORTED, "aten_sum_threads %d with %dx%d eyes: outside the restated range (1 .. 1024 threads)", T, p->eye_w, p->eye_h);
-    if (c->aten_plan) c->aten_retired.push_back(c->aten_plan);
-    if (c->aten_scratch) c->aten_retired.push_back(c->aten_scratch);
-    c->aten_plan = nullptr; c->aten_scratch = nullptr;
-    HIPCHK(hipMalloc((void**)&c->aten_plan, flat.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(c->aten_plan, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));   // a fresh buffer: nothing queued reads it yet
-    HIPCHK(hipMalloc((void**)&c->aten_scratch, (size_t)VD_MAX_BATCH * (size_t)(ns + nb) * sizeof(float)));
-    c->aten_eh = p->eye_h; c->aten_ew = p->eye_w; c->aten_T = T;
-    c->aten_n_small = ns; c->aten_n_big = nb; c->aten_nr_crop = nrc; c->aten_nr_mad = nrm;
+    // a small per-key cache: a context that alternates between eye sizes / thread counts re-uses its plans instead of allocating a new pair
+    // per change; a replaced key's buffers stay valid (queued launches may still read them) and are handed back out when the key returns
+    aten_cache_put(c);
+    if (!aten_cache_get(c, p->eye_h, p->eye_w, T)) {
+      std::vector<int> flat;
+      int ns = 0, nb = 0, nrc = 0, nrm = 0;
+      if (!vd_aten_plan_build(p->eye_h, p->eye_w, T, flat, &ns, &nb, &nrc, &nrm))
+        return set_err(VD3D_E_UNSUPPORTED, "aten_sum_threads %d with %dx%d eyes: outside the restated range (1 .. 1024 threads)", T, p->eye_w, p->eye_h);
+      if (c->aten_cache.size() >= 8) {   // bounded: drain the stream once, then free the oldest entry
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->pix_stream) HIPCHK(hipStreamSynchronize(c->pix_stream));
+        for (int k = 0; k < VD_MAX_PIX - 1; ++k) if (c->pix_x[k]) HIPCHK(hipStreamSynchronize(c->pix_x[k]));
+        (void)hipFree(c->aten_cache.front().plan); (void)hipFree(c->aten_cache.front().scratch);
+        c->aten_cache.erase(c->aten_cache.begin());
+      }
+      c->aten_plan = nullptr; c->aten_scratch = nullptr;
+      HIPCHK(hipMalloc((void**)&c->aten_plan, flat.size() * sizeof(int)));
+      HIPCHK(hipMemcpy(c->aten_plan, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));   // a fresh buffer: nothing queued reads it yet
+      HIPCHK(hipMalloc((void**)&c->aten_scratch, (size_t)VD_MAX_BATCH * (size_t)(ns + nb) * sizeof(float)));
+      c->aten_eh = p->eye_h; c->aten_ew = p->eye_w; c->aten_T = T;
+      c->aten_n_small = ns; c->aten_n_big = nb; c->aten_nr_crop = nrc; c->aten_nr_mad = nrm;
+    }
   }
   a->aten_threads = T; a->aten_n_small = c->aten_n_small; a->aten_n_big = c->aten_n_big; a->aten_nr_crop = c->aten_nr_crop; a->aten_nr_mad = c->aten_nr_mad;
   a->aten_plan = c->aten_plan; a->aten_scratch = c->aten_scratch;
@@ -1411,6 +1441,24 @@ VD3D_EXPORT int vd3d_add_layernorm(vd3d_ctx* c, int dtype, const void* x, const 
   if (!c || !x || !gamma || !beta || !out_norm || rows < 1 || (y_or_null && !out_sum)) return set_err(VD3D_E_INVALID, "bad argument");
   if (!vd_launch_add_layernorm(c->stream, dtype, x, y_or_null, gamma, beta, eps, (long long)rows, cols, out_sum, out_norm))
     return set_err(VD3D_E_UNSUPPORTED, "add_layernorm: cols %d not in {384,768,1024}", cols);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int64_t vd3d_gemm_x3_weight_bytes(int N, int K) { return (int64_t)vd_gemm_x3_weight_bytes(N, K); }
+
+VD3D_EXPORT int vd3d_gemm_x3_pack_weights(vd3d_ctx* c, const float* W, int N, int K, void* image) {
+  if (!c || !W || !image) return set_err(VD3D_E_INVALID, "bad argument");
+  if (!vd_launch_gemm_x3_pack_w(c->stream, W, N, K, image)) return set_err(VD3D_E_UNSUPPORTED, "gemm_x3: K %d must be a positive multiple of 16 (N %d)", K, N);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_gemm_x3(vd3d_ctx* c, const float* X, int64_t M, int K, const void* w_image, int N, const float* bias_or_null, int epilogue, float* Y) {
+  if (!c || !X || !w_image || !Y || M < 1) return set_err(VD3D_E_INVALID, "bad argument");
+  if (epilogue != VD3D_GEMM_EPI_NONE && epilogue != VD3D_GEMM_EPI_GELU) return set_err(VD3D_E_INVALID, "gemm_x3: unknown epilogue %d", epilogue);
+  if (!vd_launch_gemm_x3(c->stream, X, (long long)M, K, w_image, N, bias_or_null, epilogue, Y))
+    return set_err(VD3D_E_UNSUPPORTED, "gemm_x3: K %d must be a positive multiple of 16, X and the weight image 16-byte aligned", K);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -23,6 +23,7 @@
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 #include <hip/hip_fp16.h>
+#include <mutex>
 
 typedef _Float16 cv_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cv_h4 __attribute__((ext_vector_type(4)));
@@ -520,8 +521,10 @@ bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const
   static bool attr_set[64] = {};      // per device: the > 64 KB dynamic-LDS opt-in is a per-device function attribute
   static unsigned* cu_cnt[64] = {};   // per device: arrival counters of the CU slots (persistent kernel; never reset: only the parity matters)
   static int n_cu[64] = {};
+  static std::mutex init_mu;          // one context per host thread is a supported pattern: first use of a device is serialised
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::unique_lock<std::mutex> init_lock(init_mu);
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS) != hipSuccess)
       return false;
@@ -534,6 +537,7 @@ bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const
     if (hipMemset(cu_cnt[dev], 0, 2048 * sizeof(unsigned)) != hipSuccess) return false;
     attr_set[dev] = true;
   }
+  init_lock.unlock();
   const int nt8 = ((W + CV_TW - 1) / CV_TW) * ((H + CS_TH - 1) / CS_TH);
   if (g_cv_mode >= 100 || (g_cv_mode == -2 && nt8 <= 4096)) {   // the 32 x 8 / three-workgroups-per-CU kernel (persistent grid)
     const int ntx = (W + CV_TW - 1) / CV_TW, nty = (H + CS_TH - 1) / CS_TH, ntiles = ntx * nty;

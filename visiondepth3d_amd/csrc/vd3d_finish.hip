@@ -28,6 +28,7 @@
 // between the load phase and the levels instead of two: 252 -> 259 us at 4K.  Tile heights 22 / 14 at 80 VGPRs: 300 / 332 us.  Two tiles per
 // workgroup with the second tile's loads requested during the first one's epilogue: hipcc needs 185 VGPRs for the loop, and 81 for the
 // one-tile instantiation of the same source -- one register over the three-workgroup budget -- so the single-tile kernel stays as it is.)
+#include <mutex>
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 
@@ -1113,8 +1114,10 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
     // persistent route: one workgroup per CU slot; three 51.7 KB workgroups of 512 threads fit a CU (80 VGPRs).  The grid is a multiple of 8, so a
     // workgroup's virtual blocks b, b + grid, ... stay on its XCD's tile rows.
     static int n_cu[64] = {};
+    static std::mutex init_mu;   // first use per device is serialised: two host threads with a context each may arrive together
     int dev = 0;
     (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> init_lock(init_mu);
     if (dev >= 0 && dev < 64 && !n_cu[dev] && hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu[dev] = 256;
     const int ncu = (dev >= 0 && dev < 64 && n_cu[dev] > 0) ? n_cu[dev] : 256;
     const int nvb = (int)g.x;

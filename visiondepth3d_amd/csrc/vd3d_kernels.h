@@ -193,6 +193,10 @@ bool vd_launch_preview(hipStream_t s, int type, const uint8_t* L, const uint8_t*
 bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, int W, int th, int tw, const float mean[3],
                           const float stdv[3], int dtype, void* out_nhwc);
 // ---- vd3d_netops.hip
+// vd3d_gemm.hip: the transformer linears as a split-bf16 (bf16x3, six products) GEMM with float32 accumulation
+long long vd_gemm_x3_weight_bytes(int N, int K);
+bool vd_launch_gemm_x3_pack_w(hipStream_t s, const float* W, int N, int K, void* img);
+bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const void* wimg, int N, const float* bias, int epilogue, float* Y);
 bool vd_launch_add_layernorm(hipStream_t s, int dtype, const void* x, const void* y, const void* gamma, const void* beta, float eps,
                              long long rows, int cols, void* out_sum, void* out_norm);
 bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);

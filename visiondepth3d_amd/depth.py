@@ -118,14 +118,42 @@ def depth_to_u8(pred: torch.Tensor, invert: bool = False) -> torch.Tensor:
     return 255 - u8 if invert else u8
 
 
+_TUNABLE_DIR = None
+
+
+def _tunable_scratch_dir() -> str:
+    """One private scratch directory per process for TunableOp's results file (see DepthPipe._library_selection)."""
+    global _TUNABLE_DIR
+    if _TUNABLE_DIR is None:
+        import atexit
+        import glob
+        import shutil
+        import tempfile
+        import time
+        base = tempfile.gettempdir()
+        for old in glob.glob(os.path.join(base, "vd3d_tunable_*")):   # what earlier processes of this user left behind (TunableOp writes at exit, after us)
+            try:
+                if os.stat(old).st_uid == os.getuid() and time.time() - os.stat(old).st_mtime > 86400:
+                    shutil.rmtree(old, ignore_errors=True)
+            except OSError:
+                pass
+        _TUNABLE_DIR = tempfile.mkdtemp(prefix="vd3d_tunable_")
+        atexit.register(shutil.rmtree, _TUNABLE_DIR, True)
+    return _TUNABLE_DIR
+
+
 class DepthPipe:
     """``pipe(images, inference_size=None) -> [{"predicted_depth": Tensor[h, w]}]`` (reference protocol) plus a
     device-resident batch path."""
 
     def __init__(self, name: str = "depth-anything-v2-small", device="cuda", dtype=torch.float32, seed: int = 0,
                  channels_last: bool = True, renderer=None, fuse_backbone: bool = True, model=None, processor: dict | None = None,
-                 tuned_gemm: bool = True, miopen_find: bool | None = None):
+                 tuned_gemm: bool = True, miopen_find: bool | None = None, gemm: str = "f32"):
         """``dtype``: float32 (the reference's precision, default) or bfloat16.
+        ``gemm`` (float32 + ``renderer`` only; round 6): ``"f32"`` (default) -- the four linears of every transformer block are hipBLASLt's float32
+        GEMMs; ``"bf16x3"`` -- OPT-IN: the library's own split-bf16 GEMM (``vd3d_gemm_x3``: every float32 operand exactly split into three bf16
+        terms, six products per MAC on the bf16 matrix cores, float32 accumulation -- float32-faithful, see include/vd3d.h), with the exact GELU
+        folded into fc1's epilogue.  gfx950 has no TF32 and its float32-input MFMA runs at 1/16 of the bf16 rate, which caps the default mode.
         ``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream); when given the
         image-processor front end, the residual-add + LayerNorm pairs and the DPT up-samplings run as fused HIP launches.
         ``model`` / ``processor``: an already constructed Hugging Face depth model and its image-processor constants
@@ -137,6 +165,11 @@ class DepthPipe:
         first forward of a process, 4.5 % on the 4K float32 forward (profiles/r04_net_library_selection.md); opt-in, bench.py uses it.
         The flag is PyTorch's process-wide one: True / False set it, None (default) leaves it as the caller has it."""
         self.name, self.device, self.dtype = name, torch.device(device), dtype
+        if gemm not in ("f32", "bf16x3"):
+            raise ValueError("gemm must be 'f32' or 'bf16x3'")
+        if gemm == "bf16x3" and (dtype != torch.float32 or renderer is None or torch.device(device).type != "cuda"):
+            raise ValueError("gemm='bf16x3' is a mode of the float32 pipe on the GPU and needs a renderer (the GEMM lives in libvd3d_hip.so)")
+        self.gemm = gemm
         self.tuned_gemm = self.miopen_find = False
         self._flop_count = None
         if self.device.type == "cuda":
@@ -183,9 +216,11 @@ class DepthPipe:
                 return
             tn.enable(True)
             tn.tuning_enable(False)
-            # never write into the package; ONE fixed scratch name (TunableOp rewrites its results file when the process exits and this
-            # build has no switch for that: a per-pid name left one file per process behind)
-            tn.set_filename(os.path.join(tempfile.gettempdir(), "vd3d_tunableop_results.csv"))
+            # never write into the package.  TunableOp rewrites its results file when the process exits and this build has no switch for that: the
+            # file lives in a PRIVATE per-process directory (mkdtemp: mode 0700, unpredictable name -- no race between the ranks of --gpus N, no
+            # symlink to clobber in a shared /tmp) that an atexit hook registered BEFORE TunableOp's own write... cannot rely on ordering,
+            # so the hook removes what exists and the directory is also swept at the next start-up of the same user (stale entries older than a day)
+            tn.set_filename(os.path.join(_tunable_scratch_dir(), "tunableop_results.csv"))
             self.tuned_gemm = bool(tn.read_file(table))
             if not self.tuned_gemm:   # other hipBLASLt / rocBLAS / PyTorch build: the solution indices mean nothing there
                 tn.enable(False)
@@ -308,7 +343,10 @@ class DepthPipe:
 
             def tail_operands():
                 w, b = head.conv3.weight, head.conv3.bias
-                key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+                try:
+                    key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+                except RuntimeError:   # inference tensors (created / loaded under torch.inference_mode()) track no version counter: immutable outside
+                    key = (w.data_ptr(), b.data_ptr())   # inference mode, so the storage address identifies the value
                 if tail["key"] != key:
                     tail["w3"] = w.detach().reshape(-1).contiguous()
                     tail["b3"] = float(b.detach().float().item())
@@ -380,10 +418,32 @@ class DepthPipe:
             nh, hd, scaling = att.num_attention_heads, att.attention_head_size, att.scaling
             n1, n2, act = layer.norm1, layer.norm2, layer.mlp.activation
             nxt = layers[li + 1].norm1 if li + 1 < len(layers) else None
+            x3 = None
+            if self.gemm == "bf16x3":   # weights split + packed once; exact GELU only (what DINOv2's MLP uses) goes into fc1's epilogue
+                gelu_ok = isinstance(act, torch.nn.GELU) and getattr(act, "approximate", "none") == "none" or type(act).__name__ == "GELUActivation"
+                x3 = dict(qkv=(R.gemm_x3_pack(wqkv), wqkv.shape[0]), wo=(R.gemm_x3_pack(wo), wo.shape[0]),
+                          fc1=(R.gemm_x3_pack(fc1.weight), fc1.weight.shape[0]), w2=(R.gemm_x3_pack(w2), w2.shape[0]), gelu=bool(gelu_ok))
 
             def fwd(x, wqkv=wqkv, bqkv=bqkv, wo=wo, bo=bo, fc1=fc1, w2=w2, b2=b2, nh=nh, hd=hd, scaling=scaling, n1=n1, n2=n2,
-                    act=act, nxt=nxt):
+                    act=act, nxt=nxt, x3=x3):
                 B, T, d = x.shape
+                if x3 is not None and x.dtype == torch.float32 and x.is_contiguous() and d in (384, 768, 1024):
+                    lin = lambda t, key, bias, gelu=False: R.linear_x3(t if t.is_contiguous() else t.contiguous(), x3[key][0], x3[key][1], bias, gelu=gelu)
+                    h = stash["h"] if stash["x"] is x else R.add_layernorm(x, None, n1)[1]
+                    stash["x"] = stash["h"] = None
+                    qkv = lin(h, "qkv", bqkv).view(B, T, 3, nh, hd)
+                    Tk = pad_state["T"] or T
+                    q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :Tk, 1].transpose(1, 2), qkv[:, :Tk, 2].transpose(1, 2)
+                    o = F.scaled_dot_product_attention(q, k, v, scale=scaling).transpose(1, 2).reshape(B, T, d)
+                    a = lin(o, "wo", bo)
+                    x, h = R.add_layernorm(x, a, n2)
+                    hid = lin(h, "fc1", fc1.bias, gelu=True) if x3["gelu"] else act(lin(h, "fc1", fc1.bias))
+                    m = lin(hid, "w2", b2)
+                    if nxt is None:
+                        return x + m
+                    x, hn = R.add_layernorm(x, m, nxt)
+                    stash["x"], stash["h"] = x, hn
+                    return x
                 hip = R is not None and x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous() and d in (384, 768, 1024)
                 if hip:   # residual add + LayerNorm pairs as single HIP launches (vd3d_add_layernorm)
                     h = stash["h"] if stash["x"] is x else R.add_layernorm(x, None, n1)[1]

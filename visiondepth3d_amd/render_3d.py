@@ -602,6 +602,27 @@ class Renderer:
                                               _ptr(norm.bias), float(norm.eps), rows, cols, _ptr(out_s) if y is not None else None, _ptr(out_n)))
         return out_s, out_n
 
+    def gemm_x3_pack(self, weight: torch.Tensor) -> torch.Tensor:
+        """Split + pack a float32 Linear weight [N, K] once for ``linear_x3`` (include/vd3d.h vd3d_gemm_x3_pack_weights); returns the opaque image (uint8)."""
+        w = weight.detach().to(self.device, torch.float32).contiguous()
+        N, K = w.shape
+        nb = int(self._L.vd3d_gemm_x3_weight_bytes(N, K))
+        if nb < 0:
+            raise NotImplementedError(f"gemm_x3: K = {K} is not a positive multiple of 16")
+        img = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        self._enter(w, img)
+        _lib.check(self._L.vd3d_gemm_x3_pack_weights(self._ctx, _ptr(w), N, K, _ptr(img)))
+        return img
+
+    def linear_x3(self, x: torch.Tensor, w_image: torch.Tensor, N: int, bias: torch.Tensor | None = None, gelu: bool = False) -> torch.Tensor:
+        """F.linear(x, W, bias) (+ exact GELU) for contiguous float32 x [..., K] with W given as ``gemm_x3_pack(W)``: split-bf16 MFMA, float32-faithful."""
+        K = x.shape[-1]
+        M = x.numel() // K
+        out = torch.empty(x.shape[:-1] + (int(N),), dtype=torch.float32, device=x.device)
+        self._enter(x, w_image, bias, out)
+        _lib.check(self._L.vd3d_gemm_x3(self._ctx, _ptr(x), M, K, _ptr(w_image), int(N), _ptr(bias) if bias is not None else None, 1 if gelu else 0, _ptr(out)))
+        return out
+
     def upsample_bilinear(self, x: torch.Tensor, size) -> torch.Tensor:
         """F.interpolate(x, size, mode="bilinear", align_corners=True) for a float32 / bf16 channels_last [B,C,h,w] tensor."""
         B, Cc, ih, iw = x.shape
