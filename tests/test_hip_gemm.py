@@ -1,8 +1,10 @@
 """GPU tests (-m gpu) of the split-bf16 GEMM (vd3d_gemm_x3, csrc/vd3d_gemm.hip): the opt-in `gemm="bf16x3"` mode of the depth leg (round 6).
 
-A floating-point kernel: the bar is stated against FLOAT64 and beside torch's own float32 GEMM (hipBLASLt) on the same operands --
-  |y - y64| <= 4 * 2^-24 * (sum_k |x||w| + |b|)   per element (a float32 dot product's own worst case grows with K; measured: ~0.2 of that),
-  relative RMS error within 3x of the float32 library GEMM's (six accumulations per MAC instead of one, the dropped cross terms <= 2^-23 per product).
+A floating-point kernel: the bar is stated against FLOAT64, beside torch's own float32 GEMM (hipBLASLt) on the same operands --
+  max over the elements of |y - y64| / (sum_k |x||w| + |b|) <= 1.25 x the float32 library GEMM's own figure (which grows with K like any float32 sum),
+  relative RMS error <= 1.25 x the float32 library GEMM's.
+Measured on MI355X at M = 39 088 (tools/probe_gemm_x3.py, round 6): 2.6 - 3.5e-7 against 3.5 - 4.6e-7 for the float32 GEMM, RMS 0.86x of it -- the six exact
+products accumulated in float32 are, if anything, slightly MORE accurate than hipBLASLt's float32 kernel (whose MFMA sums in chunks of its own).
 Then the depth leg in that mode against the STOCK float32 Hugging Face graph with the bar the float32 leg itself meets (tests/test_hip_depth_e2e.py)."""
 import numpy as np
 import pytest
@@ -50,8 +52,8 @@ def test_gemm_x3_is_float32_faithful(R, M, K, N, bias, gelu):
         y32 = F.gelu(y32)
     e3, r3 = _err(y, x, w, b, gelu)
     e32, r32 = _err(y32, x, w, b, gelu)
-    assert e3 <= 4 * 2.0 ** -24, (e3, e32)
-    assert r3 <= 3 * r32 + 1e-8, (r3, r32)
+    assert e3 <= max(1.25 * e32, 2.0 ** -24), (e3, e32)
+    assert r3 <= 1.25 * r32 + 1e-9, (r3, r32)
     # a batch dimension in front, and the same call again (no state between calls)
     if M % 2 == 0:
         y2 = R.linear_x3(x.view(2, M // 2, K), img, N, b, gelu=gelu)

@@ -25,7 +25,10 @@ def main():
     R = Renderer(0)
     g = torch.Generator(device="cuda").manual_seed(1)
     tot_x3 = tot_f32 = 0.0
-    for (K, N, gelu) in ((768, 2304, False), (768, 768, False), (768, 3072, True), (3072, 768, False), (384, 1152, False), (1024, 4096, True)):
+    shapes = ((768, 2304, False), (768, 768, False), (768, 3072, True), (3072, 768, False), (384, 1152, False), (1024, 4096, True))
+    if len(sys.argv) > 2 and sys.argv[2] == "one":   # counter passes: one shape, a few launches
+        shapes = ((768, 2304, False),)
+    for (K, N, gelu) in shapes:
         x = torch.randn(M, K, device="cuda", generator=g) * 2.0
         w = torch.randn(N, K, device="cuda", generator=g) * 0.05
         b = torch.randn(N, device="cuda", generator=g)

@@ -8,24 +8,32 @@
 // with every bf16 x bf16 product exact in float32.  The bracket is <= 2^-23 |x w| (the size of ONE float32 rounding of the product) and is dropped;
 // the six kept products per K-step go through v_mfma_f32_32x32x16_bf16 with float32 accumulation.  Result: float32-faithful dot products (error
 // model = a float32 GEMM with another summation order plus one extra rounding-sized term per product; tests/test_hip_gemm.py checks it against
-// float64) at six bf16 MFMAs per float32 MAC: a ceiling of 2.5 PFLOP/s / 6 = 417 TFLOP/s float32-equivalent instead of 157.
+// float64, beside hipBLASLt's float32 GEMM) at six bf16 MFMAs per float32 MAC: a ceiling of 2.5 PFLOP/s / 6 = 417 TFLOP/s float32-equivalent
+// instead of 157.
 //
-// Kernel (k_gemm_bf16x3): 256 x 256 output tile per workgroup, 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA tiles
-// = 128 accumulator registers, two waves per SIMD.  K-step 16 (one MFMA K), LDS double-buffered: a stage holds the three bf16 terms of the A tile
-// and of the B tile CHUNK-major -- [term 3][k-half 2][row 256][8 bf16] = 24 KB each -- so that the 32 lanes of a fragment read hit consecutive
-// 16-byte slots (conflict-free ds_read_b128); 2 x 48 KB = 96 KB.
-//   B (weights): split and packed ONCE per model (k_gemm_x3_pack_w) into exactly that stage image, [N tile][K step][term][k-half][n][8]; a stage is
-//     24 KB of contiguous global memory and goes to LDS by global_load_lds_dwordx4 (3 per thread), no registers, no VALU.
-//   A (activations, float32 row-major as every producer writes them): two 16-byte global loads per thread per stage issued one stage ahead, split
-//     in registers (and / sub / and / sub per element, v_perm to pack) and written as 8-byte LDS stores behind the MFMAs of the current stage.
-//   Per stage and wave: 18 ds_read_b128 feed 48 MFMAs (a plain bf16 GEMM with this tiling: 6 reads per 8 MFMAs) -- the six-product form is
-//   MFMA-bound by construction; small terms are accumulated first, the two N tiles of a row alternate so that dependent MFMAs are 64 cycles apart.
+// Kernel (k_gemm_bf16x3): 256 x 256 output tile per workgroup, 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 128 = 2 x 4 MFMA tiles =
+// 128 accumulator registers, two waves per SIMD.  K-step 16 (one MFMA K).  BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4: no
+// registers, no VALU, no ds_write) into a ring of FOUR stages, three stages ahead of their use, with counted vmcnt and raw s_barrier -- a
+// __syncthreads() would drain the DMA queue at every stage.  A stage is visible one whole iteration before its MFMAs, so the split of ITS A
+// fragments runs in the shadow of the previous stage's MFMAs instead of in front of its own:
+//   A (activations, float32 row-major as every producer writes them) stays FLOAT32 in LDS, [row 256][k quad 4, XOR-swizzled][4 floats] = 16 KB per
+//     stage: the source address of a DMA is per lane and the LDS image lane-linear, so the swizzle is applied to WHICH 16 bytes a lane fetches; four
+//     neighbouring lanes fetch one row's 64 contiguous bytes.  Each wave splits ITS rows' fragments into the three bf16 terms in
+//     registers (and / sub / and / sub per element, v_perm to pack: 44 VALU per 32 x 16 fragment) in the shadow of its MFMAs.
+//   B (weights) is split and packed ONCE per model (k_gemm_x3_pack_w) into the stage image [N tile][K step][term 3][k-half 2][n 256][8 bf16]:
+//     24 KB of contiguous global memory per stage.
+//   Stage = 40 KB, ring = 160 KB = the whole LDS of a CU: one workgroup per CU.
+// (Measured, round 6, M = 39 088, K = 768: a first version with A split in registers BEFORE the LDS write -- global loads one stage ahead, 12 ds_write
+// per thread and stage, one __syncthreads() per stage, double buffer -- reached 157 - 204 TFLOP/s float32-equivalent = 0.94 - 1.22 PFLOP/s of MFMA
+// work; with 256 x 128 tiles and two workgroups per CU 153 - 182: the staging pass and the barrier drain, not the epilogue, were what idled the
+// matrix cores.)
 // Tile order: workgroup b runs on XCD b % 8 (speed assumption only): every XCD owns the M tiles mt = x (mod 8) and walks them four at a time across
 // all N tiles, so that the ~32 workgroups resident on an XCD share 4 A panels and 8 B panels through its L2.
 // Epilogue: + bias[n], optionally exact GELU (0.5 x (1 + erf(x / sqrt 2)), torch.nn.GELU()'s default form, float32 erff), float32 stores (each
 // accumulator register = two 128-byte row segments per wave).
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
+#include <cstdlib>
 
 typedef short gx_bf8 __attribute__((ext_vector_type(8)));     // 8 bf16 = one MFMA A / B fragment (4 VGPRs)
 typedef float gx_f16 __attribute__((ext_vector_type(16)));    // one 32 x 32 accumulator tile per wave
@@ -33,9 +41,12 @@ typedef float gx_f16 __attribute__((ext_vector_type(16)));    // one 32 x 32 acc
 #define GX_BM 256
 #define GX_BN 256
 #define GX_NT 512
-#define GX_STAGE_HALF (3 * 2 * 256 * 16)        // bytes of one operand's stage image: 24 576
-#define GX_STAGE (2 * GX_STAGE_HALF)             // A image + B image: 49 152
-#define GX_LDS (2 * GX_STAGE)                    // double-buffered: 98 304
+#define GX_MG 4                                  // M tiles of an XCD walked together across the N tiles
+#define GX_A_STAGE (4 * GX_BM * 16)              // float32 A image of a stage: 16 384 bytes
+#define GX_STAGE_HALF (3 * 2 * GX_BN * 16)       // B image of a stage: 24 576 bytes (the unit of the packed weights)
+#define GX_STAGE (GX_A_STAGE + GX_STAGE_HALF)    // 40 960
+#define GX_NSTAGE 4
+#define GX_LDS (GX_NSTAGE * GX_STAGE)            // 163 840 = all of a CU's LDS
 
 struct vd_gx_args {
   long long M;
@@ -55,123 +66,187 @@ VD_DEV void gx_split(float a, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
 }
 // pack the high halves of two words: lo | hi << 16
 VD_DEV uint32_t gx_pack(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+// eight float32 (k = 8 kh .. 8 kh + 7 of one row) -> the three bf16 fragments of that lane
+VD_DEV void gx_split8(const float4& lo, const float4& hi, gx_bf8 out[3]) {
+  uint32_t t1[8], t2[8], t3[8];
+  gx_split(lo.x, t1[0], t2[0], t3[0]); gx_split(lo.y, t1[1], t2[1], t3[1]); gx_split(lo.z, t1[2], t2[2], t3[2]); gx_split(lo.w, t1[3], t2[3], t3[3]);
+  gx_split(hi.x, t1[4], t2[4], t3[4]); gx_split(hi.y, t1[5], t2[5], t3[5]); gx_split(hi.z, t1[6], t2[6], t3[6]); gx_split(hi.w, t1[7], t2[7], t3[7]);
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 p1 = {gx_pack(t1[0], t1[1]), gx_pack(t1[2], t1[3]), gx_pack(t1[4], t1[5]), gx_pack(t1[6], t1[7])};
+  const u4 p2 = {gx_pack(t2[0], t2[1]), gx_pack(t2[2], t2[3]), gx_pack(t2[4], t2[5]), gx_pack(t2[6], t2[7])};
+  const u4 p3 = {gx_pack(t3[0], t3[1]), gx_pack(t3[2], t3[3]), gx_pack(t3[4], t3[5]), gx_pack(t3[6], t3[7])};
+  out[0] = __builtin_bit_cast(gx_bf8, p1); out[1] = __builtin_bit_cast(gx_bf8, p2); out[2] = __builtin_bit_cast(gx_bf8, p3);
+}
 
 VD_DEV float gx_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 typedef __attribute__((address_space(3))) void* gx_lds_vp;
 typedef const __attribute__((address_space(1))) void* gx_glb_vp;
 
+// DBG (development ablations, VD3D_GEMM_DBG; results are wrong): 1 no DMA, 2 no barrier, 4 no MFMA, 8 no A split
+template <int DBG>
 __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__ X, const uint4* __restrict__ Wimg, const float* __restrict__ bias,
                                                         float* __restrict__ Y, vd_gx_args a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t gx_lds[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t gx_lds[];   // the ONLY LDS object of the kernel (a second one makes hipcc drain the DMA queue per stage)
   // ---- tile of this workgroup (XCD-aware order, see the header)
   int mt, nt;
   {
     const int b = blockIdx.x, x = b & 7, idx = b >> 3;
-    const int per = 4 * a.nbn, mg = idx / per, rem = idx - mg * per;
-    nt = rem >> 2;
-    mt = ((mg * 4 + (rem & 3)) << 3) + x;
+    const int per = GX_MG * a.nbn, mg = idx / per, rem = idx - mg * per;
+    nt = rem / GX_MG;
+    mt = ((mg * GX_MG + (rem - nt * GX_MG)) << 3) + x;
     if (mt >= a.nbm) return;   // padding workgroup (uniform, before any barrier)
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3, li = lane & 31, kh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
   const long long m0 = (long long)mt * GX_BM;
   const int n0 = nt * GX_BN;
 
-  // ---- A staging: thread = (k quad q, rows r0 and r0 + 128); 4 lanes cover the 64 bytes a row contributes to a stage
-  const int q = tid & 3, r0 = tid >> 2;
+  // ---- A staging by LDS-DMA: piece p of thread t is 16-byte slot p * 512 + t of the stage image.  Slot s holds (row = s >> 2, quad = (s & 3) ^ ((row >> 2) & 3)):
+  // four neighbouring lanes fetch the 64 contiguous bytes a row contributes to the stage (a DMA instruction = 16 rows x 64 B, not 64 rows x 16 B), and
+  // the XOR makes the fragment reads -- one quad of 32 consecutive rows, 64 bytes apart -- conflict-free: within any 16-lane group of a ds_read_b128
+  // the four 4-row runs have distinct (row >> 2) & 3, so the 16 slots are distinct mod 16
   const float* xa[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    long long row = m0 + r0 + 128 * i;
-    if (row > a.M - 1) row = a.M - 1;   // rows past the end load a valid row and are never stored
-    xa[i] = X + row * (long long)a.K + 4 * q;
+  for (int p = 0; p < 2; ++p) {
+    const int slot = p * GX_NT + tid, r = slot >> 2;
+    long long row = m0 + r;
+    if (row > a.M - 1) row = a.M - 1;   // rows past the end fetch a valid row and are never stored
+    xa[p] = X + row * (long long)a.K + 4 * ((slot & 3) ^ ((r >> 2) & 3));
   }
-  // LDS byte offset of the thread's 8-byte slot inside a term plane pair: (k-half, row, 8-byte half of the chunk)
-  const int aw_off = ((q >> 1) * 256 + r0) * 16 + (q & 1) * 8;
   // ---- B staging: the stage image is contiguous in global memory; thread t moves 16-byte pieces t, t + 512, t + 1024
   const uint4* wb = Wimg + (size_t)nt * (size_t)a.KS * (GX_STAGE_HALF / 16) + tid;
+  const int wave_base = (tid & ~63) * 16;   // wave-uniform LDS base of a DMA instruction's 1 KB
 
-  auto stage_b = [&](int ks, int buf) {
-    uint8_t* dst = gx_lds + buf * GX_STAGE + GX_STAGE_HALF;   // B image behind the A image
+  auto stage = [&](int ks, int buf) {
+    if (DBG & 1) return;
+    uint8_t* dst = gx_lds + buf * GX_STAGE;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      __builtin_amdgcn_global_load_lds((gx_glb_vp)(xa[p] + ks * 16), (gx_lds_vp)(dst + p * (GX_NT * 16) + wave_base), 16, 0, 0);
     const uint4* src = wb + (size_t)ks * (GX_STAGE_HALF / 16);
 #pragma unroll
-    for (int p = 0; p < 3; ++p)   // wave-uniform LDS base + lane * 16: pieces of one wave-instruction are 1 KB contiguous on both sides
-      __builtin_amdgcn_global_load_lds((gx_glb_vp)(src + p * GX_NT), (gx_lds_vp)(dst + (p * GX_NT + (tid & ~63)) * 16), 16, 0, 0);
-  };
-  auto load_a = [&](int ks, float4* ra) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(xa[i] + ks * 16);
-  };
-  auto write_a = [&](const float4* ra, int buf) {
-    uint8_t* dst = gx_lds + buf * GX_STAGE + aw_off;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint32_t t1[4], t2[4], t3[4];
-      gx_split(ra[i].x, t1[0], t2[0], t3[0]); gx_split(ra[i].y, t1[1], t2[1], t3[1]);
-      gx_split(ra[i].z, t1[2], t2[2], t3[2]); gx_split(ra[i].w, t1[3], t2[3], t3[3]);
-      uint8_t* d = dst + i * (128 * 16);
-      *reinterpret_cast<uint2*>(d + 0 * 8192) = make_uint2(gx_pack(t1[0], t1[1]), gx_pack(t1[2], t1[3]));
-      *reinterpret_cast<uint2*>(d + 1 * 8192) = make_uint2(gx_pack(t2[0], t2[1]), gx_pack(t2[2], t2[3]));
-      *reinterpret_cast<uint2*>(d + 2 * 8192) = make_uint2(gx_pack(t3[0], t3[1]), gx_pack(t3[2], t3[3]));
-    }
+    for (int p = 0; p < 3; ++p)
+      __builtin_amdgcn_global_load_lds((gx_glb_vp)(src + p * GX_NT), (gx_lds_vp)(dst + GX_A_STAGE + p * (GX_NT * 16) + wave_base), 16, 0, 0);
   };
 
-  gx_f16 acc[4][2];
+  gx_f16 acc[2][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
+    for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
 
-  // fragment addresses inside a stage: A rows wm * 128 + mi * 32 + li, B columns wn * 64 + nj * 32 + li; term plane pairs are 8 192 bytes apart
-  const int fa_off = (kh * 256 + wm * 128 + li) * 16;
-  const int fb_off = GX_STAGE_HALF + (kh * 256 + wn * 64 + li) * 16;
+  // fragment addresses inside a stage: A row wm * 64 + mi * 32 + li, quads 2 kh and 2 kh + 1 at their swizzled slots (mi * 32 rows = 2 048 bytes: the swizzle
+  // term (row >> 2) & 3 does not change with mi); B columns wn * 128 + nj * 32 + li, term plane pairs 8 192 bytes apart
+  const int a_row = wm * 64 + li, a_sw = (a_row >> 2) & 3;
+  const int fa_off0 = (a_row * 4 + ((2 * kh) ^ a_sw)) * 16, fa_off1 = (a_row * 4 + ((2 * kh + 1) ^ a_sw)) * 16;
+  const int fb_off = GX_A_STAGE + (kh * GX_BN + wn * 128 + li) * 16;
 
-  float4 ra[2];
-  load_a(0, ra);
-  stage_b(0, 0);
-  write_a(ra, 0);
-  __syncthreads();   // (waits for the LDS-DMA of stage 0 as well: vmcnt(0) is part of the barrier's fence while a DMA is in flight)
+  auto load_split_a = [&](int buf, gx_bf8 (*af)[3]) {
+    const uint8_t* sa = gx_lds + buf * GX_STAGE;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      // read as the fragment type (the LDS reads of this kernel all have ONE type: hipcc orders a float4 LDS read behind every LDS-DMA in flight
+      // -- s_waitcnt vmcnt(0) at the top of each stage -- and leaves the short-vector reads alone)
+      const gx_bf8 lo8 = *reinterpret_cast<const gx_bf8*>(sa + fa_off0 + mi * 2048);
+      const gx_bf8 hi8 = *reinterpret_cast<const gx_bf8*>(sa + fa_off1 + mi * 2048);
+      if (DBG & 8) { af[mi][0] = lo8; af[mi][1] = hi8; af[mi][2] = lo8; }
+      else gx_split8(__builtin_bit_cast(float4, lo8), __builtin_bit_cast(float4, hi8), af[mi]);
+    }
+  };
 
+  // prologue: stages 0 .. 2 in flight (clamped like in the loop), stages 0 and 1 landed, the A fragments of stage 0 split
+  stage(0, 0);
+  stage(a.KS > 1 ? 1 : a.KS - 1, 1);
+  stage(a.KS > 2 ? 2 : a.KS - 1, 2);
+  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  gx_bf8 af[2][3];
+  load_split_a(0, af);
+
+  // one DMA instruction of a stage: pieces 0, 1 = A, 2 .. 4 = B
+  auto stage_piece = [&](int ks, int buf, int piece) {
+    if (DBG & 1) return;
+    uint8_t* dst = gx_lds + buf * GX_STAGE;
+    if (piece < 2) __builtin_amdgcn_global_load_lds((gx_glb_vp)(xa[piece] + ks * 16), (gx_lds_vp)(dst + piece * (GX_NT * 16) + wave_base), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gx_glb_vp)(wb + (size_t)ks * (GX_STAGE_HALF / 16) + (piece - 2) * GX_NT),
+                                          (gx_lds_vp)(dst + GX_A_STAGE + (piece - 2) * (GX_NT * 16) + wave_base), 16, 0, 0);
+  };
+
+  int cur = 0;
   for (int ks = 0; ks < a.KS; ++ks) {
-    const int cur = ks & 1;
-    const bool more = ks + 1 < a.KS;   // uniform
-    if (more) { load_a(ks + 1, ra); stage_b(ks + 1, cur ^ 1); }
+    // The DMA of stage ks + 3 goes into the buffer stage ks - 1 was read from: every wave passed the barrier that ended iteration ks - 1 after its last
+    // read of it.  Unconditional -- behind the last stage it re-fetches stage KS - 1 into a buffer nobody reads again, 3 wasted stages per tile -- and so
+    // is the split of the NEXT stage's A fragments (visible since the barrier that ended iteration ks - 1; behind the last stage its result is dropped):
+    // the iteration is straight-line code with ONE counted wait.
+    // A CU ingests ~12 bytes per cycle through its vector memory path and a wave that issues into a full queue stalls IN ORDER -- its MFMAs wait with it
+    // (measured: memory-only 0.47 ms + compute-only 0.66 ms = 0.92 ms with all five DMA instructions at the top of the iteration).  So the five
+    // instructions are dealt out between the four groups of 12 MFMAs, pinned there by sched_barrier: while one wave of a SIMD waits at a DMA, the other
+    // one has MFMAs to issue.
+    const int nxt = (cur + 1) & 3, sk = ks + 3 < a.KS ? ks + 3 : a.KS - 1, sbuf = (cur + 3) & 3;
     const uint8_t* sb = gx_lds + cur * GX_STAGE;
-    gx_bf8 bf[2][3];
+    const uint8_t* sa = gx_lds + nxt * GX_STAGE;
+    gx_bf8 an[2][3];
+    gx_bf8 raw[2][2];
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
+    for (int mi = 0; mi < 2; ++mi) {   // read as the fragment type (see load_split_a)
+      raw[mi][0] = *reinterpret_cast<const gx_bf8*>(sa + fa_off0 + mi * 2048);
+      raw[mi][1] = *reinterpret_cast<const gx_bf8*>(sa + fa_off1 + mi * 2048);
+    }
 #pragma unroll
-      for (int t = 0; t < 3; ++t) bf[nj][t] = *reinterpret_cast<const gx_bf8*>(sb + fb_off + t * 8192 + nj * 512);
+    for (int nj = 0; nj < 4; ++nj) {
+      stage_piece(sk, sbuf, nj);
+      if (nj == 3) stage_piece(sk, sbuf, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      gx_bf8 bf[3];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      gx_bf8 af[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) af[t] = *reinterpret_cast<const gx_bf8*>(sb + fa_off + t * 8192 + mi * 512);
-      // small products first; (ta, tb): x3 w1, x2 w2, x1 w3, x2 w1, x1 w2, x1 w1
-#define GX_MM(ta, tb)                                                                                   \
-  acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ta], bf[0][tb], acc[mi][0], 0, 0, 0);        \
-  acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ta], bf[1][tb], acc[mi][1], 0, 0, 0);
+      for (int t = 0; t < 3; ++t) bf[t] = *reinterpret_cast<const gx_bf8*>(sb + fb_off + t * 8192 + nj * 512);
+      if (nj == 0 || nj == 2) {   // the split of one M tile of the next stage rides on this group's MFMAs
+        const int mi = nj >> 1;
+        if (DBG & 8) { an[mi][0] = raw[mi][0]; an[mi][1] = raw[mi][1]; an[mi][2] = raw[mi][0]; }
+        else gx_split8(__builtin_bit_cast(float4, raw[mi][0]), __builtin_bit_cast(float4, raw[mi][1]), an[mi]);
+      }
+      // small products first; (ta, tb): x3 w1, x2 w2, x1 w3, x2 w1, x1 w2, x1 w1; the two M tiles alternate (dependent MFMAs 64 cycles apart)
+#define GX_MM(ta, tb)                                                                                    \
+  if (DBG & 4) { acc[0][nj][0] += (float)af[0][ta][0] * (float)bf[tb][0]; acc[1][nj][0] += (float)af[1][ta][1] * (float)bf[tb][1]; } else {            \
+  acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ta], bf[tb], acc[0][nj], 0, 0, 0);         \
+  acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ta], bf[tb], acc[1][nj], 0, 0, 0); }
       GX_MM(2, 0) GX_MM(1, 1) GX_MM(0, 2) GX_MM(1, 0) GX_MM(0, 1) GX_MM(0, 0)
 #undef GX_MM
+      if (nj == 0 || nj == 2) {   // one MFMA (32 cycles of the SIMD's matrix pipe), four VALU of the split
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) write_a(ra, cur ^ 1);
-    __syncthreads();
+    // stage ks + 2 must have landed for everyone: my own DMA of it is older than the 5 instructions of stage ks + 3 just issued.  lgkmcnt(0): this
+    // wave's LDS reads of the current buffer have RETURNED before it lets the others go on to overwrite it
+    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) af[mi][t] = an[mi][t];
+    cur = nxt;
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped DMAs of the last iterations
   // ---- epilogue: accumulator register r of tile (mi, nj) = row (r & 3) + 8 (r >> 2) + 4 kh, column li
 #pragma unroll
-  for (int nj = 0; nj < 2; ++nj) {
-    const int n = n0 + wn * 64 + nj * 32 + li;
+  for (int nj = 0; nj < 4; ++nj) {
+    const int n = n0 + wn * 128 + nj * 32 + li;
     const bool nok = n < a.N;
     const float bv = (a.has_bias && nok) ? bias[n] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const long long m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         float v = acc[mi][nj][r] + bv;
         if (a.epilogue == 1) v = gx_gelu(v);
         if (nok && m < a.M) Y[m * (long long)a.N + n] = v;
@@ -194,10 +269,10 @@ __global__ __launch_bounds__(256) void k_gemm_x3_pack_w(const float* __restrict_
     gx_split(v, w1[j], w2[j], w3[j]);
   }
   const int ntile = n / GX_BN, nl = n - ntile * GX_BN, ks = c >> 1, khf = c & 1;
-  uint4* base = img + ((size_t)ntile * (K / 16) + ks) * (GX_STAGE_HALF / 16) + khf * 256 + nl;
-  base[0 * 512] = make_uint4(gx_pack(w1[0], w1[1]), gx_pack(w1[2], w1[3]), gx_pack(w1[4], w1[5]), gx_pack(w1[6], w1[7]));
-  base[1 * 512] = make_uint4(gx_pack(w2[0], w2[1]), gx_pack(w2[2], w2[3]), gx_pack(w2[4], w2[5]), gx_pack(w2[6], w2[7]));
-  base[2 * 512] = make_uint4(gx_pack(w3[0], w3[1]), gx_pack(w3[2], w3[3]), gx_pack(w3[4], w3[5]), gx_pack(w3[6], w3[7]));
+  uint4* base = img + ((size_t)ntile * (K / 16) + ks) * (GX_STAGE_HALF / 16) + khf * GX_BN + nl;
+  base[0 * 2 * GX_BN] = make_uint4(gx_pack(w1[0], w1[1]), gx_pack(w1[2], w1[3]), gx_pack(w1[4], w1[5]), gx_pack(w1[6], w1[7]));
+  base[1 * 2 * GX_BN] = make_uint4(gx_pack(w2[0], w2[1]), gx_pack(w2[2], w2[3]), gx_pack(w2[4], w2[5]), gx_pack(w2[6], w2[7]));
+  base[2 * 2 * GX_BN] = make_uint4(gx_pack(w3[0], w3[1]), gx_pack(w3[2], w3[3]), gx_pack(w3[4], w3[5]), gx_pack(w3[6], w3[7]));
 }
 
 long long vd_gemm_x3_weight_bytes(int N, int K) {
@@ -218,16 +293,29 @@ bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const 
   if (M < 1 || vd_gemm_x3_weight_bytes(N, K) < 0 || epilogue < 0 || epilogue > 1) return false;
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(wimg) & 15)) return false;
   static bool attr_set = false;   // idempotent: a race between two first calls sets the same value twice
+  static int dbg = 0;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16x3), hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16x3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
+#ifdef VD_GEMM_ABLATE
+    for (const void* f : {reinterpret_cast<const void*>(k_gemm_bf16x3<1>), reinterpret_cast<const void*>(k_gemm_bf16x3<2>), reinterpret_cast<const void*>(k_gemm_bf16x3<4>),
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<8>), reinterpret_cast<const void*>(k_gemm_bf16x3<5>), reinterpret_cast<const void*>(k_gemm_bf16x3<3>)})
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
+    dbg = getenv("VD3D_GEMM_DBG") ? atoi(getenv("VD3D_GEMM_DBG")) : 0;
+#endif
     attr_set = true;
   }
   vd_gx_args a;
   a.M = M; a.K = K; a.N = N; a.KS = K / 16;
   a.nbm = (int)((M + GX_BM - 1) / GX_BM); a.nbn = (N + GX_BN - 1) / GX_BN;
   a.epilogue = epilogue; a.has_bias = bias ? 1 : 0;
-  const int per_xcd = (a.nbm + 7) / 8, groups = (per_xcd + 3) / 4;
-  const unsigned grid = 8u * (unsigned)groups * 4u * (unsigned)a.nbn;
-  hipLaunchKernelGGL(k_gemm_bf16x3, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a);
+  const int per_xcd = (a.nbm + 7) / 8, groups = (per_xcd + GX_MG - 1) / GX_MG;
+  const unsigned grid = 8u * (unsigned)groups * (unsigned)GX_MG * (unsigned)a.nbn;
+#ifdef VD_GEMM_ABLATE
+#define GX_L(D) hipLaunchKernelGGL(k_gemm_bf16x3<D>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a)
+  switch (dbg) { case 1: GX_L(1); return true; case 2: GX_L(2); return true; case 4: GX_L(4); return true; case 8: GX_L(8); return true; case 5: GX_L(5); return true;
+                 case 3: GX_L(3); return true; default: break; }
+#endif
+  (void)dbg;
+  hipLaunchKernelGGL(k_gemm_bf16x3<0>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a);
   return true;
 }
