@@ -396,6 +396,13 @@ int vd3d_add_layernorm(vd3d_ctx* ctx, int dtype, const void* x, const void* y_or
  * on gfx950, which has no TF32).  The weights are split and packed once: vd3d_gemm_x3_weight_bytes(N, K) bytes (< 0: K is not a positive multiple of
  * 16), filled by vd3d_gemm_x3_pack_weights; the image is opaque and only valid for this library version.  NaN / Inf inputs give NaN. */
 enum { VD3D_GEMM_EPI_NONE = 0, VD3D_GEMM_EPI_GELU = 1 };
+/* The attention of the same blocks in the same arithmetic: out[b][t][h][:] = softmax_t'(q[b][t][h] . k[b][t'][h] * scale) v[b][t'][h] with
+ * q / k / v = qkv[b][t][0 / 1 / 2][h][:], qkv the contiguous float32 output [B][T][3][H][D] of the fused QKV linear, out [B][T][H][D] float32.
+ * Q, K, V and the probabilities are split exactly into three bf16 terms, both matrix products run as six bf16 MFMA products per MAC with float32
+ * accumulation, the online softmax is float32 (exp2 of the pre-scaled logits).  D = 64 only (every DINOv2 size), else VD3D_E_UNSUPPORTED.
+ * `workspace`: vd3d_attention_x3_workspace_bytes(B, T, H, D) bytes of device memory (the split images), 16-byte aligned, owned by the caller. */
+int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D);
+int vd3d_attention_x3(vd3d_ctx* ctx, const float* qkv, int B, int T, int H, int D, float scale, void* workspace, int64_t workspace_bytes, float* out);
 int64_t vd3d_gemm_x3_weight_bytes(int N, int K);
 int vd3d_gemm_x3_pack_weights(vd3d_ctx* ctx, const float* W, int N, int K, void* image);
 int vd3d_gemm_x3(vd3d_ctx* ctx, const float* X, int64_t M, int K, const void* w_image, int N, const float* bias_or_null, int epilogue, float* Y);

@@ -1445,6 +1445,19 @@ VD3D_EXPORT int vd3d_add_layernorm(vd3d_ctx* c, int dtype, const void* x, const 
   return 0;
 }
 
+VD3D_EXPORT int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D) { return (int64_t)vd_attn_x3_workspace_bytes(B, T, H, D); }
+
+VD3D_EXPORT int vd3d_attention_x3(vd3d_ctx* c, const float* qkv, int B, int T, int H, int D, float scale, void* workspace, int64_t workspace_bytes, float* out) {
+  if (!c || !qkv || !workspace || !out) return set_err(VD3D_E_INVALID, "bad argument");
+  const long long need = vd_attn_x3_workspace_bytes(B, T, H, D);
+  if (need < 0) return set_err(VD3D_E_UNSUPPORTED, "attention_x3: head size %d not built (64), or an empty shape (B %d T %d H %d)", D, B, T, H);
+  if (workspace_bytes < need) return set_err(VD3D_E_INVALID, "attention_x3: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, need);
+  if (!vd_launch_attn_x3(c->stream, qkv, B, T, H, D, scale, workspace, out))
+    return set_err(VD3D_E_UNSUPPORTED, "attention_x3: qkv / workspace / out must be 16-byte aligned, B * H <= 65535");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int64_t vd3d_gemm_x3_weight_bytes(int N, int K) { return (int64_t)vd_gemm_x3_weight_bytes(N, K); }
 
 VD3D_EXPORT int vd3d_gemm_x3_pack_weights(vd3d_ctx* c, const float* W, int N, int K, void* image) {

@@ -1,0 +1,303 @@
+// vd3d_attn.hip -- softmax(Q K^T * scale) V of the depth network's transformer blocks (boundary B3, core/render_depth.py:1106-1119: float32 through the
+// Hugging Face pipeline) with BOTH matrix products as split-bf16 MFMA work -- the attention half of the opt-in `gemm="bf16x3"` mode (round 6; the
+// default mode keeps PyTorch's scaled_dot_product_attention = AOTriton's float32 kernel, 98 TFLOP/s on gfx950, whose float32-input MFMA runs at 1/16 of
+// the bf16 rate).  Same arithmetic idea as vd3d_gemm.hip: every float32 operand (Q, K, V and the probabilities P) is split EXACTLY into three bf16
+// terms, six of the nine term products go through v_mfma_f32_32x32x16_bf16 with float32 accumulation (the dropped ones are <= 2^-23 of a product);
+// the softmax itself is float32 (running maximum / sum, exp2 of the pre-scaled logits by v_exp_f32).
+//
+// Two kernels per call:
+//   k_attn_x3_prep   qkv [B][T][3][H][64] float32 (the fused QKV linear's output) -> three split + packed images, rows past T zero:
+//       Q  [b h][q block 32][k-step 4][term 3][k-half 2][q 32][8 bf16]       (B-operand fragments, read once per wave straight into registers)
+//       K  [b h][kv tile 64][k-step 4][term 3][k-half 2][kv 64][8 bf16]      (A-operand fragments of S^T = K Q^T; 24 KB per tile, contiguous)
+//       V^T[b h][kv tile 64][k-step 4][term 3][k-half 2][d 64][8 bf16]       (A-operand fragments of O^T = V^T P^T; the 16 kv slots of a k-step are
+//                                                                             PERMUTED to where the S^T accumulator leaves them, see below)
+//   k_attn_bf16x3    one workgroup = 256 queries of one (batch, head): 8 waves x 32 queries, 512 threads, two waves per SIMD.  Per 64-row KV tile
+//       (LDS-DMA into a ring of three 48 KB stages, two tiles ahead, counted vmcnt + raw s_barrier; a tile's six DMA instructions are dealt between the MFMA groups):
+//         S^T[kv 64][q 32] = K Q^T          2 M tiles x 4 k-steps x 6 products = 48 MFMAs.  TRANSPOSED on purpose: the accumulator layout (column =
+//                                            lane & 31 = the query, rows = kv in registers) makes every softmax reduction an IN-LANE loop over 32
+//                                            registers plus one exchange with lane ^ 32, and the per-query scalars (max, sum, rescale) per-lane values;
+//         online softmax                     z = s * (scale * log2 e), m' = max(m, max z), p = exp2(z - m'), l = l * exp2(m - m') + sum p, O *= exp2(m - m')
+//         O^T[d 64][q 32] += V^T P^T         P^T as the B operand comes straight out of the S^T accumulator registers: k-step j of M tile m uses registers
+//                                            8 j .. 8 j + 7, i.e. kv = 32 m + (e & 3) + 8 (2 j + (e >> 2)) + 4 (lane >> 5) for element e -- the order the
+//                                            V^T image is packed in.  No LDS round trip, no cross-lane movement.  2 x 4 x 6 = 48 MFMAs.
+//       Epilogue: O^T / l through LDS (272-byte rows: conflict-free 16-byte writes per query) to out[b][t][h][64] in 256-byte row segments.
+// Work per tile and wave: 96 MFMAs (3 072 cycles of a SIMD's matrix pipe) against ~500 VALU instructions (softmax + the exact split of 32
+// probabilities per lane).  A CU ingests 48 KB per tile = 8 bytes per matrix-pipe cycle: under its ~12 B / cycle vector-memory limit (with 128 queries
+// per workgroup it would be 16: the reason for the 8-wave workgroup).
+#include "vd3d_dev.h"
+#include "vd3d_kernels.h"
+
+typedef short at_bf8 __attribute__((ext_vector_type(8)));
+typedef float at_f16 __attribute__((ext_vector_type(16)));
+typedef uint32_t at_u4 __attribute__((ext_vector_type(4)));
+
+#define AT_D 64
+#define AT_BQ 256
+#define AT_BK 64
+#define AT_NT 512
+#define AT_TILE (4 * 3 * 2 * 64 * 16)        // one K or V^T tile image: 24 576 bytes
+#define AT_STAGE (2 * AT_TILE)                // K + V^T: 49 152
+#define AT_NSTAGE 3
+#define AT_LDS (AT_NSTAGE * AT_STAGE)         // 147 456
+#define AT_QBLK (4 * 3 * 2 * 32)              // uint4 per 32-query block of the Q image
+#define AT_OP 272                             // epilogue: bytes per query row in LDS (256 + 16)
+
+struct vd_at_args {
+  int B, H, T;
+  int nq32, nkv, nqb;        // 32-query blocks, 64-row KV tiles, 256-query workgroups per (b, h)
+  float c;                   // scale * log2(e)
+};
+
+VD_DEV void at_split(float a, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
+  t1 = __float_as_uint(a) & 0xffff0000u;
+  const float r1 = a - __uint_as_float(t1);
+  t2 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(t2);
+  t3 = __float_as_uint(r2);
+}
+VD_DEV uint32_t at_pack(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+VD_DEV void at_split8(const float v[8], at_bf8 out[3]) {
+  uint32_t t1[8], t2[8], t3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) at_split(v[e], t1[e], t2[e], t3[e]);
+  const at_u4 p1 = {at_pack(t1[0], t1[1]), at_pack(t1[2], t1[3]), at_pack(t1[4], t1[5]), at_pack(t1[6], t1[7])};
+  const at_u4 p2 = {at_pack(t2[0], t2[1]), at_pack(t2[2], t2[3]), at_pack(t2[4], t2[5]), at_pack(t2[6], t2[7])};
+  const at_u4 p3 = {at_pack(t3[0], t3[1]), at_pack(t3[2], t3[3]), at_pack(t3[4], t3[5]), at_pack(t3[6], t3[7])};
+  out[0] = __builtin_bit_cast(at_bf8, p1); out[1] = __builtin_bit_cast(at_bf8, p2); out[2] = __builtin_bit_cast(at_bf8, p3);
+}
+
+// ---- prep: one thread = 8 consecutive elements of one fragment chunk.  which 0 / 1 (Q, K): 8 consecutive d of one token; which 2 (V^T): the 8 kv slots
+// of one (k-step, k-half) at one d.
+__global__ __launch_bounds__(256) void k_attn_x3_prep(const float* __restrict__ qkv, vd_at_args a, uint4* __restrict__ Qimg, uint4* __restrict__ Kimg,
+                                                      uint4* __restrict__ Vimg) {
+  const int which = blockIdx.z, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int t_id = blockIdx.x * 256 + threadIdx.x;
+  const size_t tok_stride = (size_t)3 * a.H * AT_D;
+  float v[8];
+  uint4* dst;
+  if (which < 2) {
+    const int rows = which == 0 ? a.nq32 * 32 : a.nkv * 64;
+    const int t = t_id >> 3, c = t_id & 7;       // token, chunk of 8 d
+    if (t >= rows) return;
+    if (t < a.T) {
+      const float* src = qkv + ((size_t)b * a.T + t) * tok_stride + (size_t)which * a.H * AT_D + h * AT_D + c * 8;
+      const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    const int ks = c >> 1, kh = c & 1;
+    if (which == 0) dst = Qimg + ((size_t)bh * a.nq32 + (t >> 5)) * AT_QBLK + (size_t)((ks * 3) * 2 + kh) * 32 + (t & 31);
+    else dst = Kimg + ((size_t)bh * a.nkv + (t >> 6)) * (AT_TILE / 16) + (size_t)((ks * 3) * 2 + kh) * 64 + (t & 63);
+    at_bf8 o[3];
+    at_split8(v, o);
+    const int ts = which == 0 ? 2 * 32 : 2 * 64;   // term stride in uint4
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) dst[(size_t)t3 * ts] = __builtin_bit_cast(uint4, o[t3]);
+  } else {
+    // V^T: thread = (kv tile, k-step, k-half, d); d fastest so that a wave reads 64 consecutive floats of a token row
+    const int d = t_id & 63, kh = (t_id >> 6) & 1, ks = (t_id >> 7) & 3, tile = t_id >> 9;
+    if (tile >= a.nkv) return;
+    const int m = ks >> 1, j = ks & 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kv = tile * 64 + 32 * m + (e & 3) + 8 * (2 * j + (e >> 2)) + 4 * kh;
+      v[e] = kv < a.T ? qkv[((size_t)b * a.T + kv) * tok_stride + (size_t)2 * a.H * AT_D + h * AT_D + d] : 0.f;
+    }
+    at_bf8 o[3];
+    at_split8(v, o);
+    dst = Vimg + ((size_t)bh * a.nkv + tile) * (AT_TILE / 16) + (size_t)((ks * 3) * 2 + kh) * 64 + d;
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) dst[(size_t)t3 * 128] = __builtin_bit_cast(uint4, o[t3]);
+  }
+}
+
+typedef __attribute__((address_space(3))) void* at_lds_vp;
+typedef const __attribute__((address_space(1))) void* at_glb_vp;
+
+// six products (small first: x3 w1, x2 w2, x1 w3, x2 w1, x1 w2, x1 w1) into TWO accumulators that share the B operand, alternating: dependent MFMAs 64 cycles apart
+#define AT_MM1(ACC0, AF0, ACC1, AF1, BF, ta, tb)                                               \
+  ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF0[ta], BF[tb], ACC0, 0, 0, 0);              \
+  ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF1[ta], BF[tb], ACC1, 0, 0, 0);
+#define AT_MM6(ACC0, AF0, ACC1, AF1, BF)                                                       \
+  AT_MM1(ACC0, AF0, ACC1, AF1, BF, 2, 0) AT_MM1(ACC0, AF0, ACC1, AF1, BF, 1, 1) AT_MM1(ACC0, AF0, ACC1, AF1, BF, 0, 2)                               \
+  AT_MM1(ACC0, AF0, ACC1, AF1, BF, 1, 0) AT_MM1(ACC0, AF0, ACC1, AF1, BF, 0, 1) AT_MM1(ACC0, AF0, ACC1, AF1, BF, 0, 0)
+
+__global__ __launch_bounds__(AT_NT) void k_attn_bf16x3(const uint4* __restrict__ Qimg, const uint4* __restrict__ Kimg, const uint4* __restrict__ Vimg,
+                                                       float* __restrict__ out, vd_at_args a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t at_lds[];   // the only LDS object (see vd3d_gemm.hip)
+  // workgroups of one (b, h) share its K / V^T images: keep them on one XCD (workgroup id mod 8; speed only)
+  int bh, qb;
+  {
+    const int wg = blockIdx.x, x = wg & 7, idx = wg >> 3;
+    const int g = idx / a.nqb;
+    qb = idx - g * a.nqb;
+    bh = g * 8 + x;
+    if (bh >= a.B * a.H) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int q0 = qb * AT_BQ + wave * 32;                 // first query of this wave
+  const int wave_base = (tid & ~63) * 16;
+
+  // Q fragments of the wave's 32 queries (zero rows past T: the image is padded to whole 32-query blocks; a wave past the last block reads block nq32 - 1 and
+  // stores nothing)
+  at_bf8 qf[4][3];
+  {
+    const int blk = min(q0 >> 5, a.nq32 - 1);
+    const uint4* qp = Qimg + ((size_t)bh * a.nq32 + blk) * AT_QBLK + kh * 32 + li;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) qf[ks][t] = __builtin_bit_cast(at_bf8, qp[(ks * 3 + t) * 64]);
+  }
+  const uint4* kimg = Kimg + (size_t)bh * a.nkv * (AT_TILE / 16) + tid;
+  const uint4* vimg = Vimg + (size_t)bh * a.nkv * (AT_TILE / 16) + tid;
+  // one DMA instruction of a tile: pieces 0 .. 2 = K, 3 .. 5 = V^T (3 x 512 x 16 bytes each)
+  auto dma = [&](int tile, int buf, int piece) {
+    const uint4* src = (piece < 3 ? kimg : vimg) + (size_t)tile * (AT_TILE / 16) + (piece % 3) * AT_NT;
+    uint8_t* dst = at_lds + buf * AT_STAGE + (piece < 3 ? 0 : AT_TILE) + (piece % 3) * (AT_NT * 16) + wave_base;
+    __builtin_amdgcn_global_load_lds((at_glb_vp)src, (at_lds_vp)dst, 16, 0, 0);
+  };
+
+  at_f16 oacc[2];
+#pragma unroll
+  for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dm][r] = 0.f;
+  float m_run = -INFINITY, l_half = 0.f;
+
+#pragma unroll
+  for (int p = 0; p < 6; ++p) dma(0, 0, p);
+#pragma unroll
+  for (int p = 0; p < 6; ++p) dma(a.nkv > 1 ? 1 : 0, 1, p);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed, tile 1 in flight
+  __builtin_amdgcn_s_barrier();
+
+  const int frag_off = (kh * 64 + li) * 16;     // + ((ks * 3 + t) * 2) * 1024 + m * 512
+  int cur = 0;
+  for (int it = 0; it < a.nkv; ++it) {
+    // tile it + 2 goes into the buffer tile it - 1 was read from (every wave passed the barrier that ended iteration it - 1 after its last read of it); behind
+    // the last tile the DMA re-fetches tile nkv - 1 into a buffer nobody reads again: straight-line code with ONE counted wait per iteration
+    const int nt = it + 2 < a.nkv ? it + 2 : a.nkv - 1, nb = cur >= 1 ? cur - 1 : 2;   // (cur + 2) % 3
+    const uint8_t* sk = at_lds + cur * AT_STAGE;
+    const uint8_t* sv = sk + AT_TILE;
+    // ---- S^T = K Q^T
+    at_f16 sacc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[m][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) { dma(nt, nb, ks); __builtin_amdgcn_sched_barrier(0); }
+      at_bf8 kf[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) kf[m][t] = *reinterpret_cast<const at_bf8*>(sk + frag_off + ((ks * 3 + t) * 2) * 1024 + m * 512);
+      AT_MM6(sacc[0], kf[0], sacc[1], kf[1], qf[ks])
+      if (ks < 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- online softmax (in-lane over the 32 kv values this lane holds for its query; the other 32 sit in lane ^ 32)
+    float z[2][16];
+    float mx = -INFINITY;
+    const bool last = (it + 1) * AT_BK > a.T;   // uniform: only the last tile can hold rows past T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = sacc[m][r] * a.c;
+        if (last && it * AT_BK + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh >= a.T) v = -INFINITY;
+        z[m][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { z[m][r] = __builtin_amdgcn_exp2f(z[m][r] - m_new); ps += z[m][r]; }
+    l_half = l_half * alpha + ps;
+#pragma unroll
+    for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dm][r] *= alpha;
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) { dma(nt, nb, 3 + ks); __builtin_amdgcn_sched_barrier(0); }
+      const int m = ks >> 1, j = ks & 1;
+      at_bf8 pf[3];
+      at_split8(&z[m][8 * j], pf);
+      at_bf8 vf[2][3];
+#pragma unroll
+      for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) vf[dm][t] = *reinterpret_cast<const at_bf8*>(sv + frag_off + ((ks * 3 + t) * 2) * 1024 + dm * 512);
+      AT_MM6(oacc[0], vf[0], oacc[1], vf[1], pf)
+      if (ks < 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // tile it + 1 has landed for everyone (my own DMA of it is older than the six instructions of tile it + 2 just issued), and this wave's LDS reads of
+    // the current tile have returned, before anybody overwrites it
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetches of the last iterations have landed ...
+  __builtin_amdgcn_s_barrier();                        // ... everybody's, before the epilogue re-uses the ring
+
+  // ---- epilogue: O^T / l -> LDS [q 32 per wave][d 64] with 272-byte rows -> out[b][t][h][d]
+  const float l_tot = l_half + __shfl_xor(l_half, 32, 64);
+  const float inv = 1.0f / l_tot;
+  uint8_t* ow = at_lds + wave * (32 * AT_OP);
+#pragma unroll
+  for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v4 = {oacc[dm][4 * g] * inv, oacc[dm][4 * g + 1] * inv, oacc[dm][4 * g + 2] * inv, oacc[dm][4 * g + 3] * inv};
+      *reinterpret_cast<float4*>(ow + li * AT_OP + (32 * dm + 8 * g + 4 * kh) * 4) = v4;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own wave's rows only: no barrier needed (wave-private region; LDS ops of a wave complete in order)
+  const int b = bh / a.H, h = bh - b * a.H;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = i * 4 + (lane >> 4), c4 = lane & 15;   // 16 lanes x 16 bytes = one query's 256 bytes
+    const int q = q0 + row;
+    const float4 v4 = *reinterpret_cast<const float4*>(ow + row * AT_OP + c4 * 16);
+    if (q < a.T) *reinterpret_cast<float4*>(out + (((size_t)b * a.T + q) * a.H + h) * AT_D + c4 * 4) = v4;
+  }
+}
+
+long long vd_attn_x3_workspace_bytes(int B, int T, int H, int D) {
+  if (B < 1 || T < 1 || H < 1 || D != AT_D) return -1;
+  const long long nq32 = (T + 31) / 32, nkv = (T + AT_BK - 1) / AT_BK;
+  return (long long)B * H * (nq32 * AT_QBLK * 16 + 2 * nkv * (long long)AT_TILE);
+}
+
+bool vd_launch_attn_x3(hipStream_t s, const float* qkv, int B, int T, int H, int D, float scale, void* ws, float* out) {
+  if (vd_attn_x3_workspace_bytes(B, T, H, D) < 0) return false;
+  if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return false;
+  if ((long long)B * H > 65535) return false;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bf16x3), hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS) != hipSuccess) return false;
+    attr_set = true;
+  }
+  vd_at_args a;
+  a.B = B; a.H = H; a.T = T;
+  a.nq32 = (T + 31) / 32; a.nkv = (T + AT_BK - 1) / AT_BK; a.nqb = (T + AT_BQ - 1) / AT_BQ;
+  a.c = scale * 1.44269504088896340736f;
+  uint4* Qimg = reinterpret_cast<uint4*>(ws);
+  uint4* Kimg = Qimg + (size_t)B * H * a.nq32 * AT_QBLK;
+  uint4* Vimg = Kimg + (size_t)B * H * a.nkv * (AT_TILE / 16);
+  const int rows_max = a.nkv * 64 > a.nq32 * 32 ? a.nkv * 64 : a.nq32 * 32;   // Q / K: rows * 8 threads; V^T: tiles * 512 threads = the same count
+  hipLaunchKernelGGL(k_attn_x3_prep, dim3((unsigned)((rows_max * 8 + 255) / 256), (unsigned)(B * H), 3), dim3(256), 0, s, qkv, a, Qimg, Kimg, Vimg);
+  const int groups = (B * H + 7) / 8;
+  hipLaunchKernelGGL(k_attn_bf16x3, dim3((unsigned)(8 * groups * a.nqb)), dim3(AT_NT), AT_LDS, s, Qimg, Kimg, Vimg, out, a);
+  return true;
+}

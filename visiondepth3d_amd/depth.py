@@ -153,7 +153,7 @@ class DepthPipe:
         ``gemm`` (float32 + ``renderer`` only; round 6): ``"f32"`` (default) -- the four linears of every transformer block are hipBLASLt's float32
         GEMMs; ``"bf16x3"`` -- OPT-IN: the library's own split-bf16 GEMM (``vd3d_gemm_x3``: every float32 operand exactly split into three bf16
         terms, six products per MAC on the bf16 matrix cores, float32 accumulation -- float32-faithful, see include/vd3d.h), with the exact GELU
-        folded into fc1's epilogue.  gfx950 has no TF32 and its float32-input MFMA runs at 1/16 of the bf16 rate, which caps the default mode.
+        folded into fc1's epilogue, and the attention in the same arithmetic (``vd3d_attention_x3``: both products split-bf16, float32 online softmax).  gfx950 has no TF32 and its float32-input MFMA runs at 1/16 of the bf16 rate, which caps the default mode.
         ``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream); when given the
         image-processor front end, the residual-add + LayerNorm pairs and the DPT up-samplings run as fused HIP launches.
         ``model`` / ``processor``: an already constructed Hugging Face depth model and its image-processor constants
@@ -431,10 +431,14 @@ class DepthPipe:
                     lin = lambda t, key, bias, gelu=False: R.linear_x3(t if t.is_contiguous() else t.contiguous(), x3[key][0], x3[key][1], bias, gelu=gelu)
                     h = stash["h"] if stash["x"] is x else R.add_layernorm(x, None, n1)[1]
                     stash["x"] = stash["h"] = None
-                    qkv = lin(h, "qkv", bqkv).view(B, T, 3, nh, hd)
-                    Tk = pad_state["T"] or T
-                    q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :Tk, 1].transpose(1, 2), qkv[:, :Tk, 2].transpose(1, 2)
-                    o = F.scaled_dot_product_attention(q, k, v, scale=scaling).transpose(1, 2).reshape(B, T, d)
+                    qkv = lin(h, "qkv", bqkv)
+                    if hd == 64 and not pad_state["T"]:   # the library's split-bf16 attention (every DINOv2 size has 64-wide heads)
+                        o = R.attention_x3(qkv, nh, scaling)
+                    else:
+                        qkv = qkv.view(B, T, 3, nh, hd)
+                        Tk = pad_state["T"] or T
+                        q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :Tk, 1].transpose(1, 2), qkv[:, :Tk, 2].transpose(1, 2)
+                        o = F.scaled_dot_product_attention(q, k, v, scale=scaling).transpose(1, 2).reshape(B, T, d)
                     a = lin(o, "wo", bo)
                     x, h = R.add_layernorm(x, a, n2)
                     hid = lin(h, "fc1", fc1.bias, gelu=True) if x3["gelu"] else act(lin(h, "fc1", fc1.bias))

@@ -623,6 +623,24 @@ class Renderer:
         _lib.check(self._L.vd3d_gemm_x3(self._ctx, _ptr(x), M, K, _ptr(w_image), int(N), _ptr(bias) if bias is not None else None, 1 if gelu else 0, _ptr(out)))
         return out
 
+    def attention_x3(self, qkv: torch.Tensor, n_heads: int, scale: float) -> torch.Tensor:
+        """softmax(q k^T * scale) v for the contiguous float32 output ``qkv`` [B, T, 3 * H * 64] of a fused QKV linear (q / k / v = the three [H, 64] blocks of
+        a token) -> [B, T, H * 64] float32; both products as split-bf16 MFMA work (include/vd3d.h vd3d_attention_x3)."""
+        B, T, C3 = qkv.shape
+        D = C3 // (3 * n_heads)
+        if qkv.dtype != torch.float32 or not qkv.is_contiguous() or D * 3 * n_heads != C3:
+            raise AssertionError("qkv must be contiguous float32 [B, T, 3 * H * D]")
+        nb = int(self._L.vd3d_attention_x3_workspace_bytes(B, T, n_heads, D))
+        if nb < 0:
+            raise NotImplementedError(f"attention_x3: head size {D} not built")
+        ws = getattr(self, "_attn_ws", None)
+        if ws is None or ws.numel() < nb:   # one workspace per renderer, grown on demand (calls are ordered on the renderer's stream)
+            ws = self._attn_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, T, n_heads * D), dtype=torch.float32, device=self.device)
+        self._enter(qkv, ws, out)
+        _lib.check(self._L.vd3d_attention_x3(self._ctx, _ptr(qkv), B, T, n_heads, D, float(scale), _ptr(ws), ws.numel(), _ptr(out)))
+        return out
+
     def upsample_bilinear(self, x: torch.Tensor, size) -> torch.Tensor:
         """F.interpolate(x, size, mode="bilinear", align_corners=True) for a float32 / bf16 channels_last [B,C,h,w] tensor."""
         B, Cc, ih, iw = x.shape
