@@ -23,10 +23,14 @@
 //   B (weights) is split and packed ONCE per model (k_gemm_x3_pack_w) into the stage image [N tile][K step][term 3][k-half 2][n 256][8 bf16]:
 //     24 KB of contiguous global memory per stage.
 //   Stage = 40 KB, ring = 160 KB = the whole LDS of a CU: one workgroup per CU.
-// (Measured, round 6, M = 39 088, K = 768: a first version with A split in registers BEFORE the LDS write -- global loads one stage ahead, 12 ds_write
-// per thread and stage, one __syncthreads() per stage, double buffer -- reached 157 - 204 TFLOP/s float32-equivalent = 0.94 - 1.22 PFLOP/s of MFMA
-// work; with 256 x 128 tiles and two workgroups per CU 153 - 182: the staging pass and the barrier drain, not the epilogue, were what idled the
-// matrix cores.)
+// Measured (round 6, MI355X, M = 39 088 = 16 frames x 2 443 tokens, tools/probe_gemm_x3.py): 162 (K 768, N 2304) .. 204 (K 3072, N 768) TFLOP/s
+// float32-equivalent = 0.97 - 1.22 PFLOP/s of bf16 MFMA work, against 114 - 128 TFLOP/s for hipBLASLt's float32 GEMM on the same shapes; one DA-V2-Base
+// layer 3.15 ms against 4.59.  Timing ablations of this kernel (tools/ablate_gemm.sh, K 768 / N 2304, 0.855 ms): MFMAs + fragment reads alone 0.596 ms
+// (1.39 PFLOP/s: 72 % of the matrix peak at the 1.86 GHz the chip holds under this load, 10 % of it tile quantisation: 1 377 tiles on 256 CUs), + split
+// 0.627, + stores 0.682; the DMAs alone 0.347 ms.  The DMA cost that stays exposed (~0.17 ms) did not move with the issue pattern: all DMAs at the top
+// of the iteration 0.92, dealt between the MFMA groups 0.85, issued by one wave per SIMD only 0.85.  Earlier structures, for the record: A split in
+// registers before the LDS write (global loads one stage ahead, 12 ds_write per thread and stage, one __syncthreads() per stage, double buffer)
+// 0.86 - 0.92 ms; 256 x 128 tiles with two workgroups per CU 0.88; a three-stage ring with the split in front of its own MFMAs 0.92.
 // Tile order: workgroup b runs on XCD b % 8 (speed assumption only): every XCD owns the M tiles mt = x (mod 8) and walks them four at a time across
 // all N tiles, so that the ~32 workgroups resident on an XCD share 4 A panels and 8 B panels through its L2.
 // Epilogue: + bias[n], optionally exact GELU (0.5 x (1 + erf(x / sqrt 2)), torch.nn.GELU()'s default form, float32 erff), float32 stores (each
@@ -83,7 +87,7 @@ VD_DEV float gx_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118
 typedef __attribute__((address_space(3))) void* gx_lds_vp;
 typedef const __attribute__((address_space(1))) void* gx_glb_vp;
 
-// DBG (development ablations, VD3D_GEMM_DBG; results are wrong): 1 no DMA, 2 no barrier, 4 no MFMA, 8 no A split
+// DBG (development ablations, VD3D_GEMM_DBG; results are wrong): 1 no DMA, 2 no barrier, 4 no MFMA, 8 no A split, 16 no stores
 template <int DBG>
 __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__ X, const uint4* __restrict__ Wimg, const float* __restrict__ bias,
                                                         float* __restrict__ Y, vd_gx_args a) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
         const long long m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         float v = acc[mi][nj][r] + bv;
         if (a.epilogue == 1) v = gx_gelu(v);
-        if (nok && m < a.M) Y[m * (long long)a.N + n] = v;
+        if (nok && m < a.M && (!(DBG & 16) || v == 12345.678f)) Y[m * (long long)a.N + n] = v;
       }
     }
   }
@@ -298,7 +302,8 @@ bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const 
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16x3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
 #ifdef VD_GEMM_ABLATE
     for (const void* f : {reinterpret_cast<const void*>(k_gemm_bf16x3<1>), reinterpret_cast<const void*>(k_gemm_bf16x3<2>), reinterpret_cast<const void*>(k_gemm_bf16x3<4>),
-                          reinterpret_cast<const void*>(k_gemm_bf16x3<8>), reinterpret_cast<const void*>(k_gemm_bf16x3<5>), reinterpret_cast<const void*>(k_gemm_bf16x3<3>)})
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<8>), reinterpret_cast<const void*>(k_gemm_bf16x3<5>), reinterpret_cast<const void*>(k_gemm_bf16x3<3>),
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<9>), reinterpret_cast<const void*>(k_gemm_bf16x3<11>), reinterpret_cast<const void*>(k_gemm_bf16x3<16>), reinterpret_cast<const void*>(k_gemm_bf16x3<27>)})
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
     dbg = getenv("VD3D_GEMM_DBG") ? atoi(getenv("VD3D_GEMM_DBG")) : 0;
 #endif
@@ -313,7 +318,7 @@ bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const 
 #ifdef VD_GEMM_ABLATE
 #define GX_L(D) hipLaunchKernelGGL(k_gemm_bf16x3<D>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a)
   switch (dbg) { case 1: GX_L(1); return true; case 2: GX_L(2); return true; case 4: GX_L(4); return true; case 8: GX_L(8); return true; case 5: GX_L(5); return true;
-                 case 3: GX_L(3); return true; default: break; }
+                 case 3: GX_L(3); return true; case 9: GX_L(9); return true; case 11: GX_L(11); return true; case 16: GX_L(16); return true; case 27: GX_L(27); return true; default: break; }
 #endif
   (void)dbg;
   hipLaunchKernelGGL(k_gemm_bf16x3<0>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a);
