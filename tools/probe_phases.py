@@ -12,6 +12,11 @@ from visiondepth3d_amd.render_3d import Renderer
 KW = dict(output_format="Half-SBS", fg_shift=10.0, mg_shift=-2.5, bg_shift=-5.0, sharpness_factor=0.15, dof_strength=2.0,
           feather_strength=10.0, blur_ksize=9, use_subject_tracking=True, use_floating_window=True)
 H, W = 2160, 3840
+if len(sys.argv) > 1 and sys.argv[1].startswith("gui"):   # round 6: the GUI's own defaults (no feathering: k_warp_fused<.., FEATHER = false>); "gui1080" at 1920x1080
+    KW = dict(output_format="Full-SBS", fg_shift=4.5, mg_shift=-1.5, bg_shift=-6.0, sharpness_factor=0.2, dof_strength=2.0, feather_strength=0.0,
+              blur_ksize=1, use_subject_tracking=True, use_floating_window=True, zero_parallax_strength=0.01)
+    if sys.argv[1] == "gui1080":
+        H, W = 1080, 1920
 R = Renderer(0)
 p = render_kwargs_to_params(W, H, output_height=H, **KW)
 frames, depths = synth.synth_clip(4, H, W)
