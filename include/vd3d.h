@@ -474,7 +474,13 @@ int vd3d_torch_math_aten(vd3d_ctx* ctx, int op, const float* x, double param, fl
  * "select_s1", "warp" (= "shift" + "w1", the fused warp kernel alone), "finish", "handoff", "advance", "pixel_shift", "stream_copy").  vd3d_last_stage_ms = average ms per call since
  * profiling was enabled (-1 if never seen); both getters synchronise. */
 int vd3d_set_profiling(vd3d_ctx* ctx, int enable);
-/* development probe: launch-shape knobs of the batched select chain (0: workgroup divisor per frame, 1: frames per P3 group, 2: W1 tile height 16 | 32, 3: routes of the finishing stage, bit 0 = fused kernel in front of a fit it does not take, bit 1 = its epilogue as the sharpen / fit / mux kernel behind the unfused DOF kernels; default 3, 4: 1 = feather_strength <= 0 still runs the mask / window-sum / blend kernels instead of the exact no-feather warp; default 0, 5: up-scale body convolution, < 0 = one tile per workgroup (the kernel of rounds 2 - 4), 0 .. 99 = persistent 32 x 16 kernel whose second workgroup per CU starts that many microseconds late, >= 100 = the 32 x 8 kernel with (value - 100) workgroups per CU; default -2 = by size, 6: fused finishing kernel, 0 = one tile per workgroup (default), k > 0 = the persistent kernel with k workgroups per CU); results never depend on them */
+/* Route selectors for parity tests and, in development libraries only, launch-policy knobs.  Results NEVER depend on any of them (tested).
+ * Product library: which = 3 -- routes of the finishing stage (bit 0: fused kernel in front of a fit it does not take, bit 1: its epilogue as the sharpen / fit /
+ * mux kernel behind the unfused DOF kernels; default 3) and which = 4 -- 1: feather_strength <= 0 still runs the mask / window-sum / blend kernels instead of the
+ * exact no-feather warp (default 0).  Process-wide plain switches: set them while no frame is in flight.  Every other knob (0 - 2, 5 - 9: tile heights and
+ * orders, chain grouping, the parked persistent kernels) returns VD3D_E_UNSUPPORTED unless the library was built with -DVD3D_DEV_KNOBS
+ * (bash tools/build_ab.sh dev -DVD3D_DEV_KNOBS); which = -1 queries that (0 = development knobs present).  The VD3D_TUNE environment variable of the Python
+ * loader is honoured by development libraries only. */
 int vd3d_debug_tune(int which, int value);
 float vd3d_last_stage_ms(vd3d_ctx* ctx, const char* stage);
 long vd3d_stage_calls(vd3d_ctx* ctx, const char* stage);

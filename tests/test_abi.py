@@ -63,3 +63,22 @@ def test_fails_loudly_without_gpu(L):
     from visiondepth3d_amd.render_3d import Renderer
     with pytest.raises(RuntimeError):
         Renderer()
+
+
+def test_product_library_has_no_development_knobs():
+    """Round 6: the product libvd3d_hip.so answers only the two route selectors the parity tests need; launch-policy knobs, the parked persistent
+    kernels and VD3D_TUNE exist in -DVD3D_DEV_KNOBS builds (tools/build_ab.sh) only.  Pure host calls: no GPU needed."""
+    from visiondepth3d_amd import _abi, _lib
+    L = _lib.lib()
+    if L.vd3d_debug_tune(-1, 0) == 0:
+        import pytest
+        pytest.skip("a development library is loaded (VD3D_LIB_PATH)")
+    assert L.vd3d_debug_tune(3, 3) == 0 and L.vd3d_debug_tune(4, 0) == 0
+    for knob in (0, 1, 2, 5, 6, 7, 8, 9):
+        assert L.vd3d_debug_tune(knob, 1) == _abi.E_UNSUPPORTED, knob
+    assert L.vd3d_debug_tune(77, 1) == _abi.E_INVALID
+    import subprocess, sys, os
+    env = dict(os.environ, VD3D_TUNE="8:0")
+    r = subprocess.run([sys.executable, "-c", "from visiondepth3d_amd import _lib; _lib.lib()"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode != 0 and "VD3D_DEV_KNOBS" in r.stderr

@@ -130,11 +130,15 @@ def lib():
     L.vd3d_render_params_default.argtypes = [C.POINTER(RenderParams)]
     if L.vd3d_abi_version() != _abi.ABI_VERSION:
         raise ImportError("libvd3d_hip.so ABI version mismatch")
-    # development probes: VD3D_TUNE="knob:value,knob:value" applies vd3d_debug_tune at load time (launch policies only: results never depend on them)
-    for kv in filter(None, os.environ.get("VD3D_TUNE", "").split(",")):
-        k, v = kv.split(":")
-        if L.vd3d_debug_tune(int(k), int(v)) != 0:
-            raise ImportError(f"VD3D_TUNE: unknown knob {k}")
+    # development probes: VD3D_TUNE="knob:value,knob:value" applies vd3d_debug_tune at load time -- only with a development library (-DVD3D_DEV_KNOBS,
+    # tools/build_ab.sh); the product library refuses the knobs and this loader says so instead of running an experiment that silently is not one
+    if os.environ.get("VD3D_TUNE"):
+        if L.vd3d_debug_tune(-1, 0) != 0:
+            raise ImportError("VD3D_TUNE is set but this libvd3d_hip.so was built without -DVD3D_DEV_KNOBS (bash tools/build_ab.sh dev -DVD3D_DEV_KNOBS; VD3D_LIB_PATH=...)")
+        for kv in filter(None, os.environ["VD3D_TUNE"].split(",")):
+            k, v = kv.split(":")
+            if L.vd3d_debug_tune(int(k), int(v)) != 0:
+                raise ImportError(f"VD3D_TUNE: unknown knob {k}")
     _lib = L
     return L
 

@@ -1639,12 +1639,19 @@ VD3D_EXPORT int vd3d_torch_math_aten(vd3d_ctx* c, int op, const float* x, double
 }
 
 // development probe (tools/probe_step.py): 0 = workgroup divisor of the batched chain kernels, 1 = frames per P3 group
+// Process-wide launch-policy switches.  The PRODUCT library keeps the two ROUTE selectors the parity tests use to prove that two code paths give the same
+// bytes (3: fused / unfused finishing routes, 4: the long way round feather_strength 0) -- plain ints written before any frame is in flight, read per call;
+// everything else (tile heights, tile orders, the parked persistent kernels, chain grouping) exists only in development libraries built with
+// -DVD3D_DEV_KNOBS (tools/build_ab.sh dev -DVD3D_DEV_KNOBS), and so does the VD3D_TUNE environment variable (round 6).
+// which == -1: query -- 0 when the development knobs are compiled in, VD3D_E_UNSUPPORTED when not.
 VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
+  if (which == 3) { g_fused_fit = value; return 0; }
+  if (which == 4) { g_feather0_long = value; return 0; }
+#ifdef VD3D_DEV_KNOBS
+  if (which == -1) return 0;
   if (which == 0) vd_set_batch_grid_div(value);
   else if (which == 1) g_chain_group = value;
   else if (which == 2) vd_set_warp_pre_th(value);
-  else if (which == 3) g_fused_fit = value;
-  else if (which == 4) g_feather0_long = value;
   else if (which == 5) vd_set_conv_mode(value);
   else if (which == 6) vd_set_finish_persist(value);
   else if (which == 7) vd_set_warp_nofeather_th(value);
@@ -1652,6 +1659,11 @@ VD3D_EXPORT int vd3d_debug_tune(int which, int value) {
   else if (which == 9) vd_set_warp_order(value);
   else return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
   return 0;
+#else
+  (void)value;
+  if (which == -1 || (which >= 0 && which <= 9)) return set_err(VD3D_E_UNSUPPORTED, "vd3d_debug_tune(%d): development knob, this library was built without -DVD3D_DEV_KNOBS", which);
+  return set_err(VD3D_E_INVALID, "vd3d_debug_tune: unknown knob %d", which);
+#endif
 }
 
 VD3D_EXPORT int vd3d_set_profiling(vd3d_ctx* c, int enable) {

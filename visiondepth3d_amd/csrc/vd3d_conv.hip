@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256, CV_TH == 16 ? 2 : 3) void k_conv3x3_c64(const 
 
 
 
+#ifdef VD3D_DEV_KNOBS   // round 6: the parked persistent variant (no gain, profiles/r05_conv_phases.md) is built only into development libraries
 // ================================================================================================================================
 // Round 5: the same layer as a PERSISTENT kernel (k_conv3x3_c64_p, the default; k_conv3x3_c64 above stays as the A/B reference and for
 // activations too small to fill the chip).  What round 2 - 4 measured: a workgroup's three phases -- tile load (HBM read), 288 MFMAs per wave,
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c64_p(const _Float16* __rest
     CV_STAMP(blockIdx.x, 8 * cv_iter);
   }
 }
+#endif   // VD3D_DEV_KNOBS
 
 // ================================================================================================================================
 // k_conv3x3_c64_s (round 5, second step): 32 x 8 tiles, THREE workgroups per CU.  What the phase stamps of the 32 x 16 kernels showed
@@ -528,8 +530,10 @@ bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS) != hipSuccess)
       return false;
+#ifdef VD3D_DEV_KNOBS
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64_p), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS) != hipSuccess)
       return false;
+#endif
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64_s), hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS) != hipSuccess)
       return false;
     if (hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu[dev] < 8) return false;
@@ -551,16 +555,19 @@ bool vd_launch_conv3x3_c64_f16(hipStream_t s, const void* x, int H, int W, const
       return true;
     }
   }
-  const int ntx = (W + CV_TW - 1) / CV_TW, nty = (H + CV_TH - 1) / CV_TH, ntiles = ntx * nty;
+  const int ntx = (W + CV_TW - 1) / CV_TW, nty = (H + CV_TH - 1) / CV_TH;
+#ifdef VD3D_DEV_KNOBS
+  const int ntiles = ntx * nty;
   const int slots = 2 * (n_cu[dev] & ~3);           // two 78 KB workgroups per CU; a multiple of 8: every XCD gets the same number
-  if (g_cv_mode < 0 || ntiles <= slots) {           // not more tiles than slots: nothing to loop over, nothing to skew
-    dim3 grid(ntx, nty);
-    hipLaunchKernelGGL(k_conv3x3_c64, grid, dim3(256), CV_LDS, s, (const _Float16*)x, H, W, (const uint4*)wfrag, bias, slope_or_null, (_Float16*)y);
+  if (!(g_cv_mode < 0 || ntiles <= slots)) {        // the parked persistent kernel (phase skew of g_cv_mode microseconds): development libraries only
+    const int per = (ntiles + 7) / 8;
+    hipLaunchKernelGGL(k_conv3x3_c64_p, dim3(slots), dim3(256), CV_LDS, s, (const _Float16*)x, H, W, (const uint4*)wfrag, bias, slope_or_null,
+                       (_Float16*)y, ntx, ntiles, per, cu_cnt[dev], (unsigned)(g_cv_mode * 100));
     return true;
   }
-  const int per = (ntiles + 7) / 8;
-  hipLaunchKernelGGL(k_conv3x3_c64_p, dim3(slots), dim3(256), CV_LDS, s, (const _Float16*)x, H, W, (const uint4*)wfrag, bias, slope_or_null,
-                     (_Float16*)y, ntx, ntiles, per, cu_cnt[dev], (unsigned)(g_cv_mode * 100));
+#endif
+  dim3 grid(ntx, nty);
+  hipLaunchKernelGGL(k_conv3x3_c64, grid, dim3(256), CV_LDS, s, (const _Float16*)x, H, W, (const uint4*)wfrag, bias, slope_or_null, (_Float16*)y);
   return true;
 }
 

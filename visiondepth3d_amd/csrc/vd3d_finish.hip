@@ -658,6 +658,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   VD_OCC_OUT(ff_occ);
 }
 
+#ifdef VD3D_DEV_KNOBS   // round 6: the parked persistent variant (measured 7 % slower, profiles/r05_e1_persistent.md) is built only into development libraries
 // ================================================================================================================================
 // Round 5: E1 as a PERSISTENT kernel (k_finish_fused_p; dense levels, 64x26 geometry: the default route; k_finish_fused above stays for the
 // separable levels, fit factor 4 and as the A/B reference, vd3d_debug_tune(6, 0)).  What round 4's stamps showed: 28 % of a workgroup's life is the
@@ -1011,6 +1012,7 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) __attribute__((amdgpu_waves_per_eu
     __syncthreads();   // epilogue done with gb / every wave past its levels; the DMA has landed (the compiler drains vmcnt before the barrier)
   }
 }
+#endif   // VD3D_DEV_KNOBS
 
 // The epilogue alone, for eyes that are graded already (k_dof_grade4's planes: Gaussians beyond the fused kernel's 9 taps): tile of graded dwords
 // straight from the u8 planes, then sharpen + fit + mux as above.  Replaces k_sharp_mux (one thread per output pixel, 120 byte loads each: 236 us
@@ -1110,6 +1112,7 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
   dim3 g;
   ff_grid(p, th, &a, &g);
   if (dense && !w2_dev) return false;
+#ifdef VD3D_DEV_KNOBS
   if (wide && g_ff_persist && a.xcd) {
     // persistent route: one workgroup per CU slot; three 51.7 KB workgroups of 512 threads fit a CU (80 VGPRs).  The grid is a multiple of 8, so a
     // workgroup's virtual blocks b, b + grid, ... stay on its XCD's tile rows.
@@ -1134,6 +1137,7 @@ bool vd_launch_finish_fused(hipStream_t s, const uint8_t* L, const uint8_t* R, c
       return true;
     }
   }
+#endif
   if (wide) hipLaunchKernelGGL((k_finish_fused<true, FF_WIDE_TH>), g, dim3(ff_geo<FF_WIDE_TH>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   else if (dense) hipLaunchKernelGGL((k_finish_fused<true, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
   else hipLaunchKernelGGL((k_finish_fused<false, 16>), g, dim3(ff_geo<16>::NT), 0, s, L, R, dn, fc, a, w, w2_dev, out);
