@@ -104,6 +104,19 @@ def test_attention_x3_is_float32_faithful(R, B, T, H):
     assert torch.equal(R.attention_x3(qkv.view(B, T, 3 * H * D), H, scale), out)   # no state between calls
 
 
+def test_attention_x3_full_batch_is_deterministic_under_load(R):
+    """A batch that fills the chip several times over (16 frames x 12 heads x 1370 tokens = 1 152 workgroups), five times in a row: identical bits every time, and
+    frame 0 equal to the same frame computed alone.  (The first software-pipelined version of the kernel let the DMA of K tile 3 overwrite K tile 0 while slower
+    waves were still reading it -- no barrier behind the prologue's S^T -- which showed on exactly this shape, under load, and nowhere in the small cases.)"""
+    B, T, H, D = 16, 1370, 12, 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    qkv = torch.randn(B, T, 3 * H * D, device="cuda", generator=g)
+    out = R.attention_x3(qkv, H, 0.125)
+    for _ in range(5):
+        assert torch.equal(R.attention_x3(qkv, H, 0.125), out)
+    assert torch.equal(R.attention_x3(qkv[:1].contiguous(), H, 0.125), out[:1])
+
+
 def test_attention_x3_known_answers(R):
     """(i) one key: softmax is 1, the output is v itself -- bit for bit (v = v1 + v2 + v3 exactly, p = 1).  (ii) identical keys: the output is the mean of the values
     (uniform probabilities 1 / T with T a power of two: exact).  (iii) a query that matches one key by a wide margin copies that key's value."""

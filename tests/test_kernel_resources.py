@@ -67,3 +67,15 @@ def test_scalar_tail_instantiations_leave_the_video_size_kernels_alone():
     cs_tails = next(v for n, v in k.items() if n.startswith("_Z13k_chain_shapeILb1E"))
     assert cs_plain["vgpr"] <= 52 and cs_plain["spill"] == 0, cs_plain
     assert cs_tails["spill"] == 0 and cs_tails["vgpr"] <= 128, cs_tails       # 1024 threads per workgroup: 4 waves per SIMD x 128 VGPRs
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_split_bf16_kernels_fit_two_waves_per_simd():
+    """Round 6: k_gemm_bf16x3 and k_attn_bf16x3 are 512-thread workgroups (two waves per SIMD: 256 registers each at most) that keep 128 / 64 accumulator registers
+    plus their fragments live across a software-pipelined loop -- one spilled register inside that loop would cost more than any schedule could win back."""
+    k = _census("vd3d_gemm.hip")
+    g = next(v for n, v in k.items() if n.startswith("_Z13k_gemm_bf16x3ILi0E"))
+    assert g["spill"] == 0 and g["vgpr"] <= 256, g
+    k = _census("vd3d_attn.hip")
+    a = next(v for n, v in k.items() if n.startswith("_Z13k_attn_bf16x3"))
+    assert a["spill"] == 0 and a["vgpr"] <= 256, a

@@ -12,7 +12,7 @@
 //       V^T[b h][kv tile 64][k-step 4][term 3][k-half 2][d 64][8 bf16]       (A-operand fragments of O^T = V^T P^T; the 16 kv slots of a k-step are
 //                                                                             PERMUTED to where the S^T accumulator leaves them, see below)
 //   k_attn_bf16x3    one workgroup = 256 queries of one (batch, head): 8 waves x 32 queries, 512 threads, two waves per SIMD.  Per 64-row KV tile
-//       (LDS-DMA into a ring of three 48 KB stages, two tiles ahead, counted vmcnt + raw s_barrier; a tile's six DMA instructions are dealt between the MFMA groups):
+//       (LDS-DMA into a ring of three 48 KB stages, K three and V^T two tiles ahead, counted vmcnt + raw s_barrier; S^T of tile it + 1 is issued beside the softmax of tile it):
 //         S^T[kv 64][q 32] = K Q^T          2 M tiles x 4 k-steps x 6 products = 48 MFMAs.  TRANSPOSED on purpose: the accumulator layout (column =
 //                                            lane & 31 = the query, rows = kv in registers) makes every softmax reduction an IN-LANE loop over 32
 //                                            registers plus one exchange with lane ^ 32, and the per-query scalars (max, sum, rescale) per-lane values;
@@ -168,86 +168,139 @@ __global__ __launch_bounds__(AT_NT) void k_attn_bf16x3(const uint4* __restrict__
     for (int r = 0; r < 16; ++r) oacc[dm][r] = 0.f;
   float m_run = -INFINITY, l_half = 0.f;
 
+  // Software pipeline INSIDE a wave: the S^T MFMAs of tile it + 1 are issued in the same straight-line region as the softmax VALU work of tile it (independent
+  // data: hipcc interleaves them, sched_group_barrier says how), then P V of tile it with the split of the next k-step's probabilities between its MFMAs.  A
+  // wave that alternated MFMA phases and VALU phases left the matrix pipe idle whenever both waves of a SIMD were in a VALU phase -- and the per-tile barrier
+  // keeps them in step (measured: 1.89 ms per DA-V2-Base call at 4K = 0.93 PFLOP/s of MFMA work).
+  // So K (t) is read in iteration t - 1 and V^T (t) in iteration t.  Stage s of the ring holds tile t with t % 3 == s; iteration it issues the DMA of K (it + 3)
+  // [its stage's K was last read in iteration it - 1] and of V^T (it + 2) [its stage's V^T was last read in iteration it - 1]; the wait at the end lets the six
+  // instructions just issued stay in flight and so guarantees K (it + 2) and V^T (it + 1), issued one iteration earlier.
+  const int last_tile = a.nkv - 1;
+  auto tile_c = [&](int t) { return t < last_tile ? t : last_tile; };   // behind the last tile: re-fetch it into a stage nobody reads again (straight-line code)
 #pragma unroll
-  for (int p = 0; p < 6; ++p) dma(0, 0, p);
+  for (int p = 0; p < 6; ++p) dma(0, 0, p);                 // K (0), V^T (0)
 #pragma unroll
-  for (int p = 0; p < 6; ++p) dma(a.nkv > 1 ? 1 : 0, 1, p);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed, tile 1 in flight
+  for (int p = 0; p < 3; ++p) dma(tile_c(1), 1, p);         // K (1)
+#pragma unroll
+  for (int p = 3; p < 6; ++p) dma(tile_c(1), 1, p);         // V^T (1)
+#pragma unroll
+  for (int p = 0; p < 3; ++p) dma(tile_c(2), 2, p);         // K (2)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // K (0), V^T (0), K (1) landed; V^T (1), K (2) in flight
   __builtin_amdgcn_s_barrier();
 
   const int frag_off = (kh * 64 + li) * 16;     // + ((ks * 3 + t) * 2) * 1024 + m * 512
-  int cur = 0;
-  for (int it = 0; it < a.nkv; ++it) {
-    // tile it + 2 goes into the buffer tile it - 1 was read from (every wave passed the barrier that ended iteration it - 1 after its last read of it); behind
-    // the last tile the DMA re-fetches tile nkv - 1 into a buffer nobody reads again: straight-line code with ONE counted wait per iteration
-    const int nt = it + 2 < a.nkv ? it + 2 : a.nkv - 1, nb = cur >= 1 ? cur - 1 : 2;   // (cur + 2) % 3
-    const uint8_t* sk = at_lds + cur * AT_STAGE;
-    const uint8_t* sv = sk + AT_TILE;
-    // ---- S^T = K Q^T
-    at_f16 sacc[2];
+  // one k-step (16 of the 64 head dimensions) of S^T for both 32-row M tiles: 6 fragment reads, 12 MFMAs
+  auto st_step = [&](const uint8_t* sk, int ks, at_f16 (&sa)[2]) {
+    at_bf8 kf[2][3];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[m][r] = 0.f;
+      for (int t = 0; t < 3; ++t) kf[m][t] = *reinterpret_cast<const at_bf8*>(sk + frag_off + ((ks * 3 + t) * 2) * 1024 + m * 512);
+    AT_MM6(sa[0], kf[0], sa[1], kf[1], qf[ks])
+  };
+  // hint for one pinned chunk: 12 x (one MFMA = 32 cycles of the SIMD's matrix pipe, then up to n VALU), the fragment reads first
+#define AT_CHUNK_HINT(n)                                           \
+  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);               \
+  _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+    __builtin_amdgcn_sched_group_barrier(0x002, n, 0);             \
+  }                                                                \
+  __builtin_amdgcn_sched_barrier(0);
+
+  at_f16 sacc[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) { dma(nt, nb, ks); __builtin_amdgcn_sched_barrier(0); }
-      at_bf8 kf[2][3];
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[m][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) st_step(at_lds, ks, sacc);   // S^T (0)
+  // the first iteration's DMA of K (3) overwrites K (0): every wave's reads of it have returned first (found the hard way: one shape in twenty, under load)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int cur = 0;
+  for (int it = 0; it < a.nkv; ++it) {
+    const int s1 = cur == 2 ? 0 : cur + 1, s2 = cur >= 1 ? cur - 1 : 2;   // stages of tiles it + 1 and it + 2 (= it - 1)
+    const uint8_t* sk1 = at_lds + s1 * AT_STAGE;
+    const uint8_t* sv = at_lds + cur * AT_STAGE + AT_TILE;
+    // ---- tile it: logits -> z (pre-scaled; rows past T masked in the last tile: a uniform branch off the hot path)
+    float z[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[m][r] = sacc[m][r] * a.c;
+    if ((it + 1) * AT_BK > a.T) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) kf[m][t] = *reinterpret_cast<const at_bf8*>(sk + frag_off + ((ks * 3 + t) * 2) * 1024 + m * 512);
-      AT_MM6(sacc[0], kf[0], sacc[1], kf[1], qf[ks])
-      if (ks < 3) __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 16; ++r)
+          if (it * AT_BK + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh >= a.T) z[m][r] = -INFINITY;
     }
-    // ---- online softmax (in-lane over the 32 kv values this lane holds for its query; the other 32 sit in lane ^ 32)
-    float z[2][16];
-    float mx = -INFINITY;
-    const bool last = (it + 1) * AT_BK > a.T;   // uniform: only the last tile can hold rows past T
+    // ---- region A: S^T (it + 1) on the matrix pipe || softmax (it) on the VALU, in four pinned chunks of 12 MFMAs
+    at_f16 sn[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = sacc[m][r] * a.c;
-        if (last && it * AT_BK + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kh >= a.T) v = -INFINITY;
-        z[m][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) sn[m][r] = 0.f;
+    // chunk 0: running maximum
+    dma(tile_c(it + 3), cur, 0);                       // K (it + 3) -> this tile's stage (its K was consumed in iteration it - 1)
+    __builtin_amdgcn_sched_barrier(0);
+    st_step(sk1, 0, sn);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, z[m][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
+    AT_CHUNK_HINT(2)
+    // chunks 1, 2: the exponentials of one M tile each
     float ps = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+      dma(tile_c(it + 3), cur, 1 + m);
+      __builtin_amdgcn_sched_barrier(0);
+      st_step(sk1, 1 + m, sn);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { z[m][r] = __builtin_amdgcn_exp2f(z[m][r] - m_new); ps += z[m][r]; }
+      AT_CHUNK_HINT(4)
+    }
+    // chunk 3: rescale O, split the first k-step's probabilities
+    dma(tile_c(it + 2), s2, 3);                        // V^T (it + 2) -> the stage of tile it - 1 (its V^T was consumed in iteration it - 1)
+    __builtin_amdgcn_sched_barrier(0);
+    st_step(sk1, 3, sn);
     l_half = l_half * alpha + ps;
 #pragma unroll
     for (int dm = 0; dm < 2; ++dm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[dm][r] *= alpha;
-    // ---- O^T += V^T P^T
+    at_bf8 pf[2][3];
+    at_split8(&z[0][0], pf[0]);
+    AT_CHUNK_HINT(7)
+    // ---- region B: O^T += V^T P^T (tile it); the split of k-step ks + 1 rides on the MFMAs of k-step ks
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) { dma(nt, nb, 3 + ks); __builtin_amdgcn_sched_barrier(0); }
-      const int m = ks >> 1, j = ks & 1;
-      at_bf8 pf[3];
-      at_split8(&z[m][8 * j], pf);
+      if (ks < 2) { dma(tile_c(it + 2), s2, 4 + ks); __builtin_amdgcn_sched_barrier(0); }
+      if (ks < 3) at_split8(&z[(ks + 1) >> 1][8 * ((ks + 1) & 1)], pf[(ks + 1) & 1]);
       at_bf8 vf[2][3];
 #pragma unroll
       for (int dm = 0; dm < 2; ++dm)
 #pragma unroll
         for (int t = 0; t < 3; ++t) vf[dm][t] = *reinterpret_cast<const at_bf8*>(sv + frag_off + ((ks * 3 + t) * 2) * 1024 + dm * 512);
-      AT_MM6(oacc[0], vf[0], oacc[1], vf[1], pf)
-      if (ks < 3) __builtin_amdgcn_sched_barrier(0);
+      AT_MM6(oacc[0], vf[0], oacc[1], vf[1], pf[ks & 1])
+      AT_CHUNK_HINT(4)
     }
-    // tile it + 1 has landed for everyone (my own DMA of it is older than the six instructions of tile it + 2 just issued), and this wave's LDS reads of
-    // the current tile have returned, before anybody overwrites it
+    // K (it + 2) and V^T (it + 1) have landed for everyone (a wave's own DMAs of them are older than the six instructions it just issued), and this wave's LDS
+    // reads of the stages it used have returned, before anybody overwrites them
     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    cur = cur == 2 ? 0 : cur + 1;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) sacc[m] = sn[m];
+    cur = s1;
   }
+#undef AT_CHUNK_HINT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetches of the last iterations have landed ...
   __builtin_amdgcn_s_barrier();                        // ... everybody's, before the epilogue re-uses the ring
 
