@@ -28,7 +28,10 @@
 // layer 3.15 ms against 4.59.  Timing ablations of this kernel (tools/ablate_gemm.sh, K 768 / N 2304, 0.855 ms): MFMAs + fragment reads alone 0.596 ms
 // (1.39 PFLOP/s: 72 % of the matrix peak at the 1.86 GHz the chip holds under this load, 10 % of it tile quantisation: 1 377 tiles on 256 CUs), + split
 // 0.627, + stores 0.682; the DMAs alone 0.347 ms.  The DMA cost that stays exposed (~0.17 ms) did not move with the issue pattern: all DMAs at the top
-// of the iteration 0.92, dealt between the MFMA groups 0.85, issued by one wave per SIMD only 0.85.  Earlier structures, for the record: A split in
+// of the iteration 0.92, dealt between the MFMA groups 0.85, issued by one wave per SIMD only 0.85, B fragments read one chunk ahead 0.86; without the
+// counted wait AND without the barrier 0.84 (nobody waits for a DMA to land); without the A DMAs 0.79, without the B DMAs 0.81, without both 0.67.  The
+// cost follows the WORK in flight, not the schedule -- the signature of a power-limited chip (1.86 GHz under this load against 2.4 GHz nominal): what is
+// left is doing less per MAC, not ordering it better.  Earlier structures, for the record: A split in
 // registers before the LDS write (global loads one stage ahead, 12 ds_write per thread and stage, one __syncthreads() per stage, double buffer)
 // 0.86 - 0.92 ms; 256 x 128 tiles with two workgroups per CU 0.88; a three-stage ring with the split in front of its own MFMAs 0.92.
 // Tile order: workgroup b runs on XCD b % 8 (speed assumption only): every XCD owns the M tiles mt = x (mod 8) and walks them four at a time across
@@ -87,7 +90,7 @@ VD_DEV float gx_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118
 typedef __attribute__((address_space(3))) void* gx_lds_vp;
 typedef const __attribute__((address_space(1))) void* gx_glb_vp;
 
-// DBG (development ablations, VD3D_GEMM_DBG; results are wrong): 1 no DMA, 2 no barrier, 4 no MFMA, 8 no A split, 16 no stores
+// DBG (development ablations, VD3D_GEMM_DBG; results are wrong): 1 no DMA, 2 no barrier, 4 no MFMA, 8 no A split, 16 no stores, 32 no A DMA, 64 no B DMA, 128 no vmcnt wait
 template <int DBG>
 __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__ X, const uint4* __restrict__ Wimg, const float* __restrict__ bias,
                                                         float* __restrict__ Y, vd_gx_args a) {
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
   auto stage_piece = [&](int ks, int buf, int piece) {
     if (DBG & 1) return;
     uint8_t* dst = gx_lds + buf * GX_STAGE;
-    if (piece < 2) __builtin_amdgcn_global_load_lds((gx_glb_vp)(xa[piece] + ks * 16), (gx_lds_vp)(dst + piece * (GX_NT * 16) + wave_base), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gx_glb_vp)(wb + (size_t)ks * (GX_STAGE_HALF / 16) + (piece - 2) * GX_NT),
+    if (piece < 2) { if (!(DBG & 32)) __builtin_amdgcn_global_load_lds((gx_glb_vp)(xa[piece] + ks * 16), (gx_lds_vp)(dst + piece * (GX_NT * 16) + wave_base), 16, 0, 0); }
+    else if (!(DBG & 64)) __builtin_amdgcn_global_load_lds((gx_glb_vp)(wb + (size_t)ks * (GX_STAGE_HALF / 16) + (piece - 2) * GX_NT),
                                           (gx_lds_vp)(dst + GX_A_STAGE + (piece - 2) * (GX_NT * 16) + wave_base), 16, 0, 0);
   };
 
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
     }
     // stage ks + 2 must have landed for everyone: my own DMA of it is older than the 5 instructions of stage ks + 3 just issued.  lgkmcnt(0): this
     // wave's LDS reads of the current buffer have RETURNED before it lets the others go on to overwrite it
+    if (DBG & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -303,7 +307,8 @@ bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const 
 #ifdef VD_GEMM_ABLATE
     for (const void* f : {reinterpret_cast<const void*>(k_gemm_bf16x3<1>), reinterpret_cast<const void*>(k_gemm_bf16x3<2>), reinterpret_cast<const void*>(k_gemm_bf16x3<4>),
                           reinterpret_cast<const void*>(k_gemm_bf16x3<8>), reinterpret_cast<const void*>(k_gemm_bf16x3<5>), reinterpret_cast<const void*>(k_gemm_bf16x3<3>),
-                          reinterpret_cast<const void*>(k_gemm_bf16x3<9>), reinterpret_cast<const void*>(k_gemm_bf16x3<11>), reinterpret_cast<const void*>(k_gemm_bf16x3<16>), reinterpret_cast<const void*>(k_gemm_bf16x3<27>)})
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<9>), reinterpret_cast<const void*>(k_gemm_bf16x3<11>), reinterpret_cast<const void*>(k_gemm_bf16x3<16>), reinterpret_cast<const void*>(k_gemm_bf16x3<27>),
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<32>), reinterpret_cast<const void*>(k_gemm_bf16x3<64>), reinterpret_cast<const void*>(k_gemm_bf16x3<128>), reinterpret_cast<const void*>(k_gemm_bf16x3<130>)})
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
     dbg = getenv("VD3D_GEMM_DBG") ? atoi(getenv("VD3D_GEMM_DBG")) : 0;
 #endif
@@ -318,7 +323,7 @@ bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const 
 #ifdef VD_GEMM_ABLATE
 #define GX_L(D) hipLaunchKernelGGL(k_gemm_bf16x3<D>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a)
   switch (dbg) { case 1: GX_L(1); return true; case 2: GX_L(2); return true; case 4: GX_L(4); return true; case 8: GX_L(8); return true; case 5: GX_L(5); return true;
-                 case 3: GX_L(3); return true; case 9: GX_L(9); return true; case 11: GX_L(11); return true; case 16: GX_L(16); return true; case 27: GX_L(27); return true; default: break; }
+                 case 3: GX_L(3); return true; case 9: GX_L(9); return true; case 11: GX_L(11); return true; case 16: GX_L(16); return true; case 27: GX_L(27); return true; case 32: GX_L(32); return true; case 64: GX_L(64); return true; case 128: GX_L(128); return true; case 130: GX_L(130); return true; default: break; }
 #endif
   (void)dbg;
   hipLaunchKernelGGL(k_gemm_bf16x3<0>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a);
