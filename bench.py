@@ -325,13 +325,13 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
             r.set_pixel_overlap(1 if host_io else max(1, int(args.pix_streams)))   # frames' pixel passes round-robin over this many streams
 
     pipe = None
-    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f32x3": torch.float32}[depth_dtype]
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f32x3": torch.float32, "f32h2": torch.float32}[depth_dtype]
     if model_name:
         from visiondepth3d_amd.depth import DepthPipe
         # fused front end + fused backbone / neck glue; library selection: committed GEMM table + MIOpen find mode (runs during the warm-up)
         # (find mode only where the number is a parity-mode one: the bf16 sub-record keeps MIOpen's immediate mode and its shorter start)
-        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh, miopen_find=(not args.no_miopen_find) and depth_dtype in ("f32", "f32x3"),
-                         gemm="bf16x3" if depth_dtype == "f32x3" else "f32")
+        pipe = DepthPipe(model_name, device="cuda", dtype=tdt, renderer=rh, miopen_find=(not args.no_miopen_find) and depth_dtype in ("f32", "f32x3", "f32h2"),
+                         gemm={"f32x3": "bf16x3", "f32h2": "fp16x2"}.get(depth_dtype, "f32"))
 
     NBUF = 2  # double-buffered hand-off planes so batch i+1's depth inference overlaps batch i's DIBR chain
     dbuf = [torch.empty((B, sh, sw), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
@@ -717,7 +717,7 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
                                  "isolated_avg_frame_ms": iso.get("frame")}
     if res.get("net_ms") and res.get("flops_per_frame"):
         tf = res["flops_per_frame"] * res["B"] / (res["net_ms"] * 1e-3) / 1e12
-        pk = MFMA_PEAK_TFLOPS[{"f32x3": "f32"}.get(res["depth_dtype"], res["depth_dtype"])]   # f32x3: float32-equivalent flops against the float32 MFMA peak (may exceed 1)
+        pk = MFMA_PEAK_TFLOPS[{"f32x3": "f32", "f32h2": "f32"}.get(res["depth_dtype"], res["depth_dtype"])]   # f32x3: float32-equivalent flops against the float32 MFMA peak (may exceed 1)
         out["roofline_depthnet"] = {"bound": "mfma", "kernel": f"{res['model']} forward + hand-off ({res['depth_dtype']}; hipBLASLt / AOTriton / "
                                     "MIOpen through PyTorch-ROCm, glue fused in HIP)", "achieved": round(tf, 2), "peak": pk,
                                     "unit": "TFLOP/s", "frac": round(tf / pk, 4), "flops_per_frame": res["flops_per_frame"],
@@ -731,7 +731,7 @@ def sub_record(res, extra=None):
     d = {"workload": res["workload"], "description": res["desc"], "value": round(res["frames_total"] / res["dt"], 3),
          "unit": "stereo-pairs/s", "steps": res["steps"], "warmup": res["warmup"], "frames_timed": res["frames_total"],
          "ms_per_step": round(res["dt"] / res["steps"] * 1e3, 4),
-         "dtype": {None: "f32", "f32": "f32", "f32x3": "f32 (bf16x3 split MFMA, f32 accumulate)"}.get(
+         "dtype": {None: "f32", "f32": "f32", "f32x3": "f32 (bf16x3 split MFMA, f32 accumulate)", "f32h2": "f32 operands as 2 x fp16 (22 bits), MFMA, f32 accumulate"}.get(
              res["depth_dtype"], "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)")}
     if extra:
         d.update(extra)
@@ -844,7 +844,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="measure ONLY this workload (profiling runs); default: the headline + the sub-records described above")
-    ap.add_argument("--depth-dtype", default="f32", choices=("f32", "bf16", "f32x3"), help="depth-net precision of the measured workload (f32x3: float32 with the linears on the split-bf16 GEMM, opt-in) "
+    ap.add_argument("--depth-dtype", default="f32", choices=("f32", "bf16", "f32x3", "f32h2"), help="depth-net precision of the measured workload (f32x3 / f32h2: float32 with the transformer blocks on the split-bf16 / 2 x fp16 MFMA kernels, opt-in) "
                     "(f32 = the reference's; bf16 is labelled reduced precision)")
     ap.add_argument("--batch", type=int, default=16, help="frames per step")
     ap.add_argument("--clip", type=int, default=32, help="distinct synthetic frames resident in HBM (cycled); default 2 x batch so that "
@@ -925,6 +925,11 @@ def main():
             subs["4k-dibr-vr"] = (rvr, None)
         if rx3 is not None:
             subs["4k-dav2b-dibr-f32x3"] = (rx3, None)
+        try:
+            rh2 = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="f32h2", profile=prof, isolated_pass=False)
+            subs["4k-dav2b-dibr-fp16x2"] = (rh2, None)
+        except Exception as e:
+            print(f"[bench] 4k-dav2b-dibr-fp16x2 failed: {str(e)[:200]}", file=sys.stderr)
         if rhn is not None:
             subs["4k-dibr-hostio-nv12"] = (rhn, None)
         roof_src = r4
@@ -942,14 +947,16 @@ def main():
             "metric": "stereo-pairs/sec end-to-end (depth+warp+fill+mux)",
             "value": round(value, 3), "unit": "stereo-pairs/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(head["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (bf16x3 split MFMA, f32 accumulate)" if (model_name and args.depth_dtype == "f32x3") else "f32") if not reduced
+            "dtype": ({"f32x3": "f32 (bf16x3 split MFMA, f32 accumulate)", "f32h2": "f32 operands as 2 x fp16 (22 bits), MFMA, f32 accumulate"}.get(args.depth_dtype, "f32")
+                      if model_name else "f32") if not reduced
                      else "f32 DIBR + bf16 depth net (REDUCED precision vs the reference's float32)",
             "data": "synthetic (procedural frames+depth resident in HBM, deterministic synthetic depth-net weights)" if not args.host_io else
                     "synthetic; frames start in pinned host memory and muxed frames are copied back to pinned host memory (PCIe-inclusive run)",
             "config": {"workload": wl, "description": desc, "frame": f"{sw}x{sh}", "format": "Half-SBS",
                        "frames_per_step": args.batch, "depth_model": model_name,
                        "depth_net_dtype": ({"f32": "float32 (the reference's precision)", "bf16": "bfloat16",
-                                            "f32x3": "float32 via split-bf16 linears (opt-in)"}[args.depth_dtype]
+                                            "f32x3": "float32 via split-bf16 linears + attention (opt-in)",
+                                            "f32h2": "float32 via 2 x fp16 linears + attention (opt-in)"}[args.depth_dtype]
                                            if model_name else None),
                        "arithmetic": "u8 in/out, float32 DIBR kernels, float64 scalar trackers",
                        "depth_net_library_selection": head.get("lib_sel"),
@@ -1010,6 +1017,11 @@ def main():
                                      "exactly into three bf16 terms, six bf16 MFMA products per MAC, float32 accumulation, exact GELU in fc1's epilogue -- "
                                      "float32-faithful (tests/test_hip_gemm.py: vs float64, and the float32 leg's own bar against the stock graph), opt-in; the "
                                      "headline stays pure float32 (hipBLASLt)")
+                if name == "4k-dav2b-dibr-fp16x2":
+                    extra["note"] = ("same workload as the headline with the transformer blocks on the library's GEMM / attention kernels in their fp16x2 form: every "
+                                     "operand as two fp16 terms (22 significant bits, round to nearest), three MFMA products per MAC, float32 accumulation -- half the "
+                                     "matrix work of bf16x3; measured against float64 beside hipBLASLt / AOTriton in tests/test_hip_gemm.py, and on the uint8 depth plane "
+                                     "against the stock float32 graph; opt-in, never `value`")
                 if name == "4k-dav2b-dibr-bf16":
                     extra["note"] = ("same workload as the headline with the depth net in bfloat16: NOT like-for-like with the reference "
                                      "(float32); its uint8 depth-plane deviation is measured by tests/test_hip_depth_e2e.py")

@@ -387,25 +387,33 @@ int vd3d_depth_preprocess(vd3d_ctx* ctx, const uint8_t* frames_bgr, int B, int H
 int vd3d_add_layernorm(vd3d_ctx* ctx, int dtype, const void* x, const void* y_or_null, const void* gamma, const void* beta,
                        float eps, int64_t rows, int cols, void* out_sum, void* out_norm);
 
-/* The linear layers of the depth network's transformer blocks (a25; core/render_depth.py:1106-1119 runs them in float32 through the Hugging Face
- * pipeline) as a split-bf16 GEMM -- an OPT-IN mode of DepthPipe (gemm="bf16x3"; the default stays hipBLASLt's float32 GEMM).
+/* The linear layers and the attention of the depth network's transformer blocks (a25; core/render_depth.py:1106-1119 runs them in float32 through the
+ * Hugging Face pipeline) as SPLIT-operand GEMMs on the 16-bit matrix cores -- OPT-IN modes of DepthPipe (gemm="bf16x3" | "fp16x2"; the default stays
+ * hipBLASLt's float32 GEMM + PyTorch's float32 attention).  gfx950 has no TF32 and its float32-input MFMA runs at 1/16 of the bf16 / fp16 rate.
  *   Y[M][N] = X[M][K] . W[N][K]^T + bias[N]   (row-major float32 device arrays, leading dimensions K / K / N; epilogue 1: + exact GELU)
- * Every float32 operand is split EXACTLY into three bf16 terms (8 + 8 + 8 significant bits); six of the nine term products -- all but x2 w3, x3 w2,
- * x3 w3, together <= 2^-23 |x w| -- go through v_mfma_f32_32x32x16_bf16 with float32 accumulation: float32-faithful results (the error of a float32
- * GEMM in another summation order; tests/test_hip_gemm.py vs float64) at 6 bf16 MFMAs per MAC instead of the float32-input MFMA (1/16 of the bf16 rate
- * on gfx950, which has no TF32).  The weights are split and packed once: vd3d_gemm_x3_weight_bytes(N, K) bytes (< 0: K is not a positive multiple of
- * 16), filled by vd3d_gemm_x3_pack_weights; the image is opaque and only valid for this library version.  NaN / Inf inputs give NaN. */
+ * mode VD3D_X3_BF16X3: every float32 operand is split EXACTLY into three bf16 terms (8 + 8 + 8 significant bits); six of the nine term products -- all but
+ *   x2 w3, x3 w2, x3 w3, together <= 2^-23 |x w| -- go through v_mfma_f32_32x32x16_bf16 with float32 accumulation: float32-faithful (the error of a float32
+ *   GEMM in another summation order; tests/test_hip_gemm.py vs float64 beside hipBLASLt), 6 MFMAs per MAC.  NaN / Inf inputs give NaN.
+ * mode VD3D_X3_FP16X2: every operand as two fp16 terms, h1 = fp16(x), h2 = fp16(x - h1), round to nearest: 22 significant bits (|x - h1 - h2| <= 2^-22 |x|
+ *   while h2 is a normal fp16 number, i.e. |x| >= 2^-2; below that the absolute error is <= 2^-25); three products x1 w1 + x1 w2 + x2 w1 -- HALF the matrix
+ *   work.  Weight rows are pre-scaled by an exact power of two (undone in the epilogue) so that their second terms stay normal; activations are used as
+ *   they are and must stay below 65 504 in magnitude (fp16's range; larger values give Inf / NaN).  Per product up to ~3 x 2^-22 relative instead of one
+ *   float32 rounding; in a K >= 64 dot product that sits below the float32 accumulation error both modes share (measured beside hipBLASLt in the tests).
+ * The weights are split and packed once: vd3d_gemm_x3_weight_bytes(N, K, mode) bytes (< 0: K is not a positive multiple of 16, or an unknown mode), filled
+ * by vd3d_gemm_x3_pack_weights; the image is opaque, belongs to its mode and is only valid for this library version. */
 enum { VD3D_GEMM_EPI_NONE = 0, VD3D_GEMM_EPI_GELU = 1 };
+enum { VD3D_X3_BF16X3 = 0, VD3D_X3_FP16X2 = 1 };
+int64_t vd3d_gemm_x3_weight_bytes(int N, int K, int mode);
+int vd3d_gemm_x3_pack_weights(vd3d_ctx* ctx, const float* W, int N, int K, int mode, void* image);
+int vd3d_gemm_x3(vd3d_ctx* ctx, const float* X, int64_t M, int K, const void* w_image, int N, int mode, const float* bias_or_null, int epilogue, float* Y);
 /* The attention of the same blocks in the same arithmetic: out[b][t][h][:] = softmax_t'(q[b][t][h] . k[b][t'][h] * scale) v[b][t'][h] with
  * q / k / v = qkv[b][t][0 / 1 / 2][h][:], qkv the contiguous float32 output [B][T][3][H][D] of the fused QKV linear, out [B][T][H][D] float32.
- * Q, K, V and the probabilities are split exactly into three bf16 terms, both matrix products run as six bf16 MFMA products per MAC with float32
- * accumulation, the online softmax is float32 (exp2 of the pre-scaled logits).  D = 64 only (every DINOv2 size), else VD3D_E_UNSUPPORTED.
- * `workspace`: vd3d_attention_x3_workspace_bytes(B, T, H, D) bytes of device memory (the split images), 16-byte aligned, owned by the caller. */
-int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D);
-int vd3d_attention_x3(vd3d_ctx* ctx, const float* qkv, int B, int T, int H, int D, float scale, void* workspace, int64_t workspace_bytes, float* out);
-int64_t vd3d_gemm_x3_weight_bytes(int N, int K);
-int vd3d_gemm_x3_pack_weights(vd3d_ctx* ctx, const float* W, int N, int K, void* image);
-int vd3d_gemm_x3(vd3d_ctx* ctx, const float* X, int64_t M, int K, const void* w_image, int N, const float* bias_or_null, int epilogue, float* Y);
+ * Q, K, V and the probabilities are split like the GEMM operands of `mode` (fp16x2: q, k, v scaled by 2^4 and the probabilities by 2^10 before their split,
+ * exactly, undone in the logits' scale and the final normalisation), both matrix products run on the matrix cores with float32 accumulation, the online
+ * softmax is float32 (exp2 of the pre-scaled logits).  D = 64 only (every DINOv2 size), else VD3D_E_UNSUPPORTED.
+ * `workspace`: vd3d_attention_x3_workspace_bytes(B, T, H, D, mode) bytes of device memory (the split images), 16-byte aligned, owned by the caller. */
+int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D, int mode);
+int vd3d_attention_x3(vd3d_ctx* ctx, const float* qkv, int B, int T, int H, int D, float scale, int mode, void* workspace, int64_t workspace_bytes, float* out);
 
 /* F.interpolate(mode="bilinear", align_corners=True) of an NHWC (channels_last) tensor [B][ih][iw][C] -> [B][oh][ow][C] of
  * `dtype`, C a multiple of 8 (bf16) / 4 (f32): the up-samplings of the DPT neck / head (a25). */

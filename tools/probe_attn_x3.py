@@ -22,6 +22,8 @@ def bench(fn, n=10):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    mode = os.environ.get("X3_MODE", "bf16x3")
+    print("mode", mode)
     R = Renderer(0)
     g = torch.Generator(device="cuda").manual_seed(1)
     for (T, H) in ((2443, 12), (1370, 6), (1370, 12), (2443, 12), (1370, 12)):
@@ -29,16 +31,16 @@ def main():
         qkv = torch.randn(B, T, 3, H, D, device="cuda", generator=g)
         scale = D ** -0.5
         flat = qkv.view(B, T, 3 * H * D)
-        out = R.attention_x3(flat, H, scale)
+        out = R.attention_x3(flat, H, scale, mode=mode)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
         o32 = F.scaled_dot_product_attention(q, k, v, scale=scale).transpose(1, 2).reshape(B, T, H * D)
         for _ in range(5):   # repeat under load: a race shows as a run-to-run difference
-            assert torch.equal(R.attention_x3(flat, H, scale), out), 'run-to-run difference'
+            assert torch.equal(R.attention_x3(flat, H, scale, mode=mode), out), 'run-to-run difference'
         ref = (torch.softmax((q[:1].double() @ k[:1].double().transpose(-1, -2)) * scale, dim=-1) @ v[:1].double()).transpose(1, 2).reshape(1, T, H * D)
         e3, e32 = float((out[:1].double() - ref).abs().max()), float((o32[:1].double() - ref).abs().max())
         r3 = float((out[:1].double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         r32 = float((o32[:1].double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-        t3 = bench(lambda: R.attention_x3(flat, H, scale))
+        t3 = bench(lambda: R.attention_x3(flat, H, scale, mode=mode))
         t32 = bench(lambda: F.scaled_dot_product_attention(q, k, v, scale=scale))
         fl = 4.0 * B * H * T * T * D
         print(f"B {B} T {T} H {H}: x3 {t3:.3f} ms = {fl / t3 / 1e9:.0f} TF-equiv ({6 * fl / t3 / 1e9:.0f} TF bf16 MFMA) | SDPA f32 {t32:.3f} ms = {fl / t32 / 1e9:.0f} TF"

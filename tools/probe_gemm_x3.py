@@ -22,6 +22,8 @@ def bench(fn, n=10):
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 39088
+    mode = os.environ.get("X3_MODE", "bf16x3")
+    print("mode", mode)
     R = Renderer(0)
     g = torch.Generator(device="cuda").manual_seed(1)
     tot_x3 = tot_f32 = 0.0
@@ -32,8 +34,8 @@ def main():
         x = torch.randn(M, K, device="cuda", generator=g) * 2.0
         w = torch.randn(N, K, device="cuda", generator=g) * 0.05
         b = torch.randn(N, device="cuda", generator=g)
-        img = R.gemm_x3_pack(w)
-        y = R.linear_x3(x, img, N, b, gelu=gelu)
+        img = R.gemm_x3_pack(w, mode)
+        y = R.linear_x3(x, img, N, b, gelu=gelu, mode=mode)
         torch.cuda.synchronize()
         ms = 2048
         ref64 = torch.nn.functional.linear(x[:ms].double(), w.double(), b.double())
@@ -52,7 +54,7 @@ def main():
         if gelu:
             tail = torch.nn.functional.gelu(tail)
         et = ((y[-300:].double() - tail).abs() / ((x[-300:].abs().double() @ w.abs().double().T) + b.abs().double())).max().item()
-        t3 = bench(lambda: R.linear_x3(x, img, N, b, gelu=gelu))
+        t3 = bench(lambda: R.linear_x3(x, img, N, b, gelu=gelu, mode=mode))
         if gelu:
             t32 = bench(lambda: torch.nn.functional.gelu(torch.nn.functional.linear(x, w, b)))
         else:

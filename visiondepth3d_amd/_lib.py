@@ -100,13 +100,13 @@ def lib():
     L.vd3d_shard2_p3.argtypes = [vp, i32, i32, vp, vp]
     L.vd3d_shard2_r2.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_uint8), i32, vp]
     L.vd3d_depth_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp]
-    L.vd3d_gemm_x3_weight_bytes.argtypes = [i32, i32]
+    L.vd3d_gemm_x3_weight_bytes.argtypes = [i32, i32, i32]
     L.vd3d_gemm_x3_weight_bytes.restype = C.c_int64
-    L.vd3d_gemm_x3_pack_weights.argtypes = [vp, vp, i32, i32, vp]
-    L.vd3d_gemm_x3.argtypes = [vp, vp, C.c_int64, i32, vp, i32, vp, i32, vp]
-    L.vd3d_attention_x3_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.vd3d_gemm_x3_pack_weights.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.vd3d_gemm_x3.argtypes = [vp, vp, C.c_int64, i32, vp, i32, i32, vp, i32, vp]
+    L.vd3d_attention_x3_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.vd3d_attention_x3_workspace_bytes.restype = C.c_int64
-    L.vd3d_attention_x3.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, vp, C.c_int64, vp]
+    L.vd3d_attention_x3.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, i32, vp, C.c_int64, vp]
     L.vd3d_add_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, C.c_float, C.c_int64, i32, vp, vp]
     L.vd3d_upsample_bilinear_nhwc.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32]
     L.vd3d_nhwc_bias_act_f32.argtypes = [vp, vp, vp, vp, vp, i32, C.c_int64, i32, vp, vp]

@@ -1445,33 +1445,33 @@ VD3D_EXPORT int vd3d_add_layernorm(vd3d_ctx* c, int dtype, const void* x, const 
   return 0;
 }
 
-VD3D_EXPORT int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D) { return (int64_t)vd_attn_x3_workspace_bytes(B, T, H, D); }
+VD3D_EXPORT int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D, int mode) { return (int64_t)vd_attn_x3_workspace_bytes(B, T, H, D, mode); }
 
-VD3D_EXPORT int vd3d_attention_x3(vd3d_ctx* c, const float* qkv, int B, int T, int H, int D, float scale, void* workspace, int64_t workspace_bytes, float* out) {
+VD3D_EXPORT int vd3d_attention_x3(vd3d_ctx* c, const float* qkv, int B, int T, int H, int D, float scale, int mode, void* workspace, int64_t workspace_bytes, float* out) {
   if (!c || !qkv || !workspace || !out) return set_err(VD3D_E_INVALID, "bad argument");
-  const long long need = vd_attn_x3_workspace_bytes(B, T, H, D);
-  if (need < 0) return set_err(VD3D_E_UNSUPPORTED, "attention_x3: head size %d not built (64), or an empty shape (B %d T %d H %d)", D, B, T, H);
+  const long long need = vd_attn_x3_workspace_bytes(B, T, H, D, mode);
+  if (need < 0) return set_err(VD3D_E_UNSUPPORTED, "attention_x3: head size %d not built (64), an unknown mode %d or an empty shape (B %d T %d H %d)", D, mode, B, T, H);
   if (workspace_bytes < need) return set_err(VD3D_E_INVALID, "attention_x3: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, need);
-  if (!vd_launch_attn_x3(c->stream, qkv, B, T, H, D, scale, workspace, out))
+  if (!vd_launch_attn_x3(c->stream, qkv, B, T, H, D, scale, workspace, out, mode))
     return set_err(VD3D_E_UNSUPPORTED, "attention_x3: qkv / workspace / out must be 16-byte aligned, B * H <= 65535");
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-VD3D_EXPORT int64_t vd3d_gemm_x3_weight_bytes(int N, int K) { return (int64_t)vd_gemm_x3_weight_bytes(N, K); }
+VD3D_EXPORT int64_t vd3d_gemm_x3_weight_bytes(int N, int K, int mode) { return (int64_t)vd_gemm_x3_weight_bytes(N, K, mode); }
 
-VD3D_EXPORT int vd3d_gemm_x3_pack_weights(vd3d_ctx* c, const float* W, int N, int K, void* image) {
+VD3D_EXPORT int vd3d_gemm_x3_pack_weights(vd3d_ctx* c, const float* W, int N, int K, int mode, void* image) {
   if (!c || !W || !image) return set_err(VD3D_E_INVALID, "bad argument");
-  if (!vd_launch_gemm_x3_pack_w(c->stream, W, N, K, image)) return set_err(VD3D_E_UNSUPPORTED, "gemm_x3: K %d must be a positive multiple of 16 (N %d)", K, N);
+  if (!vd_launch_gemm_x3_pack_w(c->stream, W, N, K, image, mode)) return set_err(VD3D_E_UNSUPPORTED, "gemm_x3: K %d must be a positive multiple of 16 (N %d), mode %d in {0, 1}", K, N, mode);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-VD3D_EXPORT int vd3d_gemm_x3(vd3d_ctx* c, const float* X, int64_t M, int K, const void* w_image, int N, const float* bias_or_null, int epilogue, float* Y) {
+VD3D_EXPORT int vd3d_gemm_x3(vd3d_ctx* c, const float* X, int64_t M, int K, const void* w_image, int N, int mode, const float* bias_or_null, int epilogue, float* Y) {
   if (!c || !X || !w_image || !Y || M < 1) return set_err(VD3D_E_INVALID, "bad argument");
   if (epilogue != VD3D_GEMM_EPI_NONE && epilogue != VD3D_GEMM_EPI_GELU) return set_err(VD3D_E_INVALID, "gemm_x3: unknown epilogue %d", epilogue);
-  if (!vd_launch_gemm_x3(c->stream, X, (long long)M, K, w_image, N, bias_or_null, epilogue, Y))
-    return set_err(VD3D_E_UNSUPPORTED, "gemm_x3: K %d must be a positive multiple of 16, X and the weight image 16-byte aligned", K);
+  if (!vd_launch_gemm_x3(c->stream, X, (long long)M, K, w_image, N, bias_or_null, epilogue, Y, mode))
+    return set_err(VD3D_E_UNSUPPORTED, "gemm_x3: K %d must be a positive multiple of 16, mode %d in {0, 1}, X and the weight image 16-byte aligned", K, mode);
   HIPCHK(hipGetLastError());
   return 0;
 }

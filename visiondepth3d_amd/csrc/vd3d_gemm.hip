@@ -50,10 +50,13 @@ typedef float gx_f16 __attribute__((ext_vector_type(16)));    // one 32 x 32 acc
 #define GX_NT 512
 #define GX_MG 4                                  // M tiles of an XCD walked together across the N tiles
 #define GX_A_STAGE (4 * GX_BM * 16)              // float32 A image of a stage: 16 384 bytes
-#define GX_STAGE_HALF (3 * 2 * GX_BN * 16)       // B image of a stage: 24 576 bytes (the unit of the packed weights)
-#define GX_STAGE (GX_A_STAGE + GX_STAGE_HALF)    // 40 960
+// MODE 0 = bf16x3 (three exact bf16 terms per operand, six products); MODE 1 = fp16x2 (two fp16 terms per operand -- 22 bits, round to nearest -- three
+// products: HALF the matrix work; see the header)
+#define GX_NTERM(MODE) ((MODE) == 0 ? 3 : 2)
+#define GX_STAGE_HALF(MODE) (GX_NTERM(MODE) * 2 * GX_BN * 16)   // B image of a stage: 24 576 / 16 384 bytes (the unit of the packed weights)
+#define GX_STAGE(MODE) (GX_A_STAGE + GX_STAGE_HALF(MODE))       // 40 960 / 32 768
 #define GX_NSTAGE 4
-#define GX_LDS (GX_NSTAGE * GX_STAGE)            // 163 840 = all of a CU's LDS
+#define GX_LDS(MODE) (GX_NSTAGE * GX_STAGE(MODE))               // 163 840 = all of a CU's LDS / 131 072
 
 struct vd_gx_args {
   long long M;
@@ -85,15 +88,38 @@ VD_DEV void gx_split8(const float4& lo, const float4& hi, gx_bf8 out[3]) {
   out[0] = __builtin_bit_cast(gx_bf8, p1); out[1] = __builtin_bit_cast(gx_bf8, p2); out[2] = __builtin_bit_cast(gx_bf8, p3);
 }
 
+// fp16x2: a ~ h1 + h2 with h1 = fp16(a), h2 = fp16(a - h1), both round-to-nearest: |a - h1 - h2| <= 2^-22 |a| while h2 stays a normal fp16 number (|a| >= 2^-2
+// for unscaled data; below that the absolute error is <= 2^-25).  |a| must stay below 65 504.
+typedef _Float16 gx_h8 __attribute__((ext_vector_type(8)));
+VD_DEV void gx_split8_h(const float4& lo, const float4& hi, gx_bf8 out[2]) {
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  gx_h8 h1, h2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 a1 = (_Float16)v[e];
+    h1[e] = a1;
+    h2[e] = (_Float16)(v[e] - (float)a1);
+  }
+  out[0] = __builtin_bit_cast(gx_bf8, h1); out[1] = __builtin_bit_cast(gx_bf8, h2);
+}
+template <int MODE> VD_DEV void gx_split8_m(const float4& lo, const float4& hi, gx_bf8* out) {
+  if (MODE == 0) gx_split8(lo, hi, out); else gx_split8_h(lo, hi, out);
+}
+template <int MODE> VD_DEV gx_f16 gx_mfma(const gx_bf8& a, const gx_bf8& b, const gx_f16& c) {
+  if (MODE == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gx_h8, a), __builtin_bit_cast(gx_h8, b), c, 0, 0, 0);
+}
+
 VD_DEV float gx_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 typedef __attribute__((address_space(3))) void* gx_lds_vp;
 typedef const __attribute__((address_space(1))) void* gx_glb_vp;
 
-// DBG (development ablations, VD3D_GEMM_DBG; results are wrong): 1 no DMA, 2 no barrier, 4 no MFMA, 8 no A split, 16 no stores, 32 no A DMA, 64 no B DMA, 128 no vmcnt wait
-template <int DBG>
+// DBG (development ablations, VD3D_GEMM_DBG; results are wrong): 1 no DMA, 2 no barrier, 4 no MFMA, 8 no A split, 16 no stores, 32 no A DMA, 64 no B DMA, 128 no vmcnt wait, 256 three of the six products
+template <int DBG, int MODE>
 __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__ X, const uint4* __restrict__ Wimg, const float* __restrict__ bias,
-                                                        float* __restrict__ Y, vd_gx_args a) {
+                                                        const float* __restrict__ colscale, float* __restrict__ Y, vd_gx_args a) {
+  constexpr int NTERM = GX_NTERM(MODE), STAGE_HALF = GX_STAGE_HALF(MODE), STAGE = GX_STAGE(MODE), NB = STAGE_HALF / (GX_NT * 16), NDMA = 2 + NB;
   extern __shared__ __attribute__((aligned(16))) uint8_t gx_lds[];   // the ONLY LDS object of the kernel (a second one makes hipcc drain the DMA queue per stage)
   // ---- tile of this workgroup (XCD-aware order, see the header)
   int mt, nt;
@@ -122,18 +148,18 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
     xa[p] = X + row * (long long)a.K + 4 * ((slot & 3) ^ ((r >> 2) & 3));
   }
   // ---- B staging: the stage image is contiguous in global memory; thread t moves 16-byte pieces t, t + 512, t + 1024
-  const uint4* wb = Wimg + (size_t)nt * (size_t)a.KS * (GX_STAGE_HALF / 16) + tid;
+  const uint4* wb = Wimg + (size_t)nt * (size_t)a.KS * (STAGE_HALF / 16) + tid;
   const int wave_base = (tid & ~63) * 16;   // wave-uniform LDS base of a DMA instruction's 1 KB
 
   auto stage = [&](int ks, int buf) {
     if (DBG & 1) return;
-    uint8_t* dst = gx_lds + buf * GX_STAGE;
+    uint8_t* dst = gx_lds + buf * STAGE;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
       __builtin_amdgcn_global_load_lds((gx_glb_vp)(xa[p] + ks * 16), (gx_lds_vp)(dst + p * (GX_NT * 16) + wave_base), 16, 0, 0);
-    const uint4* src = wb + (size_t)ks * (GX_STAGE_HALF / 16);
+    const uint4* src = wb + (size_t)ks * (STAGE_HALF / 16);
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NB; ++p)
       __builtin_amdgcn_global_load_lds((gx_glb_vp)(src + p * GX_NT), (gx_lds_vp)(dst + GX_A_STAGE + p * (GX_NT * 16) + wave_base), 16, 0, 0);
   };
 
@@ -151,16 +177,16 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
   const int fa_off0 = (a_row * 4 + ((2 * kh) ^ a_sw)) * 16, fa_off1 = (a_row * 4 + ((2 * kh + 1) ^ a_sw)) * 16;
   const int fb_off = GX_A_STAGE + (kh * GX_BN + wn * 128 + li) * 16;
 
-  auto load_split_a = [&](int buf, gx_bf8 (*af)[3]) {
-    const uint8_t* sa = gx_lds + buf * GX_STAGE;
+  auto load_split_a = [&](int buf, gx_bf8 (*af)[NTERM]) {
+    const uint8_t* sa = gx_lds + buf * STAGE;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       // read as the fragment type (the LDS reads of this kernel all have ONE type: hipcc orders a float4 LDS read behind every LDS-DMA in flight
       // -- s_waitcnt vmcnt(0) at the top of each stage -- and leaves the short-vector reads alone)
       const gx_bf8 lo8 = *reinterpret_cast<const gx_bf8*>(sa + fa_off0 + mi * 2048);
       const gx_bf8 hi8 = *reinterpret_cast<const gx_bf8*>(sa + fa_off1 + mi * 2048);
-      if (DBG & 8) { af[mi][0] = lo8; af[mi][1] = hi8; af[mi][2] = lo8; }
-      else gx_split8(__builtin_bit_cast(float4, lo8), __builtin_bit_cast(float4, hi8), af[mi]);
+      if (DBG & 8) { af[mi][0] = lo8; af[mi][1] = hi8; af[mi][NTERM - 1] = lo8; }
+      else gx_split8_m<MODE>(__builtin_bit_cast(float4, lo8), __builtin_bit_cast(float4, hi8), af[mi]);
     }
   };
 
@@ -168,17 +194,17 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
   stage(0, 0);
   stage(a.KS > 1 ? 1 : a.KS - 1, 1);
   stage(a.KS > 2 ? 2 : a.KS - 1, 2);
-  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if (NDMA == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  gx_bf8 af[2][3];
+  gx_bf8 af[2][NTERM];
   load_split_a(0, af);
 
-  // one DMA instruction of a stage: pieces 0, 1 = A, 2 .. 4 = B
+  // one DMA instruction of a stage: pieces 0, 1 = A, 2 .. (4 | 3) = B
   auto stage_piece = [&](int ks, int buf, int piece) {
     if (DBG & 1) return;
-    uint8_t* dst = gx_lds + buf * GX_STAGE;
+    uint8_t* dst = gx_lds + buf * STAGE;
     if (piece < 2) { if (!(DBG & 32)) __builtin_amdgcn_global_load_lds((gx_glb_vp)(xa[piece] + ks * 16), (gx_lds_vp)(dst + piece * (GX_NT * 16) + wave_base), 16, 0, 0); }
-    else if (!(DBG & 64)) __builtin_amdgcn_global_load_lds((gx_glb_vp)(wb + (size_t)ks * (GX_STAGE_HALF / 16) + (piece - 2) * GX_NT),
+    else if (!(DBG & 64)) __builtin_amdgcn_global_load_lds((gx_glb_vp)(wb + (size_t)ks * (STAGE_HALF / 16) + (piece - 2) * GX_NT),
                                           (gx_lds_vp)(dst + GX_A_STAGE + (piece - 2) * (GX_NT * 16) + wave_base), 16, 0, 0);
   };
 
@@ -193,9 +219,9 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
     // instructions are dealt out between the four groups of 12 MFMAs, pinned there by sched_barrier: while one wave of a SIMD waits at a DMA, the other
     // one has MFMAs to issue.
     const int nxt = (cur + 1) & 3, sk = ks + 3 < a.KS ? ks + 3 : a.KS - 1, sbuf = (cur + 3) & 3;
-    const uint8_t* sb = gx_lds + cur * GX_STAGE;
-    const uint8_t* sa = gx_lds + nxt * GX_STAGE;
-    gx_bf8 an[2][3];
+    const uint8_t* sb = gx_lds + cur * STAGE;
+    const uint8_t* sa = gx_lds + nxt * STAGE;
+    gx_bf8 an[2][NTERM];
     gx_bf8 raw[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {   // read as the fragment type (see load_split_a)
@@ -205,22 +231,23 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj) {
       stage_piece(sk, sbuf, nj);
-      if (nj == 3) stage_piece(sk, sbuf, 4);
+      if (nj == 3 && NDMA == 5) stage_piece(sk, sbuf, 4);
       __builtin_amdgcn_sched_barrier(0);
-      gx_bf8 bf[3];
+      gx_bf8 bf[NTERM];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) bf[t] = *reinterpret_cast<const gx_bf8*>(sb + fb_off + t * 8192 + nj * 512);
+      for (int t = 0; t < NTERM; ++t) bf[t] = *reinterpret_cast<const gx_bf8*>(sb + fb_off + t * 8192 + nj * 512);
       if (nj == 0 || nj == 2) {   // the split of one M tile of the next stage rides on this group's MFMAs
         const int mi = nj >> 1;
-        if (DBG & 8) { an[mi][0] = raw[mi][0]; an[mi][1] = raw[mi][1]; an[mi][2] = raw[mi][0]; }
-        else gx_split8(__builtin_bit_cast(float4, raw[mi][0]), __builtin_bit_cast(float4, raw[mi][1]), an[mi]);
+        if (DBG & 8) { an[mi][0] = raw[mi][0]; an[mi][1] = raw[mi][1]; an[mi][NTERM - 1] = raw[mi][0]; }
+        else gx_split8_m<MODE>(__builtin_bit_cast(float4, raw[mi][0]), __builtin_bit_cast(float4, raw[mi][1]), an[mi]);
       }
       // small products first; (ta, tb): x3 w1, x2 w2, x1 w3, x2 w1, x1 w2, x1 w1; the two M tiles alternate (dependent MFMAs 64 cycles apart)
 #define GX_MM(ta, tb)                                                                                    \
   if (DBG & 4) { acc[0][nj][0] += (float)af[0][ta][0] * (float)bf[tb][0]; acc[1][nj][0] += (float)af[1][ta][1] * (float)bf[tb][1]; } else {            \
-  acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ta], bf[tb], acc[0][nj], 0, 0, 0);         \
-  acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ta], bf[tb], acc[1][nj], 0, 0, 0); }
-      GX_MM(2, 0) GX_MM(1, 1) GX_MM(0, 2) GX_MM(1, 0) GX_MM(0, 1) GX_MM(0, 0)
+  acc[0][nj] = gx_mfma<MODE>(af[0][ta], bf[tb], acc[0][nj]);         \
+  acc[1][nj] = gx_mfma<MODE>(af[1][ta], bf[tb], acc[1][nj]); }
+      if (MODE == 0 && !(DBG & 256)) { GX_MM(NTERM - 1, 0) GX_MM(1, 1) GX_MM(0, NTERM - 1) }   // (NTERM - 1 = 2 here; written so that the fp16x2 instantiation compiles)
+      GX_MM(1, 0) GX_MM(0, 1) GX_MM(0, 0)
 #undef GX_MM
       if (nj == 0 || nj == 2) {   // one MFMA (32 cycles of the SIMD's matrix pipe), four VALU of the split
 #pragma unroll
@@ -234,12 +261,12 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
     // stage ks + 2 must have landed for everyone: my own DMA of it is older than the 5 instructions of stage ks + 3 just issued.  lgkmcnt(0): this
     // wave's LDS reads of the current buffer have RETURNED before it lets the others go on to overwrite it
     if (DBG & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
-    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    if (NDMA == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) af[mi][t] = an[mi][t];
+      for (int t = 0; t < NTERM; ++t) af[mi][t] = an[mi][t];
     cur = nxt;
   }
 
@@ -250,12 +277,13 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
     const int n = n0 + wn * 128 + nj * 32 + li;
     const bool nok = n < a.N;
     const float bv = (a.has_bias && nok) ? bias[n] : 0.f;
+    const float cs = (MODE == 1 && nok) ? colscale[n] : 1.f;   // fp16x2: the weight rows were scaled by a power of two (exact) before their split
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        float v = acc[mi][nj][r] + bv;
+        float v = MODE == 1 ? acc[mi][nj][r] * cs + bv : acc[mi][nj][r] + bv;
         if (a.epilogue == 1) v = gx_gelu(v);
         if (nok && m < a.M && (!(DBG & 16) || v == 12345.678f)) Y[m * (long long)a.N + n] = v;
       }
@@ -263,53 +291,82 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
   }
 }
 
-// ---- weights: float32 [N][K] -> the stage images [N tile][K step][term][k-half][n 256][8 bf16]; rows past N are zero.  One thread per (n, 8 k).
-__global__ __launch_bounds__(256) void k_gemm_x3_pack_w(const float* __restrict__ W, int N, int K, int nbn, uint4* __restrict__ img) {
+// ---- weights: float32 [N][K] -> the stage images [N tile][K step][term][k-half][n 256][8 x 16 bit]; rows past N are zero.  One thread per (n, 8 k).
+// MODE 1 (fp16x2): row n is first multiplied by colscale_inv[n] = 2^e(n), the power of two that brings its largest magnitude into [2^13, 2^14) -- exact, and it
+// keeps the SECOND fp16 term of every weight that matters a normal number; the kernel's epilogue multiplies the column's sums by 2^-e(n) (exact).  The scales
+// live behind the stage images: float colscale[nbn * 256] = 2^-e(n).
+__global__ __launch_bounds__(256) void k_gemm_x3_rowscale(const float* __restrict__ W, int N, int K, int nbn, float* __restrict__ colscale) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per row
+  if (n >= nbn * GX_BN) return;
+  float mx = 0.f;
+  if (n < N) for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(W[(size_t)n * K + k]));
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) {
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) { e = 13 - (int)floorf(log2f(mx)); e = e < -100 ? -100 : (e > 100 ? 100 : e); }
+    colscale[n] = exp2f((float)-e);   // exact power of two
+  }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gemm_x3_pack_w(const float* __restrict__ W, int N, int K, int nbn, uint4* __restrict__ img, const float* __restrict__ colscale) {
+  constexpr int NTERM = GX_NTERM(MODE), STAGE_HALF = GX_STAGE_HALF(MODE);
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int kc = K / 8;
   const long long total = (long long)nbn * GX_BN * kc;
   if (t >= total) return;
   const int n = (int)(t / kc), c = (int)(t - (long long)n * kc);   // chunk c = 8 consecutive k
-  uint32_t w1[8], w2[8], w3[8];
+  const float sc = MODE == 1 ? 1.0f / colscale[n] : 1.0f;           // 2^e(n): the reciprocal of a power of two is exact
+  float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = n < N ? W[(size_t)n * K + c * 8 + j] : 0.f;
-    gx_split(v, w1[j], w2[j], w3[j]);
-  }
+  for (int j = 0; j < 8; ++j) v[j] = n < N ? W[(size_t)n * K + c * 8 + j] * sc : 0.f;
+  gx_bf8 o[NTERM];
+  gx_split8_m<MODE>(float4{v[0], v[1], v[2], v[3]}, float4{v[4], v[5], v[6], v[7]}, o);
   const int ntile = n / GX_BN, nl = n - ntile * GX_BN, ks = c >> 1, khf = c & 1;
-  uint4* base = img + ((size_t)ntile * (K / 16) + ks) * (GX_STAGE_HALF / 16) + khf * GX_BN + nl;
-  base[0 * 2 * GX_BN] = make_uint4(gx_pack(w1[0], w1[1]), gx_pack(w1[2], w1[3]), gx_pack(w1[4], w1[5]), gx_pack(w1[6], w1[7]));
-  base[1 * 2 * GX_BN] = make_uint4(gx_pack(w2[0], w2[1]), gx_pack(w2[2], w2[3]), gx_pack(w2[4], w2[5]), gx_pack(w2[6], w2[7]));
-  base[2 * 2 * GX_BN] = make_uint4(gx_pack(w3[0], w3[1]), gx_pack(w3[2], w3[3]), gx_pack(w3[4], w3[5]), gx_pack(w3[6], w3[7]));
+  uint4* base = img + ((size_t)ntile * (K / 16) + ks) * (STAGE_HALF / 16) + khf * GX_BN + nl;
+#pragma unroll
+  for (int t3 = 0; t3 < NTERM; ++t3) base[t3 * 2 * GX_BN] = __builtin_bit_cast(uint4, o[t3]);
 }
 
-long long vd_gemm_x3_weight_bytes(int N, int K) {
-  if (N < 1 || K < 16 || (K & 15)) return -1;
+static bool gx_mode_ok(int mode) { return mode == 0 || mode == 1; }
+long long vd_gemm_x3_weight_bytes(int N, int K, int mode) {
+  if (N < 1 || K < 16 || (K & 15) || !gx_mode_ok(mode)) return -1;
   const long long nbn = (N + GX_BN - 1) / GX_BN;
-  return nbn * (K / 16) * (long long)GX_STAGE_HALF;
+  return nbn * (K / 16) * (long long)(mode == 0 ? GX_STAGE_HALF(0) : GX_STAGE_HALF(1)) + (mode == 1 ? nbn * GX_BN * 4 : 0);
+}
+static const float* gx_colscale(const void* img, int N, int K, int mode) {
+  if (mode != 1) return nullptr;
+  const long long nbn = (N + GX_BN - 1) / GX_BN;
+  return reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(img) + nbn * (K / 16) * (long long)GX_STAGE_HALF(1));
 }
 
-bool vd_launch_gemm_x3_pack_w(hipStream_t s, const float* W, int N, int K, void* img) {
-  if (vd_gemm_x3_weight_bytes(N, K) < 0) return false;
+bool vd_launch_gemm_x3_pack_w(hipStream_t s, const float* W, int N, int K, void* img, int mode) {
+  if (vd_gemm_x3_weight_bytes(N, K, mode) < 0) return false;
   const int nbn = (N + GX_BN - 1) / GX_BN;
   const long long total = (long long)nbn * GX_BN * (K / 8);
-  hipLaunchKernelGGL(k_gemm_x3_pack_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, N, K, nbn, reinterpret_cast<uint4*>(img));
+  float* cs = const_cast<float*>(gx_colscale(img, N, K, mode));
+  if (mode == 1) {
+    hipLaunchKernelGGL(k_gemm_x3_rowscale, dim3((unsigned)((nbn * GX_BN + 3) / 4)), dim3(256), 0, s, W, N, K, nbn, cs);
+    hipLaunchKernelGGL(k_gemm_x3_pack_w<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, N, K, nbn, reinterpret_cast<uint4*>(img), (const float*)cs);
+  } else {
+    hipLaunchKernelGGL(k_gemm_x3_pack_w<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, N, K, nbn, reinterpret_cast<uint4*>(img), (const float*)nullptr);
+  }
   return true;
 }
 
-bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const void* wimg, int N, const float* bias, int epilogue, float* Y) {
-  if (M < 1 || vd_gemm_x3_weight_bytes(N, K) < 0 || epilogue < 0 || epilogue > 1) return false;
+bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const void* wimg, int N, const float* bias, int epilogue, float* Y, int mode) {
+  if (M < 1 || vd_gemm_x3_weight_bytes(N, K, mode) < 0 || epilogue < 0 || epilogue > 1) return false;
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(wimg) & 15)) return false;
   static bool attr_set = false;   // idempotent: a race between two first calls sets the same value twice
   static int dbg = 0;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16x3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16x3<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS(0)) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16x3<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS(1)) != hipSuccess) return false;
 #ifdef VD_GEMM_ABLATE
-    for (const void* f : {reinterpret_cast<const void*>(k_gemm_bf16x3<1>), reinterpret_cast<const void*>(k_gemm_bf16x3<2>), reinterpret_cast<const void*>(k_gemm_bf16x3<4>),
-                          reinterpret_cast<const void*>(k_gemm_bf16x3<8>), reinterpret_cast<const void*>(k_gemm_bf16x3<5>), reinterpret_cast<const void*>(k_gemm_bf16x3<3>),
-                          reinterpret_cast<const void*>(k_gemm_bf16x3<9>), reinterpret_cast<const void*>(k_gemm_bf16x3<11>), reinterpret_cast<const void*>(k_gemm_bf16x3<16>), reinterpret_cast<const void*>(k_gemm_bf16x3<27>),
-                          reinterpret_cast<const void*>(k_gemm_bf16x3<32>), reinterpret_cast<const void*>(k_gemm_bf16x3<64>), reinterpret_cast<const void*>(k_gemm_bf16x3<128>), reinterpret_cast<const void*>(k_gemm_bf16x3<130>)})
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS) != hipSuccess) return false;
+    for (const void* f : {reinterpret_cast<const void*>(k_gemm_bf16x3<1, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<2, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<4, 0>),
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<8, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<5, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<3, 0>),
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<9, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<11, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<16, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<27, 0>),
+                          reinterpret_cast<const void*>(k_gemm_bf16x3<32, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<64, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<128, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<130, 0>), reinterpret_cast<const void*>(k_gemm_bf16x3<256, 0>)})
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS(0)) != hipSuccess) return false;
     dbg = getenv("VD3D_GEMM_DBG") ? atoi(getenv("VD3D_GEMM_DBG")) : 0;
 #endif
     attr_set = true;
@@ -320,12 +377,17 @@ bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const 
   a.epilogue = epilogue; a.has_bias = bias ? 1 : 0;
   const int per_xcd = (a.nbm + 7) / 8, groups = (per_xcd + GX_MG - 1) / GX_MG;
   const unsigned grid = 8u * (unsigned)groups * (unsigned)GX_MG * (unsigned)a.nbn;
+  const float* cs = gx_colscale(wimg, N, K, mode);
+  if (mode == 1) {
+    hipLaunchKernelGGL((k_gemm_bf16x3<0, 1>), dim3(grid), dim3(GX_NT), GX_LDS(1), s, X, reinterpret_cast<const uint4*>(wimg), bias, cs, Y, a);
+    return true;
+  }
 #ifdef VD_GEMM_ABLATE
-#define GX_L(D) hipLaunchKernelGGL(k_gemm_bf16x3<D>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a)
+#define GX_L(D) hipLaunchKernelGGL((k_gemm_bf16x3<D, 0>), dim3(grid), dim3(GX_NT), GX_LDS(0), s, X, reinterpret_cast<const uint4*>(wimg), bias, cs, Y, a)
   switch (dbg) { case 1: GX_L(1); return true; case 2: GX_L(2); return true; case 4: GX_L(4); return true; case 8: GX_L(8); return true; case 5: GX_L(5); return true;
-                 case 3: GX_L(3); return true; case 9: GX_L(9); return true; case 11: GX_L(11); return true; case 16: GX_L(16); return true; case 27: GX_L(27); return true; case 32: GX_L(32); return true; case 64: GX_L(64); return true; case 128: GX_L(128); return true; case 130: GX_L(130); return true; default: break; }
+                 case 3: GX_L(3); return true; case 9: GX_L(9); return true; case 11: GX_L(11); return true; case 16: GX_L(16); return true; case 27: GX_L(27); return true; case 32: GX_L(32); return true; case 64: GX_L(64); return true; case 128: GX_L(128); return true; case 130: GX_L(130); return true; case 256: GX_L(256); return true; default: break; }
 #endif
   (void)dbg;
-  hipLaunchKernelGGL(k_gemm_bf16x3<0>, dim3(grid), dim3(GX_NT), GX_LDS, s, X, reinterpret_cast<const uint4*>(wimg), bias, Y, a);
+  hipLaunchKernelGGL((k_gemm_bf16x3<0, 0>), dim3(grid), dim3(GX_NT), GX_LDS(0), s, X, reinterpret_cast<const uint4*>(wimg), bias, cs, Y, a);
   return true;
 }

@@ -194,12 +194,12 @@ bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, in
                           const float stdv[3], int dtype, void* out_nhwc);
 // ---- vd3d_netops.hip
 // vd3d_gemm.hip: the transformer linears as a split-bf16 (bf16x3, six products) GEMM with float32 accumulation
-long long vd_gemm_x3_weight_bytes(int N, int K);
-bool vd_launch_gemm_x3_pack_w(hipStream_t s, const float* W, int N, int K, void* img);
-bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const void* wimg, int N, const float* bias, int epilogue, float* Y);
+long long vd_gemm_x3_weight_bytes(int N, int K, int mode);
+bool vd_launch_gemm_x3_pack_w(hipStream_t s, const float* W, int N, int K, void* img, int mode);
+bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const void* wimg, int N, const float* bias, int epilogue, float* Y, int mode);
 // vd3d_attn.hip: softmax(Q K^T scale) V with both products as split-bf16 MFMA work
-long long vd_attn_x3_workspace_bytes(int B, int T, int H, int D);
-bool vd_launch_attn_x3(hipStream_t s, const float* qkv, int B, int T, int H, int D, float scale, void* ws, float* out);
+long long vd_attn_x3_workspace_bytes(int B, int T, int H, int D, int mode);
+bool vd_launch_attn_x3(hipStream_t s, const float* qkv, int B, int T, int H, int D, float scale, void* ws, float* out, int mode);
 bool vd_launch_add_layernorm(hipStream_t s, int dtype, const void* x, const void* y, const void* gamma, const void* beta, float eps,
                              long long rows, int cols, void* out_sum, void* out_norm);
 bool vd_launch_upsample_bilinear_nhwc(hipStream_t s, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);

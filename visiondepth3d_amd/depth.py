@@ -153,7 +153,9 @@ class DepthPipe:
         ``gemm`` (float32 + ``renderer`` only; round 6): ``"f32"`` (default) -- the four linears of every transformer block are hipBLASLt's float32
         GEMMs; ``"bf16x3"`` -- OPT-IN: the library's own split-bf16 GEMM (``vd3d_gemm_x3``: every float32 operand exactly split into three bf16
         terms, six products per MAC on the bf16 matrix cores, float32 accumulation -- float32-faithful, see include/vd3d.h), with the exact GELU
-        folded into fc1's epilogue, and the attention in the same arithmetic (``vd3d_attention_x3``: both products split-bf16, float32 online softmax).  gfx950 has no TF32 and its float32-input MFMA runs at 1/16 of the bf16 rate, which caps the default mode.
+        folded into fc1's epilogue, and the attention in the same arithmetic (``vd3d_attention_x3``: both products split-bf16, float32 online softmax).
+        ``"fp16x2"`` -- OPT-IN: the same kernels with every operand as TWO fp16 terms (22 significant bits, round to nearest) and three products per MAC
+        -- half the matrix work of bf16x3; weights pre-scaled per row, activations must stay below 65 504 (include/vd3d.h).  gfx950 has no TF32 and its float32-input MFMA runs at 1/16 of the bf16 rate, which caps the default mode.
         ``renderer``: a ``visiondepth3d_amd.render_3d.Renderer`` on the SAME stream as the network (default stream); when given the
         image-processor front end, the residual-add + LayerNorm pairs and the DPT up-samplings run as fused HIP launches.
         ``model`` / ``processor``: an already constructed Hugging Face depth model and its image-processor constants
@@ -165,10 +167,10 @@ class DepthPipe:
         first forward of a process, 4.5 % on the 4K float32 forward (profiles/r04_net_library_selection.md); opt-in, bench.py uses it.
         The flag is PyTorch's process-wide one: True / False set it, None (default) leaves it as the caller has it."""
         self.name, self.device, self.dtype = name, torch.device(device), dtype
-        if gemm not in ("f32", "bf16x3"):
-            raise ValueError("gemm must be 'f32' or 'bf16x3'")
-        if gemm == "bf16x3" and (dtype != torch.float32 or renderer is None or torch.device(device).type != "cuda"):
-            raise ValueError("gemm='bf16x3' is a mode of the float32 pipe on the GPU and needs a renderer (the GEMM lives in libvd3d_hip.so)")
+        if gemm not in ("f32", "bf16x3", "fp16x2"):
+            raise ValueError("gemm must be 'f32', 'bf16x3' or 'fp16x2'")
+        if gemm != "f32" and (dtype != torch.float32 or renderer is None or torch.device(device).type != "cuda"):
+            raise ValueError("gemm='bf16x3' / 'fp16x2' are modes of the float32 pipe on the GPU and need a renderer (the kernels live in libvd3d_hip.so)")
         self.gemm = gemm
         self.tuned_gemm = self.miopen_find = False
         self._flop_count = None
@@ -419,21 +421,23 @@ class DepthPipe:
             n1, n2, act = layer.norm1, layer.norm2, layer.mlp.activation
             nxt = layers[li + 1].norm1 if li + 1 < len(layers) else None
             x3 = None
-            if self.gemm == "bf16x3":   # weights split + packed once; exact GELU only (what DINOv2's MLP uses) goes into fc1's epilogue
+            if self.gemm != "f32":   # weights split + packed once; exact GELU only (what DINOv2's MLP uses) goes into fc1's epilogue
                 gelu_ok = isinstance(act, torch.nn.GELU) and getattr(act, "approximate", "none") == "none" or type(act).__name__ == "GELUActivation"
-                x3 = dict(qkv=(R.gemm_x3_pack(wqkv), wqkv.shape[0]), wo=(R.gemm_x3_pack(wo), wo.shape[0]),
-                          fc1=(R.gemm_x3_pack(fc1.weight), fc1.weight.shape[0]), w2=(R.gemm_x3_pack(w2), w2.shape[0]), gelu=bool(gelu_ok))
+                gm = self.gemm
+                x3 = dict(qkv=(R.gemm_x3_pack(wqkv, gm), wqkv.shape[0]), wo=(R.gemm_x3_pack(wo, gm), wo.shape[0]),
+                          fc1=(R.gemm_x3_pack(fc1.weight, gm), fc1.weight.shape[0]), w2=(R.gemm_x3_pack(w2, gm), w2.shape[0]), gelu=bool(gelu_ok), mode=gm)
 
             def fwd(x, wqkv=wqkv, bqkv=bqkv, wo=wo, bo=bo, fc1=fc1, w2=w2, b2=b2, nh=nh, hd=hd, scaling=scaling, n1=n1, n2=n2,
                     act=act, nxt=nxt, x3=x3):
                 B, T, d = x.shape
                 if x3 is not None and x.dtype == torch.float32 and x.is_contiguous() and d in (384, 768, 1024):
-                    lin = lambda t, key, bias, gelu=False: R.linear_x3(t if t.is_contiguous() else t.contiguous(), x3[key][0], x3[key][1], bias, gelu=gelu)
+                    lin = lambda t, key, bias, gelu=False: R.linear_x3(t if t.is_contiguous() else t.contiguous(), x3[key][0], x3[key][1], bias, gelu=gelu,
+                                                                       mode=x3["mode"])
                     h = stash["h"] if stash["x"] is x else R.add_layernorm(x, None, n1)[1]
                     stash["x"] = stash["h"] = None
                     qkv = lin(h, "qkv", bqkv)
                     if hd == 64 and not pad_state["T"]:   # the library's split-bf16 attention (every DINOv2 size has 64-wide heads)
-                        o = R.attention_x3(qkv, nh, scaling)
+                        o = R.attention_x3(qkv, nh, scaling, mode=x3["mode"])
                     else:
                         qkv = qkv.view(B, T, 3, nh, hd)
                         Tk = pad_state["T"] or T

@@ -602,35 +602,40 @@ class Renderer:
                                               _ptr(norm.bias), float(norm.eps), rows, cols, _ptr(out_s) if y is not None else None, _ptr(out_n)))
         return out_s, out_n
 
-    def gemm_x3_pack(self, weight: torch.Tensor) -> torch.Tensor:
-        """Split + pack a float32 Linear weight [N, K] once for ``linear_x3`` (include/vd3d.h vd3d_gemm_x3_pack_weights); returns the opaque image (uint8)."""
+    X3_MODES = {"bf16x3": 0, "fp16x2": 1}
+
+    def gemm_x3_pack(self, weight: torch.Tensor, mode: str = "bf16x3") -> torch.Tensor:
+        """Split + pack a float32 Linear weight [N, K] once for ``linear_x3`` in ``mode`` (include/vd3d.h vd3d_gemm_x3_pack_weights); returns the opaque image (uint8)."""
         w = weight.detach().to(self.device, torch.float32).contiguous()
         N, K = w.shape
-        nb = int(self._L.vd3d_gemm_x3_weight_bytes(N, K))
+        m = self.X3_MODES[mode]
+        nb = int(self._L.vd3d_gemm_x3_weight_bytes(N, K, m))
         if nb < 0:
             raise NotImplementedError(f"gemm_x3: K = {K} is not a positive multiple of 16")
         img = torch.empty(nb, dtype=torch.uint8, device=self.device)
         self._enter(w, img)
-        _lib.check(self._L.vd3d_gemm_x3_pack_weights(self._ctx, _ptr(w), N, K, _ptr(img)))
+        _lib.check(self._L.vd3d_gemm_x3_pack_weights(self._ctx, _ptr(w), N, K, m, _ptr(img)))
         return img
 
-    def linear_x3(self, x: torch.Tensor, w_image: torch.Tensor, N: int, bias: torch.Tensor | None = None, gelu: bool = False) -> torch.Tensor:
-        """F.linear(x, W, bias) (+ exact GELU) for contiguous float32 x [..., K] with W given as ``gemm_x3_pack(W)``: split-bf16 MFMA, float32-faithful."""
+    def linear_x3(self, x: torch.Tensor, w_image: torch.Tensor, N: int, bias: torch.Tensor | None = None, gelu: bool = False, mode: str = "bf16x3") -> torch.Tensor:
+        """F.linear(x, W, bias) (+ exact GELU) for contiguous float32 x [..., K] with W given as ``gemm_x3_pack(W, mode)``: split-operand MFMA GEMM, float32 accumulation."""
         K = x.shape[-1]
         M = x.numel() // K
         out = torch.empty(x.shape[:-1] + (int(N),), dtype=torch.float32, device=x.device)
         self._enter(x, w_image, bias, out)
-        _lib.check(self._L.vd3d_gemm_x3(self._ctx, _ptr(x), M, K, _ptr(w_image), int(N), _ptr(bias) if bias is not None else None, 1 if gelu else 0, _ptr(out)))
+        _lib.check(self._L.vd3d_gemm_x3(self._ctx, _ptr(x), M, K, _ptr(w_image), int(N), self.X3_MODES[mode], _ptr(bias) if bias is not None else None,
+                                        1 if gelu else 0, _ptr(out)))
         return out
 
-    def attention_x3(self, qkv: torch.Tensor, n_heads: int, scale: float) -> torch.Tensor:
+    def attention_x3(self, qkv: torch.Tensor, n_heads: int, scale: float, mode: str = "bf16x3") -> torch.Tensor:
         """softmax(q k^T * scale) v for the contiguous float32 output ``qkv`` [B, T, 3 * H * 64] of a fused QKV linear (q / k / v = the three [H, 64] blocks of
-        a token) -> [B, T, H * 64] float32; both products as split-bf16 MFMA work (include/vd3d.h vd3d_attention_x3)."""
+        a token) -> [B, T, H * 64] float32; both products as split-operand MFMA work (include/vd3d.h vd3d_attention_x3)."""
         B, T, C3 = qkv.shape
         D = C3 // (3 * n_heads)
         if qkv.dtype != torch.float32 or not qkv.is_contiguous() or D * 3 * n_heads != C3:
             raise AssertionError("qkv must be contiguous float32 [B, T, 3 * H * D]")
-        nb = int(self._L.vd3d_attention_x3_workspace_bytes(B, T, n_heads, D))
+        m = self.X3_MODES[mode]
+        nb = int(self._L.vd3d_attention_x3_workspace_bytes(B, T, n_heads, D, m))
         if nb < 0:
             raise NotImplementedError(f"attention_x3: head size {D} not built")
         ws = getattr(self, "_attn_ws", None)
@@ -638,7 +643,7 @@ class Renderer:
             ws = self._attn_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
         out = torch.empty((B, T, n_heads * D), dtype=torch.float32, device=self.device)
         self._enter(qkv, ws, out)
-        _lib.check(self._L.vd3d_attention_x3(self._ctx, _ptr(qkv), B, T, n_heads, D, float(scale), _ptr(ws), ws.numel(), _ptr(out)))
+        _lib.check(self._L.vd3d_attention_x3(self._ctx, _ptr(qkv), B, T, n_heads, D, float(scale), m, _ptr(ws), ws.numel(), _ptr(out)))
         return out
 
     def upsample_bilinear(self, x: torch.Tensor, size) -> torch.Tensor:
