@@ -661,6 +661,9 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
               "k_e2w_avg_launch_ms": (e2w_ms if e2w_ms > 0 else None), "k_warp_fused_avg_launch_ms": (round(w1_ms - e2w_ms, 5) if e2w_ms > 0 else None),
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
               "traffic": w1.get("corrected_bytes_per_launch"), "traffic_source": w1.get("source"),
+              # FETCH_SIZE at face value + WRITE_SIZE: the guide's x2 read correction is calibrated on 16-byte-per-lane streaming reads; the no-feather W1's
+              # 4-byte-per-lane reads are counted at face value (raw FETCH 57.75 MB = its 3 N + 4 N of reads), so for THAT kernel this is the true figure
+              "traffic_uncorrected": (int(round((w1["fetch_size_kb_raw"] + w1["write_size_kb"]) * 1000)) if w1.get("fetch_size_kb_raw") and w1.get("write_size_kb") else None),
               "traffic_taken_at_commit": (_pmc("commit") or None),
               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": w1_ms, "avg_launch_measured": w1_src,
               "rocprof_avg_launch_ms": (round(w1["rocprof_avg_launch_us"] / 1e3, 5) if w1.get("rocprof_avg_launch_us") else None),
@@ -738,7 +741,7 @@ def sub_record(res, extra=None):
     return d
 
 COMPACT_LINE_LIMIT = 6000   # bytes; the driver reads the bench line out of an 8 KB tail of stdout (round 5's 22 KB line came back `parsed: null`)
-_ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "algorithmic_bytes_per_frame", "avg_launch_ms",
+_ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_uncorrected", "algorithmic_bytes_per_launch", "algorithmic_bytes_per_frame", "avg_launch_ms",
               "rocprof_avg_launch_ms", "in_step_avg_launch_ms", "k_e2w_avg_launch_ms", "k_warp_fused_avg_launch_ms", "k_shift_avg_launch_ms",
               "valu_frac_of_spec", "traffic_over_algorithmic", "measured_copy_GBs", "measured_on", "avg_frame_ms", "avg_batch_ms", "frames_per_batch",
               "flops_per_frame")
@@ -802,6 +805,9 @@ def compact_record(res, full_path=None):
             if rf:
                 out["sub_records"][n]["w1_frac"] = rf.get("frac")
                 out["sub_records"][n]["w1_avg_launch_ms"] = rf.get("avg_launch_ms")
+    if srs and any(n in srs for n in ("4k-dav2b-dibr-f32x3", "4k-dav2b-dibr-fp16x2")):
+        # the headline workload in the two OPT-IN float32-operand modes of the depth leg (split onto the 16-bit matrix cores, float32 accumulation; never `value`)
+        out["opt_in_depth_modes"] = {k: (srs.get(n) or {}).get("value") for k, n in (("bf16x3", "4k-dav2b-dibr-f32x3"), ("fp16x2", "4k-dav2b-dibr-fp16x2"))}
     out["note"] = ("compact line; notes, stage tables and per-sub-record rooflines: " + (full_path or "the earlier stdout line `bench_full_record`") +
                    "; W1/E1 frac = SURVEY 8(d) algorithmic bytes / HIP-event launch time / 8 TB/s; both kernels are VALU-bound (valu_*)")
     if res.get("commit"):
