@@ -898,7 +898,7 @@ def main():
         r1d = run_workload(env, args, "1080p-dibr", 10, 3, profile=prof)
         rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
         try:   # round 6: the headline workload with the transformer linears on the library's split-bf16 GEMM (float32-faithful, opt-in; never `value`)
-            rx3 = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="f32x3", profile=prof, isolated_pass=False)
+            rx3 = run_workload(env, args, HEADLINE, 12, 4, depth_dtype="f32x3", profile=prof, isolated_pass=False)
         except Exception as e:
             rx3 = None
             print(f"[bench] 4k-dav2b-dibr-f32x3 failed: {str(e)[:200]}", file=sys.stderr)
@@ -932,7 +932,7 @@ def main():
         if rx3 is not None:
             subs["4k-dav2b-dibr-f32x3"] = (rx3, None)
         try:
-            rh2 = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="f32h2", profile=prof, isolated_pass=False)
+            rh2 = run_workload(env, args, HEADLINE, 12, 4, depth_dtype="f32h2", profile=prof, isolated_pass=False)
             subs["4k-dav2b-dibr-fp16x2"] = (rh2, None)
         except Exception as e:
             print(f"[bench] 4k-dav2b-dibr-fp16x2 failed: {str(e)[:200]}", file=sys.stderr)

@@ -38,6 +38,7 @@ done
 [ -n "$ONLY_STEADY" ] || VD3D_COMMIT=${VD3D_COMMIT:-unknown} python $R/tools/pmc_to_json.py $TAG $SPECS > $O/pmc_latest.json
 [ -n "$SKIP_STEADY" ] || run_steady 4k_dav2b_f32 "python $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-sub-records --no-profile" 4
 [ -n "$SKIP_STEADY" ] || run_steady 4k_dav2b_f32x3 "python $R/bench.py --depth-dtype f32x3 --steps 6 --warmup 4 --no-cpu-baseline --no-sub-records --no-profile" 4
+[ -n "$SKIP_STEADY" ] || run_steady 4k_dav2b_fp16x2 "python $R/bench.py --depth-dtype f32h2 --steps 6 --warmup 4 --no-cpu-baseline --no-sub-records --no-profile" 4
 [ -n "$SKIP_STEADY" ] || run_steady 1080p_esrgan4k "python $R/bench.py --upscale-only" 3
 rm -rf $O/p_* $O/t_*
 ls -la $O
