@@ -139,13 +139,14 @@ def _physical_cores():
         return None
 
 
-def cpu_baseline_allcores(sh, sw, frames_per_core, max_cores=None, timeout_s=90.0):
+def cpu_baseline_allcores(sh, sw, frames_per_core, max_cores=64, timeout_s=90.0):
     """The same oracle on every host thread at once (one independent clip per PROCESS, `bench.py --cpu-worker ...`): the CPU path's
-    whole-socket throughput.  Plain subprocesses with a hard timeout -- nothing here can hang the benchmark.  One process per PHYSICAL core
-    (round 6; rounds 4 - 5 stopped at 64 of the box's 128): the oracle is float32 arithmetic, SMT siblings share the core's vector units -- one
-    process per hardware thread (256 on the MI355X box) was tried first and 103 of 256 workers had not finished one 4K frame after 120 s -- unless half
-    of the host's available memory would not hold one oracle process per core (a 4K process peaks at ~1.03 GB, a 1080p one at ~0.3 GB: measured)
-    -- then as many as fit; `cores` is what ran, `host_threads` what os.cpu_count() reports."""
+    whole-socket throughput.  Plain subprocesses with a hard timeout -- nothing here can hang the benchmark.
+    How many processes (round 6, measured on the MI355X box: 128 cores, 256 hardware threads, 4K frames): 64 processes -> 2.21 pairs/s (slowest 29 s per frame);
+    128 (one per physical core) -> 1.59 pairs/s (slowest 81 s: the oracle's float32 planes stream through memory and the sockets' bandwidth is what saturates, not the
+    cores); 256 (one per hardware thread) -> 103 of 256 workers had not finished their frame after 120 s.  The CPU path's best rate is therefore at 64 processes, and that
+    is what `max_cores` defaults to: the baseline reports the CPU at its best, `cores` is what ran, `host_threads` what os.cpu_count() reports.  Half of the host's available
+    memory must hold the processes (a 4K one peaks at ~1.03 GB, a 1080p one at ~0.3 GB: measured), else fewer run."""
     import subprocess
     host = os.cpu_count() or 1
     cores = min(_physical_cores() or host, max_cores or host)
@@ -898,7 +899,7 @@ def main():
         r1d = run_workload(env, args, "1080p-dibr", 10, 3, profile=prof)
         rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
         try:   # round 6: the headline workload with the transformer linears on the library's split-bf16 GEMM (float32-faithful, opt-in; never `value`)
-            rx3 = run_workload(env, args, HEADLINE, 12, 4, depth_dtype="f32x3", profile=prof, isolated_pass=False)
+            rx3 = run_workload(env, args, HEADLINE, 8, 4, depth_dtype="f32x3", profile=prof, isolated_pass=False)
         except Exception as e:
             rx3 = None
             print(f"[bench] 4k-dav2b-dibr-f32x3 failed: {str(e)[:200]}", file=sys.stderr)
@@ -932,7 +933,7 @@ def main():
         if rx3 is not None:
             subs["4k-dav2b-dibr-f32x3"] = (rx3, None)
         try:
-            rh2 = run_workload(env, args, HEADLINE, 12, 4, depth_dtype="f32h2", profile=prof, isolated_pass=False)
+            rh2 = run_workload(env, args, HEADLINE, 8, 4, depth_dtype="f32h2", profile=prof, isolated_pass=False)
             subs["4k-dav2b-dibr-fp16x2"] = (rh2, None)
         except Exception as e:
             print(f"[bench] 4k-dav2b-dibr-fp16x2 failed: {str(e)[:200]}", file=sys.stderr)

@@ -30,9 +30,11 @@
 extern "C" {
 #endif
 
-/* 5 (round 5): vd3d_shift_params gained aten_threads / reserved0 at its end (vd3d_render_params embeds it: its later fields moved by 8 bytes); vd3d_torch_math_aten.
+/* 6 (round 6): new entry points vd3d_gemm_x3_* / vd3d_attention_x3_* (no struct changed); vd3d_debug_tune answers only knobs 3 and 4 unless built with
+ *    -DVD3D_DEV_KNOBS; aten_threads / aten_sum_threads accept 1 .. 1024.
+ * 5 (round 5): vd3d_shift_params gained aten_threads / reserved0 at its end (vd3d_render_params embeds it: its later fields moved by 8 bytes); vd3d_torch_math_aten.
  * 4 (round 5): vd3d_render_params::reserved0 became aten_sum_threads (same layout). */
-#define VD3D_ABI_VERSION 5
+#define VD3D_ABI_VERSION 6
 
 typedef enum vd3d_status {
   VD3D_OK = 0,

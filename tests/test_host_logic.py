@@ -319,6 +319,18 @@ def test_render_sbs_3d_shell_cancel_blank_and_ffmpeg_pipe(monkeypatch):
     assert procs[0].cmd[procs[0].cmd.index("-pix_fmt") + 1] == "bgr24"
 
 
+def test_depth_pipe_split_modes_are_refused_without_the_library():
+    """The opt-in modes of round 6 are kernels of libvd3d_hip.so: a CPU pipe, a bf16 pipe or a pipe without a renderer cannot have them -- a loud ValueError, never a
+    silent fall-back to the float32 library GEMMs."""
+    import torch
+    from visiondepth3d_amd.depth import DepthPipe
+    for mode in ("bf16x3", "fp16x2"):
+        with pytest.raises(ValueError):
+            DepthPipe("depth-anything-v2-small", device="cpu", dtype=torch.float32, gemm=mode)
+    with pytest.raises(ValueError):
+        DepthPipe("depth-anything-v2-small", device="cpu", dtype=torch.float32, gemm="tf32")
+
+
 def test_dpt_front_end_matches_the_real_image_processor():
     """B3 / a25 front end against transformers' own DPTImageProcessor (the Depth-Anything-V2 preprocessor_config values): the
     target size rule on 70 frame sizes exactly, and the float statement the fused kernel is tested against (antialiased bicubic in
