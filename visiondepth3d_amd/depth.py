@@ -197,6 +197,9 @@ class DepthPipe:
         self.n_params = sum(p.numel() for p in self.model.parameters())
         self.renderer = renderer if (renderer is not None and self.device.type == "cuda") else None
         dino = self.arch == "da" and type(self.model.backbone).__name__ == "Dinov2Backbone"
+        if self.gemm != "f32" and not (dino and fuse_backbone):
+            raise NotImplementedError("gemm='bf16x3' / 'fp16x2' rewrite the fused DINOv2 backbone (Depth-Anything V1 / V2, Distill-Any-Depth with fuse_backbone=True); "
+                                      "this model runs its stock float32 graph -- nothing is substituted silently")
         if dino:
             self._cache_position_embeddings()
             if fuse_backbone:
