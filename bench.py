@@ -457,6 +457,9 @@ def run_workload(env: Env, args, workload: str, steps: int, warmup: int, depth_d
     r.close()
     if rh is not r:
         rh.close()
+    import gc
+    gc.collect()   # the fused-backbone rewrites are closures on the model's own layers (reference cycles): collect the whole pipe NOW, so that neither its
+                   # device memory nor its tens of thousands of tracked Python objects ride along through the later workloads' launch loops
     torch.cuda.empty_cache()
     return res
 
