@@ -9,7 +9,14 @@
 // the six kept products per K-step go through v_mfma_f32_32x32x16_bf16 with float32 accumulation.  Result: float32-faithful dot products (error
 // model = a float32 GEMM with another summation order plus one extra rounding-sized term per product; tests/test_hip_gemm.py checks it against
 // float64, beside hipBLASLt's float32 GEMM) at six bf16 MFMAs per float32 MAC: a ceiling of 2.5 PFLOP/s / 6 = 417 TFLOP/s float32-equivalent
-// instead of 157.
+// instead of 157.  That is MODE 0 ("bf16x3").
+// MODE 1 ("fp16x2"), same kernel: every operand as TWO fp16 terms, h1 = fp16(x), h2 = fp16(x - h1), both round-to-nearest -- 22 significant bits,
+// |x - h1 - h2| <= 2^-22 |x| while h2 is a normal fp16 number -- and the three products x1 w1 + x1 w2 + x2 w1 through v_mfma_f32_32x32x16_f16: HALF the
+// matrix work.  Per product up to ~3 x 2^-22 relative instead of one float32 rounding; summed over K >= 64 products that stays below the float32
+// accumulation error both modes share (measured: both are MORE accurate against float64 than hipBLASLt's float32 kernel, fp16x2 the most -- three
+// accumulations per MAC instead of six).  Range: fp16 stops at 65 504 and its normal numbers at 2^-14, so weight rows are multiplied by the power of two that
+// brings their largest magnitude into [2^13, 2^14) before the split (exact; the epilogue multiplies the column's sums by its reciprocal) and activations
+// are taken as they are: |x| must stay below 65 504 (else Inf / NaN), and an |x| < 2^-2 is represented with an absolute error <= 2^-25 instead of a relative one.
 //
 // Kernel (k_gemm_bf16x3): 256 x 256 output tile per workgroup, 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 128 = 2 x 4 MFMA tiles =
 // 128 accumulator registers, two waves per SIMD.  K-step 16 (one MFMA K).  BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4: no
@@ -30,8 +37,8 @@
 // 0.627, + stores 0.682; the DMAs alone 0.347 ms.  The DMA cost that stays exposed (~0.17 ms) did not move with the issue pattern: all DMAs at the top
 // of the iteration 0.92, dealt between the MFMA groups 0.85, issued by one wave per SIMD only 0.85, B fragments read one chunk ahead 0.86; without the
 // counted wait AND without the barrier 0.84 (nobody waits for a DMA to land); without the A DMAs 0.79, without the B DMAs 0.81, without both 0.67.  The
-// cost follows the WORK in flight, not the schedule -- the signature of a power-limited chip (1.86 GHz under this load against 2.4 GHz nominal): what is
-// left is doing less per MAC, not ordering it better.  Earlier structures, for the record: A split in
+// cost follows the WORK in flight, not the schedule (the chip holds 1.86 GHz under this load against 2.4 GHz nominal: consistent with a power limit, not
+// proven to be one): what moved the kernel was doing less per MAC -- MODE 1: 0.551 ms for the same shape, 228 - 339 TFLOP/s float32-equivalent over the four.  Earlier structures, for the record: A split in
 // registers before the LDS write (global loads one stage ahead, 12 ds_write per thread and stage, one __syncthreads() per stage, double buffer)
 // 0.86 - 0.92 ms; 256 x 128 tiles with two workgroups per CU 0.88; a three-stage ring with the split in front of its own MFMAs 0.92.
 // Tile order: workgroup b runs on XCD b % 8 (speed assumption only): every XCD owns the M tiles mt = x (mod 8) and walks them four at a time across

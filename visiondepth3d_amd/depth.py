@@ -433,7 +433,9 @@ class DepthPipe:
             def fwd(x, wqkv=wqkv, bqkv=bqkv, wo=wo, bo=bo, fc1=fc1, w2=w2, b2=b2, nh=nh, hd=hd, scaling=scaling, n1=n1, n2=n2,
                     act=act, nxt=nxt, x3=x3):
                 B, T, d = x.shape
-                if x3 is not None and x.dtype == torch.float32 and x.is_contiguous() and d in (384, 768, 1024):
+                if x3 is not None and not (x.dtype == torch.float32 and x.is_contiguous() and d in (384, 768, 1024)):
+                    raise NotImplementedError(f"gemm={x3['mode']!r}: hidden size {d} / dtype {x.dtype} not built (float32, 384 / 768 / 1024) -- refusing to fall back silently")
+                if x3 is not None:
                     lin = lambda t, key, bias, gelu=False: R.linear_x3(t if t.is_contiguous() else t.contiguous(), x3[key][0], x3[key][1], bias, gelu=gelu,
                                                                        mode=x3["mode"])
                     h = stash["h"] if stash["x"] is x else R.add_layernorm(x, None, n1)[1]
