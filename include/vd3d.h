@@ -417,6 +417,16 @@ int vd3d_gemm_x3(vd3d_ctx* ctx, const float* X, int64_t M, int K, const void* w_
 int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D, int mode);
 int vd3d_attention_x3(vd3d_ctx* ctx, const float* qkv, int B, int T, int H, int D, float scale, int mode, void* workspace, int64_t workspace_bytes, float* out);
 
+/* The 3 x 3 convolutions of the DPT neck / head in the fp16x2 arithmetic (the third piece of DepthPipe(gemm="fp16x2")): stride 1, zero padding 1, no bias
+ * (DepthPipe runs them bias-free with a glue launch behind each), float32 channels_last: X [B][H][W][Cin] -> Y [B][H][W][Cout], W the module's float32
+ * weight [Cout][Cin][3][3].  Cin a multiple of 16, Cout 64 or 128 (the fusion stage and the head's first convolution of DA-V2-Small / -Base), else
+ * VD3D_E_UNSUPPORTED -- the caller keeps the library convolution for those.  Same arithmetic contract as vd3d_gemm_x3 in mode VD3D_X3_FP16X2 (operands as two
+ * fp16 terms, three MFMA products, float32 accumulation, weights pre-scaled per output channel by an exact power of two, |x| < 65 504).
+ * The weights are split and packed once into vd3d_conv3x3_x2_weight_bytes(Cin, Cout) bytes (< 0: unsupported shape). */
+int64_t vd3d_conv3x3_x2_weight_bytes(int Cin, int Cout);
+int vd3d_conv3x3_x2_pack_weights(vd3d_ctx* ctx, const float* W, int Cin, int Cout, void* image);
+int vd3d_conv3x3_x2(vd3d_ctx* ctx, const float* X, int B, int H, int W, int Cin, const void* w_image, int Cout, float* Y);
+
 /* F.interpolate(mode="bilinear", align_corners=True) of an NHWC (channels_last) tensor [B][ih][iw][C] -> [B][oh][ow][C] of
  * `dtype`, C a multiple of 8 (bf16) / 4 (f32): the up-samplings of the DPT neck / head (a25). */
 int vd3d_upsample_bilinear_nhwc(vd3d_ctx* ctx, int dtype, const void* in, void* out, int B, int ih, int iw, int oh, int ow, int C);

@@ -157,6 +157,42 @@ def test_attention_x3_known_answers(R):
     assert torch.allclose(out, qkv[:, 17:18, 2].expand(1, T, H, D), rtol=0, atol=1e-30)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 32, 16, 64), (2, 37, 66, 128, 128), (1, 50, 45, 96, 128), (3, 19, 33, 64, 64), (1, 74, 132, 128, 64),
+                                              (1, 1, 1, 32, 64), (2, 17, 31, 48, 128)])
+def test_conv3x3_x2_is_float32_faithful(R, B, H, W, Cin, Cout):
+    """vd3d_conv3x3_x2 (the DPT neck / head convolutions in the fp16x2 arithmetic) against a float64 convolution, beside the float32 library convolution on the same
+    operands: RMS error <= 1.5 x, maximum <= 2.5 x the library's.  Sizes that are not multiples of the 16 x 32 tile, a one-pixel image (every tap but the centre is
+    padding), the neck's 96-channel input; post-ReLU inputs with a few large channels, like the maps the fusion stage sees."""
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + H)
+    x = torch.relu(torch.randn(B, Cin, H, W, device="cuda", generator=g)) * torch.exp(torch.randn(1, Cin, 1, 1, device="cuda", generator=g))
+    x = x.contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * 0.05
+    img = R.conv3x3_x2_pack(w)
+    assert img is not None
+    y = R.conv3x3_x2(x, img, Cout)
+    assert y.shape == (B, Cout, H, W) and y.is_contiguous(memory_format=torch.channels_last) and bool(torch.isfinite(y).all())
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    y32 = F.conv2d(x, w, None, 1, 1)
+    scale = F.conv2d(x.abs().double(), w.abs().double(), None, 1, 1) + 1e-30
+    e3, e32 = float(((y.double() - ref).abs() / scale).max()), float(((y32.double() - ref).abs() / scale).max())
+    r3 = float((y.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    r32 = float((y32.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert e3 <= max(2.5 * e32, 2.0 ** -21), (e3, e32)
+    assert r3 <= 1.5 * r32 + 1e-9, (r3, r32)
+    assert torch.equal(R.conv3x3_x2(x, img, Cout), y)
+    # exact on small integers (fp16-exact operands, power-of-two channel scales): catches a transposed tap, a shifted halo or a swapped channel half
+    xi = ((torch.arange(B * Cin * H * W, device="cuda").view(B, Cin, H, W) * 7) % 5 - 2).float().contiguous(memory_format=torch.channels_last)
+    wi = ((torch.arange(Cout * Cin * 9, device="cuda").view(Cout, Cin, 3, 3) * 11) % 7 - 3).float()
+    yi = R.conv3x3_x2(xi, R.conv3x3_x2_pack(wi), Cout)
+    assert torch.equal(yi.double(), F.conv2d(xi.double(), wi.double(), None, 1, 1))
+
+
+def test_conv3x3_x2_refuses_shapes_it_does_not_build(R):
+    assert R.conv3x3_x2_pack(torch.zeros(32, 64, 3, 3, device="cuda")) is None      # C_out 32: the head's second convolution keeps the library kernel
+    assert R.conv3x3_x2_pack(torch.zeros(64, 20, 3, 3, device="cuda")) is None      # C_in not a multiple of 16
+    assert R.conv3x3_x2_pack(torch.zeros(64, 64, 1, 1, device="cuda")) is None      # not 3 x 3
+
+
 def test_gemm_x3_argument_checks(R):
     from visiondepth3d_amd._lib import Vd3dError
     with pytest.raises(NotImplementedError):

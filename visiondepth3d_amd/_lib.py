@@ -18,7 +18,7 @@ EXPORTS = (
     "vd3d_state_reset", "vd3d_state_new_clip", "vd3d_state_export", "vd3d_state_import", "vd3d_state_planes",
     "vd3d_last_scalars", "vd3d_pixel_shift", "vd3d_render_frame", "vd3d_render_frame_blank", "vd3d_depth_handoff", "vd3d_heal_missing_pixels", "vd3d_preview_heatmap", "vd3d_preview_arrows", "vd3d_conv3x3_c64_f16", "vd3d_conv3x3_head_f16", "vd3d_esr_tail_f32", "vd3d_nv12_to_bgr", "vd3d_bgr_to_nv12", "vd3d_resize_cubic_u8", "vd3d_resize_area_u8", "vd3d_resize_linear_u8", "vd3d_format_3d_output", "vd3d_esr_preprocess", "vd3d_esr_postprocess", "vd3d_add_weighted_u8", "vd3d_rife_preprocess", "vd3d_rife_postprocess",
     "vd3d_shard_begin", "vd3d_shard_pixels", "vd3d_shard_pixels_blank", "vd3d_tdf_plane_export", "vd3d_tdf_plane_import", "vd3d_set_pixel_overlap", "vd3d_join_pixels", "vd3d_wait_pixels", "vd3d_finish_frame", "vd3d_quantiles",
-    "vd3d_subject_depth", "vd3d_shard2_p0", "vd3d_shard2_set_crops", "vd3d_shard2_p1", "vd3d_shard2_p1_batch", "vd3d_shard2_r1", "vd3d_shard2_p3", "vd3d_shard2_p3_batch", "vd3d_shard2_r2", "vd3d_depth_preprocess", "vd3d_add_layernorm", "vd3d_gemm_x3_weight_bytes", "vd3d_gemm_x3_pack_weights", "vd3d_gemm_x3", "vd3d_attention_x3_workspace_bytes", "vd3d_attention_x3", "vd3d_upsample_bilinear_nhwc", "vd3d_nhwc_bias_act_f32", "vd3d_upsample_bilinear_bias_nhwc_f32", "vd3d_dpt_head_tail_f32", "vd3d_preview_image", "vd3d_detect_black_bars", "vd3d_stream_copy", "vd3d_torch_math", "vd3d_torch_math_aten", "vd3d_debug_gaussian_kernel1d", "vd3d_debug_exp_torch", "vd3d_set_profiling", "vd3d_last_stage_ms", "vd3d_stage_calls",
+    "vd3d_subject_depth", "vd3d_shard2_p0", "vd3d_shard2_set_crops", "vd3d_shard2_p1", "vd3d_shard2_p1_batch", "vd3d_shard2_r1", "vd3d_shard2_p3", "vd3d_shard2_p3_batch", "vd3d_shard2_r2", "vd3d_depth_preprocess", "vd3d_add_layernorm", "vd3d_gemm_x3_weight_bytes", "vd3d_gemm_x3_pack_weights", "vd3d_gemm_x3", "vd3d_attention_x3_workspace_bytes", "vd3d_attention_x3", "vd3d_conv3x3_x2_weight_bytes", "vd3d_conv3x3_x2_pack_weights", "vd3d_conv3x3_x2", "vd3d_upsample_bilinear_nhwc", "vd3d_nhwc_bias_act_f32", "vd3d_upsample_bilinear_bias_nhwc_f32", "vd3d_dpt_head_tail_f32", "vd3d_preview_image", "vd3d_detect_black_bars", "vd3d_stream_copy", "vd3d_torch_math", "vd3d_torch_math_aten", "vd3d_debug_gaussian_kernel1d", "vd3d_debug_exp_torch", "vd3d_set_profiling", "vd3d_last_stage_ms", "vd3d_stage_calls",
     "vd3d_debug_planes", "vd3d_debug_tune",
 )
 
@@ -107,6 +107,10 @@ def lib():
     L.vd3d_attention_x3_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.vd3d_attention_x3_workspace_bytes.restype = C.c_int64
     L.vd3d_attention_x3.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, i32, vp, C.c_int64, vp]
+    L.vd3d_conv3x3_x2_weight_bytes.argtypes = [i32, i32]
+    L.vd3d_conv3x3_x2_weight_bytes.restype = C.c_int64
+    L.vd3d_conv3x3_x2_pack_weights.argtypes = [vp, vp, i32, i32, vp]
+    L.vd3d_conv3x3_x2.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp]
     L.vd3d_add_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, C.c_float, C.c_int64, i32, vp, vp]
     L.vd3d_upsample_bilinear_nhwc.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32]
     L.vd3d_nhwc_bias_act_f32.argtypes = [vp, vp, vp, vp, vp, i32, C.c_int64, i32, vp, vp]

@@ -1445,6 +1445,24 @@ VD3D_EXPORT int vd3d_add_layernorm(vd3d_ctx* c, int dtype, const void* x, const 
   return 0;
 }
 
+VD3D_EXPORT int64_t vd3d_conv3x3_x2_weight_bytes(int Cin, int Cout) { return (int64_t)vd_conv3x3_x2_weight_bytes(Cin, Cout); }
+
+VD3D_EXPORT int vd3d_conv3x3_x2_pack_weights(vd3d_ctx* c, const float* W, int Cin, int Cout, void* image) {
+  if (!c || !W || !image) return set_err(VD3D_E_INVALID, "bad argument");
+  if (!vd_launch_conv3x3_x2_pack(c->stream, W, Cin, Cout, image))
+    return set_err(VD3D_E_UNSUPPORTED, "conv3x3_x2: C_in %d must be a positive multiple of 16 and C_out %d one of 64, 128", Cin, Cout);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+VD3D_EXPORT int vd3d_conv3x3_x2(vd3d_ctx* c, const float* X, int B, int H, int W, int Cin, const void* w_image, int Cout, float* Y) {
+  if (!c || !X || !w_image || !Y) return set_err(VD3D_E_INVALID, "bad argument");
+  if (!vd_launch_conv3x3_x2(c->stream, X, B, H, W, Cin, w_image, Cout, Y))
+    return set_err(VD3D_E_UNSUPPORTED, "conv3x3_x2: C_in %d (multiple of 16), C_out %d (64 | 128), B %d <= 65535, 16-byte aligned input and image", Cin, Cout, B);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 VD3D_EXPORT int64_t vd3d_attention_x3_workspace_bytes(int B, int T, int H, int D, int mode) { return (int64_t)vd_attn_x3_workspace_bytes(B, T, H, D, mode); }
 
 VD3D_EXPORT int vd3d_attention_x3(vd3d_ctx* c, const float* qkv, int B, int T, int H, int D, float scale, int mode, void* workspace, int64_t workspace_bytes, float* out) {

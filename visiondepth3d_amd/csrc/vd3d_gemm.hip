@@ -283,8 +283,12 @@ __global__ __launch_bounds__(GX_NT) void k_gemm_bf16x3(const float* __restrict__
   for (int nj = 0; nj < 4; ++nj) {
     const int n = n0 + wn * 128 + nj * 32 + li;
     const bool nok = n < a.N;
-    const float bv = (a.has_bias && nok) ? bias[n] : 0.f;
-    const float cs = (MODE == 1 && nok) ? colscale[n] : 1.f;   // fp16x2: the weight rows were scaled by a power of two (exact) before their split
+    float bv = (a.has_bias && nok) ? bias[n] : 0.f;
+    asm volatile("" : "+v"(bv));
+    float cs = (MODE == 1 && nok) ? colscale[n] : 1.f;   // fp16x2: the weight rows were scaled by a power of two (exact) before their split
+    // Both loads are consumed HERE, in front of the masked stores: each store sits in its own exec-masked block, hipcc's scoreboard merges "waited" with "skipped"
+    // at every join and would put s_waitcnt vmcnt(0) in front of every one of the 128 stores -- and on gfx9 stores count in vmcnt: a serialised epilogue.
+    asm volatile("" : "+v"(cs));
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll

@@ -197,6 +197,10 @@ bool vd_launch_depth_prep(hipStream_t s, const uint8_t* frames, int B, int H, in
 long long vd_gemm_x3_weight_bytes(int N, int K, int mode);
 bool vd_launch_gemm_x3_pack_w(hipStream_t s, const float* W, int N, int K, void* img, int mode);
 bool vd_launch_gemm_x3(hipStream_t s, const float* X, long long M, int K, const void* wimg, int N, const float* bias, int epilogue, float* Y, int mode);
+// vd3d_conv2.hip: 3 x 3 convolution (stride 1, padding 1, no bias) of float32 NHWC maps in the fp16x2 arithmetic
+long long vd_conv3x3_x2_weight_bytes(int Cin, int Cout);
+bool vd_launch_conv3x3_x2_pack(hipStream_t s, const float* W, int Cin, int Cout, void* img);
+bool vd_launch_conv3x3_x2(hipStream_t s, const float* X, int B, int H, int W, int Cin, const void* wimg, int Cout, float* Y);
 // vd3d_attn.hip: softmax(Q K^T scale) V with both products as split-bf16 MFMA work
 long long vd_attn_x3_workspace_bytes(int B, int T, int H, int D, int mode);
 bool vd_launch_attn_x3(hipStream_t s, const float* qkv, int B, int T, int H, int D, float scale, void* ws, float* out, int mode);

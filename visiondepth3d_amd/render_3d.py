@@ -646,6 +646,29 @@ class Renderer:
         _lib.check(self._L.vd3d_attention_x3(self._ctx, _ptr(qkv), B, T, n_heads, D, float(scale), m, _ptr(ws), ws.numel(), _ptr(out)))
         return out
 
+    def conv3x3_x2_pack(self, weight: torch.Tensor):
+        """Split + pack a float32 3 x 3 convolution weight [Cout, Cin, 3, 3] for ``conv3x3_x2``; ``None`` when the shape is not built (Cin % 16, Cout in {64, 128})."""
+        w = weight.detach().to(self.device, torch.float32).contiguous()
+        Cout, Cin, kh, kw = w.shape
+        nb = int(self._L.vd3d_conv3x3_x2_weight_bytes(Cin, Cout)) if (kh, kw) == (3, 3) else -1
+        if nb < 0:
+            return None
+        img = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        self._enter(w, img)
+        _lib.check(self._L.vd3d_conv3x3_x2_pack_weights(self._ctx, _ptr(w), Cin, Cout, _ptr(img)))
+        return img
+
+    def conv3x3_x2(self, x: torch.Tensor, w_image: torch.Tensor, Cout: int) -> torch.Tensor:
+        """F.conv2d(x, W, None, stride 1, padding 1) for a float32 channels_last [B, Cin, H, W] tensor with W given as ``conv3x3_x2_pack(W)``: fp16x2 MFMA arithmetic,
+        float32 accumulation (include/vd3d.h vd3d_conv3x3_x2); returns a channels_last [B, Cout, H, W] tensor."""
+        B, Cin, H, W = x.shape
+        if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
+            raise AssertionError("conv3x3_x2: float32 channels_last input")
+        out = torch.empty((B, int(Cout), H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        self._enter(x, w_image, out)
+        _lib.check(self._L.vd3d_conv3x3_x2(self._ctx, _ptr(x), B, H, W, Cin, _ptr(w_image), int(Cout), _ptr(out)))
+        return out
+
     def upsample_bilinear(self, x: torch.Tensor, size) -> torch.Tensor:
         """F.interpolate(x, size, mode="bilinear", align_corners=True) for a float32 / bf16 channels_last [B,C,h,w] tensor."""
         B, Cc, ih, iw = x.shape
