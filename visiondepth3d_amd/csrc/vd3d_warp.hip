@@ -600,24 +600,26 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
           const vd_f2 A1 = {*(wf_lds_fp)(hb + r1 + xoff), *(wf_lds_fp)(hb + r1 + xoff + 4)};
           return vd_vfma(A0, (vd_f2)(wy0), wy1 * A1);
         };
+        // Round 6: the horizontal half of grid_sample per EYE on the (west, east) register pair a ds_read2_b32 delivers, in scalar v_mul / v_fma -- the packed form
+        // wanted (left, right) pairs and paid a v_mov + v_cndmask per element to transpose; the east guards are gone because an eye whose east neighbour is
+        // outside the image has ix == W - 1 exactly, i.e. ne == se == +0, and fma(finite, +0, p) == fma(0, +0, p) for the non-negative p here.
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const int co = c * cs;
-          const float orig = vd_fma(*(wf_lds_fp)(hb + co + o_r0 + xo), o_w0, o_w1 * *(wf_lds_fp)(hb + co + o_r1 + xo));
           const vd_f2 nL = pair(co + a_r0, co + a_r1, a_w0, a_w1, xl), nR = pair(co + a_r0, co + a_r1, a_w0, a_w1, xr);
-          const vd_f2 vnw = {nL.x, nR.x};
-          const vd_f2 vne = {g.e_ok[0] ? nL.y : 0.f, g.e_ok[1] ? nR.y : 0.f};
-          vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
+          vd_f2 v = {vd_fma(nL.y, g.ne.x, nL.x * g.nw.x), vd_fma(nR.y, g.ne.y, nR.x * g.nw.y)};
           if (south) {
             const vd_f2 sL = pair(co + b_r0, co + b_r1, b_w0, b_w1, xl), sR = pair(co + b_r0, co + b_r1, b_w0, b_w1, xr);
-            const vd_f2 vsw = {sL.x, sR.x};
-            const vd_f2 vse = {g.e_ok[0] ? sL.y : 0.f, g.e_ok[1] ? sR.y : 0.f};
-            v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
+            v.x = vd_fma(sL.y, g.se.x, vd_fma(sL.x, g.sw.x, v.x));
+            v.y = vd_fma(sR.y, g.se.y, vd_fma(sR.x, g.sw.y, v.y));
           }
-          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f); }
+          if (FEATHER) {
+            const float orig = vd_fma(*(wf_lds_fp)(hb + co + o_r0 + xo), o_w0, o_w1 * *(wf_lds_fp)(hb + co + o_r1 + xo));
+            v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f);
+          }
           const vd_f2 u = v * 255.0f;
-          pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
-          pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
+          pL |= (uint32_t)(uint8_t)u.x << (8 * (3 - c));
+          pR |= (uint32_t)(uint8_t)u.y << (8 * (3 - c));
         }
       } else
       {
@@ -636,32 +638,32 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
           }
           if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f); }
           const vd_f2 u = v * 255.0f;
-          pL |= (uint32_t)(uint8_t)u.x << (8 * (2 - c));
-          pR |= (uint32_t)(uint8_t)u.y << (8 * (2 - c));
+          pL |= (uint32_t)(uint8_t)u.x << (8 * (3 - c));
+          pR |= (uint32_t)(uint8_t)u.y << (8 * (3 - c));
         }
       }
     }
-    // pack 4 lanes x 3 bytes into 3 dwords (lanes 4j, 4j+1, 4j+2 store) : pX = B | G<<8 | R<<16
-    const uint32_t nL = (uint32_t)__shfl_down((int)pL, 1, 64), nR = (uint32_t)__shfl_down((int)pR, 1, 64);
+    // pack 4 lanes x 3 bytes into 3 dwords (lanes 4j, 4j+1, 4j+2 store).  pX = (B | G<<8 | R<<16) << 8: with the pixel in the upper three bytes, dword q of the
+    // 12-byte group is ONE v_alignbit of (east neighbour's pixel : own pixel) by 8q + 8 bits; the neighbour comes by DPP row_shl:1 (a lane with q < 3 never
+    // sits at the end of its row of 16) -- round 6, was two ds_bpermute and a three-way divergent select
+    const uint32_t nL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pL, 0x101, 0xf, 0xf, true) >> 8;
+    const uint32_t nR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pR, 0x101, 0xf, 0xf, true) >> 8;
     const int q = lane & 3;
     const int xq = x0 + (lane & ~3);
     const unsigned ob = ((unsigned)y * (unsigned)W + (unsigned)xq) * 3u;
     const bool full = (xq + 3 < W) && (ob % 4u == 0);
     if (full) {
       if (q < 3) {
-        uint32_t dL, dR;
-        if (q == 0) { dL = pL | (nL << 24); dR = pR | (nR << 24); }
-        else if (q == 1) { dL = (pL >> 8) | (nL << 16); dR = (pR >> 8) | (nR << 16); }
-        else { dL = (pL >> 16) | (nL << 8); dR = (pR >> 16) | (nR << 8); }
-        reinterpret_cast<uint32_t*>(L + ob)[q] = dL;
-        reinterpret_cast<uint32_t*>(R + ob)[q] = dR;
+        const uint32_t sh = 8u * (uint32_t)q + 8u;
+        reinterpret_cast<uint32_t*>(L + ob)[q] = __builtin_amdgcn_alignbit(nL, pL, sh);
+        reinterpret_cast<uint32_t*>(R + ob)[q] = __builtin_amdgcn_alignbit(nR, pR, sh);
       }
     } else if (x < W) {
       const unsigned o1 = ((unsigned)y * (unsigned)W + (unsigned)x) * 3u;
       uint8_t* ol = L + o1;
       uint8_t* orr = R + o1;
-      ol[0] = (uint8_t)pL; ol[1] = (uint8_t)(pL >> 8); ol[2] = (uint8_t)(pL >> 16);
-      orr[0] = (uint8_t)pR; orr[1] = (uint8_t)(pR >> 8); orr[2] = (uint8_t)(pR >> 16);
+      ol[0] = (uint8_t)(pL >> 8); ol[1] = (uint8_t)(pL >> 16); ol[2] = (uint8_t)(pL >> 24);
+      orr[0] = (uint8_t)(pR >> 8); orr[1] = (uint8_t)(pR >> 16); orr[2] = (uint8_t)(pR >> 24);
     }
   }
   VD_STAMP(wf_stamps, 7, true);
