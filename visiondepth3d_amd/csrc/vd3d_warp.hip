@@ -22,6 +22,7 @@
 //
 // Algorithmic HBM bytes per stereo pair: read RGB 3N (eye-res f32 x3 at N/4) + D 4N + S 4N, write 6N.
 #include <cstdio>
+#include <mutex>
 #include "vd3d_dev.h"
 #include "vd3d_kernels.h"
 
@@ -261,7 +262,7 @@ void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, 
 template <bool RESIZE, bool FEATHER, int WF_TH, bool PRE>
 __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
                                                       const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
-                                                      uint8_t* __restrict__ R, const vd_f2* __restrict__ E2) {
+                                                      uint8_t* __restrict__ R, const vd_f2* __restrict__ E2, const float* __restrict__ rowtab) {
   constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int2 rs14[64];                          // VRSQRT14 table of vd_sqrt_torch (phase B)
@@ -297,10 +298,9 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   // The shift values of this wave's phase-D rows are requested NOW (consumed after phase C): their maximum over the tile decides which 64-column
   // chunks of the pre-interpolated rows Hh phase D1 has to build at all (round 4) -- the LDS holds the worst case the parameters allow (+- 79 px at
   // 4K), a tile of an ordinary frame samples +- 10 .. 20 px around itself.
-  __shared__ __attribute__((aligned(16))) unsigned smax_slot[4];   // 16 bytes: the dynamic LDS behind it must stay 16-byte aligned (ds_read_b128 everywhere;
-                                                                   // a 4-byte static variable in front of it cost 3x the kernel time: misaligned 16-byte LDS accesses)
-  unsigned& smax_bits = smax_slot[0];
-  if (tid == 0) smax_bits = 0u;
+  __shared__ __attribute__((aligned(16))) unsigned smax_w[8];      // one slot per wave (round 6: no zeroing, no atomics -> no barrier of its own).  32 bytes: the dynamic LDS
+                                                                   // behind it must stay 16-byte aligned (ds_read_b128 everywhere; a 4-byte static variable in front of it
+                                                                   // cost 3x the kernel time: misaligned 16-byte LDS accesses)
   float sD[WF_TH / WF_NW];
 #pragma unroll
   for (int j = 0; j < WF_TH / WF_NW; ++j) {
@@ -315,23 +315,12 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   int er0 = 0;
   if (RESIZE) er0 = wf_tap(a.ih, H, a.scale_h, max(y0 - 1, 0)).i0;  // first eye-res row the tile touches
   // ---- tables
-  if (!PRE && tid < wh) {   // phase-A rows
+  if (FEATHER && !PRE && tid < wh) {   // phase-A rows
     const int y = wy0 + tid;
     int yn = 0; float n = 0.f, sr = 1.f; bool s_ok = false;
     if (y >= 0 && y < H) wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
     float* t = rowA + tid * 4;
     t[0] = __int_as_float(yn); t[1] = n; t[2] = sr; t[3] = __int_as_float((s_ok && n != 0.f) ? 1 : 0);
-  } else if (tid >= 128 && tid < 128 + WF_TH) {   // phase-D rows: the three resize taps as byte offsets of Hh rows + weights
-    const int ty = tid - 128, y = min(y0 + ty, H - 1);
-    int yn; float n, sr; bool s_ok;
-    wf_gs_row(vd_lin11_step(a.step_y, H, y), H, &yn, &n, &sr, &s_ok);
-    float* t = rowD + ty * WF_RD;
-    const vd_tap to = wf_tap(a.ih, H, a.scale_h, y), t0 = wf_tap(a.ih, H, a.scale_h, yn), t1 = wf_tap(a.ih, H, a.scale_h, min(yn + 1, H - 1));
-    const int rp = nch * 4;   // bytes per Hh row
-    t[0] = __int_as_float((to.i0 - er0) * rp); t[1] = __int_as_float((to.i1 - er0) * rp); t[2] = to.w0; t[3] = to.w1;
-    t[4] = __int_as_float((t0.i0 - er0) * rp); t[5] = __int_as_float((t0.i1 - er0) * rp); t[6] = t0.w0; t[7] = t0.w1;
-    t[8] = __int_as_float((t1.i0 - er0) * rp); t[9] = __int_as_float((t1.i1 - er0) * rp); t[10] = t1.w0; t[11] = t1.w1;
-    t[12] = n; t[13] = sr; t[14] = __int_as_float((s_ok && n != 0.f) ? 1 : 0); t[15] = __int_as_float(yn);
   }
   if (FEATHER && !PRE && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
   if (FEATHER && PRE) {
@@ -354,7 +343,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       for (int j = 0; j < NLD; ++j) if (dst[j] >= 0) e2[dst[j]] = ev[j];
     }
   }
-  __syncthreads();
+  if (FEATHER) __syncthreads();   // (without feathering nothing was written yet: the kernel's first barrier is the one behind the tile maximum below)
   VD_STAMP(wf_stamps, 1, false);
   if (FEATHER && !PRE) {
     // phase A, main block: wave = halo row (scalar row part), lane = the first 64 halo columns (gx once per lane).  The phase is
@@ -420,7 +409,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       }
     }
   }
-  if (!PRE) __syncthreads();
+  if (FEATHER && !PRE) __syncthreads();
   VD_STAMP(wf_stamps, 2, false);
   if (FEATHER && !PRE) {
     // phase B: e2 = clamp(|grad WD| * fs, 0, 1) (:347-352), zero outside the image (avg_pool2d zero padding)
@@ -495,8 +484,15 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     for (int j = 0; j < WF_TH / WF_NW; ++j) m = fmaxf(m, fabsf(sD[j]));
     unsigned mb = __float_as_uint(m);
     for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off, 64));
-    if (lane == 0) atomicMax(&smax_bits, mb);
+    if (lane == 0) smax_w[wv] = mb;
   }
+  auto build_colT = [&]() {   // column taps of the warp-res columns cb .. cb + nch - 1: (absolute eye-res column i0, weight of i0 + 1)
+    for (int j = tid; j < nch; j += WF_NT) {
+      const vd_tap t = wf_tap(a.iw, W, a.scale_w, min(cb + j, W - 1));
+      colT[2 * j] = __int_as_float(t.i0); colT[2 * j + 1] = t.w1;
+    }
+  };
+  if (RESIZE && !FEATHER) build_colT();   // no blend-weight buffer to wait for: the column taps share the barrier of the tile maximum (round 6: five barriers -> two)
   __syncthreads();
   VD_STAMP(wf_stamps, 4, false);
   // phase D0: the feather weights b of the wave's rows into registers -- bb2 dies here
@@ -508,12 +504,10 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     bD[j] = b;
   }
   if (RESIZE) {
-    // column taps of the warp-res columns cb .. cb + nch - 1: (absolute eye-res column i0, weight of i0 + 1)
-    for (int j = tid; j < nch; j += WF_NT) {
-      const vd_tap t = wf_tap(a.iw, W, a.scale_w, min(cb + j, W - 1));
-      colT[2 * j] = __int_as_float(t.i0); colT[2 * j + 1] = t.w1;
+    if (FEATHER) {
+      build_colT();
+      __syncthreads();   // bb2 fully consumed, colT complete
     }
-    __syncthreads();   // bb2 fully consumed, colT complete
     VD_STAMP(wf_stamps, 5, false);
     // phase D1: Hh[c][r][X] = the HORIZONTAL half of the resize of :595 for warp-res column cb + X and eye-res row er0 + r:
     //   fma(p[i0], 1 - w1, w1 * p[i0 + 1])  -- exactly the first two operations of ATen's bilinear (rows, then columns), computed
@@ -522,7 +516,10 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     {
       // columns of Hh this tile can sample: its own 64 plus the tile's largest shift in pixels (same margin rule as the host's `bound`) plus the east
       // neighbour of the bilinear pair; chunks outside are never read and are not built
-      const float smax = __uint_as_float((unsigned)wf_uni((int)smax_bits));   // wave-uniform: the chunk / row assignment below stays scalar
+      unsigned smb = 0u;
+#pragma unroll
+      for (int j = 0; j < WF_NW; ++j) smb = max(smb, smax_w[j]);
+      const float smax = __uint_as_float((unsigned)wf_uni((int)smb));   // wave-uniform: the chunk / row assignment below stays scalar
       int bt = a.bound;
       if (smax < 1.0f) bt = min(a.bound, (int)ceilf(smax * ((float)(W - 1) * 0.5f) * 1.0001f) + 3);
       const int c_lo = max(x0 - bt - 1 - cb, 0) >> 6, c_hi = min(x0 + WF_TW + bt + 1 - cb, nch - 1) >> 6;
@@ -561,6 +558,9 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   // their resize taps, the vertical weights) is wave-uniform and comes from rowD.  ~70 % of rows have an exactly integral sample row
   // (n == 0): there sw = se = 0 and the two south samples contribute exactly +0 -> skipped (bit-exact: fma(v, 0, acc) == acc).
   int jD = 0;
+  // (the table row of the NEXT iteration is requested a row ahead: an s_load's round trip would otherwise be exposed at the top of each of a wave's four rows)
+  const vd_f4* rt0 = reinterpret_cast<const vd_f4*>(rowtab + (size_t)(unsigned)min(y0 + wv, H - 1) * WF_RD);
+  vd_f4 ro_n = rt0[0], ra_n = rt0[1], rb_n = rt0[2], rs_n = rt0[3];
 #pragma unroll 1
   for (int ty = wv; ty < WF_TH; ty += WF_NW, ++jD) {
     const int y = y0 + ty;
@@ -569,11 +569,16 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     const vd_f2 b = bD[0];
 #pragma unroll
     for (int j = 0; j + 1 < WF_TH / WF_NW; ++j) { sD[j] = sD[j + 1]; bD[j] = bD[j + 1]; }
-    const vd_f4* rt = reinterpret_cast<const vd_f4*>(rowD + ty * WF_RD);
-    const vd_f4 ro = rt[0], ra = rt[1], rb = rt[2], rs = rt[3];
-    const float n = wf_unif(rs.x), sr = wf_unif(rs.y);
-    const bool south = wf_uni(__float_as_int(rs.z)) != 0;
-    const int yn = wf_uni(__float_as_int(rs.w));
+    // row parameters: 16 floats per frame row from the per-geometry table k_wf_rowtab wrote (round 6) -- a wave-uniform address, so they arrive by s_load in
+    // SGPRs; the LDS table this replaces cost 3 ds_read_b128 + 11 v_readfirstlane per row of a kernel that is bound by its VALU issue
+    const vd_f4 ro = ro_n, ra = ra_n, rb = rb_n, rs = rs_n;
+    {
+      const vd_f4* rt = reinterpret_cast<const vd_f4*>(rowtab + (size_t)(unsigned)min(y + WF_NW, H - 1) * WF_RD);
+      ro_n = rt[0]; ra_n = rt[1]; rb_n = rt[2]; rs_n = rt[3];
+    }
+    const float n = rs.x, sr = rs.y;
+    const bool south = __float_as_int(rs.z) != 0;
+    const int yn = __float_as_int(rs.w);
     const int x = x0 + lane;
     uint32_t pL = 0, pR = 0;
     if (x < W) {
@@ -589,35 +594,60 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
         // byte offsets: column part per lane, row / channel part wave-uniform
         const int cs = a.er_max * nch * 4;                            // channel stride
         const int xo = (x - cb) * 4, xl = (g.xw[0] - cb) * 4, xr = (g.xw[1] - cb) * 4;
-        const int o_r0 = wf_uni(__float_as_int(ro.x)), o_r1 = wf_uni(__float_as_int(ro.y));
-        const int a_r0 = wf_uni(__float_as_int(ra.x)), a_r1 = wf_uni(__float_as_int(ra.y));
-        const int b_r0 = wf_uni(__float_as_int(rb.x)), b_r1 = wf_uni(__float_as_int(rb.y));
-        const float o_w0 = wf_unif(ro.z), o_w1 = wf_unif(ro.w), a_w0 = wf_unif(ra.z), a_w1 = wf_unif(ra.w);
-        const float b_w0 = wf_unif(rb.z), b_w1 = wf_unif(rb.w);
-        // one eye's sample pair (west, east) of one row tap: the vertical half of the resize on two adjacent Hh columns at once
-        auto pair = [&](int r0, int r1, float wy0, float wy1, int xoff) {
-          const vd_f2 A0 = {*(wf_lds_fp)(hb + r0 + xoff), *(wf_lds_fp)(hb + r0 + xoff + 4)};
-          const vd_f2 A1 = {*(wf_lds_fp)(hb + r1 + xoff), *(wf_lds_fp)(hb + r1 + xoff + 4)};
-          return vd_vfma(A0, (vd_f2)(wy0), wy1 * A1);
-        };
-        // Round 6: the horizontal half of grid_sample per EYE on the (west, east) register pair a ds_read2_b32 delivers, in scalar v_mul / v_fma -- the packed form
-        // wanted (left, right) pairs and paid a v_mov + v_cndmask per element to transpose; the east guards are gone because an eye whose east neighbour is
-        // outside the image has ix == W - 1 exactly, i.e. ne == se == +0, and fma(finite, +0, p) == fma(0, +0, p) for the non-negative p here.
+        const int rp = nch * 4;                                       // bytes per Hh row; the table holds absolute eye-res rows
+        const int o_r0 = (__float_as_int(ro.x) - er0) * rp, o_r1 = (__float_as_int(ro.y) - er0) * rp;
+        const int a_r0 = (__float_as_int(ra.x) - er0) * rp, a_r1 = (__float_as_int(ra.y) - er0) * rp;
+        const int b_r0 = (__float_as_int(rb.x) - er0) * rp, b_r1 = (__float_as_int(rb.y) - er0) * rp;
+        const float o_w0 = ro.z, o_w1 = ro.w, a_w0 = ra.z, a_w1 = ra.w;
+        const float b_w0 = rb.z, b_w1 = rb.w;
+        // Round 6: (i) the horizontal half of grid_sample per EYE on the (west, east) register pair a ds_read2_b32 delivers, in scalar v_mul / v_fma -- the packed form
+        // wanted (left, right) pairs and paid a v_mov + v_cndmask per element to transpose; the east guards are gone because an eye whose east neighbour is outside the
+        // image has ix == W - 1 exactly, i.e. ne == se == +0, and fma(finite, +0, p) == fma(0, +0, p) for the non-negative p here.  (ii) All twelve reads of a row's
+        // north samples (three channels x two eyes x two resize rows) are issued before the first is used, then the twelve south ones under ONE branch: a wave used to
+        // walk channel by channel, six to ten dependent LDS round trips per row, and with six waves per SIMD those round trips -- not the instruction count -- were
+        // what a row cost (removing 14 VALU per row by moving the row table to SGPRs changed nothing; removing the waits did).
+        auto ld2 = [&](int off) { return vd_f2{*(wf_lds_fp)(hb + off), *(wf_lds_fp)(hb + off + 4)}; };
+        vd_f2 v[3];
+        {
+          vd_f2 a0L[3], a1L[3], a0R[3], a1R[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            a0L[c] = ld2(c * cs + a_r0 + xl); a1L[c] = ld2(c * cs + a_r1 + xl);
+            a0R[c] = ld2(c * cs + a_r0 + xr); a1R[c] = ld2(c * cs + a_r1 + xr);
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const vd_f2 nL = vd_vfma(a0L[c], (vd_f2)(a_w0), a_w1 * a1L[c]), nR = vd_vfma(a0R[c], (vd_f2)(a_w0), a_w1 * a1R[c]);
+            v[c] = vd_f2{vd_fma(nL.y, g.ne.x, nL.x * g.nw.x), vd_fma(nR.y, g.ne.y, nR.x * g.nw.y)};
+          }
+        }
+        if (south) {
+          vd_f2 b0L[3], b1L[3], b0R[3], b1R[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            b0L[c] = ld2(c * cs + b_r0 + xl); b1L[c] = ld2(c * cs + b_r1 + xl);
+            b0R[c] = ld2(c * cs + b_r0 + xr); b1R[c] = ld2(c * cs + b_r1 + xr);
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const vd_f2 sL = vd_vfma(b0L[c], (vd_f2)(b_w0), b_w1 * b1L[c]), sR = vd_vfma(b0R[c], (vd_f2)(b_w0), b_w1 * b1R[c]);
+            v[c].x = vd_fma(sL.y, g.se.x, vd_fma(sL.x, g.sw.x, v[c].x));
+            v[c].y = vd_fma(sR.y, g.se.y, vd_fma(sR.x, g.sw.y, v[c].y));
+          }
+        }
+        if (FEATHER) {
+          float o0[3], o1[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { o0[c] = *(wf_lds_fp)(hb + c * cs + o_r0 + xo); o1[c] = *(wf_lds_fp)(hb + c * cs + o_r1 + xo); }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float orig = vd_fma(o0[c], o_w0, o_w1 * o1[c]);
+            v[c] = v[c] * omb + orig * b; v[c].x = vd_clamp_fin(v[c].x, 0.f, 1.f); v[c].y = vd_clamp_fin(v[c].y, 0.f, 1.f);
+          }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const int co = c * cs;
-          const vd_f2 nL = pair(co + a_r0, co + a_r1, a_w0, a_w1, xl), nR = pair(co + a_r0, co + a_r1, a_w0, a_w1, xr);
-          vd_f2 v = {vd_fma(nL.y, g.ne.x, nL.x * g.nw.x), vd_fma(nR.y, g.ne.y, nR.x * g.nw.y)};
-          if (south) {
-            const vd_f2 sL = pair(co + b_r0, co + b_r1, b_w0, b_w1, xl), sR = pair(co + b_r0, co + b_r1, b_w0, b_w1, xr);
-            v.x = vd_fma(sL.y, g.se.x, vd_fma(sL.x, g.sw.x, v.x));
-            v.y = vd_fma(sR.y, g.se.y, vd_fma(sR.x, g.sw.y, v.y));
-          }
-          if (FEATHER) {
-            const float orig = vd_fma(*(wf_lds_fp)(hb + co + o_r0 + xo), o_w0, o_w1 * *(wf_lds_fp)(hb + co + o_r1 + xo));
-            v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f);
-          }
-          const vd_f2 u = v * 255.0f;
+          const vd_f2 u = v[c] * 255.0f;
           pL |= (uint32_t)(uint8_t)u.x << (8 * (3 - c));
           pR |= (uint32_t)(uint8_t)u.y << (8 * (3 - c));
         }
@@ -694,6 +724,43 @@ void vd_set_warp_pre_th(int th) { g_wf_pre_th = th == 16 ? 16 : 32; }
 static int g_wf_nf_th = WF_NOFEATHER_TH;
 void vd_set_warp_nofeather_th(int th) { g_wf_nf_th = th == 16 ? 16 : 32; }
 
+// ---- per-geometry row table of phase D2 (round 6): for every frame row y the three vertical resize taps (row y itself / the grid_sample rows yn, yn + 1) as
+// absolute eye-res rows + weights, and the grid_sample row part (n, 1 - n, south flag, yn) -- the same helpers the kernel used to call per tile.
+__global__ __launch_bounds__(256) void k_wf_rowtab(float* __restrict__ tab, int H, int ih, float scale_h, float step_y) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  if (y >= H) return;
+  int yn; float n, sr; bool s_ok;
+  wf_gs_row(vd_lin11_step(step_y, H, y), H, &yn, &n, &sr, &s_ok);
+  float* t = tab + (size_t)y * WF_RD;
+  const vd_tap to = wf_tap(ih, H, scale_h, y), t0 = wf_tap(ih, H, scale_h, yn), t1 = wf_tap(ih, H, scale_h, min(yn + 1, H - 1));
+  t[0] = __int_as_float(to.i0); t[1] = __int_as_float(to.i1); t[2] = to.w0; t[3] = to.w1;
+  t[4] = __int_as_float(t0.i0); t[5] = __int_as_float(t0.i1); t[6] = t0.w0; t[7] = t0.w1;
+  t[8] = __int_as_float(t1.i0); t[9] = __int_as_float(t1.i1); t[10] = t1.w0; t[11] = t1.w1;
+  t[12] = n; t[13] = sr; t[14] = __int_as_float((s_ok && n != 0.f) ? 1 : 0); t[15] = __int_as_float(yn);
+}
+// One table per (device, H, ih): written once, on the stream of the launch that first needs it, and that stream is drained before the pointer is handed out --
+// the pixel streams of a context are not ordered against each other.  Eight geometries are kept per process; the ninth replaces the oldest (hipFree waits
+// for the device).  138 KB at 4K.
+struct wf_rowtab_entry { int dev, H, ih; float* tab; };
+static std::mutex g_wf_rt_mu;
+static wf_rowtab_entry g_wf_rt[8];
+static int g_wf_rt_n = 0, g_wf_rt_next = 0;
+static const float* wf_rowtab_get(hipStream_t s, int H, int ih, float scale_h, float step_y) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_wf_rt_mu);
+  for (int i = 0; i < g_wf_rt_n; ++i)
+    if (g_wf_rt[i].dev == dev && g_wf_rt[i].H == H && g_wf_rt[i].ih == ih) return g_wf_rt[i].tab;
+  float* tab = nullptr;
+  if (hipMalloc(&tab, (size_t)H * WF_RD * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  hipLaunchKernelGGL(k_wf_rowtab, dim3((H + 255) / 256), dim3(256), 0, s, tab, H, ih, scale_h, step_y);
+  if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(tab); return nullptr; }
+  int slot;
+  if (g_wf_rt_n < 8) slot = g_wf_rt_n++;
+  else { slot = g_wf_rt_next++ & 7; (void)hipFree(g_wf_rt[slot].tab); }
+  g_wf_rt[slot] = wf_rowtab_entry{dev, H, ih, tab};
+  return tab;
+}
 // returns false when the fused kernel cannot be used (tiles would not fit the 160 KB LDS): caller falls back to v0.
 // E2 != NULL: the gradient mask was computed by k_e2w (PRE variants); plan_only: decide, do not launch.
 template <int WF_TH>
@@ -786,12 +853,14 @@ static bool warp_fused_impl(hipStream_t s, const float* rgb, int ih, int iw, con
     attr[dev] = true;
   }
   const vd_f2* e2p = reinterpret_cast<const vd_f2*>(E2);
-  if (resize && a.feather && pre) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
-  else if (a.feather && pre) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
-  else if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
-  else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
-  else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
-  else hipLaunchKernelGGL((k_warp_fused<false, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p);
+  const float* rowtab = wf_rowtab_get(s, H, ih, a.scale_h, a.step_y);
+  if (!rowtab) return false;
+  if (resize && a.feather && pre) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
+  else if (a.feather && pre) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
+  else if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
+  else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
+  else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
+  else hipLaunchKernelGGL((k_warp_fused<false, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
   return true;
 }
 bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
