@@ -148,9 +148,9 @@ VD_DEV vd_f2 wf_wd_combine(const wf_wdl& l, float n, float sr) {
 #define WF_OCC_ATTR   // A/B builds: -DWF_OCC_ATTR='__attribute__((amdgpu_waves_per_eu(8, 8)))'
 #endif
 #ifndef WF_HB
-#define WF_HB 6   // Hh rows a wave builds together (2 * WF_HB loads in flight).  Round 4: 14 rows cost no registers (phase C holds the kernel's
-                  // maximum) and were measured slower, 110.8 vs 107.3 us at 4K with the precomputed mask
+#define WF_HB 5    // D1 without feathering: Hh elements a thread builds together (2 * WF_HB loads in flight)
 #endif
+#define WF_HBC 6   // D1 with feathering: Hh rows of its chunk a wave builds together (round 4: 14 measured slower)
 VD_STAMP_DECL(wf_stamps);
 #ifdef VD_PHASE_STAMPS
 extern "C" __attribute__((visibility("default"))) int vd3d_debug_stamps_w1(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wf_stamps), sizeof(wf_stamps)); }
@@ -522,6 +522,41 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       const float smax = __uint_as_float((unsigned)wf_uni((int)smb));   // wave-uniform: the chunk / row assignment below stays scalar
       int bt = a.bound;
       if (smax < 1.0f) bt = min(a.bound, (int)ceilf(smax * ((float)(W - 1) * 0.5f) * 1.0001f) + 3);
+      if (!FEATHER) {
+      // Round 6, the kernel without feathering: the elements (channel, eye-res row, column) are dealt FLAT over the workgroup's threads, WF_HB per thread and batch, every
+      // load of a batch in flight before the first is used, in straight-line code.  The per-chunk form below (one wave = one cb-aligned 64-column chunk, (channel, row)
+      // pieces walked in wave-uniform loops) stood at 9 000 of a workgroup's 18 600 cycles at 4K in the phase stamps, and stayed there when its loads were a quarter as
+      // many (one 64-lane row segment + ds_bpermute, tools/r06/w1_d1_segments.patch), when they all hit the caches and -- 5 800 cycles -- when there were none: the
+      // time was the scalar loop control, the waits hipcc puts at the joins of wave-uniform branches and a 3 : 3 : 2 split of the waves over three chunks, not memory.
+      // Measured at 4K (us per launch, no feathering / feathering): per-chunk 57.1 / 89.4, flat 52.2 / 92.6, (channel, row, 64-column group) items dealt round-robin
+      // over the waves 56.3 / 94.8 -- the flat form pays ~25 VALU per element for its index arithmetic, which the feathered kernel's window sums compete for: each
+      // instantiation keeps the form that is faster for it.
+      const int X_lo = max(x0 - bt - 1 - cb, 0), X_hi = min(x0 + WF_TW + bt + 1 - cb, nch - 1);   // first / last Hh column this tile can sample
+      const int ncol = X_hi - X_lo + 1, er = a.er_max;
+      const uint32_t mcol = 0xFFFFFFFFu / (uint32_t)ncol + 1u;      // ceil(2^32 / ncol): umulhi(e, mcol) == e / ncol for e, ncol < 2^16
+      const int total = 3 * er * ncol;
+      const vd_f2* colT2 = reinterpret_cast<const vd_f2*>(colT);
+#pragma unroll 1
+      for (int e0 = tid; e0 < total; e0 += WF_HB * WF_NT) {
+        float p0[WF_HB], p1[WF_HB], w1v[WF_HB]; int dst[WF_HB];
+#pragma unroll
+        for (int j = 0; j < WF_HB; ++j) {
+          const int e = e0 + j * WF_NT;
+          const int ee = min(e, total - 1);                          // past the end: the last element again (loaded, not stored)
+          const int pc = wf_div(ee, mcol), X = X_lo + (ee - pc * ncol);
+          const vd_f2 ct = colT2[X];
+          const int i0 = __float_as_int(ct.x), i1 = min(i0 + 1, a.iw - 1);
+          const int c = (pc >= er ? 1 : 0) + (pc >= 2 * er ? 1 : 0), rr = pc - c * er;
+          const float* srow = rgb + ((unsigned)c * ni + (unsigned)min(er0 + rr, a.ih - 1) * (unsigned)a.iw);
+          p0[j] = srow[i0]; p1[j] = srow[i1];
+          w1v[j] = ct.y;
+          dst[j] = e < total ? pc * nch + X : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < WF_HB; ++j)
+          if (dst[j] >= 0) Hh[dst[j]] = vd_fma(p0[j], 1.f - w1v[j], w1v[j] * p1[j]);
+      }
+      } else {
       const int c_lo = max(x0 - bt - 1 - cb, 0) >> 6, c_hi = min(x0 + WF_TW + bt + 1 - cb, nch - 1) >> 6;
       const int nchk = c_hi - c_lo + 1;                       // 1 .. (nch + 63) / 64 chunks to build (<= WF_NW: host check)
       const int cw = wv % nchk, chunk = c_lo + cw, rstart = wv / nchk, rstep = (WF_NW - cw + nchk - 1) / nchk;
@@ -534,9 +569,9 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       int c = 0, rr = rstart;
       while (rr >= er) { rr -= er; ++c; }
       while (c < 3) {
-        float p0[WF_HB], p1[WF_HB]; int dst[WF_HB];
+        float p0[WF_HBC], p1[WF_HBC]; int dst[WF_HBC];
 #pragma unroll
-        for (int j = 0; j < WF_HB; ++j) {
+        for (int j = 0; j < WF_HBC; ++j) {
           dst[j] = -1; p0[j] = 0.f; p1[j] = 0.f;
           if (c < 3) {   // wave-uniform
             const float* srow = rgb + ((unsigned)c * ni + (unsigned)min(er0 + rr, a.ih - 1) * (unsigned)a.iw);
@@ -547,8 +582,9 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
           }
         }
 #pragma unroll
-        for (int j = 0; j < WF_HB; ++j)
+        for (int j = 0; j < WF_HBC; ++j)
           if (dst[j] >= 0 && xok) Hh[dst[j] + X] = vd_fma(p0[j], w0, w1 * p1[j]);
+      }
       }
     }
   }
