@@ -471,11 +471,15 @@ static int run_shift_and_warp(vd3d_ctx* c, const float* rgb, const float* depth_
     { int rcp = premult_resize(c, 3, &rgb, &ih, &iw, H, W, sp.aten_threads, &c->pm_rgb, &c->pm_rgb_cap); if (rcp) return rcp; }
     const vd3d_shift_params spw = warp_stage_params(sp);   // feather_strength <= 0: the exact no-feather kernels
     const bool pre = spw.enable_feathering && vd_warp_fused_ok(ih, iw, H, W, spw);   // k_e2w -> W1 (see shard_pixels_impl)
-    { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
+    // without feathering W1 computes the shift values of its own tile (round 6); this entry point keeps the plane (its callers can ask for it)
+    const bool fold = vd_warp_fold_ok(ih, iw, H, W, spw, sp);
+    const vd_shift_fold ff = {c->work, sp, c->S};
+    if (!fold) { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
     bool fused = false;
     { StageTimer t2(c, "w1");
       if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->D, c->S, H, W, (float)spw.feather_strength, c->E2); }
-      fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, spw, c->L, c->R, pre ? c->E2 : nullptr); }
+      fused = vd_launch_warp_fused(s, rgb, ih, iw, c->D, c->S, H, W, spw, c->L, c->R, pre ? c->E2 : nullptr, fold ? &ff : nullptr); }
+    if (!fused && fold) { StageTimer t1(c, "shift"); vd_launch_shift(s, c->D, H, W, c->work, sp, c->S); }
     if (!fused) {   // blur sizes / frame sizes the fused kernel refuses (its LDS tile would not fit): one stage per kernel
     if (spw.enable_feathering) {
       vd_launch_e2(s, c->D, c->S, H, W, (float)spw.feather_strength, c->e2L, c->e2R);
@@ -975,11 +979,15 @@ static int shard_pixels_impl(vd3d_ctx* c, int slot, const vd3d_render_params* p,
       if ((rc = premult_resize(c, 3, &rgb, &rih, &riw, H, W, sp.aten_threads, &c->pm_rgb, &c->pm_rgb_cap))) return rc;
     }
     const bool pre = spw.enable_feathering && vd_warp_fused_ok(rih, riw, H, W, spw);
-    { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
+    // without feathering W1 computes the shift values of its own tile (round 6): no k_shift launch, no S plane (8 N bytes of traffic less)
+    const bool fold = vd_warp_fold_ok(rih, riw, H, W, spw, sp);
+    const vd_shift_fold ff = {wk, sp, nullptr};
+    if (!fold) { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
     bool fused;
     { StageTimer t2(c, "w1");
       if (pre) { StageTimer t3(c, "e2w"); vd_launch_e2w(s, c->slot_D[slot], S, H, W, (float)spw.feather_strength, E2); }
-      fused = vd_launch_warp_fused(s, rgb, rih, riw, c->slot_D[slot], S, H, W, spw, L, R, pre ? E2 : nullptr); }
+      fused = vd_launch_warp_fused(s, rgb, rih, riw, c->slot_D[slot], S, H, W, spw, L, R, pre ? E2 : nullptr, fold ? &ff : nullptr); }
+    if (!fused && fold) { StageTimer t1(c, "shift"); vd_launch_shift(s, c->slot_D[slot], H, W, wk, sp, S); }
     if (!fused) {
       if ((rc = pix_exclusive(c))) return rc;
       if (spw.enable_feathering) {

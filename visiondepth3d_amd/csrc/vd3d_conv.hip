@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256, CV_TH == 16 ? 2 : 3) void k_conv3x3_c64(const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, g = lane >> 5;
   const int x0 = blockIdx.x * CV_TW, y0 = blockIdx.y * CV_TH;
   const int cv_lin = blockIdx.y * gridDim.x + blockIdx.x;
+  (void)cv_lin;   // (phase-stamp builds only)
   CV_STAMP(cv_lin, 0);
 
   // A (weight) fragments of steps 0 and 1: independent of the tile, issued before the tile load.  Software pipeline of the main loop:

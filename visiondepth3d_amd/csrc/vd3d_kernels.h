@@ -149,13 +149,23 @@ struct vd_finish_consts {
   float sat, con, bri;
   float sharp_kn, sharp_kc; // normalised sharpen taps
 };
+// launch constants of the shift plane (k_shift, and W1 when it computes the shift of its own tile: round 6)
+struct vd_shift_consts {
+  float mid, fg, mg, bg, fgm, bgm, pb, half_width, fs, ma, mb;
+  int edge;
+};
+vd_shift_consts vd_shift_consts_of(const vd3d_shift_params& p, int W);
 void vd_launch_shift(hipStream_t s, const float* D, int H, int W, const vd_dev_work* w, const vd3d_shift_params& p, float* S);
+// W1 without feathering can compute the shift plane of its own tile (no halo of S is needed there) instead of reading the plane k_shift wrote: `work` = the frame's
+// control block (layer shifts, zero-parallax, clamp, convergence), `S_out` = where to keep the plane for a caller who wants it, or NULL.
+struct vd_shift_fold { const vd_dev_work* work; vd3d_shift_params sp; float* S_out; };
+bool vd_warp_fold_ok(int ih, int iw, int H, int W, const vd3d_shift_params& warp_p, const vd3d_shift_params& shift_p);
 void vd_launch_e2(hipStream_t s, const float* D, const float* S, int H, int W, float fs, float* e2L, float* e2R);
 void vd_launch_pool(hipStream_t s, const float* e2L, const float* e2R, int H, int W, int k, float* bL, float* bR);
 void vd_launch_warp(hipStream_t s, const float* rgb, int ih, int iw, const float* S, const float* bL, const float* bR, int H, int W,
                     int feather, uint8_t* L, uint8_t* R);
 bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
-                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2 = nullptr);
+                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2 = nullptr, const vd_shift_fold* fold = nullptr);
 bool vd_warp_fused_ok(int ih, int iw, int H, int W, const vd3d_shift_params& p);
 // k_e2w (vd3d_warp.hip): gradient mask plane E2[H][W][2] (left, right eye) of feather_shift_edges from the shaped depth and the shift plane
 void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, float feather_strength, float* E2);

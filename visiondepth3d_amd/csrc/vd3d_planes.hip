@@ -14,10 +14,6 @@
 // ------------------------------------------------------------------------------------------------
 #define SH_TW 64
 #define SH_TH 16
-struct vd_shift_consts {
-  float mid, fg, mg, bg, fgm, bgm, pb, half_width, fs, ma, mb;
-  int edge;
-};
 template <bool TAILS>   // round 5: ATen's scalar tails (vd_tails_of) -- those pixels take glibc's expf in the sigmoid and libm's pow in the layer weight
 __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int H, int W, const vd_dev_work* __restrict__ w,
                                                vd_shift_consts c, float* __restrict__ S, vd_tails tl) {
@@ -88,7 +84,7 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
     S[(size_t)y * W + x] = sft;
   }
 }
-void vd_launch_shift(hipStream_t s, const float* D, int H, int W, const vd_dev_work* w, const vd3d_shift_params& p, float* S) {
+vd_shift_consts vd_shift_consts_of(const vd3d_shift_params& p, int W) {
   vd_shift_consts c;
   c.mid = (float)p.depth_pop_mid;
   c.fgm = (float)p.fg_pop_multiplier; c.bgm = (float)p.bg_push_multiplier; c.pb = (float)p.parallax_balance;
@@ -99,6 +95,10 @@ void vd_launch_shift(hipStream_t s, const float* D, int H, int W, const vd_dev_w
   c.ma = (float)(1.0 - ms); c.mb = (float)ms;
   c.edge = p.enable_edge_masking ? 1 : 0;
   c.fg = c.mg = c.bg = 0.f;
+  return c;
+}
+void vd_launch_shift(hipStream_t s, const float* D, int H, int W, const vd_dev_work* w, const vd3d_shift_params& p, float* S) {
+  const vd_shift_consts c = vd_shift_consts_of(p, W);
   const vd_tails tl = vd_tails_of((unsigned long long)H * W, p.aten_threads);
   if (tl.on) hipLaunchKernelGGL(k_shift<true>, dim3((W + SH_TW - 1) / SH_TW, (H + SH_TH - 1) / SH_TH), dim3(256), 0, s, D, H, W, w, c, S, tl);
   else hipLaunchKernelGGL(k_shift<false>, dim3((W + SH_TW - 1) / SH_TW, (H + SH_TH - 1) / SH_TH), dim3(256), 0, s, D, H, W, w, c, S, tl);

@@ -259,10 +259,13 @@ void vd_launch_e2w(hipStream_t s, const float* D, const float* S, int H, int W, 
 
 // PRE (round 4): the gradient mask e2 of both eyes comes from the E2 plane k_e2w wrote (8 bytes per pixel); the tile's e2 region is a
 // plain coalesced load and the kernel starts at phase C -- no rowA table, no phase A / B, no D plane.
-template <bool RESIZE, bool FEATHER, int WF_TH, bool PRE>
+// SHIFT (round 6, only without feathering): the tile computes its own shift values -- k_shift's arithmetic, expression for expression, on the tile + the 5 x 5 halo of
+// the edge mask -- instead of reading the plane k_shift wrote; S is then the plane to WRITE for a caller who wants it (or NULL), sc / work are k_shift's arguments.
+template <bool RESIZE, bool FEATHER, int WF_TH, bool PRE, bool SHIFT>
 __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const float* __restrict__ rgb, const float* __restrict__ D,
-                                                      const float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
-                                                      uint8_t* __restrict__ R, const vd_f2* __restrict__ E2, const float* __restrict__ rowtab) {
+                                                      float* __restrict__ S, vd_wf_args a, uint8_t* __restrict__ L,
+                                                      uint8_t* __restrict__ R, const vd_f2* __restrict__ E2, const float* __restrict__ rowtab,
+                                                      vd_shift_consts sc, const vd_dev_work* __restrict__ work) {
   constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int2 rs14[64];                          // VRSQRT14 table of vd_sqrt_torch (phase B)
@@ -302,10 +305,12 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
                                                                    // behind it must stay 16-byte aligned (ds_read_b128 everywhere; a 4-byte static variable in front of it
                                                                    // cost 3x the kernel time: misaligned 16-byte LDS accesses)
   float sD[WF_TH / WF_NW];
+  if (!SHIFT) {
 #pragma unroll
-  for (int j = 0; j < WF_TH / WF_NW; ++j) {
-    const int y = y0 + wv + j * WF_NW, x = x0 + lane;
-    sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
+    for (int j = 0; j < WF_TH / WF_NW; ++j) {
+      const int y = y0 + wv + j * WF_NW, x = x0 + lane;
+      sD[j] = (y < H && x < W) ? S[(unsigned)y * (unsigned)W + (unsigned)x] : 0.f;
+    }
   }
   const int wy0 = y0 - r - 1, wx0 = x0 - r - 1;
   const int cb = max(x0 - a.bound, 0);                              // first warp-res column of Hh / colT
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
     float* t = rowA + tid * 4;
     t[0] = __int_as_float(yn); t[1] = n; t[2] = sr; t[3] = __int_as_float((s_ok && n != 0.f) ? 1 : 0);
   }
-  if (FEATHER && !PRE && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
+  if (((FEATHER && !PRE) || SHIFT) && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
   if (FEATHER && PRE) {
     // the e2 region of the tile straight from the E2 plane (zero outside the image = avg_pool2d's padding); all loads of a thread in flight
     constexpr int NLD = 6;
@@ -477,6 +482,98 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
       dst[0] = vd_f4{sv[0].x, sv[0].y, sv[1].x, sv[1].y};
       dst[1] = vd_f4{sv[2].x, sv[2].y, sv[3].x, sv[3].y};
     }
+  }
+  if (SHIFT) {
+    // ---- the shift values of the tile (core/render_3d.py:620-680 + suppress_artifacts_with_edge_mask :198-216), as vd3d_planes.hip:k_shift computes them.  Three
+    // short phases in LDS that the Hh rows overwrite later: dT = the depth tile + halo (3 left / up, 2 right / down: the 5 x 5 pool's window + the gradient's
+    // neighbours), em = 1 - sigmoid(...) of the gradient magnitude on the pool's window (zero outside the image = avg_pool2d's padding), sS = the shift values.
+    constexpr int DT_W = WF_TW + 8, DT_H = WF_TH + 5, EM_W = WF_TW + 4, EM_H = WF_TH + 4;   // dT pitch 72 floats, em pitch 68 (= k_shift's: 16-byte rows)
+    float* dT = lds;                                  // [DT_H][DT_W]: dT[ty][tx] = D[y0 - 3 + ty][x0 - 3 + tx]
+    float* em = lds + ((DT_H * DT_W + 3) & ~3);       // [EM_H][EM_W]: em[ty][tx] at (y0 - 2 + ty, x0 - 2 + tx)
+    float* sS = em + EM_H * EM_W;                     // [WF_TH][WF_TW]
+    {
+      constexpr int NE = DT_H * (WF_TW + 5), NL = (NE + WF_NT - 1) / WF_NT;
+      float dv[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int t = min(tid + j * WF_NT, NE - 1);
+        const int ty = t / (WF_TW + 5), tx = t - ty * (WF_TW + 5);
+        const int y = y0 - 3 + ty, x = x0 - 3 + tx;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const float v = D[(unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(x, 0), W - 1)];
+        dv[j] = in ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int t = tid + j * WF_NT;
+        if (t < NE) { const int ty = t / (WF_TW + 5), tx = t - ty * (WF_TW + 5); dT[ty * DT_W + tx] = dv[j]; }
+      }
+    }
+    __syncthreads();
+    if (sc.edge) {
+      for (int t = tid; t < EM_H * EM_W; t += WF_NT) {
+        const int ty = t / EM_W, tx = t - ty * EM_W;
+        const int y = y0 - 2 + ty, x = x0 - 2 + tx;
+        float e = 0.f;  // zero padding of avg_pool2d
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+          const float* dp = dT + (ty + 1) * DT_W + (tx + 1);
+          const float cc = dp[0];
+          const float dx = x > 0 ? fabsf(cc - dp[-1]) : 0.f;
+          const float dy = y > 0 ? fabsf(cc - dp[-DT_W]) : 0.f;
+          const float g = vd_sqrt_torch(dx * dx + dy * dy, rs14);
+          const float z = ((g - (float)0.02) * sc.fs) * 5.f;
+          e = 1.f - vd_sigmoid_torch(z);
+        }
+        em[t] = e;
+      }
+      __syncthreads();
+    }
+    {
+      const float fgf = work->fg, mgf = work->mg, bgf = work->bg;
+      // one thread = 4 consecutive pixels of one row (WF_TH * WF_TW / 4 == WF_NT threads)
+      const int ty = tid / (WF_TW / 4), tx = (tid - ty * (WF_TW / 4)) * 4;
+      const int y = y0 + ty;
+      vd_f4 s5 = {0.f, 0.f, 0.f, 0.f};
+      if (sc.edge) {
+        // avg_pool2d(5, 1, 2) in ATen's order (cpu_avg_pool2d): ONE float32 running sum over the window, row-major; the zero padding adds exact zeros
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const vd_f4 wa = *reinterpret_cast<const vd_f4*>(em + (ty + i) * EM_W + tx), wb = *reinterpret_cast<const vd_f4*>(em + (ty + i) * EM_W + tx + 4);
+          const float win[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s5[q] += win[q + j];
+        }
+      }
+      vd_f4 so = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = x0 + tx + q;
+        if (x < W && y < H) {
+          const float Dv = dT[(ty + 3) * DT_W + (tx + q + 3)];
+          const float p15 = vd_pow15_torch(1.0f - Dv);
+          const float fgw = vd_clamp(p15, 0.f, 1.f);
+          const float mgw = vd_clamp(1.0f - fabsf(Dv - sc.mid) * 3.0f, 0.f, 1.f);
+          const float bgw = vd_clamp(Dv, 0.f, 1.f);
+          const float raw = ((fgw * fgf) * sc.fgm + mgw * mgf) + (bgw * bgf) * sc.bgm;
+          float sft = (raw * sc.pb) / sc.half_width;
+          if (work->have_zpo) sft = sft - work->zpo_f;
+          sft = vd_clamp(sft, -work->msn, work->msn);
+          if (work->have_conv) sft = sft - work->conv;
+          if (sc.edge) {
+            const float sm = s5[q] / 25.f;
+            sft = sc.ma * sft + sc.mb * (sft * sm);
+          }
+          so[q] = sft;
+          if (S) S[(unsigned)y * (unsigned)W + (unsigned)x] = sft;
+        }
+      }
+      *reinterpret_cast<vd_f4*>(sS + ty * WF_TW + tx) = so;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WF_TH / WF_NW; ++j) sD[j] = sS[(wv + j * WF_NW) * WF_TW + lane];   // zero outside the frame, like the plane loads of the other variants
   }
   {   // tile maximum of |S| (non-negative floats order like their bit patterns; a NaN would sort above everything -> the full range is built)
     float m = 0.f;
@@ -801,7 +898,7 @@ static const float* wf_rowtab_get(hipStream_t s, int H, int ih, float scale_h, f
 // E2 != NULL: the gradient mask was computed by k_e2w (PRE variants); plan_only: decide, do not launch.
 template <int WF_TH>
 static bool warp_fused_impl(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
-                            const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2, bool plan_only) {
+                            const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2, bool plan_only, const vd_shift_fold* fold = nullptr) {
   constexpr int WF_NT = WF_TH * 16, WF_NW = WF_NT / 64;
   const bool pre = E2 != nullptr && p.enable_feathering;
   vd_wf_args a;
@@ -845,6 +942,11 @@ static bool warp_fused_impl(hipStream_t s, const float* rgb, int ih, int iw, con
     a.e2_off = (int)sz_wd;
     fl = sz_wd + sz_e2 > sz_hh ? sz_wd + sz_e2 : sz_hh;
   }
+  if (fold) {   // the shift phases' scratch (depth tile + halo, edge-mask tile, shift tile) lives where the Hh rows land later
+    if (a.feather || WF_TH != 32) return false;
+    const size_t sz_sh = (((size_t)(WF_TH + 5) * (WF_TW + 8) + 3) & ~(size_t)3) + (size_t)(WF_TH + 4) * (WF_TW + 4) + (size_t)WF_TH * WF_TW;
+    if (sz_sh > fl) fl = sz_sh;
+  }
   fl = (fl + 3) & ~(size_t)3;            // tables start 16 B aligned (ds_read_b128)
   a.tab_off = (int)fl;
   const size_t t_rowA = pre ? 0 : (size_t)(WF_TH + k) * 4, t_colT = (size_t)2 * a.nch;
@@ -871,36 +973,47 @@ static bool warp_fused_impl(hipStream_t s, const float* rgb, int ih, int iw, con
   if (dev >= 0 && dev < 64 && !attr[dev]) {
     // dynamic LDS limit = the CU's 160 KB minus the kernel's static LDS (the VRSQRT14 table); a failed call would otherwise surface as a
     // sticky "invalid argument" at the next hipGetLastError
-#define WF_ATTR(R_, F_, P_)                                                                                                        \
+#define WF_ATTR(R_, F_, P_, S_)                                                                                                        \
   do {                                                                                                                             \
     hipFuncAttributes fa_;                                                                                                         \
     size_t st_ = 0;                                                                                                                \
-    if (hipFuncGetAttributes(&fa_, (const void*)k_warp_fused<R_, F_, WF_TH, P_>) == hipSuccess) st_ = fa_.sharedSizeBytes;         \
-    if (hipFuncSetAttribute((const void*)k_warp_fused<R_, F_, WF_TH, P_>, hipFuncAttributeMaxDynamicSharedMemorySize,              \
+    if (hipFuncGetAttributes(&fa_, (const void*)k_warp_fused<R_, F_, WF_TH, P_, S_>) == hipSuccess) st_ = fa_.sharedSizeBytes;         \
+    if (hipFuncSetAttribute((const void*)k_warp_fused<R_, F_, WF_TH, P_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize,              \
                             (int)(160 * 1024 - st_)) != hipSuccess) {                                                              \
       (void)hipGetLastError();                                                                                                     \
       fprintf(stderr, "vd3d: hipFuncSetAttribute(k_warp_fused, max dynamic LDS) failed; using the unfused warp kernels\n");        \
       return false;                                                                                                                \
     }                                                                                                                              \
   } while (0)
-    WF_ATTR(true, true, false); WF_ATTR(true, false, false); WF_ATTR(false, true, false); WF_ATTR(false, false, false);
-    WF_ATTR(true, true, true); WF_ATTR(false, true, true);
+    WF_ATTR(true, true, false, false); WF_ATTR(true, false, false, false); WF_ATTR(false, true, false, false); WF_ATTR(false, false, false, false);
+    WF_ATTR(true, true, true, false); WF_ATTR(false, true, true, false);
+    if (WF_TH == 32) { WF_ATTR(true, false, false, WF_TH == 32); WF_ATTR(false, false, false, WF_TH == 32); }
 #undef WF_ATTR
     attr[dev] = true;
   }
   const vd_f2* e2p = reinterpret_cast<const vd_f2*>(E2);
   const float* rowtab = wf_rowtab_get(s, H, ih, a.scale_h, a.step_y);
   if (!rowtab) return false;
-  if (resize && a.feather && pre) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
-  else if (a.feather && pre) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, true>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
-  else if (resize && a.feather) hipLaunchKernelGGL((k_warp_fused<true, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
-  else if (resize) hipLaunchKernelGGL((k_warp_fused<true, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
-  else if (a.feather) hipLaunchKernelGGL((k_warp_fused<false, true, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
-  else hipLaunchKernelGGL((k_warp_fused<false, false, WF_TH, false>), g, dim3(WF_NT), bytes, s, rgb, D, S, a, L, R, e2p, rowtab);
+  float* Sp = const_cast<float*>(S);
+  vd_shift_consts sc = {};
+  const vd_dev_work* work = nullptr;
+#define WF_GO(R_, F_, P_, S_) hipLaunchKernelGGL((k_warp_fused<R_, F_, WF_TH, P_, S_>), g, dim3(WF_NT), bytes, s, rgb, D, Sp, a, L, R, e2p, rowtab, sc, work)
+  if (fold) {
+    sc = vd_shift_consts_of(fold->sp, W); work = fold->work; Sp = fold->S_out;
+    if (resize) WF_GO(true, false, false, WF_TH == 32); else WF_GO(false, false, false, WF_TH == 32);
+  }
+  else if (resize && a.feather && pre) WF_GO(true, true, true, false);
+  else if (a.feather && pre) WF_GO(false, true, true, false);
+  else if (resize && a.feather) WF_GO(true, true, false, false);
+  else if (resize) WF_GO(true, false, false, false);
+  else if (a.feather) WF_GO(false, true, false, false);
+  else WF_GO(false, false, false, false);
+#undef WF_GO
   return true;
 }
 bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const float* D, const float* S, int H, int W,
-                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2) {
+                          const vd3d_shift_params& p, uint8_t* L, uint8_t* R, const float* E2, const vd_shift_fold* fold) {
+  if (fold) return !p.enable_feathering && warp_fused_impl<32>(s, rgb, ih, iw, D, S, H, W, p, L, R, nullptr, false, fold);
   if (E2 && p.enable_feathering && g_wf_pre_th == 16 && warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, true))
     return warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, E2, false);
   if (!p.enable_feathering && g_wf_nf_th == 16 && warp_fused_impl<16>(s, rgb, ih, iw, D, S, H, W, p, L, R, nullptr, true))
@@ -910,4 +1023,16 @@ bool vd_launch_warp_fused(hipStream_t s, const float* rgb, int ih, int iw, const
 // would vd_launch_warp_fused take this frame?  (the caller then runs k_e2w for the mask plane first)
 bool vd_warp_fused_ok(int ih, int iw, int H, int W, const vd3d_shift_params& p) {
   return warp_fused_impl<32>(nullptr, nullptr, ih, iw, nullptr, nullptr, H, W, p, nullptr, nullptr, reinterpret_cast<const float*>(16), true);
+}
+// ... and with the shift plane folded in?  Not in the N-thread ATen mode on planes that have scalar tails (k_shift<true>'s libm arithmetic is not instantiated here), not
+// with the development knob that selects the flat tile
+#ifndef WF_FOLD_DEFAULT
+#define WF_FOLD_DEFAULT 1
+#endif
+static int g_wf_fold = WF_FOLD_DEFAULT;   // A/B builds: -DWF_FOLD_DEFAULT=0
+bool vd_warp_fold_ok(int ih, int iw, int H, int W, const vd3d_shift_params& warp_p, const vd3d_shift_params& shift_p) {
+  if (!g_wf_fold || warp_p.enable_feathering || g_wf_nf_th == 16) return false;
+  if (vd_tails_of((unsigned long long)H * W, shift_p.aten_threads).on) return false;
+  vd_shift_fold f = {nullptr, shift_p, nullptr};
+  return warp_fused_impl<32>(nullptr, nullptr, ih, iw, nullptr, nullptr, H, W, warp_p, nullptr, nullptr, nullptr, true, &f);
 }
