@@ -659,8 +659,10 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
         lane = w1.get("valu_lane_instr_per_launch")
         w1_kernel = ("W1 = k_e2w (warped-depth gradient mask of both eyes) + k_warp_fused (window sums + warp + blend): the same work as round 3's "
                      "single launch, two launches since round 4") if res.get("feather_on", True) else \
-                    ("W1 = k_warp_fused<FEATHER = false> alone: feather_strength <= 0 makes feather_shift_edges an exact no-op (round 5), no mask "
-                     "kernel, no window sums, no blend -- nested-bilinear warp of both eyes + truncation")
+                    ("W1 = k_warp_fused<FEATHER = false, SHIFT = true> alone: feather_strength <= 0 makes feather_shift_edges an exact no-op (round 5), no mask "
+                     "kernel, no window sums, no blend -- nested-bilinear warp of both eyes + truncation; since round 6 the launch also computes the shift "
+                     "values of its own tile (k_shift folded in: it reads the shaped depth, 4 N, where it used to read the shift plane), so this duration "
+                     "compares with k_shift + W1 of earlier records (60 + 66 us at 4K)")
         rf = {"bound": "valu" if lane else "hbm", "kernel": w1_kernel,
               "k_e2w_avg_launch_ms": (e2w_ms if e2w_ms > 0 else None), "k_warp_fused_avg_launch_ms": (round(w1_ms - e2w_ms, 5) if e2w_ms > 0 else None),
               "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
@@ -675,7 +677,8 @@ def rooflines(res, copy_gbs=None, pmc_workload=None):
               "in_step_frac": round(alg / (w1_instep * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if w1_instep > 0 else None,
               "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
               "note": "frac prices SURVEY 8(d)'s 13 N algorithmic bytes against the 8 TB/s HBM spec (north_star's yardstick); the kernel is "
-                      "VALU-issue-bound, not HBM-bound (the reference's nested-bilinear arithmetic is kept bit-exact): `valu` prices the "
+                      "neither HBM- nor VALU-bound (the reference's nested-bilinear arithmetic is kept bit-exact; round 6's ablations, profiles/r06_w1_phases.md: "
+                      "what a workgroup waits for are dependent LDS / scalar-branch round trips at 2.5 resident workgroups per CU): `valu` prices the "
                       "PMC-counted VALU lane-instructions of one launch against the chip's MEASURED v_fma_f32 issue rate (50.2 T lane-ops/s) and the data sheet's. "
                       "ONE source prices the kernel: avg_launch_ms / achieved / frac = HIP events of the sequential pass of THIS run; rocprof_avg_launch_ms is the "
                       "committed rocprofv3 --kernel-trace figure of the same command (profiles/pmc_latest.json, taken at traffic_taken_at_commit), printed for "
