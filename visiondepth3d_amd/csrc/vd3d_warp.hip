@@ -329,20 +329,22 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
   }
   if (((FEATHER && !PRE) || SHIFT) && tid >= WF_NT - 64) rs14[tid - (WF_NT - 64)] = c_vd_rs14[tid - (WF_NT - 64)];
   if (FEATHER && PRE) {
-    // the e2 region of the tile straight from the E2 plane (zero outside the image = avg_pool2d's padding); all loads of a thread in flight
+    // the e2 region of the tile straight from the E2 plane (zero outside the image = avg_pool2d's padding); all loads of a thread in flight.  Round 6: straight-line
+    // (indices and coordinates clamped, the value zeroed afterwards) -- with the loads under `if (inside)` hipcc put a `s_waitcnt vmcnt(0)` at the first join, i.e. the S
+    // loads issued at the top of the kernel were waited for BEFORE the first E2 load went out: two dependent round trips where one was meant
     constexpr int NLD = 6;
     for (int t0 = tid; t0 < eh * ew; t0 += NLD * WF_NT) {
       vd_f2 ev[NLD]; int dst[NLD];
 #pragma unroll
       for (int j = 0; j < NLD; ++j) {
         const int t = t0 + j * WF_NT;
-        ev[j] = vd_f2{0.f, 0.f}; dst[j] = -1;
-        if (t < eh * ew) {
-          const int ty = wf_div(t, a.m_ew), tx = t - ty * ew;
-          const int y = y0 - r + ty, x = x0 - r + tx;
-          dst[j] = ty * ewp + tx;
-          if (y >= 0 && y < H && x >= 0 && x < W) ev[j] = E2[(unsigned)y * (unsigned)W + (unsigned)x];
-        }
+        const int tc = min(t, eh * ew - 1);
+        const int ty = wf_div(tc, a.m_ew), tx = tc - ty * ew;
+        const int y = y0 - r + ty, x = x0 - r + tx;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const vd_f2 v = E2[(unsigned)min(max(y, 0), H - 1) * (unsigned)W + (unsigned)min(max(x, 0), W - 1)];
+        ev[j] = vd_f2{in ? v.x : 0.f, in ? v.y : 0.f};
+        dst[j] = t < eh * ew ? ty * ewp + tx : -1;
       }
 #pragma unroll
       for (int j = 0; j < NLD; ++j) if (dst[j] >= 0) e2[dst[j]] = ev[j];
