@@ -501,6 +501,12 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
   vd_f4 alpha = {0.f, 0.f, 0.f, 0.f};
   int lmin = 9, lmax = -1;
   __syncthreads();   // lvl_mask = 0 visible before the atomicOr below; tile complete
+  // Round 6: the depth samples requested at the top are pinned HERE.  Without this hipcc hoists their first consumers (the 2:1 interpolation below) to right behind the
+  // loads, inside the `if (fast21)` block, with an `s_waitcnt vmcnt(0)` -- the kernel then sat out their round trip BEFORE issuing the tile loads: two dependent trips
+  // where the source meant one (found in the ISA after W1's wait analysis, profiles/r06_w1_phases.md).  Measured: 229.6 us against 229.4 -- E1 issues at 0.78 of the VALU rate
+  // and its other resident workgroups covered the wait either way; kept because it is what the source says.
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(p0[j]), "+v"(p1[j]));
   VD_STAMP(ff_stamps, 1, false);
   if (WIDE && DENSE) {   // halo-column windows (consumed after the next barrier)
     for (int t = tid; t < 3 * 2 * FF_IH; t += FF_NT) {
