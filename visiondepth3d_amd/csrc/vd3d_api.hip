@@ -734,8 +734,11 @@ static int run_finish(vd3d_ctx* c, const uint8_t* L, const uint8_t* R, const flo
     }
     d_wk = c->wk_tabs[c->wk_cur].dev;
   }
-  vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense, d_wk);
-  vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense, d_wk);
+  if (dense) vd_launch_dof_grade_dense(c->stream, L, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, c->gR, d_wk);   // both eyes per launch (round 6)
+  else {
+    vd_launch_dof_grade(c->stream, L, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gL, dense, d_wk);
+    vd_launch_dof_grade(c->stream, R, dn, eh, ew, p->warp_h, p->warp_w, fc, wk, focal, use_override, bw, bs, c->gR, dense, d_wk);
+  }
   // graded planes -> sharpen + fit + mux: the fused kernel's epilogue as a kernel of its own where its fit conditions hold, else the per-pixel one
   if (!((g_fused_fit & 2) && vd_launch_sharp_fit(c->stream, c->gL, c->gR, *p, fc, out))) vd_launch_sharp_mux(c->stream, c->gL, c->gR, *p, fc, out);
   HIPCHK(hipGetLastError());

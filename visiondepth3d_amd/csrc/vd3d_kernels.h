@@ -184,6 +184,9 @@ void vd_set_conv_mode(int v);   // vd3d_conv.hip: < 0 one tile per workgroup (ro
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
                          int bar_width, int bar_side, uint8_t* eye_out, int dense = 0, const float* dense_wtab = nullptr);
+void vd_launch_dof_grade_dense(hipStream_t s, const uint8_t* L_in, const uint8_t* R_in, const float* dn, int eh, int ew, int H, int W,
+                               const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
+                               int bar_width, int bar_side, uint8_t* L_out, uint8_t* R_out, const float* wtab);
 #define VD_D4_WTAB_FLOATS (4 * 31 * 32)   // dense weight table of k_dof_grade4: [level 4][row 31][pitch 32] = fl(k1[i] * k1[j])
 // sharpen + fit + mux of two graded eyes with the fused finishing kernel's epilogue (vd3d_finish.hip); false: not its fit (k_sharp_mux then)
 bool vd_launch_sharp_fit(hipStream_t s, const uint8_t* gL, const uint8_t* gR, const vd3d_render_params& p, const vd_finish_consts& fc, uint8_t* out);

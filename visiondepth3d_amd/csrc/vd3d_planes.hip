@@ -400,22 +400,42 @@ VD_DEV void d4_level_any(int k, const float* __restrict__ tile, int th, int twp,
     d4_fold(a0, a1, a2, a3, level, lo, alpha, res[c]);
   }
 }
-__global__ __launch_bounds__(512) void k_dof_grade4(const uint8_t* __restrict__ eye_in, const float* __restrict__ dn, int eh, int ew,
+// Round 6: both eyes in one launch (blockIdx.z; the second eye's workgroups fill the first one's tail), and the tile load in straight-line batches of D4_LU pixels per
+// thread -- the one-pixel-per-iteration loop it replaces was a chain of th * tw / 512 = 7 .. 12 dependent global round trips per thread (the wait pattern W1's analysis
+// found, profiles/r06_w1_phases.md).  m_tw = ceil(2^32 / tw): umulhi(t, m_tw) == t / tw for t, tw < 2^16.
+#define D4_LU 4
+__global__ __launch_bounds__(512) void k_dof_grade4(const uint8_t* __restrict__ eyeL_in, const uint8_t* __restrict__ eyeR_in, const float* __restrict__ dn, int eh, int ew,
                                                     int H, int W, vd_finish_consts fc, const vd_dev_work* __restrict__ w,
                                                     float focal_override, int use_override, int bar_width_o, int bar_side_o,
-                                                    uint8_t* __restrict__ eye_out, int twp, const float* __restrict__ wtab) {
+                                                    uint8_t* __restrict__ eyeL_out, uint8_t* __restrict__ eyeR_out, int twp, const float* __restrict__ wtab, uint32_t m_tw) {
   extern __shared__ float lds[];
+  const uint8_t* __restrict__ eye_in = blockIdx.z ? eyeR_in : eyeL_in;
+  uint8_t* __restrict__ eye_out = blockIdx.z ? eyeR_out : eyeL_out;
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   const int tw = D4_TW + 2 * R, th = D4_TH + 2 * R;
   float* tile = lds;                          // [3][th][twp], twp = 1 mod 4: the four rows of a wave's lanes fall into distinct banks
   const int x0 = blockIdx.x * D4_TW, y0 = blockIdx.y * D4_TH;
-  for (int t = threadIdx.x; t < th * tw; t += 512) {
-    const int ty = t / tw, tx = t - ty * tw;
-    const int y = vd_reflect(y0 - R + ty, H), x = vd_reflect(x0 - R + tx, W);
-    const uint8_t* px = eye_in + ((size_t)y * W + x) * 3;
-    tile[(0 * th + ty) * twp + tx] = vd_u8_unit((float)px[2]);
-    tile[(1 * th + ty) * twp + tx] = vd_u8_unit((float)px[1]);
-    tile[(2 * th + ty) * twp + tx] = vd_u8_unit((float)px[0]);
+  const int ntile = th * tw;
+#pragma unroll 1
+  for (int t0 = threadIdx.x; t0 < ntile; t0 += D4_LU * 512) {
+    uint8_t b[D4_LU][3]; int dst[D4_LU];
+#pragma unroll
+    for (int j = 0; j < D4_LU; ++j) {
+      const int t = t0 + j * 512, tc = min(t, ntile - 1);           // past the end: the last pixel again (loaded, not stored)
+      const int ty = (int)__umulhi((uint32_t)tc, m_tw), tx = tc - ty * tw;
+      const int y = vd_reflect(y0 - R + ty, H), x = vd_reflect(x0 - R + tx, W);
+      const uint8_t* px = eye_in + ((size_t)y * W + x) * 3;
+      b[j][0] = px[0]; b[j][1] = px[1]; b[j][2] = px[2];
+      dst[j] = t < ntile ? ty * twp + tx : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < D4_LU; ++j) {
+      if (dst[j] >= 0) {
+        tile[0 * th * twp + dst[j]] = vd_u8_unit((float)b[j][2]);
+        tile[1 * th * twp + dst[j]] = vd_u8_unit((float)b[j][1]);
+        tile[2 * th * twp + dst[j]] = vd_u8_unit((float)b[j][0]);
+      }
+    }
   }
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
@@ -482,24 +502,32 @@ __global__ __launch_bounds__(512) void k_dof_grade4(const uint8_t* __restrict__ 
     }
   }
 }
+// dense levels, both eyes (R_in / R_out may be NULL: one eye)
+void vd_launch_dof_grade_dense(hipStream_t s, const uint8_t* L_in, const uint8_t* R_in, const float* dn, int eh, int ew, int H, int W,
+                               const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
+                               int bar_width, int bar_side, uint8_t* L_out, uint8_t* R_out, const float* wtab) {
+  const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
+  const int tw = D4_TW + 2 * R, th = D4_TH + 2 * R;
+  int twp = tw;
+  while ((twp & 3) != 1) ++twp;
+  const size_t lds = sizeof(float) * 3 * (size_t)th * twp;
+  static bool attr[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr[dev]) {
+    (void)hipFuncSetAttribute((const void*)k_dof_grade4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr[dev] = true;
+  }
+  const uint32_t m_tw = (uint32_t)(((1ull << 32) + (uint64_t)tw - 1) / (uint64_t)tw);
+  hipLaunchKernelGGL(k_dof_grade4, dim3((W + D4_TW - 1) / D4_TW, (H + D4_TH - 1) / D4_TH, R_in ? 2 : 1), dim3(512), lds, s, L_in, R_in, dn, eh, ew, H, W, fc, w,
+                     focal_override, use_override, bar_width, bar_side, L_out, R_out, twp, wtab, m_tw);
+}
 void vd_launch_dof_grade(hipStream_t s, const uint8_t* eye_in, const float* dn, int eh, int ew, int H, int W,
                          const vd_finish_consts& fc, const vd_dev_work* w, float focal_override, int use_override,
                          int bar_width, int bar_side, uint8_t* eye_out, int dense, const float* wtab) {
   const int R = fc.nlev ? fc.ksz[fc.nlev - 1] / 2 : 0;
   if (dense) {
-    const int tw = D4_TW + 2 * R, th = D4_TH + 2 * R;
-    int twp = tw;
-    while ((twp & 3) != 1) ++twp;
-    const size_t lds = sizeof(float) * 3 * (size_t)th * twp;
-    static bool attr[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr[dev]) {
-      (void)hipFuncSetAttribute((const void*)k_dof_grade4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr[dev] = true;
-    }
-    hipLaunchKernelGGL(k_dof_grade4, dim3((W + D4_TW - 1) / D4_TW, (H + D4_TH - 1) / D4_TH), dim3(512), lds, s, eye_in, dn, eh, ew, H, W, fc, w,
-                       focal_override, use_override, bar_width, bar_side, eye_out, twp, wtab);
+    vd_launch_dof_grade_dense(s, eye_in, nullptr, dn, eh, ew, H, W, fc, w, focal_override, use_override, bar_width, bar_side, eye_out, nullptr, wtab);
     return;
   }
   const int tw = DF_TW + 2 * R, th = DF_TH + 2 * R;
