@@ -488,13 +488,27 @@ __global__ __launch_bounds__(ff_geo<TH_>::NT) FF_OCC_ATTR void k_finish_fused(co
       }
     }
   } else {
-    for (int t = tid; t < FF_IH * FF_IW; t += FF_NT) {
+    // border tiles (reflected coordinates, byte loads): all of a thread's pixels in flight together (round 6: the one-pixel-per-iteration loop was a chain of five dependent
+    // global round trips, and the border tiles were the launch's slowest workgroups)
+    constexpr int NPX = (FF_IH * FF_IW + FF_NT - 1) / FF_NT;
+    uint8_t bb[NPX][3];
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int t = min(tid + j * FF_NT, FF_IH * FF_IW - 1);
       const int ty = t / FF_IW, tx = t - ty * FF_IW;
       const int y = vd_reflect(iy0 + ty, H), x = vd_reflect(ix0 + tx, W);
       const uint8_t* px = src + ((size_t)y * W + x) * 3;
-      tile[0][ty][tx] = vd_u8_unit((float)px[2]);
-      tile[1][ty][tx] = vd_u8_unit((float)px[1]);
-      tile[2][ty][tx] = vd_u8_unit((float)px[0]);
+      bb[j][0] = px[0]; bb[j][1] = px[1]; bb[j][2] = px[2];
+    }
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int t = tid + j * FF_NT;
+      if (t < FF_IH * FF_IW) {
+        const int ty = t / FF_IW, tx = t - ty * FF_IW;
+        tile[0][ty][tx] = vd_u8_unit((float)bb[j][2]);
+        tile[1][ty][tx] = vd_u8_unit((float)bb[j][1]);
+        tile[2][ty][tx] = vd_u8_unit((float)bb[j][0]);
+      }
     }
   }
   int lo[4] = {0, 0, 0, 0};
