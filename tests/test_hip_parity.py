@@ -283,6 +283,25 @@ def test_render_frame_f32_depth_and_collapse(R, oracle):
         assert np.array_equal(got, exp), (i, u8_diff_stats(got, exp))
 
 
+@pytest.mark.parametrize("ih,iw,H,W,edge", [(108, 192, 108, 192, True), (54, 96, 108, 192, True), (135, 240, 270, 480, False), (270, 480, 540, 960, True),
+                                            (67, 101, 133, 203, True)])
+def test_pixel_shift_without_feathering_keeps_the_shift_plane(R, oracle, ih, iw, H, W, edge):
+    """Round 6: without feathering W1 computes the shift values of its own tile (k_shift's arithmetic folded into k_warp_fused<.., SHIFT = true>) and there is no
+    k_shift launch.  pixel_shift_cuda's callers can still ask for the shift map: the folded kernel writes it, and it has to be the plane k_shift would have written
+    (= the oracle's, which is pinned against the live reference's own shift map in pixel_shift_cases.npz) -- with and without the edge mask, with eyes at warp
+    resolution and at half of it, on a size that is no multiple of the tile."""
+    bgr, d = synth.synth_frame(3, ih, iw)
+    ft = oracle.frame_to_tensor(bgr)
+    for fs in (0.0, -2.0):
+        p = ShiftParams.defaults(8.0, -2.0, -5.0, feather_strength=fs, blur_ksize=1, enable_edge_masking=edge, max_pixel_shift_percent=0.05)
+        st = State()
+        o = oracle.pixel_shift(ft, d[None], W, H, p, st, want_shift=True)
+        R.reset_state()
+        L, Rr, S = R.pixel_shift(T(ft), T(d[None]), W, H, p, want_shift=True)
+        assert np.array_equal(S.cpu().numpy(), o["shift"]), (fs, float(np.abs(S.cpu().numpy() - o["shift"]).max()))
+        assert np.array_equal(L.cpu().numpy(), o["left"]) and np.array_equal(Rr.cpu().numpy(), o["right"]), fs
+
+
 KW_GUI = dict(output_format="Full-SBS", fg_shift=4.5, mg_shift=-1.5, bg_shift=-6.0, sharpness_factor=0.2, dof_strength=2.0, feather_strength=0.0,
               blur_ksize=1, use_subject_tracking=True, use_floating_window=True, zero_parallax_strength=0.01)   # VisionDepth3D.py:1405-1453
 

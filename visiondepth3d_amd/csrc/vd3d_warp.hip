@@ -788,21 +788,41 @@ __global__ __launch_bounds__(WF_TH * 16) WF_OCC_ATTR void k_warp_fused(const flo
         }
       } else
       {
+        // eyes at warp resolution: the samples are direct global gathers.  Round 6: the twelve north gathers (three channels x two eyes x west / east) are issued
+        // before the first is used, the twelve south ones under one branch, none of them guarded -- the east column is xw + 1 where that is inside the image and xw
+        // itself where it is not (there ne == se == +0: the finite sample adds nothing).  The guarded, channel-by-channel form compiled to `s_waitcnt vmcnt(0)` behind
+        // every channel's north and south group: up to six dependent GLOBAL round trips per row, four rows per wave.
+        const int xe0 = g.xw[0] + (g.e_ok[0] ? 1 : 0), xe1 = g.xw[1] + (g.e_ok[1] ? 1 : 0);
+        const unsigned rowo = (unsigned)yn * (unsigned)W;
+        float orig[3] = {0.f, 0.f, 0.f};
+        vd_f2 v[3];
+        {
+          vd_f2 vnw[3], vne[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float* r0 = rgb + (unsigned)c * ni + rowo;
+            vnw[c] = vd_f2{r0[g.xw[0]], r0[g.xw[1]]};
+            vne[c] = vd_f2{r0[xe0], r0[xe1]};
+            if (FEATHER) orig[c] = rgb[(unsigned)c * ni + o];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[c] = vd_vfma(vne[c], g.ne, vnw[c] * g.nw);
+        }
+        if (south) {
+          vd_f2 vsw[3], vse[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float* r1 = rgb + (unsigned)c * ni + rowo + (unsigned)W;
+            vsw[c] = vd_f2{r1[g.xw[0]], r1[g.xw[1]]};
+            vse[c] = vd_f2{r1[xe0], r1[xe1]};
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[c] = vd_vfma(vse[c], g.se, vd_vfma(vsw[c], g.sw, v[c]));
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float* pl = rgb + (unsigned)c * ni;
-          const float orig = pl[o];
-          const float* r0 = pl + (unsigned)yn * (unsigned)W;
-          const vd_f2 vnw = {r0[g.xw[0]], r0[g.xw[1]]};
-          const vd_f2 vne = {g.e_ok[0] ? r0[g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[g.xw[1] + 1] : 0.f};
-          vd_f2 v = vd_vfma(vne, g.ne, vnw * g.nw);
-          if (south) {
-            const vd_f2 vsw = {r0[W + g.xw[0]], r0[W + g.xw[1]]};
-            const vd_f2 vse = {g.e_ok[0] ? r0[W + g.xw[0] + 1] : 0.f, g.e_ok[1] ? r0[W + g.xw[1] + 1] : 0.f};
-            v = vd_vfma(vse, g.se, vd_vfma(vsw, g.sw, v));
-          }
-          if (FEATHER) { v = v * omb + orig * b; v.x = vd_clamp_fin(v.x, 0.f, 1.f); v.y = vd_clamp_fin(v.y, 0.f, 1.f); }
-          const vd_f2 u = v * 255.0f;
+          if (FEATHER) { v[c] = v[c] * omb + orig[c] * b; v[c].x = vd_clamp_fin(v[c].x, 0.f, 1.f); v[c].y = vd_clamp_fin(v[c].y, 0.f, 1.f); }
+          const vd_f2 u = v[c] * 255.0f;
           pL |= (uint32_t)(uint8_t)u.x << (8 * (3 - c));
           pR |= (uint32_t)(uint8_t)u.y << (8 * (3 - c));
         }
