@@ -19,7 +19,7 @@ def bench(fn, n=10):
 R = Renderer(0)
 torch.backends.cudnn.benchmark = True
 g = torch.Generator(device="cuda").manual_seed(1)
-for (H, W, Cin, Cout) in ((37, 66, 128, 128), (74, 132, 128, 128), (148, 264, 128, 128), (296, 528, 128, 64), (19, 33, 768, 128), (148, 264, 96, 128)):
+for (H, W, Cin, Cout) in ((37, 66, 128, 128), (74, 132, 128, 128), (148, 264, 128, 128), (296, 528, 128, 64), (19, 33, 768, 128), (148, 264, 96, 128), (518, 924, 64, 32)):
     B = 16
     x = torch.relu(torch.randn(B, Cin, H, W, device="cuda", generator=g)).contiguous(memory_format=torch.channels_last)
     w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * 0.05

@@ -5,7 +5,8 @@
 //
 // Implicit GEMM per workgroup: D[pixel][oc] = sum over (channel chunk, tap) of X[pixel + tap][chunk] W[oc][tap, chunk]
 //   M = 512 pixels = a 16 x 32 output tile (16 MFMA M tiles = the tile's rows), N = C_out (64 or 128), K = 9 taps x C_in in steps of 16 channels.
-//   512 threads = 8 waves as 4 (M: four tile rows each) x 2 (N), accumulators 4 x NWN tiles (NWN = C_out / 64), two waves per SIMD.
+//   512 threads = 8 waves as 4 (M: four tile rows each) x 2 (N), accumulators 4 x NWN tiles (NWN = C_out / 64), two waves per SIMD; for 32 output channels (the
+//   head's 64 -> 32 at the full 518 x 924) 8 (M: two rows each) x 1 (N).
 //   A (pixels): the input tile + 1 halo ring, ONE 16-channel chunk at a time, is fetched ONCE (LDS-DMA into a float32 staging buffer, a chunk ahead;
 //     pixels outside the image fetch a zero page), split into its two fp16 terms by an LDS -> register -> LDS pass behind the fourth tap of the previous
 //     chunk and kept in LDS [term 2][k-half 2][pixel 18 x 34][8 fp16] (39 KB, double-buffered); all nine taps of the chunk read their
@@ -47,16 +48,16 @@ struct vd_c2_args {
 typedef __attribute__((address_space(3))) void* c2_lds_vp;
 typedef const __attribute__((address_space(1))) void* c2_glb_vp;
 
-template <int NWN>   // N tiles per wave: C_out = 64 * NWN
+template <int WM, int NWN>   // WM waves along M (4: four tile rows each, two waves along N; 8: two rows each, one along N), NWN N tiles per wave: C_out = 32 (8 / WM) NWN
 __global__ __launch_bounds__(C2_NT) void k_conv3x3_x2(const float* __restrict__ X, const uint4* __restrict__ Wimg, const float* __restrict__ colscale,
                                                       const float* __restrict__ zero16, float* __restrict__ Y, vd_c2_args a) {
-  constexpr int COUT = 64 * NWN, BST = c2_b_stage(COUT), NBP = BST / (C2_NT * 16);   // B stage bytes, DMA instructions per thread and stage (1)
+  constexpr int WN = 8 / WM, MR = C2_TH / WM, COUT = 32 * WN * NWN, BST = c2_b_stage(COUT), NBP = BST / (C2_NT * 16);   // B stage bytes, DMA instructions per thread and stage (1)
   extern __shared__ __attribute__((aligned(16))) uint8_t c2_lds[];   // the only LDS object: [A buffer 0][A buffer 1][float32 staging][B ring]
   const int tile = blockIdx.x, b = blockIdx.y;
   const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
   const int y0 = tyi * C2_TH, x0 = txi * C2_TW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave - wm * WN, li = lane & 31, kh = lane >> 5;
   const int wave_base = (tid & ~63) * 16;
 
   // ---- A staging: item i = it * 512 + tid -> (pixel = i >> 2 of the 18 x 34 halo tile, quad = i & 3 = four of the chunk's 16 channels); the DMA of item i lands
@@ -105,9 +106,9 @@ __global__ __launch_bounds__(C2_NT) void k_conv3x3_x2(const float* __restrict__ 
                                        (c2_lds_vp)(c2_lds + C2_B_OFF + slot * BST + p * (C2_NT * 16) + wave_base), 16, 0, 0);
   };
 
-  c2_f16 acc[4][NWN];
+  c2_f16 acc[MR][NWN];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int n = 0; n < NWN; ++n)
 #pragma unroll
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(C2_NT) void k_conv3x3_x2(const float* __restrict__ 
   __builtin_amdgcn_s_barrier();
 
   // fragment base offsets: A: k-half plane, tile row 4 wm + m (+ 1 halo + dy), column li (+ 1 + dx); B: k-half plane, output channel (wn * NWN + n) * 32 + li
-  const int fa_base = (kh * C2_NPIX + (4 * wm + 1) * C2_PW + li + 1) * 16;
+  const int fa_base = (kh * C2_NPIX + (MR * wm + 1) * C2_PW + li + 1) * 16;
   const int fb_base = C2_B_OFF + (kh * COUT + wn * NWN * 32 + li) * 16;
   int ks = 0;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(C2_NT) void k_conv3x3_x2(const float* __restrict__ 
 #pragma unroll
         for (int t = 0; t < 2; ++t) bf[n][t] = *reinterpret_cast<const c2_h8s*>(sb + fb_base + t * (2 * COUT * 16) + n * 512);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MR; ++m) {
         c2_h8s af[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const c2_h8s*>(sat + t * (2 * C2_NPIX * 16) + m * (C2_PW * 16));
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(C2_NT) void k_conv3x3_x2(const float* __restrict__ 
     float cs = colscale[oc];
     asm volatile("" : "+v"(cs));   // consumed in front of the masked stores (vd3d_gemm.hip: else one s_waitcnt vmcnt(0) per store)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int y = y0 + 4 * wm + m;
+    for (int m = 0; m < MR; ++m) {
+      const int y = y0 + MR * wm + m;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_x2_pack(const float* __restrict
   *reinterpret_cast<c2_h8*>(base + 2 * Cout * 16) = h2;
 }
 
-static bool c2_shape_ok(int Cin, int Cout) { return Cin >= 16 && (Cin & 15) == 0 && (Cout == 64 || Cout == 128); }
+static bool c2_shape_ok(int Cin, int Cout) { return Cin >= 16 && (Cin & 15) == 0 && (Cout == 32 || Cout == 64 || Cout == 128); }
 long long vd_conv3x3_x2_weight_bytes(int Cin, int Cout) {
   if (!c2_shape_ok(Cin, Cout)) return -1;
   const long long bst = (2 * 2 * Cout * 16 + 8191) / 8192 * 8192;
@@ -245,8 +246,9 @@ bool vd_launch_conv3x3_x2(hipStream_t s, const float* X, int B, int H, int W, in
   if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(wimg) & 15)) return false;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_x2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS(64)) != hipSuccess) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_x2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS(128)) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_x2<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS(64)) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_x2<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS(128)) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_x2<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS(32)) != hipSuccess) return false;
     attr_set = true;
   }
   vd_c2_args a;
@@ -255,7 +257,8 @@ bool vd_launch_conv3x3_x2(hipStream_t s, const float* X, int B, int H, int W, in
   const float* cs = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(wimg) + nb - 64 - (long long)Cout * 4);
   const float* z16 = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(wimg) + nb - 64);
   const dim3 grid((unsigned)(a.ntx * a.nty), (unsigned)B);
-  if (Cout == 64) hipLaunchKernelGGL(k_conv3x3_x2<1>, grid, dim3(C2_NT), C2_LDS(64), s, X, reinterpret_cast<const uint4*>(wimg), cs, z16, Y, a);
-  else hipLaunchKernelGGL(k_conv3x3_x2<2>, grid, dim3(C2_NT), C2_LDS(128), s, X, reinterpret_cast<const uint4*>(wimg), cs, z16, Y, a);
+  if (Cout == 32) hipLaunchKernelGGL((k_conv3x3_x2<8, 1>), grid, dim3(C2_NT), C2_LDS(32), s, X, reinterpret_cast<const uint4*>(wimg), cs, z16, Y, a);   // the head's 64 -> 32
+  else if (Cout == 64) hipLaunchKernelGGL((k_conv3x3_x2<4, 1>), grid, dim3(C2_NT), C2_LDS(64), s, X, reinterpret_cast<const uint4*>(wimg), cs, z16, Y, a);
+  else hipLaunchKernelGGL((k_conv3x3_x2<4, 2>), grid, dim3(C2_NT), C2_LDS(128), s, X, reinterpret_cast<const uint4*>(wimg), cs, z16, Y, a);
   return true;
 }

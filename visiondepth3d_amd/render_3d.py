@@ -647,7 +647,7 @@ class Renderer:
         return out
 
     def conv3x3_x2_pack(self, weight: torch.Tensor):
-        """Split + pack a float32 3 x 3 convolution weight [Cout, Cin, 3, 3] for ``conv3x3_x2``; ``None`` when the shape is not built (Cin % 16, Cout in {64, 128})."""
+        """Split + pack a float32 3 x 3 convolution weight [Cout, Cin, 3, 3] for ``conv3x3_x2``; ``None`` when the shape is not built (Cin % 16, Cout in {32, 64, 128})."""
         w = weight.detach().to(self.device, torch.float32).contiguous()
         Cout, Cin, kh, kw = w.shape
         nb = int(self._L.vd3d_conv3x3_x2_weight_bytes(Cin, Cout)) if (kh, kw) == (3, 3) else -1
