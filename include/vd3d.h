@@ -419,7 +419,7 @@ int vd3d_attention_x3(vd3d_ctx* ctx, const float* qkv, int B, int T, int H, int 
 
 /* The 3 x 3 convolutions of the DPT neck / head in the fp16x2 arithmetic (the third piece of DepthPipe(gemm="fp16x2")): stride 1, zero padding 1, no bias
  * (DepthPipe runs them bias-free with a glue launch behind each), float32 channels_last: X [B][H][W][Cin] -> Y [B][H][W][Cout], W the module's float32
- * weight [Cout][Cin][3][3].  Cin a multiple of 16, Cout 64 or 128 (the fusion stage and the head's first convolution of DA-V2-Small / -Base), else
+ * weight [Cout][Cin][3][3].  Cin a multiple of 16, Cout 32, 64 or 128 (the fusion stage and the head's two 3 x 3 convolutions of DA-V2-Small / -Base), else
  * VD3D_E_UNSUPPORTED -- the caller keeps the library convolution for those.  Same arithmetic contract as vd3d_gemm_x3 in mode VD3D_X3_FP16X2 (operands as two
  * fp16 terms, three MFMA products, float32 accumulation, weights pre-scaled per output channel by an exact power of two, |x| < 65 504).
  * The weights are split and packed once into vd3d_conv3x3_x2_weight_bytes(Cin, Cout) bytes (< 0: unsupported shape). */
