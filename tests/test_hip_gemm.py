@@ -71,6 +71,32 @@ def test_gemm_x3_is_float32_faithful(R, M, K, N, bias, gelu, mode):
     assert torch.equal(R.linear_x3(x, img, N, b, gelu=gelu, mode=mode), y)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "fp16x2"])
+@pytest.mark.parametrize("M,K,N,gelu", [(21920, 768, 768, False), (21920, 768, 2304, False), (21920, 768, 3072, True), (21920, 3072, 768, False), (21000, 256, 1000, False)])
+def test_gemm_x3_at_the_depth_legs_batch_size(R, M, K, N, gelu, mode):
+    """The four linears at the size the benchmark runs them (16 frames x 1 370 tokens of DA-V2-Base at 4K: 86 M tiles, 11 per XCD -- every XCD's last round of tiles is
+    a short one) and one ragged shape: the bars of test_gemm_x3_is_float32_faithful per block of 4 096 rows (so that a failure names the tile rows), and identical bits
+    from two calls.  (Round 6 tried handing an XCD's short last round to split-K slice workgroups -- tools/r06/gemm_tail_splitk.patch -- and measured it SLOWER:
+    a tile that runs with most of the chip idle takes a third of the time of one that shares it, so the short round was never the cost the tile count suggests.)"""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn(M, K, device="cuda", generator=g) * torch.exp(torch.randn(1, K, device="cuda", generator=g) * 1.5)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g)
+    img = R.gemm_x3_pack(w, mode)
+    y = R.linear_x3(x, img, N, b, gelu=gelu, mode=mode)
+    y32 = F.linear(x, w, b)
+    if gelu:
+        y32 = F.gelu(y32)
+    for m0 in range(0, M, 4096):
+        sl = slice(m0, min(m0 + 4096, M))
+        e3, r3 = _err(y[sl], x[sl], w, b, gelu)
+        e32, r32 = _err(y32[sl], x[sl], w, b, gelu)
+        f_max, f_rms = (1.25, 1.25) if mode == "bf16x3" else (2.0, 1.5)
+        assert e3 <= max(f_max * e32, 2.0 ** -22), (m0, e3, e32)
+        assert r3 <= f_rms * r32 + 1e-9, (m0, r3, r32)
+    assert torch.equal(R.linear_x3(x, img, N, b, gelu=gelu, mode=mode), y)
+
+
 def test_gemm_x3_split_is_exact_and_layout_is_asymmetric(R):
     """Known answers: (i) with W = I the GEMM returns x itself BIT FOR BIT (x = x1 + x2 + x3 exactly, each term times 1.0, small terms first) -- for values across
     the exponent range, negative numbers and zeros; (ii) an asymmetric integer-valued problem, exact in every arithmetic: catches a transposed / permuted tile."""
