@@ -18,38 +18,19 @@ template <bool TAILS>   // round 5: ATen's scalar tails (vd_tails_of) -- those p
 __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int H, int W, const vd_dev_work* __restrict__ w,
                                                vd_shift_consts c, float* __restrict__ S, vd_tails tl) {
   __shared__ __attribute__((aligned(16))) float em[SH_TH + 4][SH_TW + 4];
-  __shared__ float dT[SH_TH + 5][SH_TW + 8];   // the depth tile + halo (3 left / up, 2 right / down): dT[ty][tx] = D[y0 - 3 + ty][x0 - 3 + tx]
   __shared__ int2 rs14[64];
   const int x0 = blockIdx.x * SH_TW, y0 = blockIdx.y * SH_TH;
-  {
-    // Round 6: the tile is staged by ONE batch of clamped loads per thread.  The edge-mask loop used to read its three depth samples per position from global memory
-    // under guards: three dependent round trips per position, five to six positions per thread (profiles/r06_w1_phases.md: the wait pattern).
-    constexpr int NE = (SH_TH + 5) * (SH_TW + 5), NL = (NE + 255) / 256;
-    float dv[NL];
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int t = min((int)threadIdx.x + j * 256, NE - 1);
-      const int ty = t / (SH_TW + 5), tx = t - ty * (SH_TW + 5);
-      const int y = y0 - 3 + ty, x = x0 - 3 + tx;
-      dv[j] = D[(size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)];   // outside the image: a valid neighbour, never used
-    }
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int t = (int)threadIdx.x + j * 256;
-      if (t < NE) { const int ty = t / (SH_TW + 5), tx = t - ty * (SH_TW + 5); dT[ty][tx] = dv[j]; }
-    }
+  if (c.edge) {
     vd_stage_rs14(rs14, threadIdx.x, 256);
     __syncthreads();
-  }
-  if (c.edge) {
     for (int t = threadIdx.x; t < (SH_TH + 4) * (SH_TW + 4); t += 256) {
       const int ty = t / (SH_TW + 4), tx = t - ty * (SH_TW + 4);
       const int y = y0 - 2 + ty, x = x0 - 2 + tx;
       float e = 0.f;  // zero padding of avg_pool2d
       if (y >= 0 && y < H && x >= 0 && x < W) {
-        const float cc = dT[ty + 1][tx + 1];
-        const float dx = x > 0 ? fabsf(cc - dT[ty + 1][tx]) : 0.f;
-        const float dy = y > 0 ? fabsf(cc - dT[ty][tx + 1]) : 0.f;
+        const float cc = D[(size_t)y * W + x];
+        const float dx = x > 0 ? fabsf(cc - D[(size_t)y * W + x - 1]) : 0.f;
+        const float dy = y > 0 ? fabsf(cc - D[(size_t)(y - 1) * W + x]) : 0.f;
         const float g = vd_sqrt_torch(dx * dx + dy * dy, rs14);      // torch.sqrt / torch.sigmoid: the CPU libraries' values
         const float z = ((g - (float)0.02) * c.fs) * 5.f;
         float sg;
@@ -84,7 +65,7 @@ __global__ __launch_bounds__(256) void k_shift(const float* __restrict__ D, int 
   for (int q = 0; q < 4; ++q) {
     const int x = x0 + tx + q;
     if (x >= W) break;
-    const float Dv = dT[ty + 3][tx + q + 3];
+    const float Dv = D[(size_t)y * W + x];
     float p15;
     if (TAILS && vd_in_tail(tl, (unsigned)y * (unsigned)W + (unsigned)x)) p15 = vd_pow_tail(1.0f - Dv, 1.5);
     else p15 = vd_pow15_torch(1.0f - Dv);
