@@ -900,20 +900,20 @@ def main():
     subs, roof_src = {}, head
     if env.rank == 0 and env.world == 1 and not single and not args.no_sub_records:
         nroof = max(2, math.ceil(200 / args.batch))   # >= 200 timed frames, >= 20 warm-up frames
-        r4 = run_workload(env, args, "4k-dibr", nroof, max(2, math.ceil(20 / args.batch)), profile=prof)
+        r4 = run_workload(env, args, "4k-dibr", nroof, max(6, math.ceil(20 / args.batch)), profile=prof)   # (round 6: six warm-up steps -- the sub-records follow the float32 headline and measured 3 - 8 % under a run of their own with two)
         r1e = run_workload(env, args, "1080p-dav2s-dibr", 10, 3, depth_dtype="f32", profile=prof)
-        r1d = run_workload(env, args, "1080p-dibr", 10, 3, profile=prof)
+        r1d = run_workload(env, args, "1080p-dibr", 24, 8, profile=prof)
         rbf = run_workload(env, args, HEADLINE, 10, 3, depth_dtype="bf16", profile=prof, isolated_pass=False)
-        rdn = run_workload(env, args, "4k-dibr-sepdof", 4, 2, profile=prof, isolated_pass=False)
-        rd3 = run_workload(env, args, "4k-dibr-dof3", 4, 2, profile=prof, isolated_pass=False)
-        ran = run_workload(env, args, "4k-dibr-anaglyph", 4, 2, profile=prof, isolated_pass=False)
+        rdn = run_workload(env, args, "4k-dibr-sepdof", 12, 6, profile=prof, isolated_pass=False)
+        rd3 = run_workload(env, args, "4k-dibr-dof3", 12, 6, profile=prof, isolated_pass=False)
+        ran = run_workload(env, args, "4k-dibr-anaglyph", 12, 6, profile=prof, isolated_pass=False)
         try:
-            rvr = run_workload(env, args, "4k-dibr-vr", 4, 2, profile=prof, isolated_pass=False)
+            rvr = run_workload(env, args, "4k-dibr-vr", 12, 6, profile=prof, isolated_pass=False)
         except Exception as e:   # a sub-record must never take the headline down
             rvr = None
             print(f"[bench] 4k-dibr-vr failed: {str(e)[:200]}", file=sys.stderr)
-        rg1 = run_workload(env, args, "1080p-gui-defaults", 10, 3, profile=prof)
-        rg4 = run_workload(env, args, "4k-dibr-gui", 6, 2, profile=prof)
+        rg1 = run_workload(env, args, "1080p-gui-defaults", 24, 8, profile=prof)
+        rg4 = run_workload(env, args, "4k-dibr-gui", 16, 6, profile=prof)
         rhi = run_workload(env, args, "4k-dibr", 6, 2, profile=False, isolated_pass=False, host_io=True)   # host-I/O-included figure
         rhn = None
         try:
