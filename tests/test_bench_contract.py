@@ -35,7 +35,7 @@ def test_roofline_objects_and_sub_records():
     assert abs(e1["in_step_frac"] - 10 * n / 0.47e-3 / 1e9 / 8000.0) < 1e-4
     # a run without the sequential pass prices the in-step duration and says so
     r0 = bench.rooflines(_res(iso_ms={}), copy_gbs=4600.0)["roofline"]
-    assert r0["avg_launch_ms"] == 0.16 and r0["avg_launch_measured"].startswith("inside the timed region")
+    assert r0["avg_launch_ms"] == 0.16 and r0["avg_launch_measured"].startswith("profiled pass behind the timed region")
     assert rf["roofline_chain"]["algorithmic_bytes_per_frame"] == 17 * n
     # a workload with a depth net reports the MFMA fraction against the dtype's dense peak
     rd = bench.rooflines(_res(workload="4k-dav2b-dibr", model="depth-anything-v2-base", net_ms=140.0, flops_per_frame=7.9e11, depth_dtype="f32"))
