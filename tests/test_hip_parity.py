@@ -302,6 +302,38 @@ def test_pixel_shift_without_feathering_keeps_the_shift_plane(R, oracle, ih, iw,
         assert np.array_equal(L.cpu().numpy(), o["left"]) and np.array_equal(Rr.cpu().numpy(), o["right"]), fs
 
 
+def test_pixel_shift_without_feathering_in_the_scalar_tail_mode_goes_through_k_shift(R, oracle):
+    """The folded kernel does not instantiate ATen's scalar-tail arithmetic (glibc expf / libm pow on the last elements of each thread's chunk): in the N-thread ATen
+    mode on a plane that HAS tails, vd_warp_fold_ok refuses and k_shift<true> + the unfolded W1 run.  Same bytes as the oracle in both modes (the few tail elements of this plane happen to round
+    alike in both arithmetics; tests/test_hip_widen.py's aten_any_size fixtures are where the mode shows)."""
+    ih, iw, H, W = 67, 101, 133, 203
+    bgr, d = synth.synth_frame(5, ih, iw)
+    ft = oracle.frame_to_tensor(bgr)
+    planes = {}
+    for threads in (0, 3):
+        p = ShiftParams.defaults(8.0, -2.0, -5.0, feather_strength=0.0, blur_ksize=1, max_pixel_shift_percent=0.05, aten_threads=threads)
+        o = oracle.pixel_shift(ft, d[None], W, H, p, State(), want_shift=True)
+        R.reset_state()
+        L, Rr, S = R.pixel_shift(T(ft), T(d[None]), W, H, p, want_shift=True)
+        assert np.array_equal(S.cpu().numpy(), o["shift"]), threads
+        assert np.array_equal(L.cpu().numpy(), o["left"]) and np.array_equal(Rr.cpu().numpy(), o["right"]), threads
+        planes[threads] = o["shift"]
+
+
+def test_w1_row_tables_survive_more_geometries_than_the_cache_holds(R, oracle):
+    """Round 6: W1's per-row parameters live in a per-geometry device table (k_wf_rowtab), eight geometries per process; the ninth replaces the oldest.  Eleven frame
+    heights in a row, then the first one again (its table was evicted and is rebuilt): every eye pair equals the oracle's."""
+    sizes = [(40 + 6 * i, 96) for i in range(11)] + [(40, 96)]
+    for (H, W) in sizes:
+        bgr, d = synth.synth_frame(H, H // 2, W // 2)
+        ft = oracle.frame_to_tensor(bgr)
+        p = ShiftParams.defaults(6.0, -2.0, -4.0, feather_strength=(0.0 if H % 4 else 10.0), blur_ksize=5)
+        o = oracle.pixel_shift(ft, d[None], W, H, p, State())
+        R.reset_state()
+        L, Rr = R.pixel_shift(T(ft), T(d[None]), W, H, p)[:2]
+        assert np.array_equal(L.cpu().numpy(), o["left"]) and np.array_equal(Rr.cpu().numpy(), o["right"]), (H, W)
+
+
 KW_GUI = dict(output_format="Full-SBS", fg_shift=4.5, mg_shift=-1.5, bg_shift=-6.0, sharpness_factor=0.2, dof_strength=2.0, feather_strength=0.0,
               blur_ksize=1, use_subject_tracking=True, use_floating_window=True, zero_parallax_strength=0.01)   # VisionDepth3D.py:1405-1453
 
