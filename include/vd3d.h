@@ -509,7 +509,8 @@ long vd3d_stage_calls(vd3d_ctx* ctx, const char* stage);
 int vd3d_debug_gaussian_kernel1d(int k, float sigma, float* out_host);
 /* host-only: the library's restatement of torch.exp on a float32 CPU tensor (oneMKL vsExp, not the rounded exponential) that the DOF weights use */
 int vd3d_debug_exp_torch(const float* x_host, float* out_host, long long n);
-/* internal planes of the last call (device pointers owned by ctx; tests only) */
+/* internal planes of the last call (device pointers owned by ctx; tests only).  S: the render / step path without feathering computes the shift values inside the
+ * warp kernel and does not write this plane (round 6); vd3d_pixel_shift always does. */
 int vd3d_debug_planes(vd3d_ctx* ctx, float** D, float** S, uint8_t** L, uint8_t** R, float** rgb_eye, float** dn_cur);
 
 #ifdef __cplusplus
