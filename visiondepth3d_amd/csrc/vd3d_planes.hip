@@ -574,8 +574,33 @@ __global__ __launch_bounds__(256) void k_sharp_mux(const uint8_t* __restrict__ g
   uint8_t px[2][3];
   const int ix = x - m.xo, iy = y - m.yo;
   const bool inside = ix >= 0 && ix < m.in_w && iy >= 0 && iy < m.in_h;
+  // Round 6, the VR path (pre-sharpened eyes, fractional INTER_AREA ratio): the area taps are computed ONCE per output pixel and every source pixel's three bytes are
+  // read together -- the generic loop below evaluates vd_area_taps and walks the ny x nx window per eye AND per channel.  Per channel the same float32 sums in the
+  // same order (h = h + s * alpha over the row, acc = acc + h * beta over the rows).
+  const bool fast_area = PRE && m.frac == 1;
+  if (fast_area) {
+    float ax[VD_AREA_MAXT], ay[VD_AREA_MAXT];
+    int x0s = 0, y0s = 0, nx = 0, ny = 0;
+    if (inside) { nx = vd_area_taps(m.W, m.sx, ix, &x0s, ax); ny = vd_area_taps(m.H, m.sy, iy, &y0s, ay); }
 #pragma unroll
-  for (int eye = 0; eye < 2; ++eye) {
+    for (int eye = 0; eye < 2; ++eye) {
+      const uint8_t* g = eye == 0 ? gL : gR;
+      float acc[3] = {0.f, 0.f, 0.f};
+      for (int j = 0; j < ny; ++j) {
+        float h[3] = {0.f, 0.f, 0.f};
+        const uint8_t* row = g + ((size_t)(y0s + j) * m.pre + x0s) * 3;
+        for (int k = 0; k < nx; ++k) {
+          const uint8_t b0 = row[3 * k], b1 = row[3 * k + 1], b2 = row[3 * k + 2];
+          h[0] = h[0] + (float)b0 * ax[k]; h[1] = h[1] + (float)b1 * ax[k]; h[2] = h[2] + (float)b2 * ax[k];
+        }
+        acc[0] = acc[0] + h[0] * ay[j]; acc[1] = acc[1] + h[1] * ay[j]; acc[2] = acc[2] + h[2] * ay[j];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[eye][c] = inside ? vd_sat_rne_u8(acc[c]) : (uint8_t)0;
+    }
+  }
+#pragma unroll
+  for (int eye = 0; eye < 2 && !fast_area; ++eye) {
     const uint8_t* g = eye == 0 ? gL : gR;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
