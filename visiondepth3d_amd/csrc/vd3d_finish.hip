@@ -1050,10 +1050,24 @@ __global__ __launch_bounds__(512) void k_sharp_fit(const uint8_t* __restrict__ g
   const int H = a.H, W = a.W;
   const int x0 = tbx * FF_TW, y0 = tby * FF_TH, gx0 = x0 - 4, gy0 = y0 - 1;
   const int tid = threadIdx.x;
-  for (int t = tid; t < FF_GH * FF_GW; t += FF_NT) {
-    const int row = t / FF_GW, col = t - row * FF_GW;
-    const uint8_t* px = src + ((size_t)vd_reflect(gy0 + row, H) * W + vd_reflect(gx0 + col, W)) * 3;
-    gb[row][col] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);   // byte 0 = B, 1 = G, 2 = R (the planes are BGR)
+  {   // all of a thread's pixels in one load batch (round 6; the one-pixel-per-iteration loop was four to five dependent global round trips)
+    constexpr int NPX = (FF_GH * FF_GW + FF_NT - 1) / FF_NT;
+    uint8_t bb[NPX][3];
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int t = min(tid + j * FF_NT, FF_GH * FF_GW - 1);
+      const int row = t / FF_GW, col = t - row * FF_GW;
+      const uint8_t* px = src + ((size_t)vd_reflect(gy0 + row, H) * W + vd_reflect(gx0 + col, W)) * 3;
+      bb[j][0] = px[0]; bb[j][1] = px[1]; bb[j][2] = px[2];
+    }
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int t = tid + j * FF_NT;
+      if (t < FF_GH * FF_GW) {
+        const int row = t / FF_GW, col = t - row * FF_GW;
+        gb[row][col] = (uint32_t)bb[j][0] | ((uint32_t)bb[j][1] << 8) | ((uint32_t)bb[j][2] << 16);   // byte 0 = B, 1 = G, 2 = R (the planes are BGR)
+      }
+    }
   }
   __syncthreads();
   ff_epilogue<FF_TH, FF_NT>(gb, a, fc, eye, x0, y0, gx0, gy0, tid, out);
