@@ -20,6 +20,12 @@
 //           shuffle-packed 12-byte stores per 4 lanes.
 // Arithmetic is identical to the unfused v0 kernels (same helpers, same association) => bit-exact vs the oracle.
 //
+// Round 6 (profiles/r06_w1_phases.md): the kernel is bound by DEPENDENT WAITS at 2.5 resident workgroups per CU -- not by HBM, not by issue slots -- so phase D reads a
+// row's LDS samples in one batch, packs its 12-byte store groups by DPP + v_alignbit, takes its row parameters from a per-geometry table by s_load; without feathering
+// the kernel has two barriers, deals D1 flat over the threads and (SHIFT) computes k_shift's values for its own tile, so the frame has no k_shift launch and no S plane.
+// Rule learnt the hard way: a load under a wave-uniform `if` makes hipcc put `s_waitcnt vmcnt` at the join -- between loads that do not depend on each other; every load
+// batch in this file is therefore straight-line code on clamped indices, with the guard applied to the VALUE afterwards.
+//
 // Algorithmic HBM bytes per stereo pair: read RGB 3N (eye-res f32 x3 at N/4) + D 4N + S 4N, write 6N.
 #include <cstdio>
 #include <mutex>
@@ -46,7 +52,8 @@ struct vd_wf_args {
 };
 // LDS tables (built once per tile, so the per-pixel phases only do table look-ups):
 //   rowA[wh][4]   per halo row of phase A : yn, n, 1-n, south flag                      (grid_sample row part)
-//   rowD[TH][16]  per tile row of phase D : 3 resize taps (orig / yn / yn+1) as Hh row byte offsets + weights, n, 1-n, south, yn
+//   rowD[TH][16]  (until round 5; the LDS region is still reserved) per tile row of phase D: 3 resize taps (orig / yn / yn+1) + weights, n, 1-n, south, yn.
+//                 Round 6: ONE table per geometry in global memory (k_wf_rowtab, absolute eye-res rows), read by s_load in phase D2
 //   colT[nch][2]  per warp-res column     : resize tap of that column (absolute eye-res column, weight of the next one)
 #define WF_RD 16
 VD_DEV int wf_div(int t, uint32_t m) { return (int)__umulhi((uint32_t)t, m); }
